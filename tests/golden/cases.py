@@ -1,0 +1,70 @@
+"""Case list shared by make_golden.py (which runs the genuine reference) and the
+parity tests.  Inputs are regenerated from taiyaki_amd.synth; the fixtures hold
+only the reference's OUTPUTS (plus a few small stored inputs)."""
+import numpy as np
+
+from taiyaki_amd import synth
+
+# name -> dict(T, N, seed, sharp, seqlens=None|list, nbase)
+CRF_SMALL = {
+    "t4n1": dict(T=4, N=1, seed=11, sharp=1.0, seqlens=[3]),
+    "t7n2": dict(T=7, N=2, seed=12, sharp=1.0, seqlens=[6, 2]),
+    "t7n2_len1": dict(T=7, N=2, seed=13, sharp=1.0, seqlens=[1, 5]),
+    "t50n4": dict(T=50, N=4, seed=14, sharp=1.0, seqlens=[20, 45, 1, 33]),
+    "t50n4_sharp": dict(T=50, N=4, seed=15, sharp=2.5, seqlens=[25, 40, 7, 12]),
+    "t50n3_zero_last": dict(T=50, N=3, seed=16, sharp=1.0, seqlens=[30, 17, 0]),
+    "t64n8": dict(T=64, N=8, seed=17, sharp=1.0, seqlens=None),
+    "t200n8": dict(T=200, N=8, seed=18, sharp=1.0, seqlens=None),
+    "t130n5_long": dict(T=130, N=5, seed=19, sharp=1.0,
+                        seqlens=[118, 65, 64, 63, 129]),
+    "t300n3_wide": dict(T=300, N=3, seed=20, sharp=1.0, seqlens=[270, 257, 129]),
+}
+
+CATMOD_SMALL = {
+    "t7n2": dict(T=7, N=2, seed=31, sharp=1.0, seqlens=[6, 3]),
+    "t50n4": dict(T=50, N=4, seed=32, sharp=1.0, seqlens=[20, 45, 2, 33]),
+    "t50n4_sharp": dict(T=50, N=4, seed=33, sharp=2.5, seqlens=[25, 40, 7, 12]),
+    "t200n8": dict(T=200, N=8, seed=34, sharp=1.0, seqlens=None),
+}
+
+# (T, N, nbase, seed)
+LOGZ_SMALL = {
+    "t1n1": dict(T=1, N=1, nbase=4, seed=41),
+    "t7n3_nb2": dict(T=7, N=3, nbase=2, seed=42),
+    "t50n5": dict(T=50, N=5, nbase=4, seed=43),
+    "t200n8": dict(T=200, N=8, nbase=4, seed=44),
+    "t333n70": dict(T=333, N=70, nbase=4, seed=45),
+    "t100n4_nb3": dict(T=100, N=4, nbase=3, seed=46),
+}
+
+# BASELINE.json configs at full size: only per-read scalars + checksums are kept
+FULLSIZE = {
+    "cfg2": dict(T=800, N=128, seed=1, mods=None),
+    "cfg4": dict(T=800, N=128, seed=2, mods=(1, 1, 0, 0)),
+    "cfg5": dict(T=1600, N=64, seed=3, mods=None),
+    "rowK": dict(T=4000, N=256, seed=1, mods=None),
+}
+
+NMODS = (1, 1, 0, 0)        # ACGTZY: 6mA on A, 5mC on C
+
+
+def crf_inputs(spec, mods=None):
+    seqlens = spec.get("seqlens")
+    return synth.crf_case(spec["T"], spec["N"], spec["seed"],
+                          nbase=spec.get("nbase", 4), nmods_per_base=mods,
+                          seqlens=seqlens)
+
+
+def logz_inputs(spec):
+    nb = spec["nbase"]
+    return synth.scores(spec["T"], spec["N"], 2 * nb * (nb + 1), spec["seed"])
+
+
+def grad_checksums(grad):
+    """Size-independent digest of a (T,N,S) gradient: per-read sum, sum of squares
+    (float64) and a strided sample of raw elements."""
+    g = np.asarray(grad, dtype=np.float64)
+    flat = np.asarray(grad).reshape(-1)
+    idx = np.arange(0, flat.size, max(1, flat.size // 4096))[:4096]
+    return dict(sum=g.sum(axis=(0, 2)), sumsq=(g * g).sum(axis=(0, 2)),
+                sample_idx=idx, sample=flat[idx].copy())

@@ -1,0 +1,158 @@
+/*
+ * taiyaki_amd_flipflop.h -- C ABI of the MI355X (gfx950) flip-flop CRF hot path.
+ *
+ * Drop-in boundary for the loss / decode operators of nanoporetech/taiyaki:
+ *
+ *   reference interface                                   replaced by
+ *   ----------------------------------------------------  --------------------------------
+ *   taiyaki/ctc/c_crf_flipflop.h:3-11   (libctc.pxd:5-13)   crf_flipflop_cost / _grad      (host ptrs, exact prototype)
+ *   taiyaki/ctc/c_cat_mod_flipflop.h:3-13 (libctc.pxd:16-25) cat_mod_flipflop_cost / _grad  (host ptrs, exact prototype)
+ *   taiyaki/ctc/ctc.pyx:116-153 FlipFlopCRF                 tk_crf_flipflop_dev            (device ptrs + stream)
+ *   taiyaki/ctc/ctc.pyx:258-312 CatModFlipFlop              tk_crf_flipflop_dev (mod args) (device ptrs + stream)
+ *   taiyaki/flipflopfings.py:6-31 + ctc.pyx:127-134,282-292 tk_flipflop_build_indices_dev
+ *   taiyaki/cupy_extensions/flipflop.py:88-368 (fwd/bwd/    tk_flipflop_logz_dev
+ *      make_trans/LogZ), taiyaki/layers.py:1277-1299
+ *   taiyaki/cupy_extensions/flipflop.py:470-518,            tk_flipflop_viterbi_dev
+ *      taiyaki/decode.py:75-115
+ *
+ * Conventions
+ *  - plain C: pointers and sizes only, no torch / HIP types in the signatures
+ *    (`stream` is a hipStream_t passed as void*; NULL = the default stream).
+ *  - `_dev` entry points take DEVICE pointers, enqueue work on `stream` and return
+ *    without synchronising.  The exact-prototype entry points take HOST pointers
+ *    (like the reference), stage through the device and synchronise.
+ *  - all tensors are C-contiguous fp32 (nblk, nbatch, ntrans) like the reference
+ *    (c_crf_flipflop.c:434-516); base pointers of (nblk,nbatch,ntrans) tensors must
+ *    be 16-byte aligned.
+ *  - every `_dev` function returns an int status (TK_OK or TK_ERR_*); a launch
+ *    failure is reported, never swallowed.  Non-finite results are reported
+ *    through the optional device-side `status` word (bit flags below), which the
+ *    Python shim turns into the reference's AssertionError (ctc.pyx:48,62-65,107-112).
+ *  - ownership: the caller allocates every buffer including the workspace (size
+ *    from the matching *_workspace_bytes); the library allocates nothing on the
+ *    `_dev` path.
+ *  - thread-safety: re-entrant; no global state.
+ */
+#ifndef TAIYAKI_AMD_FLIPFLOP_H
+#define TAIYAKI_AMD_FLIPFLOP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define TK_OK 0
+#define TK_ERR_BAD_ARG 1        /* NULL pointer, bad shape, misaligned tensor          */
+#define TK_ERR_UNSUPPORTED 2    /* nbase / ntrans / sequence length outside the build */
+#define TK_ERR_WORKSPACE 3      /* workspace too small                                */
+#define TK_ERR_LAUNCH 4         /* HIP launch / runtime failure                       */
+
+/* bits of the device-side status word */
+#define TK_STATUS_NONFINITE_SCORE 1u
+#define TK_STATUS_NONFINITE_GRAD 2u
+
+/* library / build identification: returns e.g. "taiyaki_amd flipflop gfx950 r1" */
+const char *tk_version(void);
+
+/* ------------------------------------------------------------------------- *
+ * Index construction on device (flipflopfings.py:6-31, ctc.pyx:127-134, 282-292)
+ *   seqs      (sum L)  int32 flip-flop codes 0..2nb-1, reads concatenated
+ *   seqlen    (nbatch) int32
+ *   mod_cats  (sum L)  int32 or NULL; can_mods_offsets (nbase+1) int32; mod_cat_weights (nbase+nmod) f32
+ * Outputs (all in the PADDED per-position layout: entry off[n]+p belongs to
+ * position p of read n; the move/mod entry of a read's last position is a
+ * sentinel):
+ *   seqoff (nbatch+1) int64 prefix offsets ; stayidx, moveidx (sum L) int32 ;
+ *   modidx (sum L) int32, modfact (sum L) f32 (only when mod_cats != NULL)
+ * ------------------------------------------------------------------------- */
+int tk_flipflop_build_indices_dev(const int32_t *seqs, const int32_t *seqlen,
+                                  size_t nbatch, size_t total_len, size_t nbase,
+                                  const int32_t *mod_cats,
+                                  const int32_t *can_mods_offsets,
+                                  const float *mod_cat_weights,
+                                  int64_t *seqoff, int32_t *stayidx,
+                                  int32_t *moveidx, int32_t *modidx,
+                                  float *modfact, void *stream);
+
+/* ------------------------------------------------------------------------- *
+ * (A) sequence-constrained flip-flop CRF score and gradient
+ *     (c_crf_flipflop.c:434-516, c_cat_mod_flipflop.c:493-582 semantics).
+ *
+ *   lp[t,n,i] = logprob[t,n,i] * (i < ncan ? sharp_can : sharp_mod)
+ *   cost[n]   = -score(lp)/nblk * out_scale          (ctc.pyx:66,113,145)
+ *   grad[t,n,i] = d(-score(lp)/nblk)/d lp[t,n,i]     (ctc.pyx:113; NULL => cost only,
+ *                 in which case score is the forward score, c_crf_flipflop.c:255-290)
+ *   seqlen[n]==0 => cost 0, zero gradient rows        (c_crf_flipflop.c:269-272,458-464)
+ *   max_seqlen: an upper bound of seqlen (0 = unknown => nblk+1 is assumed)
+ * ------------------------------------------------------------------------- */
+size_t tk_crf_flipflop_workspace_bytes(size_t ntrans, size_t nblk, size_t nbatch,
+                                       size_t max_seqlen, int want_grad);
+
+int tk_crf_flipflop_dev(const float *logprob, size_t ntrans, size_t nblk,
+                        size_t nbatch, const int32_t *stayidx,
+                        const int32_t *moveidx, const int32_t *modidx,
+                        const float *modfact, const int32_t *seqlen,
+                        const int64_t *seqoff, size_t max_seqlen, size_t ncan,
+                        float sharp_can, float sharp_mod, float out_scale,
+                        float *cost, float *grad, void *workspace,
+                        size_t workspace_bytes, uint32_t *status, void *stream);
+
+/* ------------------------------------------------------------------------- *
+ * (B) log-partition over the 2*nbase state lattice and its gradient
+ *     logz[n] = log sum_{all flip-flop paths starting in a flip state} exp(sum_t s)
+ *     grad[t,n,:] = d logz[n] / d scores[t,n,:]  == posterior transition
+ *     probabilities (decode.flipflop_make_trans); NULL => logZ only.
+ * ------------------------------------------------------------------------- */
+size_t tk_flipflop_logz_workspace_bytes(size_t nblk, size_t nbatch, size_t nbase);
+
+int tk_flipflop_logz_dev(const float *scores, size_t nblk, size_t nbatch,
+                         size_t nbase, float *logz, float *grad, void *workspace,
+                         size_t workspace_bytes, uint32_t *status, void *stream);
+
+/* ------------------------------------------------------------------------- *
+ * Viterbi decode (decode.py:75-115: first-index tie rule, bit-exact fp32 adds)
+ *   fwd (nblk+1, nbatch, 2nb) f32 ; traceback (nblk, nbatch, 2nb) int64 ;
+ *   path (nblk+1, nbatch) int64.   fwd / traceback may be NULL (path only).
+ * ------------------------------------------------------------------------- */
+size_t tk_flipflop_viterbi_workspace_bytes(size_t nblk, size_t nbatch, size_t nbase);
+
+int tk_flipflop_viterbi_dev(const float *scores, size_t nblk, size_t nbatch,
+                            size_t nbase, float *fwd, int64_t *traceback,
+                            int64_t *path, void *workspace,
+                            size_t workspace_bytes, void *stream);
+
+/* ------------------------------------------------------------------------- *
+ * Exact reference prototypes (HOST pointers; taiyaki/ctc/c_crf_flipflop.h:3-11,
+ * c_cat_mod_flipflop.h:3-13).  Index arrays use the reference layout
+ * (moves: sum(seqlen) - nbatch entries).  These stage through device memory,
+ * run the same kernels and synchronise; an internal failure yields NAN scores
+ * (the reference's own out-of-memory behaviour, c_crf_flipflop.c:278-282).
+ * ------------------------------------------------------------------------- */
+void crf_flipflop_grad(float const *logprob, size_t ntrans, size_t nblk,
+                       size_t nbatch, size_t const *moveidxs,
+                       size_t const *stayidxs, int32_t const *seqlen,
+                       float *score, float *grad);
+
+void crf_flipflop_cost(float const *logprob, size_t ntrans, size_t nblk,
+                       size_t nbatch, size_t const *moveidxs,
+                       size_t const *stayidxs, int32_t const *seqlen,
+                       float *score);
+
+void cat_mod_flipflop_grad(float const *logprob, size_t ntrans, size_t nblk,
+                           size_t nbatch, size_t const *moveidxs,
+                           size_t const *stayidxs, size_t const *modmoveidxs,
+                           float const *modmovefacts, int32_t const *seqlen,
+                           float *score, float *grad);
+
+void cat_mod_flipflop_cost(float const *logprob, size_t ntrans, size_t nblk,
+                           size_t nbatch, size_t const *moveidxs,
+                           size_t const *stayidxs, size_t const *modmoveidxs,
+                           float const *modmovefacts, int32_t const *seqlen,
+                           float *score);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* TAIYAKI_AMD_FLIPFLOP_H */

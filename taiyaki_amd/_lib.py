@@ -1,0 +1,138 @@
+"""ctypes binding of the C ABI in include/taiyaki_amd_flipflop.h.
+
+PyTorch is plumbing here (device memory, streams); every hot-path computation
+is a HIP kernel behind the C ABI.  There is NO CPU / eager fallback: if the
+shared library is missing or a tensor is not on an AMD GPU the operators raise.
+"""
+import ctypes
+import os
+import subprocess
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(_HERE, "csrc")
+LIBNAME = "libtaiyaki_amd_flipflop.so"
+LIBPATH = os.path.join(CSRC, LIBNAME)
+
+_vp = ctypes.c_void_p
+_sz = ctypes.c_size_t
+_f = ctypes.c_float
+_i = ctypes.c_int
+
+# symbol -> (restype, argtypes); mirrors include/taiyaki_amd_flipflop.h
+SIGNATURES = {
+    "tk_version": (ctypes.c_char_p, []),
+    "tk_flipflop_build_indices_dev": (_i, [_vp, _vp, _sz, _sz, _sz, _vp, _vp, _vp, _vp, _vp,
+                                          _vp, _vp, _vp, _vp]),
+    "tk_crf_flipflop_workspace_bytes": (_sz, [_sz, _sz, _sz, _sz, _i]),
+    "tk_crf_flipflop_dev": (_i, [_vp, _sz, _sz, _sz, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _sz,
+                                 _f, _f, _f, _vp, _vp, _vp, _sz, _vp, _vp]),
+    "tk_flipflop_logz_workspace_bytes": (_sz, [_sz, _sz, _sz]),
+    "tk_flipflop_logz_dev": (_i, [_vp, _sz, _sz, _sz, _vp, _vp, _vp, _sz, _vp, _vp]),
+    "tk_flipflop_viterbi_workspace_bytes": (_sz, [_sz, _sz, _sz]),
+    "tk_flipflop_viterbi_dev": (_i, [_vp, _sz, _sz, _sz, _vp, _vp, _vp, _vp, _sz, _vp]),
+    # exact reference prototypes (host pointers)
+    "crf_flipflop_grad": (None, [_vp, _sz, _sz, _sz, _vp, _vp, _vp, _vp, _vp]),
+    "crf_flipflop_cost": (None, [_vp, _sz, _sz, _sz, _vp, _vp, _vp, _vp]),
+    "cat_mod_flipflop_grad": (None, [_vp, _sz, _sz, _sz, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "cat_mod_flipflop_cost": (None, [_vp, _sz, _sz, _sz, _vp, _vp, _vp, _vp, _vp, _vp]),
+}
+
+ERRORS = {1: "bad argument (NULL / shape / 16-byte alignment)",
+          2: "unsupported nbase / ntrans / sequence length for this build",
+          3: "workspace too small", 4: "HIP launch failure"}
+
+_lib = None
+
+
+def build(force=False):
+    """Compile the gfx950 shared library in-tree (hipcc cross-compiles without a GPU)."""
+    if force:
+        subprocess.run(["make", "-C", CSRC, "clean"], check=True, stdout=subprocess.DEVNULL)
+    subprocess.run(["make", "-C", CSRC, "-j4"], check=True, stdout=subprocess.DEVNULL)
+    return LIBPATH
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIBPATH):
+            raise RuntimeError(
+                "%s is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+                "(there is no CPU fallback for the flip-flop operators)" % LIBPATH)
+        handle = ctypes.CDLL(LIBPATH)
+        for name, (res, args) in SIGNATURES.items():
+            fn = getattr(handle, name)      # AttributeError if the symbol is not exported
+            fn.restype = res
+            fn.argtypes = args
+        _lib = handle
+    return _lib
+
+
+def check(rc, what):
+    if rc != 0:
+        raise RuntimeError("%s failed: %s (code %d)" % (what, ERRORS.get(rc, "unknown"), rc))
+
+
+def require_gpu(t, what):
+    if not t.is_cuda:
+        raise RuntimeError(
+            "%s: tensor is on %s; the flip-flop operators only run as HIP kernels on an AMD GPU "
+            "(no CPU fallback)" % (what, t.device))
+
+
+def ptr(t):
+    return _vp(t.data_ptr()) if t is not None else _vp(0)
+
+
+def stream_ptr():
+    return _vp(torch.cuda.current_stream().cuda_stream)
+
+
+# --------------------------------------------------------------------------
+# non-finite reporting (reference: AssertionError in ctc.pyx:48,62-65,107-112)
+# --------------------------------------------------------------------------
+_strict = os.environ.get("TAIYAKI_AMD_STRICT", "1") != "0"
+_deferred = {}
+
+
+def set_strict(flag):
+    """strict (default): every operator call checks its device status word at once
+    (one host sync, exactly the reference's error timing).  Non-strict: status
+    words accumulate per device and are checked by `raise_if_nonfinite()`."""
+    global _strict
+    _strict = bool(flag)
+
+
+def status_word(device):
+    if _strict:
+        return torch.zeros(1, dtype=torch.int32, device=device)
+    key = (device.type, device.index)
+    if key not in _deferred:
+        _deferred[key] = torch.zeros(1, dtype=torch.int32, device=device)
+    return _deferred[key]
+
+
+def _raise(bits):
+    if bits & 4:
+        raise RuntimeError("sequence longer than the max_seqlen the kernel was launched for")
+    if bits & 1:
+        raise AssertionError("Error: all costs must be finite.\n"
+                             "Try restarting from a checkpoint with a lower learning rate.")
+    if bits & 2:
+        raise AssertionError("Error: Gradients not finite.\n"
+                             "Try restarting from a checkpoint with a lower learning rate.")
+
+
+def finish(status):
+    if _strict:
+        _raise(int(status.item()))
+
+
+def raise_if_nonfinite():
+    """Check (and clear) the deferred status words; one sync per device."""
+    for t in _deferred.values():
+        bits = int(t.item())
+        t.zero_()
+        _raise(bits)

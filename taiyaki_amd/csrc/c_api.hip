@@ -1,0 +1,241 @@
+// c_api.hip -- the extern "C" boundary declared in include/taiyaki_amd_flipflop.h.
+#include <hip/hip_runtime.h>
+#include <math.h>
+#include <stdint.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include <vector>
+
+#include "../../include/taiyaki_amd_flipflop.h"
+
+namespace tk {
+size_t logz_workspace_bytes(size_t T, size_t N, size_t nbase);
+int logz_dispatch(const float *scores, size_t T, size_t N, size_t nbase, float *logz,
+                  float *grad, void *workspace, size_t workspace_bytes, uint32_t *status,
+                  hipStream_t stream);
+size_t viterbi_workspace_bytes(size_t T, size_t N, size_t nbase);
+int viterbi_dispatch(const float *scores, size_t T, size_t N, size_t nbase, float *fwd,
+                     int64_t *tb, int64_t *path, void *workspace, size_t workspace_bytes,
+                     hipStream_t stream);
+size_t crf_workspace_bytes(size_t ntrans, size_t nblk, size_t nbatch, size_t max_seqlen,
+                           int want_grad);
+int crf_dispatch(const float *logprob, size_t ntrans, size_t nblk, size_t nbatch,
+                 const int32_t *stayidx, const int32_t *moveidx, const int32_t *modidx,
+                 const float *modfact, const int32_t *seqlen, const int64_t *seqoff,
+                 size_t max_seqlen, size_t ncan, float sharp_can, float sharp_mod,
+                 float out_scale, float *cost, float *grad, void *workspace,
+                 size_t workspace_bytes, uint32_t *status, hipStream_t stream);
+int build_indices_dispatch(const int32_t *seqs, const int32_t *seqlen, size_t nbatch,
+                           size_t nbase, const int32_t *mod_cats,
+                           const int32_t *can_mods_offsets, const float *mod_cat_weights,
+                           int64_t *seqoff, int32_t *stay, int32_t *move, int32_t *mod,
+                           float *fact, hipStream_t stream);
+}  // namespace tk
+
+static inline bool aligned16(const void *p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
+
+extern "C" {
+
+const char *tk_version(void) { return "taiyaki_amd flipflop gfx950 r1"; }
+
+int tk_flipflop_build_indices_dev(const int32_t *seqs, const int32_t *seqlen, size_t nbatch,
+                                  size_t total_len, size_t nbase, const int32_t *mod_cats,
+                                  const int32_t *can_mods_offsets,
+                                  const float *mod_cat_weights, int64_t *seqoff,
+                                  int32_t *stayidx, int32_t *moveidx, int32_t *modidx,
+                                  float *modfact, void *stream) {
+    (void)total_len;
+    if (!seqlen || !seqoff || !stayidx || !moveidx || nbatch == 0 || nbase == 0) return TK_ERR_BAD_ARG;
+    if (total_len > 0 && !seqs) return TK_ERR_BAD_ARG;
+    if (mod_cats && (!can_mods_offsets || !mod_cat_weights || !modidx || !modfact)) return TK_ERR_BAD_ARG;
+    return tk::build_indices_dispatch(seqs, seqlen, nbatch, nbase, mod_cats, can_mods_offsets,
+                                      mod_cat_weights, seqoff, stayidx, moveidx, modidx,
+                                      modfact, static_cast<hipStream_t>(stream));
+}
+
+size_t tk_crf_flipflop_workspace_bytes(size_t ntrans, size_t nblk, size_t nbatch,
+                                       size_t max_seqlen, int want_grad) {
+    return tk::crf_workspace_bytes(ntrans, nblk, nbatch, max_seqlen, want_grad);
+}
+
+int tk_crf_flipflop_dev(const float *logprob, size_t ntrans, size_t nblk, size_t nbatch,
+                        const int32_t *stayidx, const int32_t *moveidx, const int32_t *modidx,
+                        const float *modfact, const int32_t *seqlen, const int64_t *seqoff,
+                        size_t max_seqlen, size_t ncan, float sharp_can, float sharp_mod,
+                        float out_scale, float *cost, float *grad, void *workspace,
+                        size_t workspace_bytes, uint32_t *status, void *stream) {
+    if (!logprob || !stayidx || !moveidx || !seqlen || !seqoff || !cost || !workspace) return TK_ERR_BAD_ARG;
+    if (ntrans == 0 || nblk == 0 || nbatch == 0) return TK_ERR_BAD_ARG;
+    if ((modidx == nullptr) != (modfact == nullptr)) return TK_ERR_BAD_ARG;
+    return tk::crf_dispatch(logprob, ntrans, nblk, nbatch, stayidx, moveidx, modidx, modfact,
+                            seqlen, seqoff, max_seqlen, ncan, sharp_can, sharp_mod, out_scale,
+                            cost, grad, workspace, workspace_bytes, status,
+                            static_cast<hipStream_t>(stream));
+}
+
+size_t tk_flipflop_logz_workspace_bytes(size_t nblk, size_t nbatch, size_t nbase) {
+    return tk::logz_workspace_bytes(nblk, nbatch, nbase);
+}
+
+int tk_flipflop_logz_dev(const float *scores, size_t nblk, size_t nbatch, size_t nbase,
+                         float *logz, float *grad, void *workspace, size_t workspace_bytes,
+                         uint32_t *status, void *stream) {
+    if (!scores || !logz || !workspace || nblk == 0 || nbatch == 0) return TK_ERR_BAD_ARG;
+    if (!aligned16(scores) || (grad && !aligned16(grad))) return TK_ERR_BAD_ARG;
+    return tk::logz_dispatch(scores, nblk, nbatch, nbase, logz, grad, workspace,
+                             workspace_bytes, status, static_cast<hipStream_t>(stream));
+}
+
+size_t tk_flipflop_viterbi_workspace_bytes(size_t nblk, size_t nbatch, size_t nbase) {
+    return tk::viterbi_workspace_bytes(nblk, nbatch, nbase);
+}
+
+int tk_flipflop_viterbi_dev(const float *scores, size_t nblk, size_t nbatch, size_t nbase,
+                            float *fwd, int64_t *traceback, int64_t *path, void *workspace,
+                            size_t workspace_bytes, void *stream) {
+    if (!scores || !path || !workspace || nbatch == 0) return TK_ERR_BAD_ARG;
+    if (!aligned16(scores)) return TK_ERR_BAD_ARG;
+    return tk::viterbi_dispatch(scores, nblk, nbatch, nbase, fwd, traceback, path, workspace,
+                                workspace_bytes, static_cast<hipStream_t>(stream));
+}
+
+/* ------------------------------------------------------------------------- *
+ * exact reference prototypes on HOST pointers
+ * ------------------------------------------------------------------------- */
+namespace {
+
+struct DevBuf {
+    void *p = nullptr;
+    bool alloc(size_t bytes) { return hipMalloc(&p, bytes ? bytes : 16) == hipSuccess; }
+    ~DevBuf() {
+        if (p) (void)hipFree(p);
+    }
+};
+
+bool host_seq_call(float const *logprob, size_t ntrans, size_t nblk, size_t nbatch,
+                   size_t const *moveidxs, size_t const *stayidxs, size_t const *modmoveidxs,
+                   float const *modmovefacts, int32_t const *seqlen, float *score, float *grad) {
+    // reference layout -> padded per-position layout (moves: seqidx[b] - b, c_crf_flipflop.c:479)
+    std::vector<int64_t> off(nbatch + 1, 0);
+    int32_t maxlen = 0;
+    for (size_t b = 0; b < nbatch; ++b) {
+        off[b + 1] = off[b] + seqlen[b];
+        if (seqlen[b] > maxlen) maxlen = seqlen[b];
+    }
+    const size_t total = (size_t)off[nbatch];
+    std::vector<int32_t> stay(total ? total : 1), move(total ? total : 1), mod;
+    std::vector<float> fact;
+    if (modmoveidxs) {
+        mod.assign(total ? total : 1, 0);
+        fact.assign(total ? total : 1, 0.f);
+    }
+    for (size_t b = 0; b < nbatch; ++b) {
+        const size_t L = (size_t)seqlen[b];
+        for (size_t p = 0; p < L; ++p) {
+            stay[off[b] + p] = (int32_t)stayidxs[off[b] + p];
+            if (p + 1 < L) {
+                move[off[b] + p] = (int32_t)moveidxs[off[b] - b + p];
+                if (modmoveidxs) {
+                    mod[off[b] + p] = (int32_t)modmoveidxs[off[b] - b + p];
+                    fact[off[b] + p] = modmovefacts[off[b] - b + p];
+                }
+            } else {
+                move[off[b] + p] = 0;
+            }
+        }
+    }
+    const size_t nelt = nblk * nbatch * ntrans;
+    const size_t wsb = tk::crf_workspace_bytes(ntrans, nblk, nbatch, (size_t)maxlen, grad != nullptr);
+    DevBuf d_lp, d_stay, d_move, d_mod, d_fact, d_len, d_off, d_cost, d_grad, d_ws;
+    if (!d_lp.alloc(nelt * 4) || !d_stay.alloc(stay.size() * 4) || !d_move.alloc(move.size() * 4) ||
+        !d_len.alloc(nbatch * 4) || !d_off.alloc((nbatch + 1) * 8) || !d_cost.alloc(nbatch * 4) ||
+        !d_ws.alloc(wsb))
+        return false;
+    if (grad && !d_grad.alloc(nelt * 4)) return false;
+    if (modmoveidxs && (!d_mod.alloc(mod.size() * 4) || !d_fact.alloc(fact.size() * 4))) return false;
+    bool ok = true;
+    ok &= hipMemcpy(d_lp.p, logprob, nelt * 4, hipMemcpyHostToDevice) == hipSuccess;
+    ok &= hipMemcpy(d_stay.p, stay.data(), stay.size() * 4, hipMemcpyHostToDevice) == hipSuccess;
+    ok &= hipMemcpy(d_move.p, move.data(), move.size() * 4, hipMemcpyHostToDevice) == hipSuccess;
+    ok &= hipMemcpy(d_len.p, seqlen, nbatch * 4, hipMemcpyHostToDevice) == hipSuccess;
+    ok &= hipMemcpy(d_off.p, off.data(), (nbatch + 1) * 8, hipMemcpyHostToDevice) == hipSuccess;
+    if (modmoveidxs) {
+        ok &= hipMemcpy(d_mod.p, mod.data(), mod.size() * 4, hipMemcpyHostToDevice) == hipSuccess;
+        ok &= hipMemcpy(d_fact.p, fact.data(), fact.size() * 4, hipMemcpyHostToDevice) == hipSuccess;
+    }
+    if (!ok) return false;
+    // The C layer of the reference works on lp directly (no sharpening, no -1/nblk):
+    // score = +path score, grad = +posterior (c_crf_flipflop.c:434-516).  The device
+    // entry point returns cost = -score/nblk and d cost, so undo that here.
+    // canonical columns = everything below the first mod column (ids of stay/move < ncan <= mod ids)
+    size_t ncan = ntrans;
+    if (modmoveidxs) {
+        for (size_t b = 0; b < nbatch; ++b)
+            for (size_t p = 0; p + 1 < (size_t)seqlen[b]; ++p)
+                if (modmoveidxs[off[b] - b + p] < ncan) ncan = modmoveidxs[off[b] - b + p];
+    }
+    const int rc = tk::crf_dispatch(
+        static_cast<const float *>(d_lp.p), ntrans, nblk, nbatch,
+        static_cast<const int32_t *>(d_stay.p), static_cast<const int32_t *>(d_move.p),
+        modmoveidxs ? static_cast<const int32_t *>(d_mod.p) : nullptr,
+        modmoveidxs ? static_cast<const float *>(d_fact.p) : nullptr,
+        static_cast<const int32_t *>(d_len.p), static_cast<const int64_t *>(d_off.p),
+        (size_t)maxlen, ncan, 1.0f, 1.0f, 1.0f, static_cast<float *>(d_cost.p),
+        grad ? static_cast<float *>(d_grad.p) : nullptr, d_ws.p, wsb, nullptr, nullptr);
+    if (rc != 0 || hipDeviceSynchronize() != hipSuccess) return false;
+    std::vector<float> cost(nbatch);
+    if (hipMemcpy(cost.data(), d_cost.p, nbatch * 4, hipMemcpyDeviceToHost) != hipSuccess) return false;
+    for (size_t b = 0; b < nbatch; ++b) {
+        if (grad != nullptr && seqlen[b] == 0) continue;     // score untouched (:458-464)
+        score[b] = -cost[b] * (float)nblk;
+    }
+    if (grad) {
+        if (hipMemcpy(grad, d_grad.p, nelt * 4, hipMemcpyDeviceToHost) != hipSuccess) return false;
+        const float s = -(float)nblk;
+        for (size_t i = 0; i < nelt; ++i) grad[i] *= s;
+    }
+    return true;
+}
+
+void fail_scores(float *score, size_t nbatch) {
+    for (size_t b = 0; b < nbatch; ++b) score[b] = NAN;     // c_crf_flipflop.c:278-282
+}
+
+}  // namespace
+
+void crf_flipflop_grad(float const *logprob, size_t ntrans, size_t nblk, size_t nbatch,
+                       size_t const *moveidxs, size_t const *stayidxs, int32_t const *seqlen,
+                       float *score, float *grad) {
+    if (!host_seq_call(logprob, ntrans, nblk, nbatch, moveidxs, stayidxs, nullptr, nullptr, seqlen,
+                       score, grad))
+        fail_scores(score, nbatch);
+}
+
+void crf_flipflop_cost(float const *logprob, size_t ntrans, size_t nblk, size_t nbatch,
+                       size_t const *moveidxs, size_t const *stayidxs, int32_t const *seqlen,
+                       float *score) {
+    if (!host_seq_call(logprob, ntrans, nblk, nbatch, moveidxs, stayidxs, nullptr, nullptr, seqlen,
+                       score, nullptr))
+        fail_scores(score, nbatch);
+}
+
+void cat_mod_flipflop_grad(float const *logprob, size_t ntrans, size_t nblk, size_t nbatch,
+                           size_t const *moveidxs, size_t const *stayidxs,
+                           size_t const *modmoveidxs, float const *modmovefacts,
+                           int32_t const *seqlen, float *score, float *grad) {
+    if (!host_seq_call(logprob, ntrans, nblk, nbatch, moveidxs, stayidxs, modmoveidxs,
+                       modmovefacts, seqlen, score, grad))
+        fail_scores(score, nbatch);
+}
+
+void cat_mod_flipflop_cost(float const *logprob, size_t ntrans, size_t nblk, size_t nbatch,
+                           size_t const *moveidxs, size_t const *stayidxs,
+                           size_t const *modmoveidxs, float const *modmovefacts,
+                           int32_t const *seqlen, float *score) {
+    if (!host_seq_call(logprob, ntrans, nblk, nbatch, moveidxs, stayidxs, modmoveidxs,
+                       modmovefacts, seqlen, score, nullptr))
+        fail_scores(score, nbatch);
+}
+
+}  // extern "C"

@@ -1,0 +1,182 @@
+// ff_common.h -- device-side building blocks shared by the gfx950 flip-flop kernels.
+//
+// CDNA4 only: 64-lane wavefronts, LDS staging, no portability layer.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace tk {
+
+constexpr int WAVE = 64;
+typedef float f4 __attribute__((ext_vector_type(4)));
+constexpr float LOG2E = 1.4426950408889634f;
+constexpr float LN2 = 0.6931471805599453f;
+constexpr float NEG_LARGE = -1e30f;     // the reference's LARGE_VAL (c_crf_flipflop.c:11)
+
+// Flip-flop transition layout (taiyaki/layers.py:1253-1274):
+//   s[to*NS + from]      to < NB (to-flip), any from
+//   s[NS*NB + from]      from < NB: flip -> own flop ; from >= NB: flop stay
+template <int NB>
+struct FF {
+    static constexpr int NS = 2 * NB;
+    static constexpr int S = NS * (NB + 1);
+    static constexpr int PIECES = S / 4;    // float4 pieces per row; S % 4 == 0 always
+    static constexpr int FLOP0 = NS * NB;
+};
+
+__device__ __forceinline__ int lane_id() { return threadIdx.x & (WAVE - 1); }
+
+// Compiler-level ordering for wave-private LDS traffic.  The LDS unit executes
+// one wave's DS instructions in order, so no hardware barrier is needed; this
+// only stops hipcc from moving DS ops across the point.
+__device__ __forceinline__ void wave_lds_fence() {
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+}
+
+__device__ __forceinline__ float fast_exp2(float x) { return __builtin_amdgcn_exp2f(x); }
+__device__ __forceinline__ float fast_log2(float x) { return __builtin_amdgcn_logf(x); }
+__device__ __forceinline__ float fast_exp(float x) { return __builtin_amdgcn_exp2f(x * LOG2E); }
+
+// log2(2^a + 2^b) -- the reference's logaddexp (vect_mathfun.h:79-102:
+// max + log(1 + exp(-|d|)), NOT log1p) in base 2: one v_exp_f32 + one v_log_f32.
+__device__ __forceinline__ float lse2(float a, float b) {
+    const float mx = fmaxf(a, b);
+    const float d = -fabsf(a - b);
+    return mx + fast_log2(1.0f + fast_exp2(d));
+}
+
+__device__ __forceinline__ float wave_allmax(float x) {
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) {
+        x = fmaxf(x, __shfl_xor(x, m, WAVE));
+    }
+    return x;
+}
+
+__device__ __forceinline__ float wave_allsum(float x) {
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) {
+        x += __shfl_xor(x, m, WAVE);
+    }
+    return x;
+}
+
+// ---------------------------------------------------------------------------
+// "Row-set" = the S scores of 64 consecutive reads at one time step: one
+// contiguous 64*S*4-byte segment of the (T, N, S) tensor (10 KiB for S = 40).
+// A wave loads it with perfectly coalesced 16-byte pieces (lane l takes pieces
+// l, l+64, ...), then transposes through a wave-private LDS buffer so that
+// lane l ends up with the S scores of read n0 + l in registers.
+// ---------------------------------------------------------------------------
+template <int NB>
+struct RowSet {
+    using F = FF<NB>;
+    f4 v[F::PIECES];
+
+    // issue the coalesced global loads (nvalid = number of valid float4 pieces,
+    // 64*PIECES for a full column of reads; the tail is zero-filled)
+    __device__ __forceinline__ void issue(const float *__restrict__ base, int nvalid, int lane) {
+        const f4 *src = reinterpret_cast<const f4 *>(base);
+#pragma unroll
+        for (int q = 0; q < F::PIECES; ++q) {
+            const int idx = q * WAVE + lane;
+            v[q] = (idx < nvalid) ? src[idx] : f4{0.f, 0.f, 0.f, 0.f};
+        }
+    }
+
+    // pieces -> own row (in place).  buf: wave-private LDS, 64*PIECES f4.
+    __device__ __forceinline__ void to_rows(f4 *buf, int lane) {
+#pragma unroll
+        for (int q = 0; q < F::PIECES; ++q) buf[q * WAVE + lane] = v[q];
+        wave_lds_fence();
+#pragma unroll
+        for (int q = 0; q < F::PIECES; ++q) v[q] = buf[lane * F::PIECES + q];
+        wave_lds_fence();
+    }
+
+    // own row -> pieces (in place), the inverse shuffle for coalesced stores
+    __device__ __forceinline__ void to_pieces(f4 *buf, int lane) {
+#pragma unroll
+        for (int q = 0; q < F::PIECES; ++q) buf[lane * F::PIECES + q] = v[q];
+        wave_lds_fence();
+#pragma unroll
+        for (int q = 0; q < F::PIECES; ++q) v[q] = buf[q * WAVE + lane];
+        wave_lds_fence();
+    }
+
+    __device__ __forceinline__ void store(float *__restrict__ base, int nvalid, int lane) const {
+        f4 *dst = reinterpret_cast<f4 *>(base);
+#pragma unroll
+        for (int q = 0; q < F::PIECES; ++q) {
+            const int idx = q * WAVE + lane;
+            if (idx < nvalid) dst[idx] = v[q];
+        }
+    }
+
+    __device__ __forceinline__ void set(int i, float x) { v[i >> 2][i & 3] = x; }
+    __device__ __forceinline__ float get(int i) const { return v[i >> 2][i & 3]; }
+
+    // w = exp(s - rowmax); returns rowmax.  Keeps every weight in (0, 1].
+    __device__ __forceinline__ float exp_normalise() {
+        float m = get(0);
+#pragma unroll
+        for (int i = 1; i < F::S; ++i) m = fmaxf(m, get(i));
+        const float m2 = m * LOG2E;
+#pragma unroll
+        for (int i = 0; i < F::S; ++i) set(i, fast_exp2(fmaf(get(i), LOG2E, -m2)));
+        return m;
+    }
+};
+
+// One linear-space forward step of the 2*NB-state flip-flop lattice:
+//   out[to]     = sum_from in[from] * w[to*NS + from]         (to < NB)
+//   out[NB + b] = in[b] * w[FLOP0 + b] + in[NB + b] * w[FLOP0 + NB + b]
+template <int NB>
+__device__ __forceinline__ void ff_fwd_step(const float (&in)[2 * NB], const RowSet<NB> &w,
+                                            float (&out)[2 * NB]) {
+    using F = FF<NB>;
+#pragma unroll
+    for (int to = 0; to < NB; ++to) {
+        float acc = in[0] * w.get(to * F::NS);
+#pragma unroll
+        for (int from = 1; from < F::NS; ++from) acc = fmaf(in[from], w.get(to * F::NS + from), acc);
+        out[to] = acc;
+    }
+#pragma unroll
+    for (int b = 0; b < NB; ++b) {
+        out[NB + b] = fmaf(in[b], w.get(F::FLOP0 + b), in[NB + b] * w.get(F::FLOP0 + NB + b));
+    }
+}
+
+// One linear-space backward step:
+//   out[from] = sum_{to<NB} w[to*NS + from] * in[to] + w[FLOP0 + from] * in[flop(from)]
+// with flop(from) = NB + (from mod NB).
+template <int NB>
+__device__ __forceinline__ void ff_bwd_step(const float (&in)[2 * NB], const RowSet<NB> &w,
+                                            float (&out)[2 * NB]) {
+    using F = FF<NB>;
+#pragma unroll
+    for (int from = 0; from < F::NS; ++from) {
+        const int fl = NB + (from % NB);
+        float acc = w.get(F::FLOP0 + from) * in[fl];
+#pragma unroll
+        for (int to = 0; to < NB; ++to) acc = fmaf(w.get(to * F::NS + from), in[to], acc);
+        out[from] = acc;
+    }
+}
+
+// Exact power-of-two renormalisation of a short vector: x *= 2^-e with
+// e = exponent(max x); returns e (0 if the vector is all zero).
+template <int K>
+__device__ __forceinline__ int pow2_normalise(float (&x)[K]) {
+    float m = x[0];
+#pragma unroll
+    for (int i = 1; i < K; ++i) m = fmaxf(m, x[i]);
+    const int e = (m > 0.f) ? __builtin_amdgcn_frexp_expf(m) : 0;
+#pragma unroll
+    for (int i = 0; i < K; ++i) x[i] = __builtin_amdgcn_ldexpf(x[i], -e);
+    return e;
+}
+
+}  // namespace tk

@@ -1,0 +1,125 @@
+"""Drop-in for ``taiyaki.ctc`` (taiyaki/ctc/ctc.pyx): the flip-flop CRF losses.
+
+Same names, positional signatures, argument meaning and error behaviour as the
+reference's ``torch.autograd.Function``s, but ``forward`` launches the gfx950 HIP
+kernels through the C ABI on ``torch.cuda.current_stream()``: no device->host copy
+of the score tensor, no Python index building, no host->device copy of the
+gradient (ctc.pyx:119, 127-132, 139-141 in the reference).
+"""
+import numpy as np
+import torch
+
+from taiyaki_amd import _lib, flipflopfings
+
+
+def _indices(seqs, seqlen, nbase, device, mod_cats=None, can_mods_offsets=None,
+             mod_cat_weights=None):
+    """Device-side move/stay(/mod) ids in the padded per-position layout."""
+    L = _lib.lib()
+    seqs_d = seqs.to(device=device, dtype=torch.int32, non_blocking=True).contiguous()
+    seqlen_d = seqlen.to(device=device, dtype=torch.int32, non_blocking=True).contiguous()
+    nbatch = seqlen_d.numel()
+    total = seqs_d.numel()
+    seqoff = torch.empty(nbatch + 1, dtype=torch.int64, device=device)
+    stay = torch.empty(max(total, 1), dtype=torch.int32, device=device)
+    move = torch.empty(max(total, 1), dtype=torch.int32, device=device)
+    mod = fact = mc = cmo = mcw = None
+    if mod_cats is not None:
+        mc = mod_cats.to(device=device, dtype=torch.int32, non_blocking=True).contiguous()
+        cmo = torch.as_tensor(np.asarray(can_mods_offsets), dtype=torch.int32).to(device)
+        mcw = torch.as_tensor(np.asarray(mod_cat_weights), dtype=torch.float32).to(device)
+        mod = torch.empty(max(total, 1), dtype=torch.int32, device=device)
+        fact = torch.empty(max(total, 1), dtype=torch.float32, device=device)
+    rc = L.tk_flipflop_build_indices_dev(
+        _lib.ptr(seqs_d), _lib.ptr(seqlen_d), nbatch, total, nbase, _lib.ptr(mc),
+        _lib.ptr(cmo), _lib.ptr(mcw), _lib.ptr(seqoff), _lib.ptr(stay), _lib.ptr(move),
+        _lib.ptr(mod), _lib.ptr(fact), _lib.stream_ptr())
+    _lib.check(rc, "tk_flipflop_build_indices_dev")
+    # keep the staging tensors alive until the caller has enqueued its kernel
+    return seqlen_d, seqoff, stay, move, mod, fact, (seqs_d, mc, cmo, mcw)
+
+
+def _max_seqlen(seqlen):
+    """Exact bound without a device sync when seqlen lives on the host
+    (bin/train_flipflop.py:133-138); 0 (= unknown) otherwise."""
+    if seqlen.is_cuda:
+        return 0
+    return int(seqlen.max()) if seqlen.numel() else 0
+
+
+def _run(logprob, seqs, seqlen, sharp_can, sharp_mod, out_scale, ncan, want_grad,
+         mod_cats=None, can_mods_offsets=None, mod_cat_weights=None):
+    _lib.require_gpu(logprob, "flip-flop CRF loss")
+    L = _lib.lib()
+    lp = logprob.detach().float().contiguous()
+    nblk, nbatch, ntrans = lp.shape
+    nbase = flipflopfings.nbase_flipflop(ncan)
+    dev = lp.device
+    with torch.cuda.device(dev):
+        seqlen_d, seqoff, stay, move, mod, fact, keep = _indices(
+            seqs, seqlen, nbase, dev, mod_cats, can_mods_offsets, mod_cat_weights)
+        maxlen = _max_seqlen(seqlen)
+        cost = torch.empty(nbatch, dtype=torch.float32, device=dev)
+        grad = torch.empty_like(lp) if want_grad else None
+        wsb = L.tk_crf_flipflop_workspace_bytes(ntrans, nblk, nbatch, maxlen, int(want_grad))
+        ws = torch.empty(wsb, dtype=torch.uint8, device=dev)
+        status = _lib.status_word(dev)
+        rc = L.tk_crf_flipflop_dev(
+            _lib.ptr(lp), ntrans, nblk, nbatch, _lib.ptr(stay), _lib.ptr(move), _lib.ptr(mod),
+            _lib.ptr(fact), _lib.ptr(seqlen_d), _lib.ptr(seqoff), maxlen, ncan,
+            float(sharp_can), float(sharp_mod), float(out_scale), _lib.ptr(cost),
+            _lib.ptr(grad), _lib.ptr(ws), wsb, _lib.ptr(status), _lib.stream_ptr())
+        _lib.check(rc, "tk_crf_flipflop_dev")
+        _lib.finish(status)
+    del keep
+    return cost, grad
+
+
+class FlipFlopCRF(torch.autograd.Function):
+    """taiyaki/ctc/ctc.pyx:116-151"""
+
+    @staticmethod
+    def forward(ctx, logprob, seqs, seqlen, sharpfact: float):
+        ntrans = logprob.shape[2]
+        # lp = sharp * logprob; returned cost/sharp; the saved gradient is
+        # d(cost/sharp)/d logprob exactly (the two factors cancel, ctc.pyx:119,145)
+        cost, grad = _run(logprob, seqs, seqlen, sharpfact, sharpfact, 1.0 / sharpfact,
+                          ntrans, ctx.needs_input_grad[0])
+        if grad is not None:
+            ctx.save_for_backward(grad)
+        return cost
+
+    @staticmethod
+    def backward(ctx, output_grads):
+        grads, = ctx.saved_tensors
+        return grads * output_grads.unsqueeze(1), None, None, None
+
+
+crf_flipflop_loss = FlipFlopCRF.apply
+
+
+class CatModFlipFlop(torch.autograd.Function):
+    """taiyaki/ctc/ctc.pyx:258-310, including its quirk: only the canonical
+    columns are sharpened (265-267) and backward returns the saved gradient
+    d cost / d lp unscaled (306-310)."""
+
+    @staticmethod
+    def forward(ctx, logprob, seqs, seqlen, mod_cats, can_mods_offsets,
+                mod_cat_weights, sharpfact: float):
+        ntrans = logprob.shape[2]
+        n_can_trans = ntrans - int(np.asarray(can_mods_offsets)[-1])
+        cost, grad = _run(logprob, seqs, seqlen, sharpfact, 1.0, 1.0 / sharpfact,
+                          n_can_trans, ctx.needs_input_grad[0], mod_cats,
+                          can_mods_offsets, mod_cat_weights)
+        if grad is not None:
+            ctx.save_for_backward(grad)
+        return cost
+
+    @staticmethod
+    def backward(ctx, output_grads):
+        grads, = ctx.saved_tensors
+        return (grads * output_grads.unsqueeze(1),
+                None, None, None, None, None, None)
+
+
+cat_mod_flipflop_loss = CatModFlipFlop.apply

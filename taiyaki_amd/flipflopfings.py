@@ -1,0 +1,60 @@
+"""Index algebra of the flip-flop code (host side, numpy) -- same names and
+semantics as taiyaki/flipflopfings.py:6-184.  The training path does NOT use
+these (ids are built on the device, csrc/crf_kernels.hip); they exist so that
+callers and tests written against the reference module keep working."""
+import numpy as np
+
+DEFAULT_ALPHABET = 'ACGT'
+
+
+def move_indices(labels, nbase=len(DEFAULT_ALPHABET)):
+    """flipflopfings.py:6-17: labels[:-1] + min(labels[1:], nbase) * 2 nbase"""
+    labels = np.asarray(labels)
+    return labels[:-1] + np.minimum(labels[1:], nbase) * (nbase + nbase)
+
+
+def stay_indices(labels, nbase=len(DEFAULT_ALPHABET)):
+    """flipflopfings.py:20-31"""
+    labels = np.asarray(labels)
+    return labels + np.minimum(labels, nbase) * (nbase + nbase)
+
+
+def flopmask(labels):
+    """flipflopfings.py:34-53: True where a label sits at an even (2nd, 4th, ...)
+    position within a run of identical labels."""
+    labels = np.asarray(labels)
+    mask = np.zeros(len(labels), dtype=bool)
+    run = 0
+    for p in range(len(labels)):
+        run = run + 1 if (p > 0 and labels[p] == labels[p - 1]) else 0
+        mask[p] = bool(run & 1)
+    return mask
+
+
+def flipflop_code(labels, alphabet_length=4):
+    """flipflopfings.py:56-78"""
+    x = np.array(labels, copy=True)
+    x[flopmask(x)] += alphabet_length
+    return x
+
+
+def path_to_str(path, alphabet=DEFAULT_ALPHABET, include_first_source=True):
+    """flipflopfings.py:81-97: collapse a flip-flop state path into a basecall."""
+    path = np.asarray(path)
+    move = np.ediff1d(path, to_begin=1 if include_first_source else 0) != 0
+    letters = np.frombuffer((alphabet * 2).encode(), dtype='u1')
+    return letters[path[move]].tobytes().decode()
+
+
+def nstate_flipflop(nbase):
+    """flipflopfings.py:146-168: 2 nbase (nbase + 1) transitions"""
+    return 2 * nbase * (nbase + 1)
+
+
+def nbase_flipflop(nstate):
+    """flipflopfings.py:171-184 (asserts that nstate is a valid flip-flop size)"""
+    nbase_f = np.sqrt(0.25 + (0.5 * np.float32(nstate))) - 0.5
+    assert np.mod(nbase_f, 1) == 0, (
+        'Number of states not valid for flip-flop model. '
+        'nstates: {}\tconverted nbases: {}').format(nstate, nbase_f)
+    return int(np.round(nbase_f))

@@ -1,0 +1,48 @@
+"""The train step around the flip-flop loss: counterpart of `calculate_loss`
+(bin/train_flipflop.py:145-198) and the optimiser step of `train_model`
+(532-627), without per-step host synchronisation."""
+import torch
+
+from taiyaki_amd import ctc, layers
+
+
+def calculate_loss(net, indata, seqs, seqlens, sharpen=1.0, mod_cats=None,
+                   can_mods_offsets=None, mod_cat_weights=None):
+    """lossvector = (A) crf / cat-mod loss + (B) logZ(outputs[:, :, :ntrans]) / nblk;
+    loss = mean (bin/train_flipflop.py:161-182)."""
+    outputs = net(indata)
+    nblk = float(outputs.shape[0])
+    ntrans = outputs.shape[2]
+    if mod_cats is not None:
+        lossvector = ctc.cat_mod_flipflop_loss(outputs, seqs, seqlens, mod_cats,
+                                               can_mods_offsets, mod_cat_weights, sharpen)
+        ntrans -= int(can_mods_offsets[-1])
+    else:
+        lossvector = ctc.crf_flipflop_loss(outputs, seqs, seqlens, sharpen)
+    lossvector = lossvector + layers.flipflop_logpartition(outputs[:, :, :ntrans]) / nblk
+    return lossvector.mean(), lossvector
+
+
+class Trainer:
+    """One optimiser step = forward, loss, backward, flat all-reduce, clip, AdamW.
+    Defaults follow bin/_bin_argparse.py:16-193 (AdamW lr 4e-3, wd 0.01, eps 1e-6)."""
+
+    def __init__(self, net, arena, lr=4e-3, weight_decay=0.01, eps=1e-6, grad_clip=None):
+        self.net = net
+        self.arena = arena
+        self.opt = torch.optim.AdamW(arena.params, lr=lr, weight_decay=weight_decay, eps=eps,
+                                     betas=(0.9, 0.999))
+        self.grad_clip = grad_clip
+
+    def step(self, batch):
+        self.arena.zero()
+        loss, _ = calculate_loss(self.net, **batch)
+        loss.backward()
+        self.arena.allreduce_async()
+        self.arena.finish()
+        if self.grad_clip is not None:
+            # device-side clip (the reference's apply_clipping syncs once per
+            # parameter tensor, bin/train_flipflop.py:201-212)
+            self.arena.flat.clamp_(min=-self.grad_clip, max=self.grad_clip)
+        self.opt.step()
+        return loss

@@ -86,16 +86,13 @@ __global__ __launch_bounds__(WAVE) void crf_kernel(CrfArgs a) {
 
     // ---- tile movers: rows t0 .. t0+nrows-1 of this read <-> LDS ------------
     auto tile_fetch = [&](int t0, float (&pre)[MAXK]) {
+        // unconditional loads (index clamped): no exec-mask branches, no vmcnt(0) stalls
         const int total = min(CK, T - t0) * S;
 #pragma unroll
         for (int k = 0; k < MAXK; ++k) {
-            const int e = lane + WAVE * k;
-            if (e < total) {
-                const int row = e / S, col = e - row * S;
-                pre[k] = lpn[(size_t)(t0 + row) * rowstride + col];
-            } else {
-                pre[k] = 0.f;
-            }
+            const int e = min(lane + WAVE * k, total - 1);
+            const int row = e / S, col = e - row * S;
+            pre[k] = lpn[(size_t)(t0 + row) * rowstride + col];
         }
     };
     auto tile_commit = [&](int t0, const float (&pre)[MAXK]) {
@@ -453,6 +450,7 @@ static int crf_launch_mod(int R, const CrfArgs &a, hipStream_t stream) {
         case 8: return crf_launch_one<8, MOD>(a, stream);
         case 16: return crf_launch_one<16, MOD>(a, stream);
         case 32: return crf_launch_one<32, MOD>(a, stream);
+        case 64: return crf_launch_one<64, MOD>(a, stream);
         default: return 2;
     }
 }
@@ -466,7 +464,7 @@ int crf_dispatch(const float *logprob, size_t ntrans, size_t nblk, size_t nbatch
     if (ntrans > 62 || ncan > ntrans || ncan == 0) return 2;
     if (max_seqlen == 0) max_seqlen = nblk + 1;
     const int R = crf_pick_R(max_seqlen);
-    if (R > 32) return 2;
+    if (R > 64) return 2;
     const size_t need = crf_workspace_bytes(ntrans, nblk, nbatch, max_seqlen, grad != nullptr);
     if (need > workspace_bytes) return 3;
     CrfArgs a;

@@ -75,14 +75,14 @@ struct RowSet {
     f4 v[F::PIECES];
 
     // issue the coalesced global loads (nvalid = number of valid float4 pieces,
-    // 64*PIECES for a full column of reads; the tail is zero-filled)
+    // 64*PIECES for a full column of reads).  Loads are UNCONDITIONAL: the piece
+    // index is clamped, so lanes past the end re-read the last valid piece
+    // (finite filler for reads that do not exist) and hipcc emits one straight
+    // run of global_load_dwordx4 with no exec-mask branches or vmcnt(0) waits.
     __device__ __forceinline__ void issue(const float *__restrict__ base, int nvalid, int lane) {
         const f4 *src = reinterpret_cast<const f4 *>(base);
 #pragma unroll
-        for (int q = 0; q < F::PIECES; ++q) {
-            const int idx = q * WAVE + lane;
-            v[q] = (idx < nvalid) ? src[idx] : f4{0.f, 0.f, 0.f, 0.f};
-        }
+        for (int q = 0; q < F::PIECES; ++q) v[q] = src[min(q * WAVE + lane, nvalid - 1)];
     }
 
     // pieces -> own row (in place).  buf: wave-private LDS, 64*PIECES f4.

@@ -10,23 +10,250 @@
 //     coalesced 16-byte-per-lane stream; a wave-private LDS buffer transposes
 //     pieces -> rows.  No cross-lane arithmetic anywhere.
 //   * the time axis is parallelised exactly with (sum,*)-semiring transfer
-//     matrices: K1 computes the 2nb x 2nb transfer matrix of every 32-row chunk
-//     (one wave per chunk, matrix in registers), K2 scans the chunk matrices
-//     (forward and backward boundary vectors + logZ), K3 re-reads each chunk
-//     ONCE, rows held in registers, runs the in-chunk forward/backward and
-//     writes the normalised posterior.  HBM traffic = 2 reads + 1 write of the
-//     score tensor = the algorithmic minimum 3*T*N*S*4 bytes (+ ~6% workspace).
+//     matrices:
+//       K1  transfer  : one wave per 32-row chunk, 2nb x 2nb matrix in registers
+//       K1b combine   : per super-chunk (8 chunks) prefix / suffix / total products
+//       K2  scan      : serial scan over the super totals only (16 steps at
+//                       T = 4000), register-ring prefetch -> boundary vectors, logZ
+//       K3  posterior : one 512-thread block per chunk, rows held in registers,
+//                       in-chunk forward/backward chained through LDS, normalised
+//                       posterior streamed out.
+//     HBM traffic = 2 reads + 1 write of the score tensor = the algorithmic
+//     minimum 3*T*N*S*4 bytes (+ ~10% workspace, L2/MALL resident).
 //   * arithmetic is linear-space fp32 with exact power-of-two renormalisation
 //     (integer exponents are accumulated exactly; row maxima in fp64), so no
-//     transcendental sits on the serial dependency chain.
+//     transcendental sits on a serial dependency chain.
 #include "ff_common.h"
 
 namespace tk {
 
 constexpr int LOGZ_CH = 32;             // rows per chunk
+constexpr int LOGZ_SUPER = 8;           // chunks per super-chunk
 constexpr int K1_WAVES = 4;             // independent chunks per K1 block
 constexpr int K3_WAVES = 8;             // waves per K3 block: 8 x 4 rows = 1 chunk
 constexpr int K3_ROWS = LOGZ_CH / K3_WAVES;
+constexpr int ZERO_ROW_EXP = -(1 << 28);    // exponent of an all-zero matrix row
+
+// ---------------------------------------------------------------------------
+// XMat: a 2nb x 2nb transfer matrix  value[i][j] = m[i][j] * 2^e[i] * exp(M)
+// stored per read as NF4 float4 (lane = read => [mat][q][Npad] float4 layout,
+// every access is a coalesced 1 KiB wave transaction).
+// ---------------------------------------------------------------------------
+template <int NB>
+struct XMat {
+    static constexpr int NS = 2 * NB;
+    static constexpr int NW = NS * NS + NS + 2;         // payload dwords
+    static constexpr int NF4 = (NW + 3) / 4;
+    float m[NS][NS];
+    int e[NS];
+    double M;
+
+    __device__ __forceinline__ void set_identity() {
+#pragma unroll
+        for (int i = 0; i < NS; ++i) {
+            e[i] = 0;
+#pragma unroll
+            for (int j = 0; j < NS; ++j) m[i][j] = (i == j) ? 1.f : 0.f;
+        }
+        M = 0.0;
+    }
+    __device__ __forceinline__ float word(int k) const {
+        if (k < NS * NS) return m[k / NS][k % NS];
+        if (k < NS * NS + NS) return __int_as_float(e[k - NS * NS]);
+        if (k == NS * NS + NS) return __int_as_float(__double2loint(M));
+        if (k == NS * NS + NS + 1) return __int_as_float(__double2hiint(M));
+        return 0.f;
+    }
+    __device__ __forceinline__ void store(f4 *base, size_t Npad) const {
+#pragma unroll
+        for (int q = 0; q < NF4; ++q)
+            base[(size_t)q * Npad] = f4{word(4 * q), word(4 * q + 1), word(4 * q + 2), word(4 * q + 3)};
+    }
+    __device__ __forceinline__ void load(const f4 *base, size_t Npad) {
+        f4 raw[NF4];
+#pragma unroll
+        for (int q = 0; q < NF4; ++q) raw[q] = base[(size_t)q * Npad];
+        unpack(raw);
+    }
+    __device__ __forceinline__ void unpack(const f4 (&raw)[NF4]) {
+#pragma unroll
+        for (int k = 0; k < NS * NS; ++k) m[k / NS][k % NS] = raw[k >> 2][k & 3];
+#pragma unroll
+        for (int k = 0; k < NS; ++k) e[k] = __float_as_int(raw[(NS * NS + k) >> 2][(NS * NS + k) & 3]);
+        const int lo = __float_as_int(raw[(NS * NS + NS) >> 2][(NS * NS + NS) & 3]);
+        const int hi = __float_as_int(raw[(NS * NS + NS + 1) >> 2][(NS * NS + NS + 1) & 3]);
+        M = __hiloint2double(hi, lo);
+    }
+    // exact power-of-two renormalisation of every row
+    __device__ __forceinline__ void renorm() {
+#pragma unroll
+        for (int i = 0; i < NS; ++i) {
+            float mx = m[i][0];
+#pragma unroll
+            for (int j = 1; j < NS; ++j) mx = fmaxf(mx, m[i][j]);
+            if (mx > 0.f) {
+                const int ex = __builtin_amdgcn_frexp_expf(mx);
+#pragma unroll
+                for (int j = 0; j < NS; ++j) m[i][j] = __builtin_amdgcn_ldexpf(m[i][j], -ex);
+                e[i] += ex;
+            } else {
+                e[i] = ZERO_ROW_EXP;
+            }
+        }
+    }
+};
+
+// C = A (x) B
+template <int NB>
+__device__ __forceinline__ void xmat_mul(const XMat<NB> &A, const XMat<NB> &B, XMat<NB> &C) {
+    constexpr int NS = 2 * NB;
+    int ebmax = ZERO_ROW_EXP;
+#pragma unroll
+    for (int k = 0; k < NS; ++k) ebmax = max(ebmax, B.e[k]);
+    float bs[NS][NS];
+#pragma unroll
+    for (int k = 0; k < NS; ++k) {
+        const int sh = max(B.e[k] - ebmax, -300);
+#pragma unroll
+        for (int j = 0; j < NS; ++j) bs[k][j] = __builtin_amdgcn_ldexpf(B.m[k][j], sh);
+    }
+#pragma unroll
+    for (int i = 0; i < NS; ++i) {
+#pragma unroll
+        for (int j = 0; j < NS; ++j) {
+            float acc = A.m[i][0] * bs[0][j];
+#pragma unroll
+            for (int k = 1; k < NS; ++k) acc = fmaf(A.m[i][k], bs[k][j], acc);
+            C.m[i][j] = acc;
+        }
+        C.e[i] = (A.e[i] == ZERO_ROW_EXP || ebmax == ZERO_ROW_EXP) ? ZERO_ROW_EXP : A.e[i] + ebmax;
+    }
+    C.M = A.M + B.M;
+    C.renorm();
+}
+
+// out = normalise(v (x) A); returns the binary exponent taken out (v is a row
+// vector of weights with max ~1)
+template <int NB>
+__device__ __forceinline__ int xvec_mat(const float (&v)[2 * NB], const XMat<NB> &A,
+                                        float (&out)[2 * NB]) {
+    constexpr int NS = 2 * NB;
+    int emax = ZERO_ROW_EXP;
+#pragma unroll
+    for (int i = 0; i < NS; ++i)
+        if (v[i] > 0.f && A.e[i] != ZERO_ROW_EXP)
+            emax = max(emax, A.e[i] + __builtin_amdgcn_frexp_expf(v[i]));
+    if (emax == ZERO_ROW_EXP) emax = 0;
+    float vs[NS];
+#pragma unroll
+    for (int i = 0; i < NS; ++i) vs[i] = __builtin_amdgcn_ldexpf(v[i], max(A.e[i] - emax, -300));
+#pragma unroll
+    for (int j = 0; j < NS; ++j) {
+        float acc = vs[0] * A.m[0][j];
+#pragma unroll
+        for (int i = 1; i < NS; ++i) acc = fmaf(vs[i], A.m[i][j], acc);
+        out[j] = acc;
+    }
+    return emax + pow2_normalise(out);
+}
+
+// out = normalise(A (x) u)  (scale is irrelevant for backward vectors)
+template <int NB>
+__device__ __forceinline__ void xmat_vec(const XMat<NB> &A, const float (&u)[2 * NB],
+                                         float (&out)[2 * NB]) {
+    constexpr int NS = 2 * NB;
+    float y[NS];
+    int emax = ZERO_ROW_EXP;
+#pragma unroll
+    for (int i = 0; i < NS; ++i) {
+        float acc = A.m[i][0] * u[0];
+#pragma unroll
+        for (int j = 1; j < NS; ++j) acc = fmaf(A.m[i][j], u[j], acc);
+        y[i] = acc;
+        if (acc > 0.f && A.e[i] != ZERO_ROW_EXP)
+            emax = max(emax, A.e[i] + __builtin_amdgcn_frexp_expf(acc));
+    }
+    if (emax == ZERO_ROW_EXP) emax = 0;
+#pragma unroll
+    for (int i = 0; i < NS; ++i) out[i] = __builtin_amdgcn_ldexpf(y[i], max(A.e[i] - emax, -300));
+}
+
+// Streaming forms of the two products for K3's prologue: the matrix is consumed
+// float4 by float4 straight from global memory (no 2nb x 2nb register copy).
+template <int NB>
+__device__ __forceinline__ void xvec_mat_stream(float (&v)[2 * NB], const f4 *base, size_t Npad) {
+    constexpr int NS = 2 * NB, NN = NS * NS;
+    using X = XMat<NB>;
+    int e[NS];
+#pragma unroll
+    for (int q = NN / 4; q < X::NF4; ++q) {
+        const f4 f = base[(size_t)q * Npad];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int k = 4 * q + r - NN;
+            if (k >= 0 && k < NS) e[k] = __float_as_int(f[r]);
+        }
+    }
+    int emax = ZERO_ROW_EXP;
+#pragma unroll
+    for (int i = 0; i < NS; ++i)
+        if (v[i] > 0.f && e[i] != ZERO_ROW_EXP) emax = max(emax, e[i] + __builtin_amdgcn_frexp_expf(v[i]));
+    if (emax == ZERO_ROW_EXP) emax = 0;
+    float vs[NS], out[NS];
+#pragma unroll
+    for (int i = 0; i < NS; ++i) {
+        vs[i] = __builtin_amdgcn_ldexpf(v[i], max(e[i] - emax, -300));
+        out[i] = 0.f;
+    }
+#pragma unroll
+    for (int q = 0; q < (NN + 3) / 4; ++q) {
+        const f4 f = base[(size_t)q * Npad];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int k = 4 * q + r;
+            if (k < NN) out[k % NS] = fmaf(vs[k / NS], f[r], out[k % NS]);
+        }
+    }
+    (void)pow2_normalise(out);
+#pragma unroll
+    for (int i = 0; i < NS; ++i) v[i] = out[i];
+}
+
+template <int NB>
+__device__ __forceinline__ void xmat_vec_stream(float (&u)[2 * NB], const f4 *base, size_t Npad) {
+    constexpr int NS = 2 * NB, NN = NS * NS;
+    using X = XMat<NB>;
+    float y[NS];
+    int e[NS];
+#pragma unroll
+    for (int i = 0; i < NS; ++i) y[i] = 0.f;
+#pragma unroll
+    for (int q = 0; q < X::NF4; ++q) {
+        const f4 f = base[(size_t)q * Npad];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int k = 4 * q + r;
+            if (k < NN) y[k / NS] = fmaf(f[r], u[k % NS], y[k / NS]);
+            else if (k < NN + NS) e[k - NN] = __float_as_int(f[r]);
+        }
+    }
+    int emax = ZERO_ROW_EXP;
+#pragma unroll
+    for (int i = 0; i < NS; ++i)
+        if (y[i] > 0.f && e[i] != ZERO_ROW_EXP) emax = max(emax, e[i] + __builtin_amdgcn_frexp_expf(y[i]));
+    if (emax == ZERO_ROW_EXP) emax = 0;
+#pragma unroll
+    for (int i = 0; i < NS; ++i) u[i] = __builtin_amdgcn_ldexpf(y[i], max(e[i] - emax, -300));
+}
+
+struct LogzWs {
+    f4 *Pc;         // [C]    chunk transfer matrices            (XMat layout)
+    f4 *Fp;         // [C]    prefix products inside the super-chunk (identity for its first chunk: unused)
+    f4 *Bs;         // [C]    suffix products inside the super-chunk (identity for its last chunk: unused)
+    f4 *Tot;        // [NSUP] super-chunk totals
+    float *Vs;      // [NSUP][NS][Npad] forward vector entering super-chunk s
+    float *Us;      // [NSUP][NS][Npad] backward vector leaving super-chunk s
+};
 
 // per-wave LDS buffer of K3 in f4 units: the row-set transpose buffer, which
 // doubles as storage for the wave's K3_ROWS forward vectors
@@ -36,14 +263,6 @@ __host__ __device__ constexpr int k3_buf_f4() {
     constexpr int b = K3_ROWS * FF<NB>::NS * WAVE / 4;
     return a > b ? a : b;
 }
-
-struct LogzWs {
-    float *P;        // [C][NS*NS][Npad]  chunk transfer matrices (row-scaled mantissas)
-    int32_t *E;      // [C][NS][Npad]     per-row binary exponents
-    double *M;       // [C][Npad]         sum of row maxima of the chunk
-    float *Vin;      // [C][NS][Npad]     forward vector entering chunk c
-    float *Uout;     // [C][NS][Npad]     backward vector leaving chunk c
-};
 
 // ---------------------------------------------------------------------------
 // K1: chunk transfer matrices.  grid = (ncols, ceil(C / K1_WAVES)), block = 256.
@@ -63,137 +282,143 @@ __global__ __launch_bounds__(K1_WAVES *WAVE) void logz_transfer_kernel(
     const size_t rowstride = (size_t)N * F::S;
     const float *base = scores + (size_t)n0 * F::S;
 
-    float P[F::NS][F::NS];
-    int e[F::NS];
-    double msum = 0.0;
-#pragma unroll
-    for (int i = 0; i < F::NS; ++i) {
-        e[i] = 0;
-#pragma unroll
-        for (int j = 0; j < F::NS; ++j) P[i][j] = (i == j) ? 1.f : 0.f;
-    }
+    XMat<NB> P;
+    P.set_identity();
 
-    RowSet<NB> cur, nxt;
-    cur.issue(base + (size_t)t0 * rowstride, nvalid, lane);
-    for (int t = t0; t < t1; ++t) {
-        if (t + 1 < t1) nxt.issue(base + (size_t)(t + 1) * rowstride, nvalid, lane);
+    // two row-sets in flight ahead of the one being consumed; row indices are
+    // clamped (never branched on) so the load stream has no control flow
+    RowSet<NB> r0, r1, r2;
+    auto rowptr = [&](int t) { return base + (size_t)min(t, t1 - 1) * rowstride; };
+    auto consume = [&](RowSet<NB> &cur, int t) {
         cur.to_rows(buf, lane);
-        msum += (double)cur.exp_normalise();
+        P.M += (double)cur.exp_normalise();
 #pragma unroll
         for (int i = 0; i < F::NS; ++i) {
             float out[F::NS];
-            ff_fwd_step<NB>(P[i], cur, out);
+            ff_fwd_step<NB>(P.m[i], cur, out);
 #pragma unroll
-            for (int j = 0; j < F::NS; ++j) P[i][j] = out[j];
+            for (int j = 0; j < F::NS; ++j) P.m[i][j] = out[j];
         }
-        if (((t - t0) & 3) == 3) {
-#pragma unroll
-            for (int i = 0; i < F::NS; ++i) e[i] += pow2_normalise(P[i]);
-        }
-        cur = nxt;
+        if (((t - t0) & 3) == 3) P.renorm();
+    };
+    r0.issue(rowptr(t0), nvalid, lane);
+    r1.issue(rowptr(t0 + 1), nvalid, lane);
+    for (int t = t0; t < t1; t += 3) {
+        r2.issue(rowptr(t + 2), nvalid, lane);
+        consume(r0, t);
+        if (t + 1 >= t1) break;
+        r0.issue(rowptr(t + 3), nvalid, lane);
+        consume(r1, t + 1);
+        if (t + 2 >= t1) break;
+        r1.issue(rowptr(t + 4), nvalid, lane);
+        consume(r2, t + 2);
     }
-#pragma unroll
-    for (int i = 0; i < F::NS; ++i) e[i] += pow2_normalise(P[i]);
-
+    P.renorm();
     const size_t n = (size_t)n0 + lane;     // < Npad always
-    float *Pout = ws.P + (size_t)c * (F::NS * F::NS) * Npad + n;
-#pragma unroll
-    for (int i = 0; i < F::NS; ++i)
-#pragma unroll
-        for (int j = 0; j < F::NS; ++j) Pout[(size_t)(i * F::NS + j) * Npad] = P[i][j];
-    int32_t *Eout = ws.E + (size_t)c * F::NS * Npad + n;
-#pragma unroll
-    for (int i = 0; i < F::NS; ++i) Eout[(size_t)i * Npad] = e[i];
-    ws.M[(size_t)c * Npad + n] = msum;
+    P.store(ws.Pc + (size_t)c * XMat<NB>::NF4 * Npad + n, Npad);
 }
 
 // ---------------------------------------------------------------------------
-// K2: scan over chunk matrices.  grid = ncols, block = 128: wave 0 runs the
-// forward scan (Vin[c], logZ), wave 1 the backward scan (Uout[c]).
+// K1b: per super-chunk prefix / suffix / total products.
+// grid = (ncols, NSUP), block = 128: wave 0 prefix chain (+ total), wave 1 suffix.
 // ---------------------------------------------------------------------------
 template <int NB>
-__global__ __launch_bounds__(2 * WAVE) void logz_scan_kernel(int N, int C, int Npad, LogzWs ws,
-                                                          float *__restrict__ logz,
-                                                          int want_bwd,
-                                                          uint32_t *__restrict__ status) {
-    using F = FF<NB>;
+__global__ __launch_bounds__(2 * WAVE) void logz_combine_kernel(int C, int Npad, LogzWs ws) {
+    using X = XMat<NB>;
     const int wave = threadIdx.x >> 6, lane = lane_id();
     const size_t n = (size_t)blockIdx.x * WAVE + lane;
-    const size_t cstrideP = (size_t)(F::NS * F::NS) * Npad, cstrideV = (size_t)F::NS * Npad;
-
+    const int s = blockIdx.y;
+    const int c0 = s * LOGZ_SUPER, c1 = min(C, c0 + LOGZ_SUPER);      // [c0, c1)
+    const size_t mstride = (size_t)X::NF4 * Npad;
     if (wave == 0) {
-        // paths start in any flip state with weight 1 (layers.py:1289-1295,
-        // cupy flipflop.py:115-118)
-        float v[F::NS];
-#pragma unroll
-        for (int s = 0; s < F::NS; ++s) v[s] = (s < NB) ? 1.f : 0.f;
-        double macc = 0.0;
-        long long eacc = 0;
-        for (int c = 0; c < C; ++c) {
-            float *vin = ws.Vin + (size_t)c * cstrideV + n;
-#pragma unroll
-            for (int s = 0; s < F::NS; ++s) vin[(size_t)s * Npad] = v[s];
-            const float *Pc = ws.P + (size_t)c * cstrideP + n;
-            const int32_t *Ec = ws.E + (size_t)c * cstrideV + n;
-            // bring v[i] * 2^e[i] to a common exponent
-            int te[F::NS], emax = INT32_MIN;
-#pragma unroll
-            for (int i = 0; i < F::NS; ++i) {
-                const int ei = Ec[(size_t)i * Npad];
-                te[i] = ei;
-                if (v[i] > 0.f) emax = max(emax, ei + __builtin_amdgcn_frexp_expf(v[i]));
-            }
-            if (emax == INT32_MIN) emax = 0;
-            float vs[F::NS], out[F::NS];
-#pragma unroll
-            for (int i = 0; i < F::NS; ++i) vs[i] = __builtin_amdgcn_ldexpf(v[i], te[i] - emax);
-#pragma unroll
-            for (int j = 0; j < F::NS; ++j) {
-                float acc = 0.f;
-#pragma unroll
-                for (int i = 0; i < F::NS; ++i) acc = fmaf(vs[i], Pc[(size_t)(i * F::NS + j) * Npad], acc);
-                out[j] = acc;
-            }
-            const int ex = pow2_normalise(out);
-#pragma unroll
-            for (int j = 0; j < F::NS; ++j) v[j] = out[j];
-            eacc += (long long)emax + ex;
-            macc += ws.M[(size_t)c * Npad + n];
+        X acc, nxt, prod;
+        acc.load(ws.Pc + (size_t)c0 * mstride + n, Npad);
+        for (int c = c0 + 1; c < c1; ++c) {
+            nxt.load(ws.Pc + (size_t)c * mstride + n, Npad);
+            acc.store(ws.Fp + (size_t)c * mstride + n, Npad);      // P_c0 ... P_{c-1}
+            xmat_mul<NB>(acc, nxt, prod);
+            acc = prod;
         }
+        acc.store(ws.Tot + (size_t)s * mstride + n, Npad);
+    } else {
+        X acc, nxt, prod;
+        acc.load(ws.Pc + (size_t)(c1 - 1) * mstride + n, Npad);
+        for (int c = c1 - 2; c >= c0; --c) {
+            nxt.load(ws.Pc + (size_t)c * mstride + n, Npad);
+            acc.store(ws.Bs + (size_t)c * mstride + n, Npad);      // P_{c+1} ... P_{c1-1}
+            xmat_mul<NB>(nxt, acc, prod);
+            acc = prod;
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------
+// K2: serial scan over the super totals.  grid = (ncols, 2), block = 64:
+// blockIdx.y == 0 forward (Vs[s], logZ), == 1 backward (Us[s]).
+// A ring of 3 matrices is kept in flight (57 outstanding 16-byte loads).
+// ---------------------------------------------------------------------------
+template <int NB>
+__global__ __launch_bounds__(WAVE) void logz_scan_kernel(int N, int NSUP, int Npad, LogzWs ws,
+                                                        float *__restrict__ logz,
+                                                        uint32_t *__restrict__ status) {
+    using F = FF<NB>;
+    using X = XMat<NB>;
+    constexpr int RING = 3;
+    const int lane = lane_id();
+    const size_t n = (size_t)blockIdx.x * WAVE + lane;
+    const size_t mstride = (size_t)X::NF4 * Npad, vstride = (size_t)F::NS * Npad;
+    const bool fwd = blockIdx.y == 0;
+    f4 raw[RING][X::NF4];
+    auto fetch = [&](int slot_s, f4 (&dst)[X::NF4]) {
+        const int s = fwd ? slot_s : NSUP - 1 - slot_s;
+        const f4 *src = ws.Tot + (size_t)s * mstride + n;
+#pragma unroll
+        for (int q = 0; q < X::NF4; ++q) dst[q] = src[(size_t)q * Npad];
+    };
+#pragma unroll
+    for (int k = 0; k < RING; ++k)
+        if (k < NSUP) fetch(k, raw[k]);
+
+    float v[F::NS];
+    // forward: paths start in any flip state with weight 1 (layers.py:1289-1295,
+    // cupy flipflop.py:115-118); backward: may end in any state (flipflop.py:163-166)
+#pragma unroll
+    for (int k = 0; k < F::NS; ++k) v[k] = fwd ? ((k < NB) ? 1.f : 0.f) : 1.f;
+    double macc = 0.0;
+    long long eacc = 0;
+    for (int i0 = 0; i0 < NSUP; i0 += RING) {
+#pragma unroll
+        for (int k = 0; k < RING; ++k) {
+            const int i = i0 + k;
+            if (i < NSUP) {
+                const int s = fwd ? i : NSUP - 1 - i;
+                float *dst = (fwd ? ws.Vs : ws.Us) + (size_t)s * vstride + n;
+#pragma unroll
+                for (int q = 0; q < F::NS; ++q) dst[(size_t)q * Npad] = v[q];
+                X A;
+                A.unpack(raw[k]);
+                if (i + RING < NSUP) fetch(i + RING, raw[k]);
+                float out[F::NS];
+                if (fwd) {
+                    eacc += xvec_mat<NB>(v, A, out);
+                    macc += A.M;
+                } else {
+                    xmat_vec<NB>(A, v, out);
+                }
+#pragma unroll
+                for (int q = 0; q < F::NS; ++q) v[q] = out[q];
+            }
+        }
+    }
+    if (fwd) {
         float tot = 0.f;
 #pragma unroll
-        for (int s = 0; s < F::NS; ++s) tot += v[s];
+        for (int k = 0; k < F::NS; ++k) tot += v[k];
         const double lz = macc + (double)eacc * 0.6931471805599453 + (double)logf(tot);
         if (n < (size_t)N) {
             const float lzf = (float)lz;
             logz[n] = lzf;
             if (status != nullptr && !isfinite(lzf)) atomicOr(status, 1u);
-        }
-    } else if (want_bwd) {
-        // paths may end in any state (cupy flipflop.py:163-166); scale is free
-        float u[F::NS];
-#pragma unroll
-        for (int s = 0; s < F::NS; ++s) u[s] = 1.f;
-        for (int c = C - 1; c >= 0; --c) {
-            float *uo = ws.Uout + (size_t)c * cstrideV + n;
-#pragma unroll
-            for (int s = 0; s < F::NS; ++s) uo[(size_t)s * Npad] = u[s];
-            const float *Pc = ws.P + (size_t)c * cstrideP + n;
-            const int32_t *Ec = ws.E + (size_t)c * cstrideV + n;
-            float y[F::NS];
-            int te[F::NS], emax = INT32_MIN;
-#pragma unroll
-            for (int i = 0; i < F::NS; ++i) {
-                float acc = 0.f;
-#pragma unroll
-                for (int j = 0; j < F::NS; ++j) acc = fmaf(Pc[(size_t)(i * F::NS + j) * Npad], u[j], acc);
-                y[i] = acc;
-                te[i] = Ec[(size_t)i * Npad];
-                if (acc > 0.f) emax = max(emax, te[i] + __builtin_amdgcn_frexp_expf(acc));
-            }
-            if (emax == INT32_MIN) emax = 0;
-#pragma unroll
-            for (int i = 0; i < F::NS; ++i) u[i] = __builtin_amdgcn_ldexpf(y[i], te[i] - emax);
         }
     }
 }
@@ -206,9 +431,10 @@ __global__ __launch_bounds__(2 * WAVE) void logz_scan_kernel(int N, int C, int N
 // ---------------------------------------------------------------------------
 template <int NB>
 __global__ __launch_bounds__(K3_WAVES *WAVE, 2) void logz_posterior_kernel(
-    const float *__restrict__ scores, float *__restrict__ grad, int T, int N, int Npad,
+    const float *__restrict__ scores, float *__restrict__ grad, int T, int N, int C, int Npad,
     LogzWs ws, uint32_t *__restrict__ status) {
     using F = FF<NB>;
+    using X = XMat<NB>;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int wave = threadIdx.x >> 6, lane = lane_id();
     constexpr int BUF_F4 = k3_buf_f4<NB>();
@@ -224,12 +450,28 @@ __global__ __launch_bounds__(K3_WAVES *WAVE, 2) void logz_posterior_kernel(
     const size_t rowstride = (size_t)N * F::S;
     const int tw = c * LOGZ_CH + wave * K3_ROWS;        // first row of this wave
     const float *base = scores + (size_t)n0 * F::S;
+    const size_t n = (size_t)n0 + lane;
+    const size_t vstride = (size_t)F::NS * Npad, mstride = (size_t)X::NF4 * Npad;
+    const int s = c / LOGZ_SUPER, c0 = s * LOGZ_SUPER, c1 = min(C, c0 + LOGZ_SUPER);
 
     // 1. rows -> registers (weights w = exp(s - rowmax))
     RowSet<NB> w[K3_ROWS];
 #pragma unroll
-    for (int j = 0; j < K3_ROWS; ++j) {
-        if (tw + j < T) w[j].issue(base + (size_t)(tw + j) * rowstride, nvalid, lane);
+    for (int j = 0; j < K3_ROWS; ++j)
+        w[j].issue(base + (size_t)min(tw + j, T - 1) * rowstride, nvalid, lane);
+    // chain heads: expand the super-chunk boundary vector to this chunk while
+    // the rows are in flight (wave 0: forward, last wave: backward)
+    float head[F::NS];
+    if (wave == 0) {
+        const float *vs = ws.Vs + (size_t)s * vstride + n;
+#pragma unroll
+        for (int k = 0; k < F::NS; ++k) head[k] = vs[(size_t)k * Npad];
+        if (c > c0) xvec_mat_stream<NB>(head, ws.Fp + (size_t)c * mstride + n, Npad);
+    } else if (wave == K3_WAVES - 1) {
+        const float *us = ws.Us + (size_t)s * vstride + n;
+#pragma unroll
+        for (int k = 0; k < F::NS; ++k) head[k] = us[(size_t)k * Npad];
+        if (c < c1 - 1) xmat_vec_stream<NB>(head, ws.Bs + (size_t)c * mstride + n, Npad);
     }
 #pragma unroll
     for (int j = 0; j < K3_ROWS; ++j) {
@@ -240,21 +482,13 @@ __global__ __launch_bounds__(K3_WAVES *WAVE, 2) void logz_posterior_kernel(
     }
 
     // 2. chain the boundary vectors through the 8 waves
-    const size_t n = (size_t)n0 + lane;
-    const size_t cstrideV = (size_t)F::NS * Npad;
     float bexit[F::NS];             // backward vector AFTER this wave's last row
 #pragma unroll 1
-    for (int s = 0; s < K3_WAVES; ++s) {
-        if (wave == s) {
+    for (int st = 0; st < K3_WAVES; ++st) {
+        if (wave == st) {
             float f[F::NS];
-            if (s == 0) {
-                const float *vin = ws.Vin + (size_t)c * cstrideV + n;
 #pragma unroll
-                for (int k = 0; k < F::NS; ++k) f[k] = vin[(size_t)k * Npad];
-            } else {
-#pragma unroll
-                for (int k = 0; k < F::NS; ++k) f[k] = chainF[k * WAVE + lane];
-            }
+            for (int k = 0; k < F::NS; ++k) f[k] = (st == 0) ? head[k] : chainF[k * WAVE + lane];
 #pragma unroll
             for (int j = 0; j < K3_ROWS; ++j) {
 #pragma unroll
@@ -270,16 +504,10 @@ __global__ __launch_bounds__(K3_WAVES *WAVE, 2) void logz_posterior_kernel(
 #pragma unroll
             for (int k = 0; k < F::NS; ++k) chainF[k * WAVE + lane] = f[k];
         }
-        if (wave == K3_WAVES - 1 - s) {
+        if (wave == K3_WAVES - 1 - st) {
             float b[F::NS];
-            if (s == 0) {
-                const float *uo = ws.Uout + (size_t)c * cstrideV + n;
 #pragma unroll
-                for (int k = 0; k < F::NS; ++k) b[k] = uo[(size_t)k * Npad];
-            } else {
-#pragma unroll
-                for (int k = 0; k < F::NS; ++k) b[k] = chainB[k * WAVE + lane];
-            }
+            for (int k = 0; k < F::NS; ++k) b[k] = (st == 0) ? head[k] : chainB[k * WAVE + lane];
 #pragma unroll
             for (int k = 0; k < F::NS; ++k) bexit[k] = b[k];
 #pragma unroll
@@ -359,7 +587,9 @@ static inline size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; 
 template <int NB>
 static size_t logz_ws_layout(size_t T, size_t N, void *base, LogzWs *ws) {
     using F = FF<NB>;
+    using X = XMat<NB>;
     const size_t C = (T + LOGZ_CH - 1) / LOGZ_CH, Npad = align_up(N, WAVE);
+    const size_t NSUP = (C + LOGZ_SUPER - 1) / LOGZ_SUPER;
     size_t off = 0;
     char *p = static_cast<char *>(base);
     auto take = [&](size_t bytes) {
@@ -367,12 +597,14 @@ static size_t logz_ws_layout(size_t T, size_t N, void *base, LogzWs *ws) {
         off += align_up(bytes, 256);
         return r;
     };
-    float *P = reinterpret_cast<float *>(take(C * F::NS * F::NS * Npad * sizeof(float)));
-    int32_t *E = reinterpret_cast<int32_t *>(take(C * F::NS * Npad * sizeof(int32_t)));
-    double *M = reinterpret_cast<double *>(take(C * Npad * sizeof(double)));
-    float *Vin = reinterpret_cast<float *>(take(C * F::NS * Npad * sizeof(float)));
-    float *Uout = reinterpret_cast<float *>(take(C * F::NS * Npad * sizeof(float)));
-    if (ws) *ws = LogzWs{P, E, M, Vin, Uout};
+    const size_t mbytes = (size_t)X::NF4 * Npad * sizeof(f4);
+    f4 *Pc = reinterpret_cast<f4 *>(take(C * mbytes));
+    f4 *Fp = reinterpret_cast<f4 *>(take(C * mbytes));
+    f4 *Bs = reinterpret_cast<f4 *>(take(C * mbytes));
+    f4 *Tot = reinterpret_cast<f4 *>(take(NSUP * mbytes));
+    float *Vs = reinterpret_cast<float *>(take(NSUP * F::NS * Npad * sizeof(float)));
+    float *Us = reinterpret_cast<float *>(take(NSUP * F::NS * Npad * sizeof(float)));
+    if (ws) *ws = LogzWs{Pc, Fp, Bs, Tot, Vs, Us};
     return off;
 }
 
@@ -385,6 +617,7 @@ static int logz_launch(const float *scores, size_t T, size_t N, float *logz, flo
     const size_t need = logz_ws_layout<NB>(T, N, workspace, &ws);
     if (need > workspace_bytes) return 3;
     const int C = (int)((T + LOGZ_CH - 1) / LOGZ_CH);
+    const int NSUP = (C + LOGZ_SUPER - 1) / LOGZ_SUPER;
     const int ncols = (int)((N + WAVE - 1) / WAVE), Npad = ncols * WAVE;
     const size_t bufbytes = (size_t)WAVE * F::PIECES * sizeof(f4);
     {
@@ -392,11 +625,10 @@ static int logz_launch(const float *scores, size_t T, size_t N, float *logz, flo
         hipLaunchKernelGGL(logz_transfer_kernel<NB>, grid, block, K1_WAVES * bufbytes, stream,
                            scores, (int)T, (int)N, C, Npad, ws);
     }
-    {
-        dim3 grid(ncols), block(2 * WAVE);
-        hipLaunchKernelGGL(logz_scan_kernel<NB>, grid, block, 0, stream, (int)N, C, Npad, ws,
-                           logz, grad != nullptr ? 1 : 0, status);
-    }
+    hipLaunchKernelGGL(logz_combine_kernel<NB>, dim3(ncols, NSUP), dim3(2 * WAVE), 0, stream, C,
+                       Npad, ws);
+    hipLaunchKernelGGL(logz_scan_kernel<NB>, dim3(ncols, grad != nullptr ? 2 : 1), dim3(WAVE), 0,
+                       stream, (int)N, NSUP, Npad, ws, logz, status);
     if (grad != nullptr) {
         dim3 grid(ncols, C), block(K3_WAVES * WAVE);
         const size_t lds = K3_WAVES * (size_t)k3_buf_f4<NB>() * sizeof(f4) +
@@ -406,7 +638,7 @@ static int logz_launch(const float *scores, size_t T, size_t N, float *logz, flo
                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
             return 4;
         hipLaunchKernelGGL(logz_posterior_kernel<NB>, grid, block, lds, stream, scores, grad,
-                           (int)T, (int)N, Npad, ws, status);
+                           (int)T, (int)N, C, Npad, ws, status);
     }
     return hipGetLastError() == hipSuccess ? 0 : 4;
 }

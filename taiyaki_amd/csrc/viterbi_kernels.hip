@@ -46,7 +46,7 @@ __global__ __launch_bounds__(WAVE) void viterbi_kernel(const float *__restrict__
     RowSet<NB> cur, nxt;
     if (T > 0) cur.issue(base, nvalid, lane);
     for (int t = 0; t < T; ++t) {
-        if (t + 1 < T) nxt.issue(base + (size_t)(t + 1) * rowstride, nvalid, lane);
+        nxt.issue(base + (size_t)min(t + 1, T - 1) * rowstride, nvalid, lane);
         cur.to_rows(buf, lane);
         float g[F::NS];
         uint32_t word = 0;
@@ -107,8 +107,8 @@ __global__ __launch_bounds__(WAVE) void viterbi_kernel(const float *__restrict__
         uint32_t wd[VIT_PF];
 #pragma unroll
         for (int k = 0; k < VIT_PF; ++k) {
-            const int t = thi - 1 - k;
-            wd[k] = (t >= 0) ? packed[(size_t)t * Npad + n] : 0u;
+            const int t = max(thi - 1 - k, 0);      // clamped, never branched: one straight load run
+            wd[k] = packed[(size_t)t * Npad + n];
         }
 #pragma unroll
         for (int k = 0; k < VIT_PF; ++k) {

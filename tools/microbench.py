@@ -1,0 +1,67 @@
+#!/usr/bin/env python
+"""Loss-kernel microbenchmark (run it under rocprofv3 --kernel-trace --stats).
+
+    python tools/microbench.py [--reps 10] [--shapes rowK,cfg2,cfg5] [--ops logz,crf,viterbi]
+Prints one line per (op, shape): HIP-event mean / min duration and the
+algorithmic-bytes GB/s (3*T*N*S*4 for forward-backward+grad ops,
+1*T*N*S*4 for forward-only ops).
+"""
+import argparse
+import os
+import sys
+
+import numpy as np
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from taiyaki_amd import ctc, decode, layers, synth  # noqa: E402
+
+SHAPES = {"rowK": (4000, 256), "cfg2": (800, 128), "cfg5": (1600, 64), "big": (4000, 1024)}
+
+
+def timed(fn, reps):
+    for _ in range(2):
+        fn()
+    torch.cuda.synchronize()
+    evs = []
+    for _ in range(reps):
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        a.record()
+        fn()
+        b.record()
+        evs.append((a, b))
+    torch.cuda.synchronize()
+    ms = [a.elapsed_time(b) for a, b in evs]
+    return float(np.mean(ms)) * 1e-3, float(np.min(ms)) * 1e-3
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--reps", type=int, default=10)
+    ap.add_argument("--shapes", default="rowK,cfg2")
+    ap.add_argument("--ops", default="logz,logz_fwd,crf,crf_fwd,viterbi")
+    args = ap.parse_args()
+    dev = torch.device("cuda:0")
+    for sh in args.shapes.split(","):
+        T, N = SHAPES[sh]
+        inp = synth.crf_case(T, N, 1)
+        x = torch.from_numpy(inp["scores"]).to(dev)
+        seqs, seqlens = torch.from_numpy(inp["seqs"]), torch.from_numpy(inp["seqlens"])
+        nbytes = T * N * 40 * 4
+        ops = {
+            "logz": (lambda: layers._logz_launch(x, True), 3),
+            "logz_fwd": (lambda: layers._logz_launch(x, False), 1),
+            "crf": (lambda: ctc._run(x, seqs, seqlens, 1.0, 1.0, 1.0, 40, True), 3),
+            "crf_fwd": (lambda: ctc._run(x, seqs, seqlens, 1.0, 1.0, 1.0, 40, False), 1),
+            "viterbi": (lambda: decode.flipflop_viterbi(x), 1),
+        }
+        for name in args.ops.split(","):
+            fn, mult = ops[name]
+            mean, mn = timed(fn, args.reps)
+            print("%-9s %-5s T=%d N=%d  mean %9.1f us  min %9.1f us  alg %7.1f GB/s (%.1f%% of 8 TB/s)"
+                  % (name, sh, T, N, mean * 1e6, mn * 1e6, mult * nbytes / mean / 1e9,
+                     mult * nbytes / mean / 8e12 * 100), flush=True)
+
+
+if __name__ == "__main__":
+    main()

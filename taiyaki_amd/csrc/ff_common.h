@@ -85,6 +85,22 @@ struct RowSet {
         for (int q = 0; q < F::PIECES; ++q) v[q] = src[min(q * WAVE + lane, nvalid - 1)];
     }
 
+    // streaming variants: last use of the data / write-once output
+    __device__ __forceinline__ void issue_nt(const float *__restrict__ base, int nvalid, int lane) {
+        const f4 *src = reinterpret_cast<const f4 *>(base);
+#pragma unroll
+        for (int q = 0; q < F::PIECES; ++q)
+            v[q] = __builtin_nontemporal_load(src + min(q * WAVE + lane, nvalid - 1));
+    }
+    __device__ __forceinline__ void store_nt(float *__restrict__ base, int nvalid, int lane) const {
+        f4 *dst = reinterpret_cast<f4 *>(base);
+#pragma unroll
+        for (int q = 0; q < F::PIECES; ++q) {
+            const int idx = q * WAVE + lane;
+            if (idx < nvalid) __builtin_nontemporal_store(v[q], dst + idx);
+        }
+    }
+
     // pieces -> own row (in place).  buf: wave-private LDS, 64*PIECES f4.
     __device__ __forceinline__ void to_rows(f4 *buf, int lane) {
 #pragma unroll

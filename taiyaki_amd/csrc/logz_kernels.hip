@@ -11,15 +11,20 @@
 //     pieces -> rows.  No cross-lane arithmetic anywhere.
 //   * the time axis is parallelised exactly with (sum,*)-semiring transfer
 //     matrices:
-//       K1  transfer  : one wave per 32-row chunk, 2nb x 2nb matrix in registers
-//       K1b combine   : per super-chunk (8 chunks) prefix / suffix / total products
+//       K1  transfer  : one 4-wave block per 32-row chunk; each wave folds 8 rows
+//                       into a 2nb x 2nb matrix in registers, then a 2-level
+//                       LDS tree combines the four into the chunk matrix
+//       K1b combine   : total product of each super-chunk (8 chunks)
 //       K2  scan      : serial scan over the super totals only (16 steps at
-//                       T = 4000), register-ring prefetch -> boundary vectors, logZ
+//                       T = 4000), register-ring prefetch -> super boundary
+//                       vectors, logZ
+//       K2b expand    : super boundary vectors -> per-chunk boundary vectors
+//                       (parallel over super-chunks)
 //       K3  posterior : one 512-thread block per chunk, rows held in registers,
 //                       in-chunk forward/backward chained through LDS, normalised
 //                       posterior streamed out.
 //     HBM traffic = 2 reads + 1 write of the score tensor = the algorithmic
-//     minimum 3*T*N*S*4 bytes (+ ~10% workspace, L2/MALL resident).
+//     minimum 3*T*N*S*4 bytes (+ workspace that stays L2/MALL resident).
 //   * arithmetic is linear-space fp32 with exact power-of-two renormalisation
 //     (integer exponents are accumulated exactly; row maxima in fp64), so no
 //     transcendental sits on a serial dependency chain.
@@ -29,7 +34,8 @@ namespace tk {
 
 constexpr int LOGZ_CH = 32;             // rows per chunk
 constexpr int LOGZ_SUPER = 8;           // chunks per super-chunk
-constexpr int K1_WAVES = 4;             // independent chunks per K1 block
+constexpr int K1_WAVES = 4;             // waves per K1 block (one chunk): 4 x 8 rows
+constexpr int K1_ROWS = LOGZ_CH / K1_WAVES;
 constexpr int K3_WAVES = 8;             // waves per K3 block: 8 x 4 rows = 1 chunk
 constexpr int K3_ROWS = LOGZ_CH / K3_WAVES;
 constexpr int ZERO_ROW_EXP = -(1 << 28);    // exponent of an all-zero matrix row
@@ -103,27 +109,27 @@ struct XMat {
     }
 };
 
-// C = A (x) B
+// C = A (x) B.  B's mantissas are rescaled IN PLACE to a common exponent (B is
+// dead afterwards) so only three matrices are ever live.
 template <int NB>
-__device__ __forceinline__ void xmat_mul(const XMat<NB> &A, const XMat<NB> &B, XMat<NB> &C) {
+__device__ __forceinline__ void xmat_mul(const XMat<NB> &A, XMat<NB> &B, XMat<NB> &C) {
     constexpr int NS = 2 * NB;
     int ebmax = ZERO_ROW_EXP;
 #pragma unroll
     for (int k = 0; k < NS; ++k) ebmax = max(ebmax, B.e[k]);
-    float bs[NS][NS];
 #pragma unroll
     for (int k = 0; k < NS; ++k) {
         const int sh = max(B.e[k] - ebmax, -300);
 #pragma unroll
-        for (int j = 0; j < NS; ++j) bs[k][j] = __builtin_amdgcn_ldexpf(B.m[k][j], sh);
+        for (int j = 0; j < NS; ++j) B.m[k][j] = __builtin_amdgcn_ldexpf(B.m[k][j], sh);
     }
 #pragma unroll
     for (int i = 0; i < NS; ++i) {
 #pragma unroll
         for (int j = 0; j < NS; ++j) {
-            float acc = A.m[i][0] * bs[0][j];
+            float acc = A.m[i][0] * B.m[0][j];
 #pragma unroll
-            for (int k = 1; k < NS; ++k) acc = fmaf(A.m[i][k], bs[k][j], acc);
+            for (int k = 1; k < NS; ++k) acc = fmaf(A.m[i][k], B.m[k][j], acc);
             C.m[i][j] = acc;
         }
         C.e[i] = (A.e[i] == ZERO_ROW_EXP || ebmax == ZERO_ROW_EXP) ? ZERO_ROW_EXP : A.e[i] + ebmax;
@@ -246,13 +252,30 @@ __device__ __forceinline__ void xmat_vec_stream(float (&u)[2 * NB], const f4 *ba
     for (int i = 0; i < NS; ++i) u[i] = __builtin_amdgcn_ldexpf(y[i], max(e[i] - emax, -300));
 }
 
+template <int NB>
+__device__ __forceinline__ void xmat_lds_put(const XMat<NB> &A, float *region, int lane) {
+#pragma unroll
+    for (int k = 0; k < XMat<NB>::NW; ++k) region[k * WAVE + lane] = A.word(k);
+}
+
+template <int NB>
+__device__ __forceinline__ void xmat_lds_get(XMat<NB> &A, const float *region, int lane) {
+    constexpr int NS = 2 * NB;
+#pragma unroll
+    for (int k = 0; k < NS * NS; ++k) A.m[k / NS][k % NS] = region[k * WAVE + lane];
+#pragma unroll
+    for (int k = 0; k < NS; ++k) A.e[k] = __float_as_int(region[(NS * NS + k) * WAVE + lane]);
+    A.M = __hiloint2double(__float_as_int(region[(NS * NS + NS + 1) * WAVE + lane]),
+                           __float_as_int(region[(NS * NS + NS) * WAVE + lane]));
+}
+
 struct LogzWs {
     f4 *Pc;         // [C]    chunk transfer matrices            (XMat layout)
-    f4 *Fp;         // [C]    prefix products inside the super-chunk (identity for its first chunk: unused)
-    f4 *Bs;         // [C]    suffix products inside the super-chunk (identity for its last chunk: unused)
     f4 *Tot;        // [NSUP] super-chunk totals
     float *Vs;      // [NSUP][NS][Npad] forward vector entering super-chunk s
     float *Us;      // [NSUP][NS][Npad] backward vector leaving super-chunk s
+    float *Vin;     // [C][NS][Npad]    forward vector entering chunk c
+    float *Uout;    // [C][NS][Npad]    backward vector leaving chunk c
 };
 
 // per-wave LDS buffer of K3 in f4 units: the row-set transpose buffer, which
@@ -265,90 +288,149 @@ __host__ __device__ constexpr int k3_buf_f4() {
 }
 
 // ---------------------------------------------------------------------------
-// K1: chunk transfer matrices.  grid = (ncols, ceil(C / K1_WAVES)), block = 256.
+// K1: chunk transfer matrices.  grid = (ncols, C), block = 256 = one chunk:
+// wave w folds rows [8w, 8w+8) of the chunk; a 2-level tree through LDS
+// (the waves' transpose buffers, idle by then) yields P0 P1 P2 P3.
 // ---------------------------------------------------------------------------
 template <int NB>
-__global__ __launch_bounds__(K1_WAVES *WAVE) void logz_transfer_kernel(
-    const float *__restrict__ scores, int T, int N, int C, int Npad, LogzWs ws) {
+__global__ __launch_bounds__(K1_WAVES *WAVE, 2) void logz_transfer_kernel(
+    const float *__restrict__ scores, int T, int N, int Npad, LogzWs ws) {
     using F = FF<NB>;
+    using X = XMat<NB>;
+    static_assert(2 * WAVE * F::S >= X::NW * WAVE, "pair region must hold one XMat");
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int wave = threadIdx.x >> 6, lane = lane_id();
-    const int c = blockIdx.y * K1_WAVES + wave;
-    if (c >= C) return;
+    const int c = blockIdx.y;
     f4 *buf = reinterpret_cast<f4 *>(smem) + wave * (WAVE * F::PIECES);
     const int n0 = blockIdx.x * WAVE;
     const int nvalid = min(WAVE, N - n0) * F::PIECES;
-    const int t0 = c * LOGZ_CH, t1 = min(T, t0 + LOGZ_CH);
+    const int t0 = c * LOGZ_CH + wave * K1_ROWS, t1 = min(T, t0 + K1_ROWS);
     const size_t rowstride = (size_t)N * F::S;
     const float *base = scores + (size_t)n0 * F::S;
 
-    XMat<NB> P;
+    X P;
     P.set_identity();
-
-    // two row-sets in flight ahead of the one being consumed; row indices are
-    // clamped (never branched on) so the load stream has no control flow
-    RowSet<NB> r0, r1, r2;
-    auto rowptr = [&](int t) { return base + (size_t)min(t, t1 - 1) * rowstride; };
-    auto consume = [&](RowSet<NB> &cur, int t) {
-        cur.to_rows(buf, lane);
-        P.M += (double)cur.exp_normalise();
+    if (t0 < t1) {
+        // one row-set in flight ahead of the one being consumed (2000 waves at
+        // T=4000/N=256 give the memory system its depth); row indices are clamped
+        // (never branched on) so the load stream has no control flow
+        RowSet<NB> r0, r1;
+        auto rowptr = [&](int t) { return base + (size_t)min(t, t1 - 1) * rowstride; };
+        auto consume = [&](RowSet<NB> &cur, int t) {
+            cur.to_rows(buf, lane);
+            P.M += (double)cur.exp_normalise();
 #pragma unroll
-        for (int i = 0; i < F::NS; ++i) {
-            float out[F::NS];
-            ff_fwd_step<NB>(P.m[i], cur, out);
+            for (int i = 0; i < F::NS; ++i) {
+                float out[F::NS];
+                ff_fwd_step<NB>(P.m[i], cur, out);
 #pragma unroll
-            for (int j = 0; j < F::NS; ++j) P.m[i][j] = out[j];
+                for (int j = 0; j < F::NS; ++j) P.m[i][j] = out[j];
+            }
+            if (((t - t0) & 3) == 3) P.renorm();
+        };
+        r0.issue(rowptr(t0), nvalid, lane);
+        for (int t = t0; t < t1; t += 2) {
+            r1.issue(rowptr(t + 1), nvalid, lane);
+            consume(r0, t);
+            if (t + 1 >= t1) break;
+            r0.issue(rowptr(t + 2), nvalid, lane);
+            consume(r1, t + 1);
         }
-        if (((t - t0) & 3) == 3) P.renorm();
-    };
-    r0.issue(rowptr(t0), nvalid, lane);
-    r1.issue(rowptr(t0 + 1), nvalid, lane);
-    for (int t = t0; t < t1; t += 3) {
-        r2.issue(rowptr(t + 2), nvalid, lane);
-        consume(r0, t);
-        if (t + 1 >= t1) break;
-        r0.issue(rowptr(t + 3), nvalid, lane);
-        consume(r1, t + 1);
-        if (t + 2 >= t1) break;
-        r1.issue(rowptr(t + 4), nvalid, lane);
-        consume(r2, t + 2);
+        P.renorm();
     }
-    P.renorm();
-    const size_t n = (size_t)n0 + lane;     // < Npad always
-    P.store(ws.Pc + (size_t)c * XMat<NB>::NF4 * Npad + n, Npad);
+    // tree combine: (P0 P1) (P2 P3)
+    float *pair = reinterpret_cast<float *>(smem) + (wave >> 1) * (2 * WAVE * F::S);
+    float *pair0 = reinterpret_cast<float *>(smem);
+    __syncthreads();
+    if (wave & 1) xmat_lds_put<NB>(P, pair, lane);
+    __syncthreads();
+    X Q, R;
+    if (!(wave & 1)) {
+        xmat_lds_get<NB>(Q, pair, lane);
+        xmat_mul<NB>(P, Q, R);
+    }
+    __syncthreads();
+    if (wave == 2) xmat_lds_put<NB>(R, pair0, lane);
+    __syncthreads();
+    if (wave == 0) {
+        xmat_lds_get<NB>(Q, pair0, lane);
+        xmat_mul<NB>(R, Q, P);
+        const size_t n = (size_t)n0 + lane;     // < Npad always
+        P.store(ws.Pc + (size_t)c * X::NF4 * Npad + n, Npad);
+    }
 }
 
 // ---------------------------------------------------------------------------
-// K1b: per super-chunk prefix / suffix / total products.
-// grid = (ncols, NSUP), block = 128: wave 0 prefix chain (+ total), wave 1 suffix.
+// K1b: total product of each super-chunk.  grid = (ncols, NSUP), block = 512.
+// Row i of (A (x) B) is (row i of A) (x) B, so wave i carries ONE row of the
+// running product through the super-chunk's matrices with cheap mat-vecs; the
+// matrices are staged once in LDS (wave w loads chunk c0 + w), no exchange
+// between the waves is ever needed.
 // ---------------------------------------------------------------------------
 template <int NB>
-__global__ __launch_bounds__(2 * WAVE) void logz_combine_kernel(int C, int Npad, LogzWs ws) {
+__global__ __launch_bounds__(LOGZ_SUPER *WAVE) void logz_combine_kernel(int C, int Npad,
+                                                                     LogzWs ws) {
+    using F = FF<NB>;
     using X = XMat<NB>;
+    static_assert(LOGZ_SUPER >= F::NS, "one wave per matrix row");
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    float *mats = reinterpret_cast<float *>(smem);          // [LOGZ_SUPER][NW][64]
     const int wave = threadIdx.x >> 6, lane = lane_id();
     const size_t n = (size_t)blockIdx.x * WAVE + lane;
     const int s = blockIdx.y;
     const int c0 = s * LOGZ_SUPER, c1 = min(C, c0 + LOGZ_SUPER);      // [c0, c1)
+    const int nc = c1 - c0;
     const size_t mstride = (size_t)X::NF4 * Npad;
+    if (wave < nc) {
+        const f4 *src = ws.Pc + (size_t)(c0 + wave) * mstride + n;
+        f4 raw[X::NF4];
+#pragma unroll
+        for (int q = 0; q < X::NF4; ++q) raw[q] = src[(size_t)q * Npad];
+        float *dst = mats + (size_t)wave * X::NW * WAVE;
+#pragma unroll
+        for (int k = 0; k < X::NW; ++k) dst[k * WAVE + lane] = raw[k >> 2][k & 3];
+    }
+    __syncthreads();
+    const bool rowwave = wave < F::NS;       // (no early return: every wave reaches the barriers)
+    // row `wave` of the total: v = e_wave (x) P_c0 (x) ... (x) P_{c1-1}
+    float v[F::NS];
+#pragma unroll
+    for (int k = 0; k < F::NS; ++k) v[k] = (k == wave) ? 1.f : 0.f;
+    long long eacc = 0;
+    double macc = 0.0;
+    for (int i = 0; rowwave && i < nc; ++i) {
+        X A;
+        xmat_lds_get<NB>(A, mats + (size_t)i * X::NW * WAVE, lane);
+        float out[F::NS];
+        eacc += xvec_mat<NB>(v, A, out);
+        macc += A.M;
+#pragma unroll
+        for (int k = 0; k < F::NS; ++k) v[k] = out[k];
+    }
+    // assemble Tot[s]: row `wave` -> words [wave*NS, wave*NS+NS), exponent, M
+    float mx = v[0];
+#pragma unroll
+    for (int k = 1; k < F::NS; ++k) mx = fmaxf(mx, v[k]);
+    const int erow = (mx > 0.f) ? (int)eacc : ZERO_ROW_EXP;
+    __syncthreads();            // every wave is done reading `mats`
+    float *tot = mats;          // reuse: [NW][64]
+    if (rowwave) {
+#pragma unroll
+        for (int k = 0; k < F::NS; ++k) tot[(wave * F::NS + k) * WAVE + lane] = v[k];
+        tot[(F::NS * F::NS + wave) * WAVE + lane] = __int_as_float(erow);
+    }
     if (wave == 0) {
-        X acc, nxt, prod;
-        acc.load(ws.Pc + (size_t)c0 * mstride + n, Npad);
-        for (int c = c0 + 1; c < c1; ++c) {
-            nxt.load(ws.Pc + (size_t)c * mstride + n, Npad);
-            acc.store(ws.Fp + (size_t)c * mstride + n, Npad);      // P_c0 ... P_{c-1}
-            xmat_mul<NB>(acc, nxt, prod);
-            acc = prod;
-        }
-        acc.store(ws.Tot + (size_t)s * mstride + n, Npad);
-    } else {
-        X acc, nxt, prod;
-        acc.load(ws.Pc + (size_t)(c1 - 1) * mstride + n, Npad);
-        for (int c = c1 - 2; c >= c0; --c) {
-            nxt.load(ws.Pc + (size_t)c * mstride + n, Npad);
-            acc.store(ws.Bs + (size_t)c * mstride + n, Npad);      // P_{c+1} ... P_{c1-1}
-            xmat_mul<NB>(nxt, acc, prod);
-            acc = prod;
-        }
+        tot[(F::NS * F::NS + F::NS) * WAVE + lane] = __int_as_float(__double2loint(macc));
+        tot[(F::NS * F::NS + F::NS + 1) * WAVE + lane] = __int_as_float(__double2hiint(macc));
+    }
+    __syncthreads();
+    // coalesced store: word k of lane `lane` -> f4 q = k/4
+    f4 *dstT = ws.Tot + (size_t)s * mstride + n;
+    for (int q = wave; q < X::NF4; q += LOGZ_SUPER) {
+        f4 o;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) o[r] = (4 * q + r < X::NW) ? tot[(4 * q + r) * WAVE + lane] : 0.f;
+        dstT[(size_t)q * Npad] = o;
     }
 }
 
@@ -370,14 +452,14 @@ __global__ __launch_bounds__(WAVE) void logz_scan_kernel(int N, int NSUP, int Np
     const bool fwd = blockIdx.y == 0;
     f4 raw[RING][X::NF4];
     auto fetch = [&](int slot_s, f4 (&dst)[X::NF4]) {
-        const int s = fwd ? slot_s : NSUP - 1 - slot_s;
+        const int i = min(slot_s, NSUP - 1);                // clamped: loads are unconditional
+        const int s = fwd ? i : NSUP - 1 - i;
         const f4 *src = ws.Tot + (size_t)s * mstride + n;
 #pragma unroll
         for (int q = 0; q < X::NF4; ++q) dst[q] = src[(size_t)q * Npad];
     };
 #pragma unroll
-    for (int k = 0; k < RING; ++k)
-        if (k < NSUP) fetch(k, raw[k]);
+    for (int k = 0; k < RING; ++k) fetch(k, raw[k]);
 
     float v[F::NS];
     // forward: paths start in any flip state with weight 1 (layers.py:1289-1295,
@@ -397,7 +479,7 @@ __global__ __launch_bounds__(WAVE) void logz_scan_kernel(int N, int NSUP, int Np
                 for (int q = 0; q < F::NS; ++q) dst[(size_t)q * Npad] = v[q];
                 X A;
                 A.unpack(raw[k]);
-                if (i + RING < NSUP) fetch(i + RING, raw[k]);
+                fetch(i + RING, raw[k]);
                 float out[F::NS];
                 if (fwd) {
                     eacc += xvec_mat<NB>(v, A, out);
@@ -424,6 +506,60 @@ __global__ __launch_bounds__(WAVE) void logz_scan_kernel(int N, int NSUP, int Np
 }
 
 // ---------------------------------------------------------------------------
+// K2b: expand super-chunk boundary vectors to chunk granularity.
+// grid = (ncols, NSUP), block = 128: wave 0 forward (Vin[c]), wave 1 backward
+// (Uout[c]).  Each step is one streamed mat-vec; the next chunk matrix is in
+// flight while the current one is applied.
+// ---------------------------------------------------------------------------
+template <int NB>
+__global__ __launch_bounds__(2 * WAVE) void logz_expand_kernel(int C, int Npad, LogzWs ws) {
+    using F = FF<NB>;
+    using X = XMat<NB>;
+    const int wave = threadIdx.x >> 6, lane = lane_id();
+    const size_t n = (size_t)blockIdx.x * WAVE + lane;
+    const int s = blockIdx.y;
+    const int c0 = s * LOGZ_SUPER, c1 = min(C, c0 + LOGZ_SUPER);
+    const int nc = c1 - c0;
+    const size_t mstride = (size_t)X::NF4 * Npad, vstride = (size_t)F::NS * Npad;
+    const bool fwd = wave == 0;
+    auto chunk_of = [&](int i) { return fwd ? c0 + min(i, nc - 1) : c1 - 1 - min(i, nc - 1); };
+    auto fetch = [&](int i, f4 (&dst)[X::NF4]) {
+        const f4 *src = ws.Pc + (size_t)chunk_of(i) * mstride + n;
+#pragma unroll
+        for (int q = 0; q < X::NF4; ++q) dst[q] = src[(size_t)q * Npad];
+    };
+    f4 ra[X::NF4], rb[X::NF4];
+    fetch(0, ra);
+    fetch(1, rb);
+    float v[F::NS];
+    {
+        const float *src = (fwd ? ws.Vs : ws.Us) + (size_t)s * vstride + n;
+#pragma unroll
+        for (int k = 0; k < F::NS; ++k) v[k] = src[(size_t)k * Npad];
+    }
+    float *dstbase = fwd ? ws.Vin : ws.Uout;
+    auto apply = [&](int i, const f4 (&raw)[X::NF4]) {
+        float *dst = dstbase + (size_t)chunk_of(i) * vstride + n;
+#pragma unroll
+        for (int k = 0; k < F::NS; ++k) dst[(size_t)k * Npad] = v[k];
+        X A;
+        A.unpack(raw);
+        float out[F::NS];
+        if (fwd) (void)xvec_mat<NB>(v, A, out);
+        else xmat_vec<NB>(A, v, out);
+#pragma unroll
+        for (int k = 0; k < F::NS; ++k) v[k] = out[k];
+    };
+    for (int i = 0; i < nc; i += 2) {
+        apply(i, ra);
+        fetch(i + 2, ra);
+        if (i + 1 >= nc) break;
+        apply(i + 1, rb);
+        fetch(i + 3, rb);
+    }
+}
+
+// ---------------------------------------------------------------------------
 // K3: posterior.  grid = (ncols, C), block = 512 (8 waves x 4 rows = one chunk).
 // Rows live in registers; forward / backward boundary vectors are chained
 // between the waves through LDS; posteriors overwrite the rows in place and
@@ -431,10 +567,9 @@ __global__ __launch_bounds__(WAVE) void logz_scan_kernel(int N, int NSUP, int Np
 // ---------------------------------------------------------------------------
 template <int NB>
 __global__ __launch_bounds__(K3_WAVES *WAVE, 2) void logz_posterior_kernel(
-    const float *__restrict__ scores, float *__restrict__ grad, int T, int N, int C, int Npad,
+    const float *__restrict__ scores, float *__restrict__ grad, int T, int N, int Npad,
     LogzWs ws, uint32_t *__restrict__ status) {
     using F = FF<NB>;
-    using X = XMat<NB>;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int wave = threadIdx.x >> 6, lane = lane_id();
     constexpr int BUF_F4 = k3_buf_f4<NB>();
@@ -451,27 +586,20 @@ __global__ __launch_bounds__(K3_WAVES *WAVE, 2) void logz_posterior_kernel(
     const int tw = c * LOGZ_CH + wave * K3_ROWS;        // first row of this wave
     const float *base = scores + (size_t)n0 * F::S;
     const size_t n = (size_t)n0 + lane;
-    const size_t vstride = (size_t)F::NS * Npad, mstride = (size_t)X::NF4 * Npad;
-    const int s = c / LOGZ_SUPER, c0 = s * LOGZ_SUPER, c1 = min(C, c0 + LOGZ_SUPER);
+    const size_t vstride = (size_t)F::NS * Npad;
 
     // 1. rows -> registers (weights w = exp(s - rowmax))
     RowSet<NB> w[K3_ROWS];
 #pragma unroll
     for (int j = 0; j < K3_ROWS; ++j)
-        w[j].issue(base + (size_t)min(tw + j, T - 1) * rowstride, nvalid, lane);
-    // chain heads: expand the super-chunk boundary vector to this chunk while
-    // the rows are in flight (wave 0: forward, last wave: backward)
+        w[j].issue_nt(base + (size_t)min(tw + j, T - 1) * rowstride, nvalid, lane);     // last use
+    // chain heads (wave 0: forward vector entering the chunk, last wave: backward
+    // vector leaving it), loaded while the rows are in flight
     float head[F::NS];
-    if (wave == 0) {
-        const float *vs = ws.Vs + (size_t)s * vstride + n;
+    {
+        const float *src = ((wave == 0) ? ws.Vin : ws.Uout) + (size_t)c * vstride + n;
 #pragma unroll
-        for (int k = 0; k < F::NS; ++k) head[k] = vs[(size_t)k * Npad];
-        if (c > c0) xvec_mat_stream<NB>(head, ws.Fp + (size_t)c * mstride + n, Npad);
-    } else if (wave == K3_WAVES - 1) {
-        const float *us = ws.Us + (size_t)s * vstride + n;
-#pragma unroll
-        for (int k = 0; k < F::NS; ++k) head[k] = us[(size_t)k * Npad];
-        if (c < c1 - 1) xmat_vec_stream<NB>(head, ws.Bs + (size_t)c * mstride + n, Npad);
+        for (int k = 0; k < F::NS; ++k) head[k] = src[(size_t)k * Npad];
     }
 #pragma unroll
     for (int j = 0; j < K3_ROWS; ++j) {
@@ -574,7 +702,7 @@ __global__ __launch_bounds__(K3_WAVES *WAVE, 2) void logz_posterior_kernel(
     for (int j = 0; j < K3_ROWS; ++j) {
         if (tw + j < T) {
             w[j].to_pieces(buf, lane);
-            w[j].store(gbase + (size_t)(tw + j) * rowstride, nvalid, lane);
+            w[j].store_nt(gbase + (size_t)(tw + j) * rowstride, nvalid, lane);
         }
     }
 }
@@ -599,12 +727,12 @@ static size_t logz_ws_layout(size_t T, size_t N, void *base, LogzWs *ws) {
     };
     const size_t mbytes = (size_t)X::NF4 * Npad * sizeof(f4);
     f4 *Pc = reinterpret_cast<f4 *>(take(C * mbytes));
-    f4 *Fp = reinterpret_cast<f4 *>(take(C * mbytes));
-    f4 *Bs = reinterpret_cast<f4 *>(take(C * mbytes));
     f4 *Tot = reinterpret_cast<f4 *>(take(NSUP * mbytes));
     float *Vs = reinterpret_cast<float *>(take(NSUP * F::NS * Npad * sizeof(float)));
     float *Us = reinterpret_cast<float *>(take(NSUP * F::NS * Npad * sizeof(float)));
-    if (ws) *ws = LogzWs{Pc, Fp, Bs, Tot, Vs, Us};
+    float *Vin = reinterpret_cast<float *>(take(C * F::NS * Npad * sizeof(float)));
+    float *Uout = reinterpret_cast<float *>(take(C * F::NS * Npad * sizeof(float)));
+    if (ws) *ws = LogzWs{Pc, Tot, Vs, Us, Vin, Uout};
     return off;
 }
 
@@ -620,16 +748,22 @@ static int logz_launch(const float *scores, size_t T, size_t N, float *logz, flo
     const int NSUP = (C + LOGZ_SUPER - 1) / LOGZ_SUPER;
     const int ncols = (int)((N + WAVE - 1) / WAVE), Npad = ncols * WAVE;
     const size_t bufbytes = (size_t)WAVE * F::PIECES * sizeof(f4);
+    hipLaunchKernelGGL(logz_transfer_kernel<NB>, dim3(ncols, C), dim3(K1_WAVES * WAVE),
+                       K1_WAVES * bufbytes, stream, scores, (int)T, (int)N, Npad, ws);
     {
-        dim3 grid(ncols, (C + K1_WAVES - 1) / K1_WAVES), block(K1_WAVES * WAVE);
-        hipLaunchKernelGGL(logz_transfer_kernel<NB>, grid, block, K1_WAVES * bufbytes, stream,
-                           scores, (int)T, (int)N, C, Npad, ws);
+        const size_t lds = (size_t)LOGZ_SUPER * XMat<NB>::NW * WAVE * sizeof(float);
+        if (lds > 64 * 1024 &&
+            hipFuncSetAttribute(reinterpret_cast<const void *>(&logz_combine_kernel<NB>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+            return 4;
+        hipLaunchKernelGGL(logz_combine_kernel<NB>, dim3(ncols, NSUP), dim3(LOGZ_SUPER * WAVE), lds,
+                           stream, C, Npad, ws);
     }
-    hipLaunchKernelGGL(logz_combine_kernel<NB>, dim3(ncols, NSUP), dim3(2 * WAVE), 0, stream, C,
-                       Npad, ws);
     hipLaunchKernelGGL(logz_scan_kernel<NB>, dim3(ncols, grad != nullptr ? 2 : 1), dim3(WAVE), 0,
                        stream, (int)N, NSUP, Npad, ws, logz, status);
     if (grad != nullptr) {
+        hipLaunchKernelGGL(logz_expand_kernel<NB>, dim3(ncols, NSUP), dim3(2 * WAVE), 0, stream, C,
+                           Npad, ws);
         dim3 grid(ncols, C), block(K3_WAVES * WAVE);
         const size_t lds = K3_WAVES * (size_t)k3_buf_f4<NB>() * sizeof(f4) +
                            2 * F::NS * WAVE * sizeof(float);
@@ -638,7 +772,7 @@ static int logz_launch(const float *scores, size_t T, size_t N, float *logz, flo
                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
             return 4;
         hipLaunchKernelGGL(logz_posterior_kernel<NB>, grid, block, lds, stream, scores, grad,
-                           (int)T, (int)N, C, Npad, ws, status);
+                           (int)T, (int)N, Npad, ws, status);
     }
     return hipGetLastError() == hipSuccess ? 0 : 4;
 }

@@ -1,0 +1,109 @@
+"""CPU-only tests of the host side: the C-ABI library loads and exports every symbol
+include/taiyaki_amd_flipflop.h declares (no compute calls without a GPU), the index algebra
+and synthetic generators agree with the oracle / the reference's documented examples, the
+PyTorch layer stack has the reference's shapes and parameter counts, and the operators fail
+loudly on CPU tensors."""
+import os
+import re
+
+import numpy as np
+import pytest
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_c_abi_exports_every_declared_symbol():
+    from taiyaki_amd import _lib
+    _lib.build()
+    handle = _lib.lib()
+    header = open(os.path.join(ROOT, "include", "taiyaki_amd_flipflop.h")).read()
+    header = re.sub(r"/\*.*?\*/", "", header, flags=re.S)
+    declared = set(re.findall(r"\b(tk_\w+|crf_flipflop_\w+|cat_mod_flipflop_\w+)\s*\(", header))
+    assert len(declared) >= 12
+    for name in declared:
+        assert hasattr(handle, name), name
+        assert name in _lib.SIGNATURES, "binding missing for %s" % name
+    assert set(_lib.SIGNATURES) == declared
+    assert handle.tk_version().startswith(b"taiyaki_amd flipflop gfx950")
+
+
+def test_workspace_queries_need_no_gpu():
+    from taiyaki_amd import _lib
+    L = _lib.lib()
+    assert L.tk_flipflop_logz_workspace_bytes(4000, 256, 4) > 0
+    assert L.tk_flipflop_logz_workspace_bytes(4000, 256, 9) == 0      # nbase not built
+    assert L.tk_crf_flipflop_workspace_bytes(40, 800, 128, 480, 1) > \
+        L.tk_crf_flipflop_workspace_bytes(40, 800, 128, 480, 0)
+    assert L.tk_flipflop_viterbi_workspace_bytes(800, 128, 4) == 800 * 128 * 4
+
+
+def test_flipflopfings_reference_docstring_examples(oracle_mod):
+    """flipflopfings.py:44-47, 70-73 doctests + agreement with the oracle's C version."""
+    from taiyaki_amd import flipflopfings as ff
+    x = np.array([1, 3, 2, 3, 3, 3, 3, 1, 1])
+    np.testing.assert_array_equal(
+        ff.flopmask(x), [False, False, False, False, True, False, True, False, True])
+    np.testing.assert_array_equal(ff.flipflop_code(x), [1, 3, 2, 3, 7, 3, 7, 1, 5])
+    np.testing.assert_array_equal(ff.flipflop_code(x), oracle_mod.flipflop_code(x))
+    codes = ff.flipflop_code(np.array([0, 0, 1, 1, 1, 3, 2, 2]))
+    move, stay = oracle_mod.flipflop_indices(codes, [len(codes)], 4)
+    np.testing.assert_array_equal(ff.stay_indices(codes), stay[:len(codes)])
+    np.testing.assert_array_equal(ff.move_indices(codes), move[:len(codes) - 1])
+    assert ff.nstate_flipflop(4) == 40 and ff.nbase_flipflop(40) == 4
+    with pytest.raises(AssertionError):
+        ff.nbase_flipflop(41)
+    assert ff.path_to_str(np.array([0, 0, 1, 5, 5, 2])) == "ACCG"
+
+
+def test_synth_is_deterministic_and_matches_speedtest_rule():
+    from taiyaki_amd import synth
+    a = synth.crf_case(50, 6, 3)
+    b = synth.crf_case(50, 6, 3)
+    for k in a:
+        np.testing.assert_array_equal(a[k], b[k])
+    assert a["scores"].dtype == np.float32 and a["scores"].min() >= -5 and a["scores"].max() < 5
+    # c_crf_flipflop.c:813: nblock * (1 + (i - nbatch/2) / (5 nbatch)) / 2
+    np.testing.assert_array_equal(synth.speedtest_seqlens(800, 128)[[0, 64, 127]], [360, 400, 439])
+    assert a["seqs"].max() < 8 and len(a["seqs"]) == a["seqlens"].sum()
+    m = synth.crf_case(50, 6, 3, nmods_per_base=(1, 1, 0, 0))
+    assert m["scores"].shape[2] == 46
+    np.testing.assert_array_equal(m["can_mods_offsets"], [0, 2, 4, 5, 6])   # layers.py:1495-1497
+    bases = m["seqs"] % 4
+    assert np.all(m["mod_cats"][bases >= 2] == 0) and m["mod_cats"].max() == 1
+
+
+def test_model_shapes_and_parameter_counts():
+    """(4000,2,1) -> (800,2,40) / (800,2,46); 2,715,280 trainable parameters."""
+    from taiyaki_amd import models
+    x = torch.randn(4000, 2, 1)
+    net = models.mLstm_flipflop()
+    assert net(x).shape == (800, 2, 40)
+    assert sum(p.numel() for p in net.parameters() if p.requires_grad) == 2715280
+    assert sum(p.numel() for p in net.parameters()) == 2720400
+    out = models.mLstm_cat_mod_flipflop()(x)
+    assert out.shape == (800, 2, 46)
+    assert float(out[:, :, :40].detach().abs().max()) <= 5.0
+    # per-base log-softmax groups A,(6mA) C,(5mC) G T  (layers.py:1616-1640)
+    np.testing.assert_allclose(out[:, :, 40:42].exp().sum(2).detach().numpy(), 1.0, atol=1e-5)
+    np.testing.assert_allclose(out[:, :, 44:].detach().numpy(), 0.0, atol=1e-6)
+    assert models.mGru_flipflop(size=96)(torch.randn(2000, 2, 1)).shape == (1000, 2, 40)
+
+
+def test_operators_refuse_cpu_tensors():
+    from taiyaki_amd import ctc, decode, layers
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        layers.flipflop_logpartition(torch.zeros(4, 1, 40))
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        ctc.crf_flipflop_loss(torch.zeros(4, 1, 40), torch.tensor([0, 1]), torch.tensor([2]), 1.0)
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        decode.flipflop_viterbi(torch.zeros(4, 1, 40))
+
+
+def test_product_code_never_imports_the_oracle():
+    for dirpath, _, files in os.walk(os.path.join(ROOT, "taiyaki_amd")):
+        for f in files:
+            if f.endswith((".py", ".hip", ".h")):
+                src = open(os.path.join(dirpath, f)).read()
+                assert not re.search(r"^\s*(import oracle|from oracle)", src, flags=re.M), f
+                assert "liboracle" not in src and "/root/reference" not in src, f

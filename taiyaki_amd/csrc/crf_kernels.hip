@@ -6,22 +6,26 @@
 // taiyaki/flipflopfings.py:6-31 / ctc.pyx:127-134,282-292.
 //
 // Design (see DESIGN.md "Kernel A"):
-//   * one wavefront per read; lane l owns the R consecutive lattice positions
-//     [l*R, (l+1)*R) in registers, so one time step is R independent cells per
-//     lane plus ONE neighbour exchange; no workgroup barrier anywhere.
+//   * one workgroup of W wavefronts per read, position-parallel: thread g owns
+//     the R consecutive lattice positions [g*R, (g+1)*R) in registers.  One time
+//     step = R independent cells per lane, ONE neighbour exchange (a DPP
+//     wave_shr/wave_shl inside a wave, a double-buffered LDS word between
+//     waves) and ONE s_barrier.  (R, W) are picked from the longest sequence so
+//     that a cfg-2 read (L ~ 450) runs on 4 waves x 2 cells.
 //   * arithmetic is log2-space (v_exp_f32 / v_log_f32 are base-2 natively):
 //     cell = max(a,b) + log2(1 + 2^-|a-b|), the reference's logaddexp.  The
 //     per-column max-subtraction of the reference (c_crf_flipflop.c:73-77) is
-//     applied every 4th column (any common offset is exact to account for).
+//     applied every 4th column (a common offset is exact to account for; it is
+//     tracked in fp64); the block-wide max rides on the step barrier.
 //   * score rows are staged CK rows at a time in LDS and gathered by
 //     transition id; stay / move / mod ids live in registers.
 //   * the (T+1) x L forward lattice is never written out: the forward sweep
 //     stores one checkpoint column every CK steps; the backward sweep
-//     recomputes each CK-column tile into LDS, walks it backwards fused with the
-//     backward recursion and scatter-adds the posteriors into an LDS tile of
-//     per-row transition bins (ds_add_f32, deterministic within one wave),
-//     which is normalised per row (the reference's per-column softmax,
-//     c_crf_flipflop.c:400-401) and streamed out once.
+//     recomputes each CK-column tile into LDS ("LDS-tiled"), walks it backwards
+//     fused with the backward recursion and scatter-adds the posteriors into
+//     per-wave LDS bins (ds_add_f32; per-wave bins + fixed-order reduction keep
+//     the result deterministic), normalised per row (the reference's per-column
+//     softmax, c_crf_flipflop.c:400-401) and streamed out once.
 #include "ff_common.h"
 
 namespace tk {
@@ -46,94 +50,105 @@ struct CrfArgs {
     uint32_t *status;
 };
 
-template <int R>
+template <int R, int W>
 struct CrfCfg {
-    static constexpr int CK = (256 / R) > 32 ? 32 : ((256 / R) < 4 ? 4 : (256 / R));
-    static constexpr int MAXK = CK;     // tile prefetch registers: CK*64 floats >= CK*S
+    static constexpr int NT = W * WAVE;                 // threads per read
+    static constexpr int LPAD = R * NT;                 // lattice positions covered
+    static constexpr int CK0 = 16384 / LPAD;            // recompute tile <= 64 KiB of LDS
+    static constexpr int CK = CK0 > 16 ? 16 : (CK0 < 4 ? 4 : CK0);
+    static constexpr int MAXK = (CK + W - 1) / W;           // tile rows moved per wave (S <= 64)
 };
 
-__host__ __device__ inline size_t crf_lds_bytes(int R, int CK, int S) {
-    const int SP = S + 2;
-    size_t b = 0;
-    b += (size_t)CK * SP * 4;           // score tile
-    b += (size_t)CK * SP * 4;           // gradient bins
-    b += (size_t)CK * R * WAVE * 4;     // recomputed forward columns
-    b += (size_t)CK * 8;                // per-row forward offsets (double)
-    b += (size_t)CK * 4;                // per-row scale
-    return (b + 15) / 16 * 16;
+__host__ __device__ inline int crf_ck(int R, int W) {
+    const int c = 16384 / (R * W * WAVE);
+    return c > 16 ? 16 : (c < 4 ? 4 : c);
 }
 
-template <int R, bool MOD>
-__global__ __launch_bounds__(WAVE) void crf_kernel(CrfArgs a) {
-    constexpr int CK = CrfCfg<R>::CK;
-    constexpr int MAXK = CrfCfg<R>::MAXK;
+// LDS carve (bytes): tile | bins[W] | Fblk | offs(double) | rscale | edgeF[2][W] | edgeB[2][W] | red[W] | misc[4]
+__host__ __device__ inline size_t crf_lds_bytes(int R, int W, int S) {
+    const int SP = S + 2, CK = crf_ck(R, W), NT = W * WAVE;
+    size_t f = 0;
+    f += (size_t)CK * SP;               // score tile
+    f += (size_t)W * CK * SP;           // per-wave gradient bins
+    f += (size_t)CK * R * NT;           // recomputed forward columns
+    f += (size_t)2 * CK;                // per-row forward offsets (double)
+    f += (size_t)CK;                    // per-row scale
+    f += (size_t)5 * W + 8;             // edges, reduction slots, scalars
+    return (f * 4 + 15) / 16 * 16;
+}
+
+template <int R, int W, bool MOD>
+__global__ __launch_bounds__(W *WAVE) void crf_kernel(CrfArgs a) {
+    using Cfg = CrfCfg<R, W>;
+    constexpr int CK = Cfg::CK, NT = Cfg::NT, MAXK = Cfg::MAXK;
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    const int lane = lane_id();
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & (WAVE - 1);
     const int n = blockIdx.x;
     const int T = a.T, N = a.N, S = a.S, SP = S + 2;
     const int L = a.seqlen[n];
     const bool want_grad = a.grad != nullptr;
 
-    float *tile = reinterpret_cast<float *>(smem);                    // [CK][SP]
-    float *gt = tile + CK * SP;                                       // [CK][SP]
-    float *Fblk = gt + CK * SP;                                       // [CK][R][64]
-    double *offs = reinterpret_cast<double *>(
-        smem + (((size_t)(2 * CK * SP + CK * R * WAVE) * 4 + 7) / 8) * 8);  // [CK]
-    float *rscale = reinterpret_cast<float *>(offs + CK);             // [CK]
+    float *tile = reinterpret_cast<float *>(smem);              // [CK][SP]
+    float *bins = tile + CK * SP;                               // [W][CK][SP]
+    float *Fblk = bins + W * CK * SP;                           // [CK][R][NT]
+    // (all three sizes are multiples of 2 floats, so the double array is 8-byte aligned)
+    double *offs = reinterpret_cast<double *>(Fblk + (size_t)CK * R * NT + ((CK * SP * (1 + W)) & 1));
+    float *rscale = reinterpret_cast<float *>(offs + CK);       // [CK]
+    float *edgeF = rscale + CK;                                 // [2][W]
+    float *edgeB = edgeF + 2 * W;                               // [2][W]
+    float *red = edgeB + 2 * W;                                 // [W]
+    float *misc = red + W;                                      // [4]
+    float *mybins = bins + wave * CK * SP;
 
     const size_t rowstride = (size_t)N * S;
     const float *lpn = a.lp + (size_t)n * S;
 
-    // ---- tile movers: rows t0 .. t0+nrows-1 of this read <-> LDS ------------
-    auto tile_fetch = [&](int t0, float (&pre)[MAXK]) {
-        // unconditional loads (index clamped): no exec-mask branches, no vmcnt(0) stalls
-        const int total = min(CK, T - t0) * S;
-#pragma unroll
-        for (int k = 0; k < MAXK; ++k) {
-            const int e = min(lane + WAVE * k, total - 1);
-            const int row = e / S, col = e - row * S;
-            pre[k] = lpn[(size_t)(t0 + row) * rowstride + col];
-        }
-    };
-    auto tile_commit = [&](int t0, const float (&pre)[MAXK]) {
-        const int total = min(CK, T - t0) * S;
-        wave_lds_fence();
-#pragma unroll
-        for (int k = 0; k < MAXK; ++k) {
-            const int e = lane + WAVE * k;
-            if (e < total) {
-                const int row = e / S, col = e - row * S;
-                tile[row * SP + col] = pre[k];
-            }
-        }
-        wave_lds_fence();
-    };
-
     if (L == 0) {
         // c_crf_flipflop.c:269-272 / 458-464: cost 0, zero gradient rows
-        if (lane == 0) a.cost[n] = 0.f;
-        if (want_grad) {
-            for (int t = 0; t < T; ++t)
-                for (int col = lane; col < S; col += WAVE)
-                    a.grad[(size_t)t * rowstride + (size_t)n * S + col] = 0.f;
+        if (tid == 0) a.cost[n] = 0.f;
+        if (want_grad && lane < S) {
+            for (int t = wave; t < T; t += W)
+                a.grad[(size_t)t * rowstride + (size_t)n * S + lane] = 0.f;
         }
         return;
     }
-    if (L > R * WAVE) {
-        if (lane == 0) {
+    if (L > R * NT) {
+        if (tid == 0) {
             a.cost[n] = __builtin_nanf("");
             if (a.status) atomicOr(a.status, 4u);
         }
         return;
     }
 
+    // ---- tile movers: rows t0 .. t0+nrows-1 of this read <-> LDS.  Wave w moves
+    //      rows w, w+W, ...; lane = column (S <= 64): no index arithmetic, and the
+    //      loads are unconditional (indices clamped) so they pipeline freely. -----------
+    auto tile_fetch = [&](int t0, float (&pre)[MAXK]) {
+        const int nrows = min(CK, T - t0);
+        const int col = min(lane, S - 1);
+#pragma unroll
+        for (int k = 0; k < MAXK; ++k) {
+            const int row = min(wave + W * k, nrows - 1);
+            pre[k] = lpn[(size_t)(t0 + row) * rowstride + col];
+        }
+    };
+    auto tile_commit = [&](int t0, const float (&pre)[MAXK]) {
+        const int nrows = min(CK, T - t0);
+#pragma unroll
+        for (int k = 0; k < MAXK; ++k) {
+            const int row = wave + W * k;
+            if (row < nrows && lane < S) tile[row * SP + lane] = pre[k];
+        }
+    };
+
     // ---- per-position transition ids -> registers ---------------------------
     const int64_t off = a.seqoff[n];
+    const int p0 = tid * R;
     int st[R], mv[R], md[MOD ? R : 1];
     float fw[MOD ? R : 1];
 #pragma unroll
     for (int j = 0; j < R; ++j) {
-        const int p = lane * R + j;
+        const int p = p0 + j;
         st[j] = (p < L) ? a.stay[off + p] : S;                // S   = -LARGE sentinel slot
         mv[j] = (p < L - 1) ? a.move[off + p] : S;
         if (MOD) {
@@ -141,27 +156,46 @@ __global__ __launch_bounds__(WAVE) void crf_kernel(CrfArgs a) {
             fw[j] = (p < L - 1) ? a.modfact[off + p] * a.c_mod : 0.f;
         }
     }
-    // transition INTO this lane's first position comes from the left neighbour
-    int mvin0 = __shfl_up(mv[R - 1], 1, WAVE);
-    int mdin0 = MOD ? __shfl_up(md[R - 1], 1, WAVE) : 0;
-    float fwin0 = MOD ? __shfl_up(fw[R - 1], 1, WAVE) : 0.f;
-    if (lane == 0) {
-        mvin0 = S;
-        mdin0 = S + 1;
-        fwin0 = 0.f;
-    }
+    // transition INTO this thread's first position (from position p0 - 1)
+    const bool has_in = (p0 >= 1) && (p0 - 1 < L - 1);
+    const int mvin0 = has_in ? a.move[off + p0 - 1] : S;
+    const int mdin0 = (MOD && has_in) ? a.mod[off + p0 - 1] : S + 1;
+    const float fwin0 = (MOD && has_in) ? a.modfact[off + p0 - 1] * a.c_mod : 0.f;
     // sentinel slots of every LDS row (tile loads never touch them)
-    for (int r = lane; r < CK; r += WAVE) {
+    for (int r = tid; r < CK; r += NT) {
         tile[r * SP + S] = NEG_LARGE;
         tile[r * SP + S + 1] = 0.f;
     }
     const float c = a.c_can;
     const float neg = NEG_LARGE * LOG2E;
 
-    // ---- one forward column update (c_crf_flipflop.c:43-78) ------------------
-    auto fwd_step = [&](float (&f)[R], const float *row) {
-        float left0 = __shfl_up(f[R - 1], 1, WAVE);
-        if (lane == 0) left0 = neg;
+    // block-wide column max of step t rides on the step barrier: every wave drops
+    // its max into red[] at the end of step t, everybody folds it in at step t+1
+    auto fold_norm = [&](float (&x)[R], float &edge_val, double &offacc) {
+        float mx = red[0];
+#pragma unroll
+        for (int w = 1; w < W; ++w) mx = fmaxf(mx, red[w]);
+        if (!(mx > -1e29f)) mx = 0.f;           // nothing reachable yet: keep the scale
+#pragma unroll
+        for (int j = 0; j < R; ++j) x[j] -= mx;
+        edge_val -= mx;
+        offacc += (double)mx;
+    };
+    auto post_max = [&](const float (&x)[R]) {
+        float mx = x[0];
+#pragma unroll
+        for (int j = 1; j < R; ++j) mx = fmaxf(mx, x[j]);
+        mx = wave_allmax_dpp(mx);
+        if (lane == 0) red[wave] = mx;
+    };
+
+    // ---- one forward column update (c_crf_flipflop.c:43-78); t = index of the row
+    //      consumed; ends with the step barrier ------------------------------------------
+    auto fwd_step = [&](float (&f)[R], const float *row, int t, bool norm_in, double &offacc) {
+        float ein = (W > 1 && wave > 0) ? edgeF[((t - 1) & 1) * W + wave - 1] : neg;
+        if (norm_in) fold_norm(f, ein, offacc);
+        float left0 = wave_shift_up1(f[R - 1], neg);
+        if (W > 1 && lane == 0) left0 = ein;
 #pragma unroll
         for (int j = R - 1; j >= 0; --j) {
             const float ls = row[st[j]];
@@ -177,56 +211,59 @@ __global__ __launch_bounds__(WAVE) void crf_kernel(CrfArgs a) {
             }
             f[j] = lse2(av, bv);
         }
+        if (W > 1 && lane == WAVE - 1) edgeF[(t & 1) * W + wave] = f[R - 1];
+        if (((t + 1) & 3) == 0) post_max(f);
+        __syncthreads();
     };
-    auto normalise = [&](float (&f)[R], double &offacc) {
-        float mx = f[0];
-#pragma unroll
-        for (int j = 1; j < R; ++j) mx = fmaxf(mx, f[j]);
-        mx = wave_allmax(mx);
-#pragma unroll
-        for (int j = 0; j < R; ++j) f[j] -= mx;
-        offacc += (double)mx;
+    // publish the column's wave-boundary values before the first step from it
+    auto fwd_edge_init = [&](const float (&f)[R], int t0) {
+        if (W > 1 && lane == WAVE - 1) edgeF[((t0 - 1) & 1) * W + wave] = f[R - 1];
+        __syncthreads();
     };
 
     const int NK = (T + CK - 1) / CK;
-    float *ck_n = a.ckpt + (size_t)n * NK * (R * WAVE);
+    float *ck_n = a.ckpt + (size_t)n * NK * (R * NT);
     double *ckoff_n = a.ckoff + (size_t)n * NK;
 
     // ======================= forward sweep ===================================
     float f[R];
 #pragma unroll
-    for (int j = 0; j < R; ++j) f[j] = (lane * R + j == 0) ? 0.f : neg;     // :113-116
+    for (int j = 0; j < R; ++j) f[j] = (p0 + j == 0) ? 0.f : neg;           // :113-116
     double offF = 0.0;
+    fwd_edge_init(f, 0);
     {
         float pre[MAXK];
         tile_fetch(0, pre);
         for (int k = 0; k < NK; ++k) {
             const int t0 = k * CK, nrows = min(CK, T - t0);
-            tile_commit(t0, pre);
+            tile_commit(t0, pre);           // (the previous tile's last step ended with a barrier)
+            __syncthreads();
             if (k + 1 < NK) tile_fetch(t0 + CK, pre);
             if (want_grad) {
 #pragma unroll
-                for (int j = 0; j < R; ++j) ck_n[((size_t)k * R + j) * WAVE + lane] = f[j];
-                if (lane == 0) ckoff_n[k] = offF;
+                for (int j = 0; j < R; ++j) ck_n[((size_t)k * R + j) * NT + tid] = f[j];
+                if (tid == 0) ckoff_n[k] = offF;
             }
             for (int i = 0; i < nrows; ++i) {
-                fwd_step(f, tile + i * SP);
-                if (((t0 + i + 1) & 3) == 0) normalise(f, offF);
+                const int t = t0 + i;
+                fwd_step(f, tile + i * SP, t, t > 0 && (t & 3) == 0, offF);
             }
         }
     }
+    // a column max published by the very last step is never folded in: harmless.
     // score = sum of factors + fwd[T][L-1]  (c_crf_flipflop.c:131)
-    float last = 0.f;
-    {
+    if (tid == (L - 1) / R) {
         const int jj = (L - 1) % R;
+        float last = 0.f;
 #pragma unroll
         for (int j = 0; j < R; ++j)
             if (j == jj) last = f[j];
-        last = __shfl(last, (L - 1) / R, WAVE);
+        misc[0] = last;
     }
-    const double fwd_score2 = offF + (double)last;
+    __syncthreads();
+    const double fwd_score2 = offF + (double)misc[0];
     if (!want_grad) {
-        if (lane == 0) {
+        if (tid == 0) {
             const float cst = (float)(-(fwd_score2 * 0.6931471805599453) / (double)T) * a.out_scale;
             a.cost[n] = cst;
             if (a.status && !isfinite(cst)) atomicOr(a.status, 1u);
@@ -237,10 +274,14 @@ __global__ __launch_bounds__(WAVE) void crf_kernel(CrfArgs a) {
     // ======================= backward sweep + posterior =======================
     float b[R];
 #pragma unroll
-    for (int j = 0; j < R; ++j) b[j] = (lane * R + j == L - 1) ? 0.f : neg;  // :216-220
+    for (int j = 0; j < R; ++j) b[j] = (p0 + j == L - 1) ? 0.f : neg;       // :216-220
     double offB = 0.0;
     bool bad = false;
+    int nbwd = 0;                       // backward steps done so far
+    bool bnorm_pending = false;
     const float inv_cmod = MOD ? (1.0f / a.c_mod) : 0.f;
+    if (W > 1 && lane == 0) edgeB[1 * W + wave] = b[0];        // slot (nbwd-1)&1 with nbwd = 0
+    __syncthreads();
     {
         float pre[MAXK];
         tile_fetch((NK - 1) * CK, pre);
@@ -250,25 +291,34 @@ __global__ __launch_bounds__(WAVE) void crf_kernel(CrfArgs a) {
             if (k > 0) tile_fetch(t0 - CK, pre);
             // -- recompute the forward columns of this tile from its checkpoint
 #pragma unroll
-            for (int j = 0; j < R; ++j) f[j] = ck_n[((size_t)k * R + j) * WAVE + lane];
+            for (int j = 0; j < R; ++j) f[j] = ck_n[((size_t)k * R + j) * NT + tid];
             offF = ckoff_n[k];
+            for (int e = tid; e < W * CK * SP; e += NT) bins[e] = 0.f;
+            fwd_edge_init(f, t0);       // barrier: tile, bins and edges are visible
             for (int i = 0; i < nrows; ++i) {
+                const int t = t0 + i;
+                // The checkpoint holds the column BEFORE the fold that was pending at
+                // the tile boundary (CK % 4 == 0): re-post its column max so the step
+                // folds exactly what the forward sweep folded.
+                if (i == 0 && t > 0 && (t & 3) == 0) {
+                    post_max(f);
+                    __syncthreads();
+                }
+                // (column, offset) are stored pre-fold: a consistent pair
 #pragma unroll
-                for (int j = 0; j < R; ++j) Fblk[(i * R + j) * WAVE + lane] = f[j];
-                if (lane == 0) offs[i] = offF;
-                fwd_step(f, tile + i * SP);
-                if (((t0 + i + 1) & 3) == 0) normalise(f, offF);
+                for (int j = 0; j < R; ++j) Fblk[((size_t)i * R + j) * NT + tid] = f[j];
+                if (tid == 0) offs[i] = offF;
+                fwd_step(f, tile + i * SP, t, t > 0 && (t & 3) == 0, offF);
             }
-            for (int e = lane; e < CK * SP; e += WAVE) gt[e] = 0.f;
-            wave_lds_fence();
             // -- walk the tile backwards (c_crf_flipflop.c:150-182 fused with 372-413)
             for (int i = nrows - 1; i >= 0; --i) {
-                const int t = t0 + i;
                 const float *row = tile + i * SP;
-                float *grow = gt + i * SP;
+                float *grow = mybins + i * SP;
+                float ein = (W > 1 && wave < W - 1) ? edgeB[((nbwd - 1) & 1) * W + wave + 1] : neg;
+                if (bnorm_pending) fold_norm(b, ein, offB);
                 const float ct = (float)(fwd_score2 - offs[i] - offB);
-                float right0 = __shfl_down(b[0], 1, WAVE);
-                if (lane == WAVE - 1) right0 = neg;
+                float right0 = wave_shift_down1(b[0], neg);
+                if (W > 1 && lane == WAVE - 1) right0 = ein;
 #pragma unroll
                 for (int j = 0; j < R; ++j) {
                     const float ls = row[st[j]];
@@ -277,7 +327,7 @@ __global__ __launch_bounds__(WAVE) void crf_kernel(CrfArgs a) {
                     const float as = fmaf(ls, c, b[j]);
                     float am = fmaf(lm, c, br);
                     if (MOD) am = fmaf(row[md[j]], fw[j], am);
-                    const float fc = Fblk[(i * R + j) * WAVE + lane] - ct;
+                    const float fc = Fblk[((size_t)i * R + j) * NT + tid] - ct;
                     const float ps = fast_exp2(fc + as);
                     const float pm = fast_exp2(fc + am);
                     atomicAdd(grow + st[j], ps);
@@ -285,37 +335,44 @@ __global__ __launch_bounds__(WAVE) void crf_kernel(CrfArgs a) {
                     if (MOD) atomicAdd(grow + md[j], pm * (fw[j] * inv_cmod));
                     b[j] = lse2(as, am);
                 }
-                if (((T - t) & 3) == 0) normalise(b, offB);
+                if (W > 1 && lane == 0) edgeB[(nbwd & 1) * W + wave] = b[0];
+                ++nbwd;
+                bnorm_pending = (nbwd & 3) == 0;
+                if (bnorm_pending) post_max(b);
+                __syncthreads();
             }
-            wave_lds_fence();
             // -- per-row normalisation (the reference's softmax over the column's
-            //    2L-1 transitions, c_crf_flipflop.c:400-401) and output scaling
-            //    -1/T (ctc.pyx:113)
-            if (lane < nrows) {
+            //    2L-1 transitions, c_crf_flipflop.c:400-401), fixed-order reduction of
+            //    the per-wave bins, output scaling -1/T (ctc.pyx:113)
+            if (tid < nrows) {
                 // every posterior lands in exactly one stay/move bin (ids < ncan);
                 // for cat-mod the mod bins hold p * fact ON TOP and are not summed
                 float sum = 0.f;
-                for (int col = 0; col < a.ncan; ++col) sum += gt[lane * SP + col];
-                rscale[lane] = sum;
+                for (int w = 0; w < W; ++w)
+                    for (int col = 0; col < a.ncan; ++col) sum += bins[(w * CK + tid) * SP + col];
+                rscale[tid] = sum;
             }
-            wave_lds_fence();
-            {
-                const int total = nrows * S;
-                for (int e = lane; e < total; e += WAVE) {
-                    const int row = e / S, col = e - row * S;
-                    const float sc = -1.0f / (rscale[row] * (float)T);
-                    const float g = gt[row * SP + col] * sc;
+            __syncthreads();
+            if (lane < S) {
+                for (int row = wave; row < nrows; row += W) {
+                    float g = 0.f;
+#pragma unroll
+                    for (int w = 0; w < W; ++w) g += bins[(w * CK + row) * SP + lane];
+                    g *= -1.0f / (rscale[row] * (float)T);
                     bad |= !isfinite(g);
-                    a.grad[(size_t)(t0 + row) * rowstride + (size_t)n * S + col] = g;
+                    a.grad[(size_t)(t0 + row) * rowstride + (size_t)n * S + lane] = g;
                 }
             }
-            wave_lds_fence();
+            __syncthreads();
         }
     }
     // bwd score = bwd[0][0] + sum of factors (c_crf_flipflop.c:234); score = mean (:482-491)
-    const float first = __shfl(b[0], 0, WAVE);
-    const double bwd_score2 = offB + (double)first;
-    if (lane == 0) {
+    if (bnorm_pending) {
+        float ein = 0.f;
+        fold_norm(b, ein, offB);
+    }
+    if (tid == 0) {
+        const double bwd_score2 = offB + (double)b[0];
         const double score2 = 0.5 * (fwd_score2 + bwd_score2);
         const float cst = (float)(-(score2 * 0.6931471805599453) / (double)T) * a.out_scale;
         a.cost[n] = cst;
@@ -404,15 +461,18 @@ int build_indices_dispatch(const int32_t *seqs, const int32_t *seqlen, size_t nb
 // ---------------------------------------------------------------------------
 // launcher
 // ---------------------------------------------------------------------------
-static int crf_pick_R(size_t max_seqlen) {
-    int R = 1;
-    while ((size_t)R * WAVE < max_seqlen) R *= 2;
-    return R;
-}
+struct CrfShape {
+    int R, W;
+};
 
-static int crf_ck(int R) {
-    const int c = 256 / R;
-    return c > 32 ? 32 : (c < 4 ? 4 : c);
+// (R, W) from the longest sequence: 2 cells per lane, up to 16 waves, then deeper strips
+static CrfShape crf_pick_shape(size_t max_seqlen) {
+    if (max_seqlen <= WAVE) return {1, 1};
+    int W = 1;
+    while ((size_t)2 * W * WAVE < max_seqlen && W < 16) W *= 2;
+    int R = 2;
+    while ((size_t)R * W * WAVE < max_seqlen) R *= 2;
+    return {R, W};
 }
 
 size_t crf_workspace_bytes(size_t ntrans, size_t nblk, size_t nbatch, size_t max_seqlen,
@@ -420,37 +480,39 @@ size_t crf_workspace_bytes(size_t ntrans, size_t nblk, size_t nbatch, size_t max
     (void)ntrans;
     if (!want_grad) return 256;
     if (max_seqlen == 0) max_seqlen = nblk + 1;
-    const int R = crf_pick_R(max_seqlen);
-    const size_t NK = (nblk + crf_ck(R) - 1) / crf_ck(R);
-    const size_t ck = nbatch * NK * (size_t)R * WAVE * sizeof(float);
+    const CrfShape sh = crf_pick_shape(max_seqlen);
+    const int CK = crf_ck(sh.R, sh.W);
+    const size_t NK = (nblk + CK - 1) / CK;
+    const size_t ck = nbatch * NK * (size_t)sh.R * sh.W * WAVE * sizeof(float);
     const size_t co = nbatch * NK * sizeof(double);
     return (ck + 255) / 256 * 256 + (co + 255) / 256 * 256 + 256;
 }
 
-template <int R, bool MOD>
+template <int R, int W, bool MOD>
 static int crf_launch_one(const CrfArgs &a, hipStream_t stream) {
-    const size_t lds = crf_lds_bytes(R, CrfCfg<R>::CK, a.S);
+    const size_t lds = crf_lds_bytes(R, W, a.S);
     if (lds > 160 * 1024) return 2;
     if (lds > 64 * 1024) {
-        if (hipFuncSetAttribute(reinterpret_cast<const void *>(&crf_kernel<R, MOD>),
+        if (hipFuncSetAttribute(reinterpret_cast<const void *>(&crf_kernel<R, W, MOD>),
                                 hipFuncAttributeMaxDynamicSharedMemorySize,
                                 (int)lds) != hipSuccess)
             return 4;
     }
-    hipLaunchKernelGGL((crf_kernel<R, MOD>), dim3(a.N), dim3(WAVE), lds, stream, a);
+    hipLaunchKernelGGL((crf_kernel<R, W, MOD>), dim3(a.N), dim3(W * WAVE), lds, stream, a);
     return hipGetLastError() == hipSuccess ? 0 : 4;
 }
 
 template <bool MOD>
-static int crf_launch_mod(int R, const CrfArgs &a, hipStream_t stream) {
-    switch (R) {
-        case 1: return crf_launch_one<1, MOD>(a, stream);
-        case 2: return crf_launch_one<2, MOD>(a, stream);
-        case 4: return crf_launch_one<4, MOD>(a, stream);
-        case 8: return crf_launch_one<8, MOD>(a, stream);
-        case 16: return crf_launch_one<16, MOD>(a, stream);
-        case 32: return crf_launch_one<32, MOD>(a, stream);
-        case 64: return crf_launch_one<64, MOD>(a, stream);
+static int crf_launch_mod(CrfShape sh, const CrfArgs &a, hipStream_t stream) {
+    const int key = sh.R * 100 + sh.W;
+    switch (key) {
+        case 101: return crf_launch_one<1, 1, MOD>(a, stream);
+        case 201: return crf_launch_one<2, 1, MOD>(a, stream);
+        case 202: return crf_launch_one<2, 2, MOD>(a, stream);
+        case 204: return crf_launch_one<2, 4, MOD>(a, stream);
+        case 208: return crf_launch_one<2, 8, MOD>(a, stream);
+        case 216: return crf_launch_one<2, 16, MOD>(a, stream);
+        case 416: return crf_launch_one<4, 16, MOD>(a, stream);
         default: return 2;
     }
 }
@@ -463,8 +525,8 @@ int crf_dispatch(const float *logprob, size_t ntrans, size_t nblk, size_t nbatch
                  size_t workspace_bytes, uint32_t *status, hipStream_t stream) {
     if (ntrans > 62 || ncan > ntrans || ncan == 0) return 2;
     if (max_seqlen == 0) max_seqlen = nblk + 1;
-    const int R = crf_pick_R(max_seqlen);
-    if (R > 64) return 2;
+    const CrfShape sh = crf_pick_shape(max_seqlen);
+    if ((size_t)sh.R * sh.W * WAVE < max_seqlen || sh.R > 4) return 2;
     const size_t need = crf_workspace_bytes(ntrans, nblk, nbatch, max_seqlen, grad != nullptr);
     if (need > workspace_bytes) return 3;
     CrfArgs a;
@@ -484,13 +546,14 @@ int crf_dispatch(const float *logprob, size_t ntrans, size_t nblk, size_t nbatch
     a.out_scale = out_scale;
     a.cost = cost;
     a.grad = grad;
-    const size_t NK = (nblk + crf_ck(R) - 1) / crf_ck(R);
-    const size_t ckb = (nbatch * NK * (size_t)R * WAVE * sizeof(float) + 255) / 256 * 256;
+    const int CK = crf_ck(sh.R, sh.W);
+    const size_t NK = (nblk + CK - 1) / CK;
+    const size_t ckb = (nbatch * NK * (size_t)sh.R * sh.W * WAVE * sizeof(float) + 255) / 256 * 256;
     a.ckpt = static_cast<float *>(workspace);
     a.ckoff = reinterpret_cast<double *>(static_cast<char *>(workspace) + (grad ? ckb : 0));
     a.status = status;
-    return modidx != nullptr ? crf_launch_mod<true>(R, a, stream)
-                             : crf_launch_mod<false>(R, a, stream);
+    return modidx != nullptr ? crf_launch_mod<true>(sh, a, stream)
+                             : crf_launch_mod<false>(sh, a, stream);
 }
 
 }  // namespace tk

@@ -46,6 +46,41 @@ __device__ __forceinline__ float lse2(float a, float b) {
     return mx + fast_log2(1.0f + fast_exp2(d));
 }
 
+// ---- DPP cross-lane primitives (GFX9 data-parallel-primitive controls) ------
+// quad_perm[1,0,3,2] = 0xB1, quad_perm[2,3,0,1] = 0x4E, row_half_mirror = 0x141,
+// row_mirror = 0x140, wave_shl:1 = 0x130, wave_shr:1 = 0x138.
+template <int CTRL>
+__device__ __forceinline__ float dpp_f32(float old, float src) {
+    return __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(old), __float_as_int(src),
+                                                      CTRL, 0xF, 0xF, false));
+}
+
+// lane l receives src of lane l-1 (lane 0 keeps `fill`): one VALU op, no LDS crossbar
+__device__ __forceinline__ float wave_shift_up1(float src, float fill) {
+    return dpp_f32<0x138>(fill, src);
+}
+// lane l receives src of lane l+1 (lane 63 keeps `fill`)
+__device__ __forceinline__ float wave_shift_down1(float src, float fill) {
+    return dpp_f32<0x130>(fill, src);
+}
+__device__ __forceinline__ int wave_shift_up1(int src, int fill) {
+    return __builtin_amdgcn_update_dpp(fill, src, 0x138, 0xF, 0xF, false);
+}
+
+// max over the 64 lanes, result uniform: 4 DPP butterflies inside each 16-lane
+// row, then 4 v_readlane across the rows (max is idempotent, so mirrors suffice)
+__device__ __forceinline__ float wave_allmax_dpp(float x) {
+    x = fmaxf(x, dpp_f32<0xB1>(x, x));
+    x = fmaxf(x, dpp_f32<0x4E>(x, x));
+    x = fmaxf(x, dpp_f32<0x141>(x, x));
+    x = fmaxf(x, dpp_f32<0x140>(x, x));
+    const float r0 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(x), 0));
+    const float r1 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(x), 16));
+    const float r2 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(x), 32));
+    const float r3 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(x), 48));
+    return fmaxf(fmaxf(r0, r1), fmaxf(r2, r3));
+}
+
 __device__ __forceinline__ float wave_allmax(float x) {
 #pragma unroll
     for (int m = 32; m >= 1; m >>= 1) {

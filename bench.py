@@ -14,8 +14,8 @@ HBM before the timed region), random-init weights.  Weak scaling: per-GPU batch
 is fixed, value = all ranks' chunks / max-over-ranks time.
 
 Rank 0 prints ONE JSON line with the contract fields plus
-  "roofline":     the logZ forward-backward op (K1+K2+K3 launches) timed with HIP
-                  events on its own stream inside the timed train steps;
+  "roofline":     the logZ forward-backward op (5 launches) at the train step's shape,
+                  timed with HIP events on its launching stream;
                   achieved = 3*T*N*S*4 bytes / mean duration
   "roofline_rowK": the same op at the north_star kernel shape T=4000 / N=256
   "cpu_baseline": the reference C (oracle/_ref) or the oracle port on host cores.
@@ -23,8 +23,16 @@ Rank 0 prints ONE JSON line with the contract fields plus
 import argparse
 import json
 import os
+import subprocess
 import sys
 import time
+
+# hipBLASLt's bias-epilogue path copies its user arguments with a call that is illegal
+# during stream capture (hard abort); plain rocBLAS GEMMs capture fine.
+os.environ.setdefault("DISABLE_ADDMM_CUDA_LT", "1")
+os.environ.setdefault("TORCH_BLAS_PREFER_HIPBLASLT", "0")
+os.environ.setdefault("ROCBLAS_USE_HIPBLASLT", "0")            # rocBLAS -> its own Tensile kernels
+os.environ.setdefault("MIOPEN_GEMM_ENFORCE_BACKEND", "1")      # MIOpen RNN GEMMs -> rocBLAS
 
 import numpy as np
 import torch
@@ -46,7 +54,8 @@ def make_batches(nbatch, chunk_len, stride, seed, dev, n=4):
         seqs, _ = synth.sequences(seqlens, s)
         sig = synth.signal_chunks(chunk_len, nbatch, s)
         out.append(dict(indata=torch.from_numpy(sig).to(dev),
-                        seqs=torch.from_numpy(seqs), seqlens=torch.from_numpy(seqlens)))
+                        seqs=torch.from_numpy(seqs).to(device=dev, dtype=torch.int32),
+                        seqlens=torch.from_numpy(seqlens).to(device=dev, dtype=torch.int32)))
     return out
 
 
@@ -92,25 +101,36 @@ def cpu_baseline(T, N, budget_s=12.0):
     from taiyaki_amd import synth
     oracle.build()
     cores = os.cpu_count() or 1
-    threads = min(cores, 8)     # the reference's own advice: OMP_NUM_THREADS=8 (README.md:362-372)
-    oracle.set_threads(threads)
     inp = synth.crf_case(T, N, 1)
     use_ref = oracle.ref_available()
-    oracle.crf_flipflop_loss(inp["scores"], inp["seqs"], inp["seqlens"], 1.0, use_ref=use_ref)
-    reps, t0 = 0, time.perf_counter()
-    while True:
+
+    def run(threads, budget):
+        oracle.set_threads(threads)
         oracle.crf_flipflop_loss(inp["scores"], inp["seqs"], inp["seqlens"], 1.0, use_ref=use_ref)
-        oracle.flipflop_logz_grad(inp["scores"])
-        reps += 1
-        el = time.perf_counter() - t0
-        if el > budget_s or reps >= 50:
-            break
-    return dict(value=round(N * reps / el, 2), unit="chunks/s (loss path only: crf grad + logZ fwd-bwd)",
-                cores=threads, kind="reference" if use_ref else "port",
-                sample="%d reps of T=%d N=%d (cfg 2 shape, SPEED_TEST inputs), %.1f s; host has %d cores; "
-                       "A = %s, B = oracle port" % (reps, T, N, el, cores,
-                                                    "genuine reference C (oracle/_ref)" if use_ref
-                                                    else "oracle port"))
+        reps, t0 = 0, time.perf_counter()
+        while True:
+            oracle.crf_flipflop_loss(inp["scores"], inp["seqs"], inp["seqlens"], 1.0, use_ref=use_ref)
+            oracle.flipflop_logz_grad(inp["scores"])
+            reps += 1
+            el = time.perf_counter() - t0
+            if el > budget:
+                return reps, el
+
+    threads = min(cores, 8)     # the reference's own advice: OMP_NUM_THREADS=8 (README.md:362-372)
+    reps, el = run(threads, budget_s)
+    out = dict(value=round(N * reps / el, 2),
+               unit="chunks/s (loss path only: crf grad + logZ fwd-bwd)",
+               cores=threads, kind="reference" if use_ref else "port",
+               sample="%d reps of T=%d N=%d (cfg 2 shape, SPEED_TEST inputs), %.1f s; host has %d "
+                      "cores; A = %s, B = oracle port" % (
+                          reps, T, N, el, cores,
+                          "genuine reference C (oracle/_ref)" if use_ref else "oracle port"))
+    if cores > threads:
+        allc = min(cores, N)
+        reps2, el2 = run(allc, budget_s / 2)
+        out["value_all_cores"] = round(N * reps2 / el2, 2)
+        out["cores_all"] = allc
+    return out
 
 
 def main():
@@ -121,13 +141,29 @@ def main():
     ap.add_argument("--chunk-len", type=int, default=4000)
     ap.add_argument("--batch", type=int, default=128, help="chunks per GPU")
     ap.add_argument("--size", type=int, default=256)
+    ap.add_argument("--conv", choices=["gemm", "miopen"], default="gemm",
+                    help="evaluate the Convolution layers as unfold+GEMM (default) or nn.Conv1d")
+    ap.add_argument("--miopen-find", action="store_true", help="torch.backends.cudnn.benchmark")
+    ap.add_argument("--lstm", choices=["miopen", "native"], default="miopen",
+                    help="native = ATen per-timestep LSTM (torch.backends.cudnn.enabled=False), "
+                         "capturable into a hipGraph; miopen = fused MIOpen RNN")
+    ap.add_argument("--graph", action="store_true",
+                    help="replay the whole step from a captured hipGraph (probed in a child process "
+                         "first).  Default for --lstm native; with the MIOpen LSTM the RNN backward "
+                         "is not capturable on ROCm 7.2 (hipBLASLt call inside capture), so the "
+                         "default there is eager launch")
+    ap.add_argument("--no-graph", action="store_true", help="force eager launch")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-rowk", action="store_true")
+    ap.add_argument("--probe-graph", action="store_true", help=argparse.SUPPRESS)
     args = ap.parse_args()
 
     from taiyaki_amd import _lib, layers, models, parallel, train
-    rank, local, world = parallel.init_from_env()
-    if world != args.gpus:
+    if args.probe_graph:
+        rank, local, world = 0, int(os.environ.get("LOCAL_RANK", "0")), 1
+    else:
+        rank, local, world = parallel.init_from_env()
+    if world != args.gpus and not args.probe_graph:
         if rank == 0:
             print("warning: --gpus %d but WORLD_SIZE=%d" % (args.gpus, world), file=sys.stderr)
     if not torch.cuda.is_available():
@@ -140,43 +176,67 @@ def main():
     stride = 5
     T = args.chunk_len // stride
     torch.manual_seed(1234)     # same init on every rank, then broadcast anyway
+    torch.backends.cudnn.benchmark = bool(args.miopen_find)
+    if args.lstm == "native":
+        torch.backends.cudnn.enabled = False
+    try:
+        torch.backends.cuda.preferred_blas_library("cublas")        # = rocBLAS on ROCm
+    except Exception:
+        pass
+    use_graph = (args.graph or args.lstm == "native") and not args.no_graph
+    if use_graph and not args.probe_graph:
+        # a failed capture aborts the process inside the HIP runtime, so try it in a child first
+        # (tiny shapes: what is probed is whether LSTM forward+backward captures at all)
+        cmd = [sys.executable, os.path.abspath(__file__), "--probe-graph", "--chunk-len", "200",
+               "--batch", "4", "--size", "32", "--conv", args.conv, "--lstm", args.lstm]
+        env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE")}
+        try:
+            pr = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900)
+            use_graph = pr.returncode == 0 and "graph-probe-ok" in pr.stdout
+            if not use_graph and rank == 0:
+                print("hipGraph probe failed (rc %d): %s" % (pr.returncode, pr.stderr[-400:]),
+                      file=sys.stderr)
+        except subprocess.TimeoutExpired:
+            use_graph = False
     net = models.mLstm_flipflop(size=args.size, stride=stride).to(dev)
+    for m in net.modules():
+        if hasattr(m, "use_gemm"):
+            m.use_gemm = args.conv == "gemm"
     parallel.broadcast_parameters(net)
     arena = parallel.FlatGradArena(net)
     trainer = train.Trainer(net, arena)
-    batches = make_batches(args.batch, args.chunk_len, stride, 17 + rank, dev)
-
-    # ---- HIP-event instrumentation of the logZ op inside the train step ------
-    events = []
-    orig_launch = layers._logz_launch
-    timing = {"on": False}
-
-    def timed_launch(x, want_grad):
-        if not timing["on"]:
-            return orig_launch(x, want_grad)
-        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        a.record()      # torch's current stream == the stream the kernels are launched on
-        r = orig_launch(x, want_grad)
-        b.record()
-        events.append((a, b))
-        return r
-    layers._logz_launch = timed_launch
+    batches = make_batches(args.batch, args.chunk_len, stride, 17 + rank, dev,
+                           n=2 if args.probe_graph else 4)
+    mode = "eager"
+    stepper = trainer
+    if use_graph:
+        try:
+            g = train.GraphedTrainer(trainer, batches[0], seq_capacity=args.batch * (T + 1))
+            g.load(batches[0])
+            g.capture()
+            stepper, mode = g, "hipGraph replay of the whole step"
+        except Exception as exc:      # report, never hide
+            print("hipGraph capture failed (%s: %s); running eagerly" % (type(exc).__name__, exc),
+                  file=sys.stderr)
+    if args.probe_graph:
+        stepper.step(batches[1])
+        torch.cuda.synchronize()
+        _lib.raise_if_nonfinite()
+        print("graph-probe-ok" if mode != "eager" else "graph-probe-eager")
+        return
 
     for i in range(args.warmup):
-        trainer.step(batches[i % len(batches)])
+        stepper.step(batches[i % len(batches)])
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
-    timing["on"] = True
     t0 = time.perf_counter()
     for i in range(args.steps):
-        trainer.step(batches[i % len(batches)])
+        stepper.step(batches[i % len(batches)])
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
-    timing["on"] = False
-    layers._logz_launch = orig_launch
     _lib.raise_if_nonfinite()
     if world > 1:
         tmax = torch.tensor([elapsed], dtype=torch.float64, device=dev)
@@ -185,14 +245,17 @@ def main():
 
     if rank == 0:
         nglobal = args.batch * world
-        ms = [a.elapsed_time(b) for a, b in events]
-        dur = float(np.mean(ms)) * 1e-3
+        # the loss path's roofline kernel at the train step's own shape, HIP events on
+        # the launching stream, right after the timed steps (the step itself is a
+        # hipGraph replay, so per-launch events cannot be interleaved with it)
+        dur, dmin = time_logz_op(T, args.batch, dev, 30)
         alg = 3.0 * T * args.batch * 40 * 4
-        roofline = dict(bound="hbm", kernel="logZ forward-backward op (logz_transfer + logz_scan + "
-                        "logz_posterior), T=%d N=%d in-step" % (T, args.batch),
+        roofline = dict(bound="hbm", kernel="logZ forward-backward op (logz_transfer + combine + scan + "
+                        "expand + logz_posterior), T=%d N=%d (the train step's shape)" % (T, args.batch),
                         achieved=round(alg / dur / 1e9, 1), peak=HBM_PEAK_GBS, unit="GB/s",
                         frac=round(alg / dur / 1e9 / HBM_PEAK_GBS, 4), traffic=None,
-                        algorithmic_bytes=alg, mean_us=round(dur * 1e6, 2), launches=len(ms))
+                        algorithmic_bytes=alg, mean_us=round(dur * 1e6, 2), min_us=round(dmin * 1e6, 2),
+                        launches=30)
         out = dict(metric="signal-chunks/sec (T=4000) flip-flop train step", value=round(
                        nglobal * args.steps / elapsed, 2),
                    unit="chunks/s", n_gpus=world, steps=args.steps, warmup=args.warmup,
@@ -201,7 +264,8 @@ def main():
                    config=dict(workload="configs[1]: mLstm_flipflop r9.4.1 DNA, chunk_len=%d (T=%d "
                                "blocks), %d chunks/GPU, size %d, HIP flip-flop CRF loss + logZ, AdamW"
                                % (args.chunk_len, T, args.batch, args.size),
-                               global_batch=nglobal, chunk_len=args.chunk_len,
+                               global_batch=nglobal, chunk_len=args.chunk_len, launch=mode,
+                               conv=args.conv, lstm=args.lstm,
                                parallelism="dp%d (reads sharded, flat RCCL all-reduce)" % world),
                    roofline=roofline)
         if not args.no_rowk:

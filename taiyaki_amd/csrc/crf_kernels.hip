@@ -492,11 +492,15 @@ template <int R, int W, bool MOD>
 static int crf_launch_one(const CrfArgs &a, hipStream_t stream) {
     const size_t lds = crf_lds_bytes(R, W, a.S);
     if (lds > 160 * 1024) return 2;
-    if (lds > 64 * 1024) {
+    // raise the dynamic-LDS cap once per instantiation (kept out of the launch path so
+    // that launches are capturable into a hipGraph)
+    static size_t cap = 64 * 1024;
+    if (lds > cap) {
         if (hipFuncSetAttribute(reinterpret_cast<const void *>(&crf_kernel<R, W, MOD>),
                                 hipFuncAttributeMaxDynamicSharedMemorySize,
-                                (int)lds) != hipSuccess)
+                                160 * 1024) != hipSuccess)
             return 4;
+        cap = 160 * 1024;
     }
     hipLaunchKernelGGL((crf_kernel<R, W, MOD>), dim3(a.N), dim3(W * WAVE), lds, stream, a);
     return hipGetLastError() == hipSuccess ? 0 : 4;

@@ -752,10 +752,14 @@ static int logz_launch(const float *scores, size_t T, size_t N, float *logz, flo
                        K1_WAVES * bufbytes, stream, scores, (int)T, (int)N, Npad, ws);
     {
         const size_t lds = (size_t)LOGZ_SUPER * XMat<NB>::NW * WAVE * sizeof(float);
-        if (lds > 64 * 1024 &&
-            hipFuncSetAttribute(reinterpret_cast<const void *>(&logz_combine_kernel<NB>),
-                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
-            return 4;
+        static bool raised = false;
+        if (lds > 64 * 1024 && !raised) {
+            if (hipFuncSetAttribute(reinterpret_cast<const void *>(&logz_combine_kernel<NB>),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize,
+                                    160 * 1024) != hipSuccess)
+                return 4;
+            raised = true;
+        }
         hipLaunchKernelGGL(logz_combine_kernel<NB>, dim3(ncols, NSUP), dim3(LOGZ_SUPER * WAVE), lds,
                            stream, C, Npad, ws);
     }
@@ -767,10 +771,14 @@ static int logz_launch(const float *scores, size_t T, size_t N, float *logz, flo
         dim3 grid(ncols, C), block(K3_WAVES * WAVE);
         const size_t lds = K3_WAVES * (size_t)k3_buf_f4<NB>() * sizeof(f4) +
                            2 * F::NS * WAVE * sizeof(float);
-        if (lds > 64 * 1024 &&
-            hipFuncSetAttribute(reinterpret_cast<const void *>(&logz_posterior_kernel<NB>),
-                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
-            return 4;
+        static bool raised3 = false;
+        if (lds > 64 * 1024 && !raised3) {
+            if (hipFuncSetAttribute(reinterpret_cast<const void *>(&logz_posterior_kernel<NB>),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize,
+                                    160 * 1024) != hipSuccess)
+                return 4;
+            raised3 = true;
+        }
         hipLaunchKernelGGL(logz_posterior_kernel<NB>, grid, block, lds, stream, scores, grad,
                            (int)T, (int)N, Npad, ws, status);
     }

@@ -92,10 +92,21 @@ def _truncated_normal_(param, sd):
 
 
 class Convolution(nn.Module):
-    """layers.py:744-850: TBF in/out, pad (winlen//2, (winlen-1)//2), then activation."""
+    """layers.py:744-850: TBF in/out, pad (winlen//2, (winlen-1)//2), then activation.
 
-    def __init__(self, insize, size, winlen, stride=1, fun=torch.tanh):
+    Same parameters as the reference (`conv.weight` (size, insize, winlen), `conv.bias`),
+    but evaluated as window-unfold + GEMM: MIOpen's choices for these skinny 1-D
+    shapes (batch 128 x 4000 samples, 1->4->16->256 channels) fall back to naive
+    direct/weight-gradient kernels that cost more than the whole LSTM stack, while
+    the same contraction as a rocBLAS GEMM is a few hundred microseconds.  Set
+    `use_gemm=False` for the plain nn.Conv1d evaluation (identical result).
+    """
+
+    def __init__(self, insize, size, winlen, stride=1, fun=torch.tanh, use_gemm=True):
         super().__init__()
+        self.winlen = winlen
+        self.stride = stride
+        self.use_gemm = use_gemm
         self.pad = nn.ConstantPad1d((winlen // 2, (winlen - 1) // 2), 0)
         self.conv = nn.Conv1d(insize, size, winlen, stride=stride)
         self.activation = fun
@@ -103,8 +114,16 @@ class Convolution(nn.Module):
         _truncated_normal_(self.conv.bias, 0.5)
 
     def forward(self, x):
-        out = self.activation(self.conv(self.pad(x.permute(1, 2, 0))))
-        return out.permute(2, 0, 1)
+        if not self.use_gemm:
+            out = self.activation(self.conv(self.pad(x.permute(1, 2, 0))))
+            return out.permute(2, 0, 1)
+        # x: (T, N, C) -> pad time -> windows (Tout, N, C, winlen) -> GEMM with (C*winlen, size)
+        xp = nn.functional.pad(x, (0, 0, 0, 0, self.winlen // 2, (self.winlen - 1) // 2))
+        win = xp.unfold(0, self.winlen, self.stride)            # (Tout, N, C, winlen) view
+        tout, n = win.shape[0], win.shape[1]
+        w = self.conv.weight.reshape(self.conv.weight.shape[0], -1)     # (size, C*winlen)
+        out = torch.addmm(self.conv.bias, win.reshape(tout * n, -1), w.t())
+        return self.activation(out.view(tout, n, -1))
 
 
 class _Rnn(nn.Module):

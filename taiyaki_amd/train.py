@@ -31,7 +31,8 @@ class Trainer:
         self.net = net
         self.arena = arena
         self.opt = torch.optim.AdamW(arena.params, lr=lr, weight_decay=weight_decay, eps=eps,
-                                     betas=(0.9, 0.999))
+                                     betas=(0.9, 0.999),
+                                     capturable=arena.flat.is_cuda)  # no host sync in step()
         self.grad_clip = grad_clip
 
     def step(self, batch):
@@ -46,3 +47,50 @@ class Trainer:
             self.arena.flat.clamp_(min=-self.grad_clip, max=self.grad_clip)
         self.opt.step()
         return loss
+
+
+class GraphedTrainer:
+    """The whole optimiser step captured ONCE into a hipGraph and replayed.
+
+    The PyTorch-ROCm LSTM issues ~16,000 tiny per-timestep kernels per step at
+    T = 800 x 5 layers; launched eagerly the step is bound by the host (190 ms),
+    replayed from a graph it is bound by the GPU.  Requirements met here: static
+    input buffers (each batch is copied in), sequence tensors resident on the
+    device and padded to a fixed capacity, no host synchronisation inside the step
+    (`_lib.set_strict(False)`, capturable AdamW), loss kernels launched on the
+    capturing stream through the C ABI.
+    """
+
+    def __init__(self, trainer, example_batch, seq_capacity):
+        self.trainer = trainer
+        dev = trainer.arena.flat.device
+        self.static = dict(
+            indata=torch.zeros_like(example_batch["indata"], device=dev),
+            seqs=torch.zeros(seq_capacity, dtype=torch.int32, device=dev),
+            seqlens=torch.zeros_like(example_batch["seqlens"], dtype=torch.int32, device=dev))
+        self.loss = None
+        self.graph = None
+
+    def load(self, batch):
+        self.static["indata"].copy_(batch["indata"], non_blocking=True)
+        n = batch["seqs"].numel()
+        self.static["seqs"][:n].copy_(batch["seqs"], non_blocking=True)
+        self.static["seqlens"].copy_(batch["seqlens"], non_blocking=True)
+
+    def capture(self, warmup=3):
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            for _ in range(warmup):
+                self.trainer.step(self.static)
+        torch.cuda.current_stream().wait_stream(side)
+        torch.cuda.synchronize()
+        self.graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(self.graph):
+            self.loss = self.trainer.step(self.static)
+        torch.cuda.synchronize()
+
+    def step(self, batch):
+        self.load(batch)
+        self.graph.replay()
+        return self.loss

@@ -107,3 +107,22 @@ def test_product_code_never_imports_the_oracle():
                 src = open(os.path.join(dirpath, f)).read()
                 assert not re.search(r"^\s*(import oracle|from oracle)", src, flags=re.M), f
                 assert "liboracle" not in src and "/root/reference" not in src, f
+
+
+@pytest.mark.parametrize("cin,cout,k,stride", [(1, 4, 5, 1), (4, 16, 5, 1), (16, 32, 19, 5), (3, 8, 4, 2)])
+def test_convolution_gemm_form_equals_conv1d(cin, cout, k, stride):
+    """The unfold+GEMM evaluation of `Convolution` is the reference layer
+    (layers.py:816-831: pad, nn.Conv1d, activation) value- and gradient-wise."""
+    from taiyaki_amd import layers
+    torch.manual_seed(3)
+    conv = layers.Convolution(cin, cout, k, stride=stride, fun=layers.swish)
+    x = torch.randn(203, 3, cin, requires_grad=True)
+    outs = []
+    for use_gemm in (True, False):
+        conv.use_gemm = use_gemm
+        y = conv(x)
+        gx, gw, gb = torch.autograd.grad(y.square().mean(), [x, conv.conv.weight, conv.conv.bias])
+        outs.append((y.detach(), gx, gw, gb))
+    for a, b in zip(*outs):
+        assert a.shape == b.shape
+        torch.testing.assert_close(a, b, rtol=1e-4, atol=1e-6)

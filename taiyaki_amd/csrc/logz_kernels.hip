@@ -297,7 +297,6 @@ __global__ __launch_bounds__(K1_WAVES *WAVE, 2) void logz_transfer_kernel(
     const float *__restrict__ scores, int T, int N, int Npad, LogzWs ws) {
     using F = FF<NB>;
     using X = XMat<NB>;
-    static_assert(2 * WAVE * F::S >= X::NW * WAVE, "pair region must hold one XMat");
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int wave = threadIdx.x >> 6, lane = lane_id();
     const int c = blockIdx.y;
@@ -338,25 +337,70 @@ __global__ __launch_bounds__(K1_WAVES *WAVE, 2) void logz_transfer_kernel(
         }
         P.renorm();
     }
-    // tree combine: (P0 P1) (P2 P3)
-    float *pair = reinterpret_cast<float *>(smem) + (wave >> 1) * (2 * WAVE * F::S);
-    float *pair0 = reinterpret_cast<float *>(smem);
+    // combine P0 P1 P2 P3 row-parallel: row r of the product is (row r of P0) (x) P1
+    // (x) P2 (x) P3, three cheap mat-vecs, and the rows are spread over the 4 waves
+    // (a serial 8x8 x 8x8 tree kept three waves idle for ~30 % of the block's life).
+    float *mats = reinterpret_cast<float *>(smem);          // [K1_WAVES][NW][64], overlays the buffers
     __syncthreads();
-    if (wave & 1) xmat_lds_put<NB>(P, pair, lane);
+    xmat_lds_put<NB>(P, mats + (size_t)wave * X::NW * WAVE, lane);
     __syncthreads();
-    X Q, R;
-    if (!(wave & 1)) {
-        xmat_lds_get<NB>(Q, pair, lane);
-        xmat_mul<NB>(P, Q, R);
+    constexpr int RPW = (F::NS + K1_WAVES - 1) / K1_WAVES;  // rows per wave
+    float rows[RPW][F::NS];
+    int rexp[RPW];
+    double msum = 0.0;
+#pragma unroll
+    for (int q = 0; q < RPW; ++q) {
+        const int r = wave * RPW + q;
+        if (r < F::NS) {
+            float v[F::NS];
+#pragma unroll
+            for (int k = 0; k < F::NS; ++k) v[k] = mats[(r * F::NS + k) * WAVE + lane];
+            long long eacc = __float_as_int(mats[(F::NS * F::NS + r) * WAVE + lane]);
+            const bool zero_row = eacc == ZERO_ROW_EXP;
+#pragma unroll
+            for (int m = 1; m < K1_WAVES; ++m) {
+                X A;
+                xmat_lds_get<NB>(A, mats + (size_t)m * X::NW * WAVE, lane);
+                float out[F::NS];
+                eacc += xvec_mat<NB>(v, A, out);
+                if (q == 0) msum += A.M;
+#pragma unroll
+                for (int k = 0; k < F::NS; ++k) v[k] = out[k];
+            }
+            float mx = v[0];
+#pragma unroll
+            for (int k = 1; k < F::NS; ++k) mx = fmaxf(mx, v[k]);
+            rexp[q] = (zero_row || !(mx > 0.f)) ? ZERO_ROW_EXP : (int)eacc;
+#pragma unroll
+            for (int k = 0; k < F::NS; ++k) rows[q][k] = v[k];
+        }
+    }
+    if (wave == 0) msum += P.M;         // M of P0 (each wave added P1..P3 once)
+    __syncthreads();                    // all reads of `mats` done
+    float *tot = mats;                  // assemble [NW][64]
+#pragma unroll
+    for (int q = 0; q < RPW; ++q) {
+        const int r = wave * RPW + q;
+        if (r < F::NS) {
+#pragma unroll
+            for (int k = 0; k < F::NS; ++k) tot[(r * F::NS + k) * WAVE + lane] = rows[q][k];
+            tot[(F::NS * F::NS + r) * WAVE + lane] = __int_as_float(rexp[q]);
+        }
+    }
+    if (wave == 0) {
+        tot[(F::NS * F::NS + F::NS) * WAVE + lane] = __int_as_float(__double2loint(msum));
+        tot[(F::NS * F::NS + F::NS + 1) * WAVE + lane] = __int_as_float(__double2hiint(msum));
     }
     __syncthreads();
-    if (wave == 2) xmat_lds_put<NB>(R, pair0, lane);
-    __syncthreads();
-    if (wave == 0) {
-        xmat_lds_get<NB>(Q, pair0, lane);
-        xmat_mul<NB>(R, Q, P);
+    {
         const size_t n = (size_t)n0 + lane;     // < Npad always
-        P.store(ws.Pc + (size_t)c * X::NF4 * Npad + n, Npad);
+        f4 *dst = ws.Pc + (size_t)c * X::NF4 * Npad + n;
+        for (int q = wave; q < X::NF4; q += K1_WAVES) {
+            f4 o;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) o[r] = (4 * q + r < X::NW) ? tot[(4 * q + r) * WAVE + lane] : 0.f;
+            dst[(size_t)q * Npad] = o;
+        }
     }
 }
 
@@ -748,8 +792,20 @@ static int logz_launch(const float *scores, size_t T, size_t N, float *logz, flo
     const int NSUP = (C + LOGZ_SUPER - 1) / LOGZ_SUPER;
     const int ncols = (int)((N + WAVE - 1) / WAVE), Npad = ncols * WAVE;
     const size_t bufbytes = (size_t)WAVE * F::PIECES * sizeof(f4);
-    hipLaunchKernelGGL(logz_transfer_kernel<NB>, dim3(ncols, C), dim3(K1_WAVES * WAVE),
-                       K1_WAVES * bufbytes, stream, scores, (int)T, (int)N, Npad, ws);
+    {
+        const size_t matbytes = (size_t)K1_WAVES * XMat<NB>::NW * WAVE * sizeof(float);
+        const size_t lds = matbytes > K1_WAVES * bufbytes ? matbytes : K1_WAVES * bufbytes;
+        static bool raised1 = false;
+        if (lds > 64 * 1024 && !raised1) {
+            if (hipFuncSetAttribute(reinterpret_cast<const void *>(&logz_transfer_kernel<NB>),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize,
+                                    160 * 1024) != hipSuccess)
+                return 4;
+            raised1 = true;
+        }
+        hipLaunchKernelGGL(logz_transfer_kernel<NB>, dim3(ncols, C), dim3(K1_WAVES * WAVE), lds,
+                           stream, scores, (int)T, (int)N, Npad, ws);
+    }
     {
         const size_t lds = (size_t)LOGZ_SUPER * XMat<NB>::NW * WAVE * sizeof(float);
         static bool raised = false;

@@ -405,145 +405,240 @@ __global__ __launch_bounds__(K1_WAVES *WAVE, 2) void logz_transfer_kernel(
 }
 
 // ---------------------------------------------------------------------------
-// K1b: total product of each super-chunk.  grid = (ncols, NSUP), block = 512.
-// Row i of (A (x) B) is (row i of A) (x) B, so wave i carries ONE row of the
-// running product through the super-chunk's matrices with cheap mat-vecs; the
-// matrices are staged once in LDS (wave w loads chunk c0 + w), no exchange
-// between the waves is ever needed.
+// The three small "middle" kernels work with EIGHT LANES PER READ (lane g of the
+// group owns row g / column g of the 2nb x 2nb matrices; groups of 8 are
+// half-rows of the DPP network, so group max is 3 DPP ops and a broadcast is one
+// ds_bpermute).  A serial step is ~40 instructions instead of a 64-FMA mat-vec
+// per lane, and a whole chain's matrices fit in registers up front.
+// Word k of read n lives at f4 index (k / 4) * Npad + n, component k % 4.
 // ---------------------------------------------------------------------------
+constexpr int GRP = 8;
+
+__device__ __forceinline__ float grp_bcast(float x, int i) {
+    return __shfl(x, (lane_id() & ~(GRP - 1)) | i, WAVE);
+}
+__device__ __forceinline__ int grp_bcast(int x, int i) {
+    return __shfl(x, (lane_id() & ~(GRP - 1)) | i, WAVE);
+}
+__device__ __forceinline__ int grp_max_i(int x) {
+    x = max(x, __builtin_amdgcn_update_dpp(x, x, 0xB1, 0xF, 0xF, false));
+    x = max(x, __builtin_amdgcn_update_dpp(x, x, 0x4E, 0xF, 0xF, false));
+    x = max(x, __builtin_amdgcn_update_dpp(x, x, 0x141, 0xF, 0xF, false));
+    return x;
+}
+__device__ __forceinline__ float grp_max_f(float x) {
+    x = fmaxf(x, dpp_f32<0xB1>(x, x));
+    x = fmaxf(x, dpp_f32<0x4E>(x, x));
+    x = fmaxf(x, dpp_f32<0x141>(x, x));
+    return x;
+}
+// Stage the matrices `mat[m]` (m < NM) of NR consecutive reads starting at read n0 into
+// LDS with coalesced 16-byte loads: image[m][r][4*NF4] words.  One wave; NM*NR*NF4
+// float4 pieces spread over the 64 lanes (all loads of a stage are issued back to back).
+template <int NB, int NR, int NM, typename MatOf>
+__device__ __forceinline__ void stage_mats(MatOf mat_of, size_t Npad, size_t n0, float *image,
+                                           int lane) {
+    using X = XMat<NB>;
+    constexpr int PER = NR * X::NF4;                // pieces per matrix
+    constexpr int TOTAL = NM * PER;
+    constexpr int NIT = (TOTAL + WAVE - 1) / WAVE;
+    f4 tmp[NIT];
+#pragma unroll
+    for (int it = 0; it < NIT; ++it) {
+        const int idx = min(it * WAVE + lane, TOTAL - 1);
+        const int m = idx / PER, rem = idx % PER, q = rem / NR, r = rem % NR;
+        tmp[it] = mat_of(m)[(size_t)q * Npad + min(n0 + r, Npad - 1)];
+    }
+#pragma unroll
+    for (int it = 0; it < NIT; ++it) {
+        const int idx = it * WAVE + lane;
+        if (idx < TOTAL) {
+            const int m = idx / PER, rem = idx % PER, q = rem / NR, r = rem % NR;
+            *reinterpret_cast<f4 *>(image + ((size_t)(m * NR + r) * X::NF4 + q) * 4) = tmp[it];
+        }
+    }
+    wave_lds_fence();
+}
+
+// one lane's share of a matrix for v (x) A: column g (NS words) + exponent of row g
 template <int NB>
-__global__ __launch_bounds__(LOGZ_SUPER *WAVE) void logz_combine_kernel(int C, int Npad,
-                                                                     LogzWs ws) {
+struct ColShare {
+    float a[2 * NB];
+    int e;
+    double M;
+    __device__ __forceinline__ void load(const float *img, int g) {     // img: one read's words
+        constexpr int NS = 2 * NB;
+        const int gc = min(g, NS - 1);
+#pragma unroll
+        for (int i = 0; i < NS; ++i) a[i] = img[i * NS + gc];
+        e = (g < NS) ? __float_as_int(img[NS * NS + gc]) : ZERO_ROW_EXP;
+        M = __hiloint2double(__float_as_int(img[NS * NS + NS + 1]), __float_as_int(img[NS * NS + NS]));
+    }
+};
+
+// one lane's share for A (x) u: row g (NS words) + exponent of row g
+template <int NB>
+struct RowShare {
+    float a[2 * NB];
+    int e;
+    __device__ __forceinline__ void load(const float *img, int g) {
+        constexpr int NS = 2 * NB;
+        const int gc = min(g, NS - 1);
+#pragma unroll
+        for (int j = 0; j < NS; ++j) a[j] = img[gc * NS + j];
+        e = (g < NS) ? __float_as_int(img[NS * NS + gc]) : ZERO_ROW_EXP;
+    }
+};
+
+// v (lane g holds v[g]) <- normalise(v (x) A); returns the exponent taken out (group-uniform)
+template <int NB>
+__device__ __forceinline__ int grp_vec_mat(float &v, const ColShare<NB> &A, int g) {
+    constexpr int NS = 2 * NB;
+    const int t = (v > 0.f && A.e != ZERO_ROW_EXP) ? A.e + __builtin_amdgcn_frexp_expf(v) : ZERO_ROW_EXP;
+    int emax = grp_max_i(t);
+    if (emax == ZERO_ROW_EXP) emax = 0;
+    const float vs = __builtin_amdgcn_ldexpf(v, max(A.e - emax, -300));     // row g's scaled weight
+    float acc = 0.f;
+#pragma unroll
+    for (int i = 0; i < NS; ++i) acc = fmaf(grp_bcast(vs, i), A.a[i], acc);
+    if (g >= NS) acc = 0.f;
+    const float mx = grp_max_f(acc);
+    const int ex = (mx > 0.f) ? __builtin_amdgcn_frexp_expf(mx) : 0;
+    v = __builtin_amdgcn_ldexpf(acc, -ex);
+    return emax + ex;
+}
+
+// u (lane g holds u[g]) <- normalise(A (x) u)
+template <int NB>
+__device__ __forceinline__ void grp_mat_vec(float &u, const RowShare<NB> &A, int g) {
+    constexpr int NS = 2 * NB;
+    float acc = 0.f;
+#pragma unroll
+    for (int j = 0; j < NS; ++j) acc = fmaf(A.a[j], grp_bcast(u, j), acc);
+    if (g >= NS) acc = 0.f;
+    const int t = (acc > 0.f && A.e != ZERO_ROW_EXP) ? A.e + __builtin_amdgcn_frexp_expf(acc) : ZERO_ROW_EXP;
+    int emax = grp_max_i(t);
+    if (emax == ZERO_ROW_EXP) emax = 0;
+    u = __builtin_amdgcn_ldexpf(acc, max(A.e - emax, -300));
+}
+
+// ---------------------------------------------------------------------------
+// K1b: total product of each super-chunk.  ONE WAVE PER READ: lane (i, k) holds
+// element (i, k) of the running product (group i = row i; row_i(AB) = row_i(A) B,
+// so the 8 groups advance independently and every matrix column is loaded once
+// per wave).  grid = (ceil(N/4), NSUP), block = 256 (4 reads).
+// ---------------------------------------------------------------------------
+constexpr int K1B_WAVES = 4;
+
+template <int NB>
+__global__ __launch_bounds__(K1B_WAVES *WAVE) void logz_combine_kernel(int N, int C, int Npad,
+                                                                    LogzWs ws) {
     using F = FF<NB>;
     using X = XMat<NB>;
-    static_assert(LOGZ_SUPER >= F::NS, "one wave per matrix row");
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    float *mats = reinterpret_cast<float *>(smem);          // [LOGZ_SUPER][NW][64]
+    constexpr int NFW = 4 * X::NF4;
+    __shared__ __attribute__((aligned(16))) float image[K1B_WAVES][LOGZ_SUPER][NFW];
     const int wave = threadIdx.x >> 6, lane = lane_id();
-    const size_t n = (size_t)blockIdx.x * WAVE + lane;
+    const int g = lane & (GRP - 1), row = lane >> 3;
+    const size_t nreal = (size_t)blockIdx.x * K1B_WAVES + wave;
+    const size_t n = min(nreal, (size_t)Npad - 1);
     const int s = blockIdx.y;
-    const int c0 = s * LOGZ_SUPER, c1 = min(C, c0 + LOGZ_SUPER);      // [c0, c1)
+    const int c0 = s * LOGZ_SUPER, c1 = min(C, c0 + LOGZ_SUPER);
     const int nc = c1 - c0;
     const size_t mstride = (size_t)X::NF4 * Npad;
-    if (wave < nc) {
-        const f4 *src = ws.Pc + (size_t)(c0 + wave) * mstride + n;
-        f4 raw[X::NF4];
-#pragma unroll
-        for (int q = 0; q < X::NF4; ++q) raw[q] = src[(size_t)q * Npad];
-        float *dst = mats + (size_t)wave * X::NW * WAVE;
-#pragma unroll
-        for (int k = 0; k < X::NW; ++k) dst[k * WAVE + lane] = raw[k >> 2][k & 3];
-    }
-    __syncthreads();
-    const bool rowwave = wave < F::NS;       // (no early return: every wave reaches the barriers)
-    // row `wave` of the total: v = e_wave (x) P_c0 (x) ... (x) P_{c1-1}
-    float v[F::NS];
-#pragma unroll
-    for (int k = 0; k < F::NS; ++k) v[k] = (k == wave) ? 1.f : 0.f;
+    stage_mats<NB, 1, LOGZ_SUPER>(
+        [&](int m) { return ws.Pc + (size_t)(c0 + min(m, nc - 1)) * mstride; }, Npad, n,
+        &image[wave][0][0], lane);
+    float v = (g == row && row < F::NS) ? 1.f : 0.f;
     long long eacc = 0;
     double macc = 0.0;
-    for (int i = 0; rowwave && i < nc; ++i) {
-        X A;
-        xmat_lds_get<NB>(A, mats + (size_t)i * X::NW * WAVE, lane);
-        float out[F::NS];
-        eacc += xvec_mat<NB>(v, A, out);
-        macc += A.M;
 #pragma unroll
-        for (int k = 0; k < F::NS; ++k) v[k] = out[k];
+    for (int i = 0; i < LOGZ_SUPER; ++i) {
+        if (i < nc) {
+            ColShare<NB> A;
+            A.load(&image[wave][i][0], g);
+            eacc += grp_vec_mat<NB>(v, A, g);
+            macc += A.M;
+        }
     }
-    // assemble Tot[s]: row `wave` -> words [wave*NS, wave*NS+NS), exponent, M
-    float mx = v[0];
-#pragma unroll
-    for (int k = 1; k < F::NS; ++k) mx = fmaxf(mx, v[k]);
-    const int erow = (mx > 0.f) ? (int)eacc : ZERO_ROW_EXP;
-    __syncthreads();            // every wave is done reading `mats`
-    float *tot = mats;          // reuse: [NW][64]
-    if (rowwave) {
-#pragma unroll
-        for (int k = 0; k < F::NS; ++k) tot[(wave * F::NS + k) * WAVE + lane] = v[k];
-        tot[(F::NS * F::NS + wave) * WAVE + lane] = __int_as_float(erow);
-    }
-    if (wave == 0) {
-        tot[(F::NS * F::NS + F::NS) * WAVE + lane] = __int_as_float(__double2loint(macc));
-        tot[(F::NS * F::NS + F::NS + 1) * WAVE + lane] = __int_as_float(__double2hiint(macc));
-    }
-    __syncthreads();
-    // coalesced store: word k of lane `lane` -> f4 q = k/4
-    f4 *dstT = ws.Tot + (size_t)s * mstride + n;
-    for (int q = wave; q < X::NF4; q += LOGZ_SUPER) {
-        f4 o;
-#pragma unroll
-        for (int r = 0; r < 4; ++r) o[r] = (4 * q + r < X::NW) ? tot[(4 * q + r) * WAVE + lane] : 0.f;
-        dstT[(size_t)q * Npad] = o;
+    if (nreal >= (size_t)Npad) return;
+    const float mx = grp_max_f(v);
+    f4 *dstT = ws.Tot + (size_t)s * mstride;
+    auto put = [&](int k, float w) {
+        reinterpret_cast<float *>(dstT + (size_t)(k >> 2) * Npad + n)[k & 3] = w;
+    };
+    if (row < F::NS && g < F::NS) put(row * F::NS + g, v);
+    if (row < F::NS && g == 0)
+        put(F::NS * F::NS + row, __int_as_float((mx > 0.f) ? (int)eacc : ZERO_ROW_EXP));
+    if (row == 0 && g == 0) {
+        put(F::NS * F::NS + F::NS, __int_as_float(__double2loint(macc)));
+        put(F::NS * F::NS + F::NS + 1, __int_as_float(__double2hiint(macc)));
     }
 }
 
 // ---------------------------------------------------------------------------
-// K2: serial scan over the super totals.  grid = (ncols, 2), block = 64:
-// blockIdx.y == 0 forward (Vs[s], logZ), == 1 backward (Us[s]).
-// A ring of 3 matrices is kept in flight (57 outstanding 16-byte loads).
+// K2: serial scan over the super totals.  grid = (ceil(N/8), 2), block = 64 (8 reads
+// x 8 lanes): blockIdx.y == 0 forward (Vs[s], logZ), == 1 backward (Us[s]).
+// All matrices of a pass (16 supers) are pulled into registers first, so the
+// chain itself touches no memory.
 // ---------------------------------------------------------------------------
+constexpr int K2_PASS = 16;
+
 template <int NB>
 __global__ __launch_bounds__(WAVE) void logz_scan_kernel(int N, int NSUP, int Npad, LogzWs ws,
                                                         float *__restrict__ logz,
                                                         uint32_t *__restrict__ status) {
     using F = FF<NB>;
     using X = XMat<NB>;
-    constexpr int RING = 3;
-    const int lane = lane_id();
-    const size_t n = (size_t)blockIdx.x * WAVE + lane;
+    constexpr int NFW = 4 * X::NF4;
+    __shared__ __attribute__((aligned(16))) float image[K2_PASS][GRP][NFW];
+    const int lane = lane_id(), g = lane & (GRP - 1), rloc = lane >> 3;
+    const size_t n0 = (size_t)blockIdx.x * GRP;
+    const size_t nreal = n0 + rloc;
+    const size_t n = min(nreal, (size_t)Npad - 1);
     const size_t mstride = (size_t)X::NF4 * Npad, vstride = (size_t)F::NS * Npad;
     const bool fwd = blockIdx.y == 0;
-    f4 raw[RING][X::NF4];
-    auto fetch = [&](int slot_s, f4 (&dst)[X::NF4]) {
-        const int i = min(slot_s, NSUP - 1);                // clamped: loads are unconditional
-        const int s = fwd ? i : NSUP - 1 - i;
-        const f4 *src = ws.Tot + (size_t)s * mstride + n;
-#pragma unroll
-        for (int q = 0; q < X::NF4; ++q) dst[q] = src[(size_t)q * Npad];
-    };
-#pragma unroll
-    for (int k = 0; k < RING; ++k) fetch(k, raw[k]);
-
-    float v[F::NS];
+    const bool live = g < F::NS && nreal < (size_t)Npad;
     // forward: paths start in any flip state with weight 1 (layers.py:1289-1295,
     // cupy flipflop.py:115-118); backward: may end in any state (flipflop.py:163-166)
-#pragma unroll
-    for (int k = 0; k < F::NS; ++k) v[k] = fwd ? ((k < NB) ? 1.f : 0.f) : 1.f;
+    float v = fwd ? ((g < NB) ? 1.f : 0.f) : ((g < F::NS) ? 1.f : 0.f);
     double macc = 0.0;
     long long eacc = 0;
-    for (int i0 = 0; i0 < NSUP; i0 += RING) {
+    for (int base = 0; base < NSUP; base += K2_PASS) {
+        wave_lds_fence();
+        stage_mats<NB, GRP, K2_PASS>(
+            [&](int m) {
+                const int i = min(base + m, NSUP - 1);
+                return ws.Tot + (size_t)(fwd ? i : NSUP - 1 - i) * mstride;
+            },
+            Npad, n0, &image[0][0][0], lane);
 #pragma unroll
-        for (int k = 0; k < RING; ++k) {
-            const int i = i0 + k;
+        for (int k = 0; k < K2_PASS; ++k) {
+            const int i = base + k;
             if (i < NSUP) {
                 const int s = fwd ? i : NSUP - 1 - i;
-                float *dst = (fwd ? ws.Vs : ws.Us) + (size_t)s * vstride + n;
-#pragma unroll
-                for (int q = 0; q < F::NS; ++q) dst[(size_t)q * Npad] = v[q];
-                X A;
-                A.unpack(raw[k]);
-                fetch(i + RING, raw[k]);
-                float out[F::NS];
                 if (fwd) {
-                    eacc += xvec_mat<NB>(v, A, out);
+                    if (live) ws.Vs[(size_t)s * vstride + (size_t)g * Npad + n] = v;
+                    ColShare<NB> A;
+                    A.load(&image[k][rloc][0], g);
+                    eacc += grp_vec_mat<NB>(v, A, g);
                     macc += A.M;
                 } else {
-                    xmat_vec<NB>(A, v, out);
+                    if (live) ws.Us[(size_t)s * vstride + (size_t)g * Npad + n] = v;
+                    RowShare<NB> A;
+                    A.load(&image[k][rloc][0], g);
+                    grp_mat_vec<NB>(v, A, g);
                 }
-#pragma unroll
-                for (int q = 0; q < F::NS; ++q) v[q] = out[q];
             }
         }
     }
     if (fwd) {
         float tot = 0.f;
 #pragma unroll
-        for (int k = 0; k < F::NS; ++k) tot += v[k];
+        for (int i = 0; i < F::NS; ++i) tot += grp_bcast(v, i);
         const double lz = macc + (double)eacc * 0.6931471805599453 + (double)logf(tot);
-        if (n < (size_t)N) {
+        if (g == 0 && nreal < (size_t)N) {
             const float lzf = (float)lz;
-            logz[n] = lzf;
+            logz[nreal] = lzf;
             if (status != nullptr && !isfinite(lzf)) atomicOr(status, 1u);
         }
     }
@@ -551,55 +646,52 @@ __global__ __launch_bounds__(WAVE) void logz_scan_kernel(int N, int NSUP, int Np
 
 // ---------------------------------------------------------------------------
 // K2b: expand super-chunk boundary vectors to chunk granularity.
-// grid = (ncols, NSUP), block = 128: wave 0 forward (Vin[c]), wave 1 backward
-// (Uout[c]).  Each step is one streamed mat-vec; the next chunk matrix is in
-// flight while the current one is applied.
+// grid = (ceil(N/8), NSUP), block = 128: wave 0 forward (Vin[c]), wave 1 backward
+// (Uout[c]); 8 reads x 8 lanes per wave, all 8 chunk matrices prefetched.
 // ---------------------------------------------------------------------------
 template <int NB>
 __global__ __launch_bounds__(2 * WAVE) void logz_expand_kernel(int C, int Npad, LogzWs ws) {
     using F = FF<NB>;
     using X = XMat<NB>;
+    constexpr int NFW = 4 * X::NF4;
+    __shared__ __attribute__((aligned(16))) float image[2][LOGZ_SUPER][GRP][NFW];
     const int wave = threadIdx.x >> 6, lane = lane_id();
-    const size_t n = (size_t)blockIdx.x * WAVE + lane;
+    const int g = lane & (GRP - 1), rloc = lane >> 3;
+    const size_t n0 = (size_t)blockIdx.x * GRP;
+    const size_t nreal = n0 + rloc;
+    const size_t n = min(nreal, (size_t)Npad - 1);
     const int s = blockIdx.y;
     const int c0 = s * LOGZ_SUPER, c1 = min(C, c0 + LOGZ_SUPER);
     const int nc = c1 - c0;
     const size_t mstride = (size_t)X::NF4 * Npad, vstride = (size_t)F::NS * Npad;
+    const bool live = g < F::NS && nreal < (size_t)Npad;
+    const int gc = min(g, F::NS - 1);
     const bool fwd = wave == 0;
-    auto chunk_of = [&](int i) { return fwd ? c0 + min(i, nc - 1) : c1 - 1 - min(i, nc - 1); };
-    auto fetch = [&](int i, f4 (&dst)[X::NF4]) {
-        const f4 *src = ws.Pc + (size_t)chunk_of(i) * mstride + n;
+    // (each wave stages its own copy; image slot i = the i-th matrix it will apply)
+    stage_mats<NB, GRP, LOGZ_SUPER>(
+        [&](int m) {
+            const int i = min(m, nc - 1);
+            return ws.Pc + (size_t)(fwd ? c0 + i : c1 - 1 - i) * mstride;
+        },
+        Npad, n0, &image[wave][0][0][0], lane);
+    float v = (fwd ? ws.Vs : ws.Us)[(size_t)s * vstride + (size_t)gc * Npad + n];
+    if (g >= F::NS) v = 0.f;
+    float *dst = fwd ? ws.Vin : ws.Uout;
 #pragma unroll
-        for (int q = 0; q < X::NF4; ++q) dst[q] = src[(size_t)q * Npad];
-    };
-    f4 ra[X::NF4], rb[X::NF4];
-    fetch(0, ra);
-    fetch(1, rb);
-    float v[F::NS];
-    {
-        const float *src = (fwd ? ws.Vs : ws.Us) + (size_t)s * vstride + n;
-#pragma unroll
-        for (int k = 0; k < F::NS; ++k) v[k] = src[(size_t)k * Npad];
-    }
-    float *dstbase = fwd ? ws.Vin : ws.Uout;
-    auto apply = [&](int i, const f4 (&raw)[X::NF4]) {
-        float *dst = dstbase + (size_t)chunk_of(i) * vstride + n;
-#pragma unroll
-        for (int k = 0; k < F::NS; ++k) dst[(size_t)k * Npad] = v[k];
-        X A;
-        A.unpack(raw);
-        float out[F::NS];
-        if (fwd) (void)xvec_mat<NB>(v, A, out);
-        else xmat_vec<NB>(A, v, out);
-#pragma unroll
-        for (int k = 0; k < F::NS; ++k) v[k] = out[k];
-    };
-    for (int i = 0; i < nc; i += 2) {
-        apply(i, ra);
-        fetch(i + 2, ra);
-        if (i + 1 >= nc) break;
-        apply(i + 1, rb);
-        fetch(i + 3, rb);
+    for (int i = 0; i < LOGZ_SUPER; ++i) {
+        if (i < nc) {
+            const int c = fwd ? c0 + i : c1 - 1 - i;
+            if (live) dst[(size_t)c * vstride + (size_t)g * Npad + n] = v;
+            if (fwd) {
+                ColShare<NB> A;
+                A.load(&image[wave][i][rloc][0], g);
+                (void)grp_vec_mat<NB>(v, A, g);
+            } else {
+                RowShare<NB> A;
+                A.load(&image[wave][i][rloc][0], g);
+                grp_mat_vec<NB>(v, A, g);
+            }
+        }
     }
 }
 
@@ -806,23 +898,14 @@ static int logz_launch(const float *scores, size_t T, size_t N, float *logz, flo
         hipLaunchKernelGGL(logz_transfer_kernel<NB>, dim3(ncols, C), dim3(K1_WAVES * WAVE), lds,
                            stream, scores, (int)T, (int)N, Npad, ws);
     }
-    {
-        const size_t lds = (size_t)LOGZ_SUPER * XMat<NB>::NW * WAVE * sizeof(float);
-        static bool raised = false;
-        if (lds > 64 * 1024 && !raised) {
-            if (hipFuncSetAttribute(reinterpret_cast<const void *>(&logz_combine_kernel<NB>),
-                                    hipFuncAttributeMaxDynamicSharedMemorySize,
-                                    160 * 1024) != hipSuccess)
-                return 4;
-            raised = true;
-        }
-        hipLaunchKernelGGL(logz_combine_kernel<NB>, dim3(ncols, NSUP), dim3(LOGZ_SUPER * WAVE), lds,
-                           stream, C, Npad, ws);
-    }
-    hipLaunchKernelGGL(logz_scan_kernel<NB>, dim3(ncols, grad != nullptr ? 2 : 1), dim3(WAVE), 0,
+    const int ngrp = (int)((N + GRP - 1) / GRP);
+    hipLaunchKernelGGL(logz_combine_kernel<NB>,
+                       dim3((unsigned)((Npad + K1B_WAVES - 1) / K1B_WAVES), NSUP),
+                       dim3(K1B_WAVES * WAVE), 0, stream, (int)N, C, Npad, ws);
+    hipLaunchKernelGGL(logz_scan_kernel<NB>, dim3(ngrp, grad != nullptr ? 2 : 1), dim3(WAVE), 0,
                        stream, (int)N, NSUP, Npad, ws, logz, status);
     if (grad != nullptr) {
-        hipLaunchKernelGGL(logz_expand_kernel<NB>, dim3(ncols, NSUP), dim3(2 * WAVE), 0, stream, C,
+        hipLaunchKernelGGL(logz_expand_kernel<NB>, dim3(ngrp, NSUP), dim3(2 * WAVE), 0, stream, C,
                            Npad, ws);
         dim3 grid(ncols, C), block(K3_WAVES * WAVE);
         const size_t lds = K3_WAVES * (size_t)k3_buf_f4<NB>() * sizeof(f4) +

@@ -270,12 +270,9 @@ __device__ __forceinline__ void xmat_lds_get(XMat<NB> &A, const float *region, i
 }
 
 struct LogzWs {
-    f4 *Pc;         // [C]    chunk transfer matrices            (XMat layout)
-    f4 *Tot;        // [NSUP] super-chunk totals
-    float *Vs;      // [NSUP][NS][Npad] forward vector entering super-chunk s
-    float *Us;      // [NSUP][NS][Npad] backward vector leaving super-chunk s
-    float *Vin;     // [C][NS][Npad]    forward vector entering chunk c
-    float *Uout;    // [C][NS][Npad]    backward vector leaving chunk c
+    f4 *Pc;         // [Npad][C][NF4] chunk transfer matrices, read-major (XMat words)
+    float *Vin;     // [Npad][C][NS]    forward vector entering chunk c   (read-major)
+    float *Uout;    // [Npad][C][NS]    backward vector leaving chunk c
 };
 
 // per-wave LDS buffer of K3 in f4 units: the row-set transpose buffer, which
@@ -294,7 +291,7 @@ __host__ __device__ constexpr int k3_buf_f4() {
 // ---------------------------------------------------------------------------
 template <int NB>
 __global__ __launch_bounds__(K1_WAVES *WAVE, 2) void logz_transfer_kernel(
-    const float *__restrict__ scores, int T, int N, int Npad, LogzWs ws) {
+    const float *__restrict__ scores, int T, int N, int C, int Npad, LogzWs ws) {
     using F = FF<NB>;
     using X = XMat<NB>;
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -393,13 +390,17 @@ __global__ __launch_bounds__(K1_WAVES *WAVE, 2) void logz_transfer_kernel(
     }
     __syncthreads();
     {
-        const size_t n = (size_t)n0 + lane;     // < Npad always
-        f4 *dst = ws.Pc + (size_t)c * X::NF4 * Npad + n;
-        for (int q = wave; q < X::NF4; q += K1_WAVES) {
+        // Pc is READ-major ([read][chunk][NF4] float4): the middle kernel streams one
+        // read's matrices as a single contiguous run (a [chunk][q][read] layout put
+        // all of a read's pieces 16*Npad bytes apart = on ONE L2 channel).
+        // 64 reads x NF4 pieces; thread handles piece p -> (read p / NF4, q p % NF4).
+        f4 *dst = ws.Pc + ((size_t)n0 * C + c) * X::NF4;
+        for (int p = threadIdx.x; p < WAVE * X::NF4; p += K1_WAVES * WAVE) {
+            const int r = p / X::NF4, q = p - r * X::NF4;
             f4 o;
 #pragma unroll
-            for (int r = 0; r < 4; ++r) o[r] = (4 * q + r < X::NW) ? tot[(4 * q + r) * WAVE + lane] : 0.f;
-            dst[(size_t)q * Npad] = o;
+            for (int k = 0; k < 4; ++k) o[k] = (4 * q + k < X::NW) ? tot[(4 * q + k) * WAVE + r] : 0.f;
+            dst[(size_t)r * C * X::NF4 + q] = o;
         }
     }
 }
@@ -432,34 +433,6 @@ __device__ __forceinline__ float grp_max_f(float x) {
     x = fmaxf(x, dpp_f32<0x141>(x, x));
     return x;
 }
-// Stage the matrices `mat[m]` (m < NM) of NR consecutive reads starting at read n0 into
-// LDS with coalesced 16-byte loads: image[m][r][4*NF4] words.  One wave; NM*NR*NF4
-// float4 pieces spread over the 64 lanes (all loads of a stage are issued back to back).
-template <int NB, int NR, int NM, typename MatOf>
-__device__ __forceinline__ void stage_mats(MatOf mat_of, size_t Npad, size_t n0, float *image,
-                                           int lane) {
-    using X = XMat<NB>;
-    constexpr int PER = NR * X::NF4;                // pieces per matrix
-    constexpr int TOTAL = NM * PER;
-    constexpr int NIT = (TOTAL + WAVE - 1) / WAVE;
-    f4 tmp[NIT];
-#pragma unroll
-    for (int it = 0; it < NIT; ++it) {
-        const int idx = min(it * WAVE + lane, TOTAL - 1);
-        const int m = idx / PER, rem = idx % PER, q = rem / NR, r = rem % NR;
-        tmp[it] = mat_of(m)[(size_t)q * Npad + min(n0 + r, Npad - 1)];
-    }
-#pragma unroll
-    for (int it = 0; it < NIT; ++it) {
-        const int idx = it * WAVE + lane;
-        if (idx < TOTAL) {
-            const int m = idx / PER, rem = idx % PER, q = rem / NR, r = rem % NR;
-            *reinterpret_cast<f4 *>(image + ((size_t)(m * NR + r) * X::NF4 + q) * 4) = tmp[it];
-        }
-    }
-    wave_lds_fence();
-}
-
 // one lane's share of a matrix for v (x) A: column g (NS words) + exponent of row g
 template <int NB>
 struct ColShare {
@@ -498,9 +471,13 @@ __device__ __forceinline__ int grp_vec_mat(float &v, const ColShare<NB> &A, int 
     int emax = grp_max_i(t);
     if (emax == ZERO_ROW_EXP) emax = 0;
     const float vs = __builtin_amdgcn_ldexpf(v, max(A.e - emax, -300));     // row g's scaled weight
-    float acc = 0.f;
+    float acc0 = 0.f, acc1 = 0.f;
 #pragma unroll
-    for (int i = 0; i < NS; ++i) acc = fmaf(grp_bcast(vs, i), A.a[i], acc);
+    for (int i = 0; i < NS; i += 2) {
+        acc0 = fmaf(grp_bcast(vs, i), A.a[i], acc0);
+        acc1 = fmaf(grp_bcast(vs, i + 1), A.a[i + 1], acc1);
+    }
+    float acc = acc0 + acc1;
     if (g >= NS) acc = 0.f;
     const float mx = grp_max_f(acc);
     const int ex = (mx > 0.f) ? __builtin_amdgcn_frexp_expf(mx) : 0;
@@ -512,9 +489,13 @@ __device__ __forceinline__ int grp_vec_mat(float &v, const ColShare<NB> &A, int 
 template <int NB>
 __device__ __forceinline__ void grp_mat_vec(float &u, const RowShare<NB> &A, int g) {
     constexpr int NS = 2 * NB;
-    float acc = 0.f;
+    float acc0 = 0.f, acc1 = 0.f;
 #pragma unroll
-    for (int j = 0; j < NS; ++j) acc = fmaf(A.a[j], grp_bcast(u, j), acc);
+    for (int j = 0; j < NS; j += 2) {
+        acc0 = fmaf(A.a[j], grp_bcast(u, j), acc0);
+        acc1 = fmaf(A.a[j + 1], grp_bcast(u, j + 1), acc1);
+    }
+    float acc = acc0 + acc1;
     if (g >= NS) acc = 0.f;
     const int t = (acc > 0.f && A.e != ZERO_ROW_EXP) ? A.e + __builtin_amdgcn_frexp_expf(acc) : ZERO_ROW_EXP;
     int emax = grp_max_i(t);
@@ -523,172 +504,131 @@ __device__ __forceinline__ void grp_mat_vec(float &u, const RowShare<NB> &A, int
 }
 
 // ---------------------------------------------------------------------------
-// K1b: total product of each super-chunk.  ONE WAVE PER READ: lane (i, k) holds
-// element (i, k) of the running product (group i = row i; row_i(AB) = row_i(A) B,
-// so the 8 groups advance independently and every matrix column is loaded once
-// per wave).  grid = (ceil(N/4), NSUP), block = 256 (4 reads).
+// K2 (fused middle): combine + scan + expand in ONE launch, one 4-wave block per
+// read.  The read's chunk matrices (C x 304 B, 38 KB at T = 4000) are staged in
+// LDS once; then
+//   combine : super s -> wave s % 4; the 8 groups of the wave are the 8 rows of the
+//             running product (row_i(AB) = row_i(A) B), 8 chained mat-vecs each
+//   scan    : forward by group 0 of wave 0 (-> logZ), backward by group 0 of wave 1
+//   expand  : 2*NSUP independent 8-step chains over the 32 groups of the block
+// Everything between the stage-in and the final stores runs out of LDS/registers,
+// and the three launch/ramp/latency floors (~5 us each) collapse into one.
+// grid = N, block = 256.
 // ---------------------------------------------------------------------------
-constexpr int K1B_WAVES = 4;
+constexpr int K2_WAVES = 16;
 
 template <int NB>
-__global__ __launch_bounds__(K1B_WAVES *WAVE) void logz_combine_kernel(int N, int C, int Npad,
-                                                                    LogzWs ws) {
+__global__ __launch_bounds__(K2_WAVES *WAVE) void logz_middle_kernel(int N, int C, int NSUP, int Npad,
+                                                                  LogzWs ws,
+                                                                  float *__restrict__ logz,
+                                                                  int want_grad,
+                                                                  uint32_t *__restrict__ status) {
     using F = FF<NB>;
     using X = XMat<NB>;
-    constexpr int NFW = 4 * X::NF4;
-    __shared__ __attribute__((aligned(16))) float image[K1B_WAVES][LOGZ_SUPER][NFW];
-    const int wave = threadIdx.x >> 6, lane = lane_id();
-    const int g = lane & (GRP - 1), row = lane >> 3;
-    const size_t nreal = (size_t)blockIdx.x * K1B_WAVES + wave;
-    const size_t n = min(nreal, (size_t)Npad - 1);
-    const int s = blockIdx.y;
-    const int c0 = s * LOGZ_SUPER, c1 = min(C, c0 + LOGZ_SUPER);
-    const int nc = c1 - c0;
-    const size_t mstride = (size_t)X::NF4 * Npad;
-    stage_mats<NB, 1, LOGZ_SUPER>(
-        [&](int m) { return ws.Pc + (size_t)(c0 + min(m, nc - 1)) * mstride; }, Npad, n,
-        &image[wave][0][0], lane);
-    float v = (g == row && row < F::NS) ? 1.f : 0.f;
-    long long eacc = 0;
-    double macc = 0.0;
-#pragma unroll
-    for (int i = 0; i < LOGZ_SUPER; ++i) {
-        if (i < nc) {
-            ColShare<NB> A;
-            A.load(&image[wave][i][0], g);
-            eacc += grp_vec_mat<NB>(v, A, g);
-            macc += A.M;
-        }
-    }
-    if (nreal >= (size_t)Npad) return;
-    const float mx = grp_max_f(v);
-    f4 *dstT = ws.Tot + (size_t)s * mstride;
-    auto put = [&](int k, float w) {
-        reinterpret_cast<float *>(dstT + (size_t)(k >> 2) * Npad + n)[k & 3] = w;
-    };
-    if (row < F::NS && g < F::NS) put(row * F::NS + g, v);
-    if (row < F::NS && g == 0)
-        put(F::NS * F::NS + row, __int_as_float((mx > 0.f) ? (int)eacc : ZERO_ROW_EXP));
-    if (row == 0 && g == 0) {
-        put(F::NS * F::NS + F::NS, __int_as_float(__double2loint(macc)));
-        put(F::NS * F::NS + F::NS + 1, __int_as_float(__double2hiint(macc)));
-    }
-}
+    constexpr int NFW = 4 * X::NF4, NT = K2_WAVES * WAVE;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    float *pcimg = reinterpret_cast<float *>(smem);             // [C][NFW]
+    float *totimg = pcimg + (size_t)C * NFW;                    // [NSUP][NFW]
+    float *vsl = totimg + (size_t)NSUP * NFW;                   // [NSUP][GRP]
+    float *usl = vsl + (size_t)NSUP * GRP;                      // [NSUP][GRP]
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & (WAVE - 1);
+    const int g = lane & (GRP - 1), grp = lane >> 3;
+    const size_t n = blockIdx.x;
 
-// ---------------------------------------------------------------------------
-// K2: serial scan over the super totals.  grid = (ceil(N/8), 2), block = 64 (8 reads
-// x 8 lanes): blockIdx.y == 0 forward (Vs[s], logZ), == 1 backward (Us[s]).
-// All matrices of a pass (16 supers) are pulled into registers first, so the
-// chain itself touches no memory.
-// ---------------------------------------------------------------------------
-constexpr int K2_PASS = 16;
-
-template <int NB>
-__global__ __launch_bounds__(WAVE) void logz_scan_kernel(int N, int NSUP, int Npad, LogzWs ws,
-                                                        float *__restrict__ logz,
-                                                        uint32_t *__restrict__ status) {
-    using F = FF<NB>;
-    using X = XMat<NB>;
-    constexpr int NFW = 4 * X::NF4;
-    __shared__ __attribute__((aligned(16))) float image[K2_PASS][GRP][NFW];
-    const int lane = lane_id(), g = lane & (GRP - 1), rloc = lane >> 3;
-    const size_t n0 = (size_t)blockIdx.x * GRP;
-    const size_t nreal = n0 + rloc;
-    const size_t n = min(nreal, (size_t)Npad - 1);
-    const size_t mstride = (size_t)X::NF4 * Npad, vstride = (size_t)F::NS * Npad;
-    const bool fwd = blockIdx.y == 0;
-    const bool live = g < F::NS && nreal < (size_t)Npad;
-    // forward: paths start in any flip state with weight 1 (layers.py:1289-1295,
-    // cupy flipflop.py:115-118); backward: may end in any state (flipflop.py:163-166)
-    float v = fwd ? ((g < NB) ? 1.f : 0.f) : ((g < F::NS) ? 1.f : 0.f);
-    double macc = 0.0;
-    long long eacc = 0;
-    for (int base = 0; base < NSUP; base += K2_PASS) {
-        wave_lds_fence();
-        stage_mats<NB, GRP, K2_PASS>(
-            [&](int m) {
-                const int i = min(base + m, NSUP - 1);
-                return ws.Tot + (size_t)(fwd ? i : NSUP - 1 - i) * mstride;
-            },
-            Npad, n0, &image[0][0][0], lane);
+    // ---- 1. stage the read's chunk matrices: one contiguous run of C*NF4 float4
+    {
+        const int total = C * X::NF4;
+        const f4 *src = ws.Pc + n * (size_t)total;
+        for (int base = 0; base < total; base += 4 * NT) {
+            f4 tmp[4];
 #pragma unroll
-        for (int k = 0; k < K2_PASS; ++k) {
-            const int i = base + k;
-            if (i < NSUP) {
-                const int s = fwd ? i : NSUP - 1 - i;
-                if (fwd) {
-                    if (live) ws.Vs[(size_t)s * vstride + (size_t)g * Npad + n] = v;
-                    ColShare<NB> A;
-                    A.load(&image[k][rloc][0], g);
-                    eacc += grp_vec_mat<NB>(v, A, g);
-                    macc += A.M;
-                } else {
-                    if (live) ws.Us[(size_t)s * vstride + (size_t)g * Npad + n] = v;
-                    RowShare<NB> A;
-                    A.load(&image[k][rloc][0], g);
-                    grp_mat_vec<NB>(v, A, g);
-                }
+            for (int k = 0; k < 4; ++k) tmp[k] = src[min(base + k * NT + tid, total - 1)];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const int idx = base + k * NT + tid;
+                if (idx < total) *reinterpret_cast<f4 *>(pcimg + (size_t)idx * 4) = tmp[k];
             }
         }
     }
-    if (fwd) {
+    __syncthreads();
+
+    // ---- 2. combine: group `grp` of the wave carries row `grp` of the super's product
+    for (int s = wave; s < NSUP; s += K2_WAVES) {
+        const int c0 = s * LOGZ_SUPER, c1 = min(C, c0 + LOGZ_SUPER);
+        float v = (g == grp && grp < F::NS) ? 1.f : 0.f;
+        long long eacc = 0;
+        double macc = 0.0;
+        for (int c = c0; c < c1; ++c) {
+            ColShare<NB> A;
+            A.load(pcimg + (size_t)c * NFW, g);
+            eacc += grp_vec_mat<NB>(v, A, g);
+            macc += A.M;
+        }
+        const float mx = grp_max_f(v);
+        float *t = totimg + (size_t)s * NFW;
+        if (grp < F::NS && g < F::NS) t[grp * F::NS + g] = v;
+        if (grp < F::NS && g == 0) t[F::NS * F::NS + grp] = __int_as_float((mx > 0.f) ? (int)eacc : ZERO_ROW_EXP);
+        if (lane == 0) {
+            t[F::NS * F::NS + F::NS] = __int_as_float(__double2loint(macc));
+            t[F::NS * F::NS + F::NS + 1] = __int_as_float(__double2hiint(macc));
+        }
+    }
+    __syncthreads();
+
+    // ---- 3. scan over the super totals (one 8-lane group per direction)
+    if (wave == 0) {
+        // forward: paths start in any flip state with weight 1 (layers.py:1289-1295,
+        // cupy flipflop.py:115-118)
+        float v = (g < NB) ? 1.f : 0.f;
+        double macc = 0.0;
+        long long eacc = 0;
+        for (int s = 0; s < NSUP; ++s) {
+            if (grp == 0) vsl[s * GRP + g] = v;
+            ColShare<NB> A;
+            A.load(totimg + (size_t)s * NFW, g);
+            eacc += grp_vec_mat<NB>(v, A, g);
+            macc += A.M;
+        }
         float tot = 0.f;
 #pragma unroll
         for (int i = 0; i < F::NS; ++i) tot += grp_bcast(v, i);
-        const double lz = macc + (double)eacc * 0.6931471805599453 + (double)logf(tot);
-        if (g == 0 && nreal < (size_t)N) {
-            const float lzf = (float)lz;
-            logz[nreal] = lzf;
+        if (lane == 0) {
+            const float lzf = (float)(macc + (double)eacc * 0.6931471805599453 + (double)logf(tot));
+            logz[n] = lzf;
             if (status != nullptr && !isfinite(lzf)) atomicOr(status, 1u);
         }
+    } else if (wave == 1 && want_grad) {
+        // backward: paths may end in any state (cupy flipflop.py:163-166); scale is free
+        float u = (g < F::NS) ? 1.f : 0.f;
+        for (int s = NSUP - 1; s >= 0; --s) {
+            if (grp == 0) usl[s * GRP + g] = u;
+            RowShare<NB> A;
+            A.load(totimg + (size_t)s * NFW, g);
+            grp_mat_vec<NB>(u, A, g);
+        }
     }
-}
+    if (!want_grad) return;
+    __syncthreads();
 
-// ---------------------------------------------------------------------------
-// K2b: expand super-chunk boundary vectors to chunk granularity.
-// grid = (ceil(N/8), NSUP), block = 128: wave 0 forward (Vin[c]), wave 1 backward
-// (Uout[c]); 8 reads x 8 lanes per wave, all 8 chunk matrices prefetched.
-// ---------------------------------------------------------------------------
-template <int NB>
-__global__ __launch_bounds__(2 * WAVE) void logz_expand_kernel(int C, int Npad, LogzWs ws) {
-    using F = FF<NB>;
-    using X = XMat<NB>;
-    constexpr int NFW = 4 * X::NF4;
-    __shared__ __attribute__((aligned(16))) float image[2][LOGZ_SUPER][GRP][NFW];
-    const int wave = threadIdx.x >> 6, lane = lane_id();
-    const int g = lane & (GRP - 1), rloc = lane >> 3;
-    const size_t n0 = (size_t)blockIdx.x * GRP;
-    const size_t nreal = n0 + rloc;
-    const size_t n = min(nreal, (size_t)Npad - 1);
-    const int s = blockIdx.y;
-    const int c0 = s * LOGZ_SUPER, c1 = min(C, c0 + LOGZ_SUPER);
-    const int nc = c1 - c0;
-    const size_t mstride = (size_t)X::NF4 * Npad, vstride = (size_t)F::NS * Npad;
-    const bool live = g < F::NS && nreal < (size_t)Npad;
-    const int gc = min(g, F::NS - 1);
-    const bool fwd = wave == 0;
-    // (each wave stages its own copy; image slot i = the i-th matrix it will apply)
-    stage_mats<NB, GRP, LOGZ_SUPER>(
-        [&](int m) {
-            const int i = min(m, nc - 1);
-            return ws.Pc + (size_t)(fwd ? c0 + i : c1 - 1 - i) * mstride;
-        },
-        Npad, n0, &image[wave][0][0][0], lane);
-    float v = (fwd ? ws.Vs : ws.Us)[(size_t)s * vstride + (size_t)gc * Npad + n];
-    if (g >= F::NS) v = 0.f;
-    float *dst = fwd ? ws.Vin : ws.Uout;
-#pragma unroll
-    for (int i = 0; i < LOGZ_SUPER; ++i) {
-        if (i < nc) {
+    // ---- 4. expand to chunk granularity: lower half of the waves forward chains, upper
+    //         half backward chains; one 8-lane group per chain
+    constexpr int HALF = K2_WAVES / 2;
+    const bool fwd = wave < HALF;
+    const int slot = (wave % HALF) * GRP + grp;
+    float *dstbase = (fwd ? ws.Vin : ws.Uout) + n * (size_t)C * F::NS;     // [read][c][NS]
+    for (int s = slot; s < NSUP; s += HALF * GRP) {
+        const int c0 = s * LOGZ_SUPER, c1 = min(C, c0 + LOGZ_SUPER);
+        float v = (fwd ? vsl : usl)[s * GRP + g];
+        for (int i = 0; i < c1 - c0; ++i) {
             const int c = fwd ? c0 + i : c1 - 1 - i;
-            if (live) dst[(size_t)c * vstride + (size_t)g * Npad + n] = v;
+            if (g < F::NS) dstbase[(size_t)c * F::NS + g] = v;
             if (fwd) {
                 ColShare<NB> A;
-                A.load(&image[wave][i][rloc][0], g);
+                A.load(pcimg + (size_t)c * NFW, g);
                 (void)grp_vec_mat<NB>(v, A, g);
             } else {
                 RowShare<NB> A;
-                A.load(&image[wave][i][rloc][0], g);
+                A.load(pcimg + (size_t)c * NFW, g);
                 grp_mat_vec<NB>(v, A, g);
             }
         }
@@ -722,7 +662,6 @@ __global__ __launch_bounds__(K3_WAVES *WAVE, 2) void logz_posterior_kernel(
     const int tw = c * LOGZ_CH + wave * K3_ROWS;        // first row of this wave
     const float *base = scores + (size_t)n0 * F::S;
     const size_t n = (size_t)n0 + lane;
-    const size_t vstride = (size_t)F::NS * Npad;
 
     // 1. rows -> registers (weights w = exp(s - rowmax))
     RowSet<NB> w[K3_ROWS];
@@ -733,9 +672,9 @@ __global__ __launch_bounds__(K3_WAVES *WAVE, 2) void logz_posterior_kernel(
     // vector leaving it), loaded while the rows are in flight
     float head[F::NS];
     {
-        const float *src = ((wave == 0) ? ws.Vin : ws.Uout) + (size_t)c * vstride + n;
+        const float *src = ((wave == 0) ? ws.Vin : ws.Uout) + (n * gridDim.y + c) * F::NS;    // [read][c][NS]
 #pragma unroll
-        for (int k = 0; k < F::NS; ++k) head[k] = src[(size_t)k * Npad];
+        for (int k = 0; k < F::NS; ++k) head[k] = src[k];
     }
 #pragma unroll
     for (int j = 0; j < K3_ROWS; ++j) {
@@ -863,12 +802,10 @@ static size_t logz_ws_layout(size_t T, size_t N, void *base, LogzWs *ws) {
     };
     const size_t mbytes = (size_t)X::NF4 * Npad * sizeof(f4);
     f4 *Pc = reinterpret_cast<f4 *>(take(C * mbytes));
-    f4 *Tot = reinterpret_cast<f4 *>(take(NSUP * mbytes));
-    float *Vs = reinterpret_cast<float *>(take(NSUP * F::NS * Npad * sizeof(float)));
-    float *Us = reinterpret_cast<float *>(take(NSUP * F::NS * Npad * sizeof(float)));
     float *Vin = reinterpret_cast<float *>(take(C * F::NS * Npad * sizeof(float)));
     float *Uout = reinterpret_cast<float *>(take(C * F::NS * Npad * sizeof(float)));
-    if (ws) *ws = LogzWs{Pc, Tot, Vs, Us, Vin, Uout};
+    (void)NSUP;
+    if (ws) *ws = LogzWs{Pc, Vin, Uout};
     return off;
 }
 
@@ -896,17 +833,23 @@ static int logz_launch(const float *scores, size_t T, size_t N, float *logz, flo
             raised1 = true;
         }
         hipLaunchKernelGGL(logz_transfer_kernel<NB>, dim3(ncols, C), dim3(K1_WAVES * WAVE), lds,
-                           stream, scores, (int)T, (int)N, Npad, ws);
+                           stream, scores, (int)T, (int)N, C, Npad, ws);
     }
-    const int ngrp = (int)((N + GRP - 1) / GRP);
-    hipLaunchKernelGGL(logz_combine_kernel<NB>,
-                       dim3((unsigned)((Npad + K1B_WAVES - 1) / K1B_WAVES), NSUP),
-                       dim3(K1B_WAVES * WAVE), 0, stream, (int)N, C, Npad, ws);
-    hipLaunchKernelGGL(logz_scan_kernel<NB>, dim3(ngrp, grad != nullptr ? 2 : 1), dim3(WAVE), 0,
-                       stream, (int)N, NSUP, Npad, ws, logz, status);
+    {
+        const size_t lds = ((size_t)(C + NSUP) * 4 * XMat<NB>::NF4 + 2 * (size_t)NSUP * GRP) * sizeof(float);
+        if (lds > 160 * 1024) return 2;         // T > ~16000 blocks: not built
+        static bool raised2 = false;
+        if (lds > 64 * 1024 && !raised2) {
+            if (hipFuncSetAttribute(reinterpret_cast<const void *>(&logz_middle_kernel<NB>),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize,
+                                    160 * 1024) != hipSuccess)
+                return 4;
+            raised2 = true;
+        }
+        hipLaunchKernelGGL(logz_middle_kernel<NB>, dim3((unsigned)N), dim3(K2_WAVES * WAVE), lds, stream,
+                           (int)N, C, NSUP, Npad, ws, logz, grad != nullptr ? 1 : 0, status);
+    }
     if (grad != nullptr) {
-        hipLaunchKernelGGL(logz_expand_kernel<NB>, dim3(ngrp, NSUP), dim3(2 * WAVE), 0, stream, C,
-                           Npad, ws);
         dim3 grid(ncols, C), block(K3_WAVES * WAVE);
         const size_t lds = K3_WAVES * (size_t)k3_buf_f4<NB>() * sizeof(f4) +
                            2 * F::NS * WAVE * sizeof(float);

@@ -22,10 +22,15 @@
 //   * the (T+1) x L forward lattice is never written out: the forward sweep
 //     stores one checkpoint column every CK steps; the backward sweep
 //     recomputes each CK-column tile into LDS ("LDS-tiled"), walks it backwards
-//     fused with the backward recursion and scatter-adds the posteriors into
-//     per-wave LDS bins (ds_add_f32; per-wave bins + fixed-order reduction keep
-//     the result deterministic), normalised per row (the reference's per-column
-//     softmax, c_crf_flipflop.c:400-401) and streamed out once.
+//     fused with the backward recursion and writes every posterior to a slot
+//     that was PRE-SORTED by transition id (positions are ranked once per read
+//     with ballots, deterministically).  At tile flush a wave turns a row into
+//     per-id sums with a DPP prefix scan and boundary differences -- no atomics
+//     (ds_add_f32 costs ~10 cycles per lane and was half of the kernel) -- then
+//     normalises the row (the reference's per-column softmax,
+//     c_crf_flipflop.c:400-401) and streams it out once.
+#include <stdlib.h>
+
 #include "ff_common.h"
 
 namespace tk {
@@ -48,39 +53,48 @@ struct CrfArgs {
     float *ckpt;                // workspace: checkpoint columns
     double *ckoff;              // workspace: checkpoint offsets
     uint32_t *status;
+    int debug;                  // profiling switches (TK_CRF_DEBUG): 1 no atomics, 2 no posterior, 4 no recompute
 };
 
-template <int R, int W>
+__host__ __device__ inline int crf_ck(int R, int W, int kinds) {
+    // recompute tile + sorted-posterior tile <= 112 KiB of LDS
+    const int c = 28672 / (R * W * WAVE * (kinds + 1));
+    return c >= 16 ? 16 : (c >= 8 ? 8 : (c >= 4 ? 4 : 2));
+}
+
+template <int R, int W, bool MOD>
 struct CrfCfg {
     static constexpr int NT = W * WAVE;                 // threads per read
     static constexpr int LPAD = R * NT;                 // lattice positions covered
-    static constexpr int CK0 = 16384 / LPAD;            // recompute tile <= 64 KiB of LDS
-    static constexpr int CK = CK0 > 16 ? 16 : (CK0 < 4 ? 4 : CK0);
-    static constexpr int MAXK = (CK + W - 1) / W;           // tile rows moved per wave (S <= 64)
+    static constexpr int KINDS = MOD ? 3 : 2;           // stay, move(, mod) posterior streams
+    static constexpr int CK0 = 28672 / (LPAD * (KINDS + 1));
+    static constexpr int CK = CK0 >= 16 ? 16 : (CK0 >= 8 ? 8 : (CK0 >= 4 ? 4 : 2));
+    static constexpr int MAXK = (CK + W - 1) / W;       // tile rows moved per wave (S <= 64)
+    static constexpr int EPL = LPAD / WAVE;             // sorted elements per lane in the flush
 };
 
-__host__ __device__ inline int crf_ck(int R, int W) {
-    const int c = 16384 / (R * W * WAVE);
-    return c > 16 ? 16 : (c < 4 ? 4 : c);
-}
-
-// LDS carve (bytes): tile | bins[W] | Fblk | offs(double) | rscale | edgeF[2][W] | edgeB[2][W] | red[W] | misc[4]
-__host__ __device__ inline size_t crf_lds_bytes(int R, int W, int S) {
-    const int SP = S + 2, CK = crf_ck(R, W), NT = W * WAVE;
+// LDS carve (floats): tile[CK][SP] | Psort[CK][KINDS][LPAD] | Fblk[CK][R][NT] | offs (2*CK) |
+// segstart[KINDS][SP+1] | lanebase[W][64] | edgeF[2][W] | edgeB[2][W] | red[W] | misc[8]
+// (the ranking scratch wcnt[KINDS][W][SP] overlays Fblk during set-up)
+__host__ __device__ inline size_t crf_lds_bytes(int R, int W, int S, int kinds) {
+    const int SP = S + 2, CK = crf_ck(R, W, kinds), NT = W * WAVE;
     size_t f = 0;
-    f += (size_t)CK * SP;               // score tile
-    f += (size_t)W * CK * SP;           // per-wave gradient bins
-    f += (size_t)CK * R * NT;           // recomputed forward columns
-    f += (size_t)2 * CK;                // per-row forward offsets (double)
-    f += (size_t)CK;                    // per-row scale
-    f += (size_t)5 * W + 8;             // edges, reduction slots, scalars
+    f += (size_t)CK * SP;
+    f += (size_t)CK * kinds * R * NT;
+    size_t fb = (size_t)CK * R * NT, scratch = (size_t)kinds * W * SP + kinds * SP;
+    f += fb > scratch ? fb : scratch;
+    f += (size_t)2 * CK + 2;
+    f += (size_t)kinds * (SP + 1);
+    f += (size_t)W * WAVE;
+    f += (size_t)5 * W + 8;
     return (f * 4 + 15) / 16 * 16;
 }
 
 template <int R, int W, bool MOD>
 __global__ __launch_bounds__(W *WAVE) void crf_kernel(CrfArgs a) {
-    using Cfg = CrfCfg<R, W>;
-    constexpr int CK = Cfg::CK, NT = Cfg::NT, MAXK = Cfg::MAXK;
+    using Cfg = CrfCfg<R, W, MOD>;
+    constexpr int CK = Cfg::CK, NT = Cfg::NT, MAXK = Cfg::MAXK, LPAD = Cfg::LPAD;
+    constexpr int KINDS = Cfg::KINDS, EPL = Cfg::EPL;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & (WAVE - 1);
     const int n = blockIdx.x;
@@ -89,16 +103,22 @@ __global__ __launch_bounds__(W *WAVE) void crf_kernel(CrfArgs a) {
     const bool want_grad = a.grad != nullptr;
 
     float *tile = reinterpret_cast<float *>(smem);              // [CK][SP]
-    float *bins = tile + CK * SP;                               // [W][CK][SP]
-    float *Fblk = bins + W * CK * SP;                           // [CK][R][NT]
-    // (all three sizes are multiples of 2 floats, so the double array is 8-byte aligned)
-    double *offs = reinterpret_cast<double *>(Fblk + (size_t)CK * R * NT + ((CK * SP * (1 + W)) & 1));
-    float *rscale = reinterpret_cast<float *>(offs + CK);       // [CK]
-    float *edgeF = rscale + CK;                                 // [2][W]
+    float *Psort = tile + CK * SP;                              // [CK][KINDS][LPAD]
+    float *Fblk = Psort + (size_t)CK * KINDS * LPAD;            // [CK][R][NT]
+    size_t fbsz = (size_t)CK * R * NT;
+    {
+        const size_t scratch = (size_t)KINDS * W * SP + KINDS * SP;
+        if (scratch > fbsz) fbsz = scratch;
+    }
+    float *after = Fblk + fbsz;
+    after += ((after - tile) & 1);                              // 8-byte alignment for the doubles
+    double *offs = reinterpret_cast<double *>(after);           // [CK]
+    int *segstart = reinterpret_cast<int *>(offs + CK);         // [KINDS][SP + 1]
+    float *lanebase = reinterpret_cast<float *>(segstart + KINDS * (SP + 1));   // [W][64]
+    float *edgeF = lanebase + W * WAVE;                         // [2][W]
     float *edgeB = edgeF + 2 * W;                               // [2][W]
     float *red = edgeB + 2 * W;                                 // [W]
     float *misc = red + W;                                      // [4]
-    float *mybins = bins + wave * CK * SP;
 
     const size_t rowstride = (size_t)N * S;
     const float *lpn = a.lp + (size_t)n * S;
@@ -168,6 +188,66 @@ __global__ __launch_bounds__(W *WAVE) void crf_kernel(CrfArgs a) {
     }
     const float c = a.c_can;
     const float neg = NEG_LARGE * LOG2E;
+
+    // ---- sorted slots for the posterior streams (gradient path only) -------------------
+    // Every (position, kind) gets a slot such that slots with the same transition id are
+    // contiguous: key-major, then (wave, j, lane).  Ranks come from ballots, so the layout
+    // (and therefore every floating-point sum) is identical from run to run.
+    int slot[KINDS][R];
+    if (want_grad) {
+        const int K = SP;                                       // keys 0 .. S+1
+        int *wcnt = reinterpret_cast<int *>(Fblk);              // [KINDS][W][K]   (set-up scratch)
+        int *ktot = wcnt + KINDS * W * K;                       // [KINDS][K]
+#pragma unroll
+        for (int kind = 0; kind < KINDS; ++kind) {
+            int cnt = 0;            // lane b: occurrences of key b seen so far in this wave
+#pragma unroll
+            for (int j = 0; j < R; ++j) {
+                const int key = (kind == 0) ? st[j] : ((kind == 1) ? mv[j] : md[MOD ? j : 0]);
+                int rank = 0;
+                for (int b = 0; b < K; ++b) {
+                    const unsigned long long mask = __ballot(key == b);
+                    if (key == b)
+                        rank = __builtin_amdgcn_readlane(cnt, b) +
+                               __popcll(mask & ((1ull << lane) - 1ull));
+                    if (lane == b) cnt += __popcll(mask);
+                }
+                slot[kind][j] = rank;                           // rank within (wave, key) for now
+            }
+            if (lane < K) wcnt[(kind * W + wave) * K + lane] = cnt;
+        }
+        __syncthreads();
+        for (int e = tid; e < KINDS * K; e += NT) {
+            const int kind = e / K, b = e - kind * K;
+            int tot = 0;
+            for (int w = 0; w < W; ++w) tot += wcnt[(kind * W + w) * K + b];
+            ktot[e] = tot;
+        }
+        __syncthreads();
+        for (int e = tid; e < KINDS * K; e += NT) {
+            const int kind = e / K, b = e - kind * K;
+            int start = 0;
+            for (int bb = 0; bb < b; ++bb) start += ktot[kind * K + bb];
+            segstart[kind * (SP + 1) + b] = start;
+            if (b == K - 1) segstart[kind * (SP + 1) + K] = start + ktot[e];
+            // per-wave base of this key: overwrite the counts with exclusive prefix + start
+            int run = start;
+            for (int w = 0; w < W; ++w) {
+                const int cwb = wcnt[(kind * W + w) * K + b];
+                wcnt[(kind * W + w) * K + b] = run;
+                run += cwb;
+            }
+        }
+        __syncthreads();
+#pragma unroll
+        for (int kind = 0; kind < KINDS; ++kind)
+#pragma unroll
+            for (int j = 0; j < R; ++j) {
+                const int key = (kind == 0) ? st[j] : ((kind == 1) ? mv[j] : md[MOD ? j : 0]);
+                slot[kind][j] += wcnt[(kind * W + wave) * K + key];
+            }
+        __syncthreads();            // the scratch region becomes Fblk again
+    }
 
     // block-wide column max of step t rides on the step barrier: every wave drops
     // its max into red[] at the end of step t, everybody folds it in at step t+1
@@ -293,9 +373,8 @@ __global__ __launch_bounds__(W *WAVE) void crf_kernel(CrfArgs a) {
 #pragma unroll
             for (int j = 0; j < R; ++j) f[j] = ck_n[((size_t)k * R + j) * NT + tid];
             offF = ckoff_n[k];
-            for (int e = tid; e < W * CK * SP; e += NT) bins[e] = 0.f;
-            fwd_edge_init(f, t0);       // barrier: tile, bins and edges are visible
-            for (int i = 0; i < nrows; ++i) {
+            fwd_edge_init(f, t0);       // barrier: tile and edges are visible
+            for (int i = 0; i < ((a.debug & 4) ? 0 : nrows); ++i) {
                 const int t = t0 + i;
                 // The checkpoint holds the column BEFORE the fold that was pending at
                 // the tile boundary (CK % 4 == 0): re-post its column max so the step
@@ -313,7 +392,7 @@ __global__ __launch_bounds__(W *WAVE) void crf_kernel(CrfArgs a) {
             // -- walk the tile backwards (c_crf_flipflop.c:150-182 fused with 372-413)
             for (int i = nrows - 1; i >= 0; --i) {
                 const float *row = tile + i * SP;
-                float *grow = mybins + i * SP;
+                float *prow = Psort + (size_t)i * KINDS * LPAD;
                 float ein = (W > 1 && wave < W - 1) ? edgeB[((nbwd - 1) & 1) * W + wave + 1] : neg;
                 if (bnorm_pending) fold_norm(b, ein, offB);
                 const float ct = (float)(fwd_score2 - offs[i] - offB);
@@ -328,11 +407,15 @@ __global__ __launch_bounds__(W *WAVE) void crf_kernel(CrfArgs a) {
                     float am = fmaf(lm, c, br);
                     if (MOD) am = fmaf(row[md[j]], fw[j], am);
                     const float fc = Fblk[((size_t)i * R + j) * NT + tid] - ct;
-                    const float ps = fast_exp2(fc + as);
-                    const float pm = fast_exp2(fc + am);
-                    atomicAdd(grow + st[j], ps);
-                    atomicAdd(grow + mv[j], pm);
-                    if (MOD) atomicAdd(grow + md[j], pm * (fw[j] * inv_cmod));
+                    if (!(a.debug & 2)) {
+                        const float ps = fast_exp2(fc + as);
+                        const float pm = fast_exp2(fc + am);
+                        if (!(a.debug & 1)) {
+                            prow[slot[0][j]] = ps;
+                            prow[LPAD + slot[1][j]] = pm;
+                            if (MOD) prow[2 * LPAD + slot[MOD ? 2 : 0][j]] = pm * (fw[j] * inv_cmod);
+                        }
+                    }
                     b[j] = lse2(as, am);
                 }
                 if (W > 1 && lane == 0) edgeB[(nbwd & 1) * W + wave] = b[0];
@@ -341,24 +424,54 @@ __global__ __launch_bounds__(W *WAVE) void crf_kernel(CrfArgs a) {
                 if (bnorm_pending) post_max(b);
                 __syncthreads();
             }
-            // -- per-row normalisation (the reference's softmax over the column's
-            //    2L-1 transitions, c_crf_flipflop.c:400-401), fixed-order reduction of
-            //    the per-wave bins, output scaling -1/T (ctc.pyx:113)
-            if (tid < nrows) {
-                // every posterior lands in exactly one stay/move bin (ids < ncan);
-                // for cat-mod the mod bins hold p * fact ON TOP and are not summed
-                float sum = 0.f;
-                for (int w = 0; w < W; ++w)
-                    for (int col = 0; col < a.ncan; ++col) sum += bins[(w * CK + tid) * SP + col];
-                rscale[tid] = sum;
-            }
-            __syncthreads();
-            if (lane < S) {
-                for (int row = wave; row < nrows; row += W) {
-                    float g = 0.f;
+            // -- flush: one wave per row.  For each posterior stream the row's sorted
+            //    array becomes lane-local inclusive prefixes (+ a per-lane base from a DPP
+            //    wave scan); lane = transition id then takes the difference of the prefixes
+            //    at its segment boundaries.  The row total (stay + move streams) is the
+            //    reference's per-column softmax normaliser (c_crf_flipflop.c:400-401); output
+            //    scaling -1/T (ctc.pyx:113).
+            for (int row = wave; row < nrows; row += W) {
+                float colval = 0.f, total = 0.f;
+                float *lb = lanebase + wave * WAVE;
 #pragma unroll
-                    for (int w = 0; w < W; ++w) g += bins[(w * CK + row) * SP + lane];
-                    g *= -1.0f / (rscale[row] * (float)T);
+                for (int kind = 0; kind < KINDS; ++kind) {
+                    float *arr = Psort + ((size_t)row * KINDS + kind) * LPAD;
+                    float run = 0.f;
+                    if constexpr (EPL % 4 == 0) {
+                        // 16-byte LDS accesses (a scalar walk at stride EPL is 16-way bank-conflicted)
+                        f4 *av = reinterpret_cast<f4 *>(arr + lane * EPL);
+#pragma unroll
+                        for (int e = 0; e < EPL / 4; ++e) {
+                            f4 x = av[e];
+                            x[0] += run;
+                            x[1] += x[0];
+                            x[2] += x[1];
+                            x[3] += x[2];
+                            run = x[3];
+                            av[e] = x;
+                        }
+                    } else {
+#pragma unroll
+                        for (int e = 0; e < EPL; ++e) {
+                            run += arr[lane * EPL + e];
+                            arr[lane * EPL + e] = run;
+                        }
+                    }
+                    const float inc = wave_inclusive_scan_dpp(run);
+                    lb[lane] = inc - run;
+                    wave_lds_fence();
+                    if (kind < 2) total += __int_as_float(__builtin_amdgcn_readlane(__float_as_int(inc), 63));
+                    if (lane < S) {
+                        const int s0 = segstart[kind * (SP + 1) + lane];
+                        const int s1 = segstart[kind * (SP + 1) + lane + 1];
+                        const float p1 = (s1 > 0) ? arr[s1 - 1] + lb[(s1 - 1) / EPL] : 0.f;
+                        const float p0s = (s0 > 0) ? arr[s0 - 1] + lb[(s0 - 1) / EPL] : 0.f;
+                        colval += (s1 > s0) ? (p1 - p0s) : 0.f;
+                    }
+                    wave_lds_fence();
+                }
+                const float g = colval * (-1.0f / (total * (float)T));
+                if (lane < S) {
                     bad |= !isfinite(g);
                     a.grad[(size_t)(t0 + row) * rowstride + (size_t)n * S + lane] = g;
                 }
@@ -481,7 +594,7 @@ size_t crf_workspace_bytes(size_t ntrans, size_t nblk, size_t nbatch, size_t max
     if (!want_grad) return 256;
     if (max_seqlen == 0) max_seqlen = nblk + 1;
     const CrfShape sh = crf_pick_shape(max_seqlen);
-    const int CK = crf_ck(sh.R, sh.W);
+    const int CK = crf_ck(sh.R, sh.W, 3);   // the cat-mod tile is the smaller one: upper bound
     const size_t NK = (nblk + CK - 1) / CK;
     const size_t ck = nbatch * NK * (size_t)sh.R * sh.W * WAVE * sizeof(float);
     const size_t co = nbatch * NK * sizeof(double);
@@ -490,7 +603,7 @@ size_t crf_workspace_bytes(size_t ntrans, size_t nblk, size_t nbatch, size_t max
 
 template <int R, int W, bool MOD>
 static int crf_launch_one(const CrfArgs &a, hipStream_t stream) {
-    const size_t lds = crf_lds_bytes(R, W, a.S);
+    const size_t lds = crf_lds_bytes(R, W, a.S, MOD ? 3 : 2);
     if (lds > 160 * 1024) return 2;
     // raise the dynamic-LDS cap once per instantiation (kept out of the launch path so
     // that launches are capturable into a hipGraph)
@@ -550,12 +663,16 @@ int crf_dispatch(const float *logprob, size_t ntrans, size_t nblk, size_t nbatch
     a.out_scale = out_scale;
     a.cost = cost;
     a.grad = grad;
-    const int CK = crf_ck(sh.R, sh.W);
+    const int CK = crf_ck(sh.R, sh.W, modidx != nullptr ? 3 : 2);
     const size_t NK = (nblk + CK - 1) / CK;
     const size_t ckb = (nbatch * NK * (size_t)sh.R * sh.W * WAVE * sizeof(float) + 255) / 256 * 256;
     a.ckpt = static_cast<float *>(workspace);
     a.ckoff = reinterpret_cast<double *>(static_cast<char *>(workspace) + (grad ? ckb : 0));
     a.status = status;
+    {
+        const char *dbg = getenv("TK_CRF_DEBUG");
+        a.debug = dbg ? atoi(dbg) : 0;
+    }
     return modidx != nullptr ? crf_launch_mod<true>(sh, a, stream)
                              : crf_launch_mod<false>(sh, a, stream);
 }

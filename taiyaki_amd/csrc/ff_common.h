@@ -81,6 +81,24 @@ __device__ __forceinline__ float wave_allmax_dpp(float x) {
     return fmaxf(fmaxf(r0, r1), fmaxf(r2, r3));
 }
 
+// Inclusive prefix sum over the 64 lanes with DPP only (row_shr 1/2/4/8 inside each
+// 16-lane row, then row_bcast:15 into rows 1,3 and row_bcast:31 into rows 2,3).
+// Lanes without a source keep the `old` operand = 0.
+template <int CTRL, int ROWMASK>
+__device__ __forceinline__ float dpp_add_masked(float x) {
+    const float y = __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), CTRL, ROWMASK, 0xF, false));
+    return x + y;
+}
+__device__ __forceinline__ float wave_inclusive_scan_dpp(float x) {
+    x = dpp_add_masked<0x111, 0xF>(x);      // row_shr:1
+    x = dpp_add_masked<0x112, 0xF>(x);      // row_shr:2
+    x = dpp_add_masked<0x114, 0xF>(x);      // row_shr:4
+    x = dpp_add_masked<0x118, 0xF>(x);      // row_shr:8
+    x = dpp_add_masked<0x142, 0xA>(x);      // row_bcast:15 -> rows 1, 3
+    x = dpp_add_masked<0x143, 0xC>(x);      // row_bcast:31 -> rows 2, 3
+    return x;
+}
+
 __device__ __forceinline__ float wave_allmax(float x) {
 #pragma unroll
     for (int m = 32; m >= 1; m >>= 1) {

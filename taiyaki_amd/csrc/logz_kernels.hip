@@ -28,16 +28,17 @@
 //   * arithmetic is linear-space fp32 with exact power-of-two renormalisation
 //     (integer exponents are accumulated exactly; row maxima in fp64), so no
 //     transcendental sits on a serial dependency chain.
+#include <stdlib.h>
+
 #include "ff_common.h"
 
 namespace tk {
 
-constexpr int LOGZ_CH = 32;             // rows per chunk
+// rows per chunk (CH) is a template parameter of K1 / K3, picked per problem so that
+// the grid fills the chip: 32 for big tensors, 16 / 8 for small ones
 constexpr int LOGZ_SUPER = 8;           // chunks per super-chunk
-constexpr int K1_WAVES = 4;             // waves per K1 block (one chunk): 4 x 8 rows
-constexpr int K1_ROWS = LOGZ_CH / K1_WAVES;
-constexpr int K3_WAVES = 8;             // waves per K3 block: 8 x 4 rows = 1 chunk
-constexpr int K3_ROWS = LOGZ_CH / K3_WAVES;
+constexpr int K1_WAVES = 4;             // waves per K1 block (one chunk): 4 x CH/4 rows
+constexpr int K3_WAVES = 8;             // waves per K3 block: 8 x CH/8 rows = 1 chunk
 constexpr int ZERO_ROW_EXP = -(1 << 28);    // exponent of an all-zero matrix row
 
 // ---------------------------------------------------------------------------
@@ -277,10 +278,10 @@ struct LogzWs {
 
 // per-wave LDS buffer of K3 in f4 units: the row-set transpose buffer, which
 // doubles as storage for the wave's K3_ROWS forward vectors
-template <int NB>
+template <int NB, int CH>
 __host__ __device__ constexpr int k3_buf_f4() {
     constexpr int a = WAVE * FF<NB>::PIECES;
-    constexpr int b = K3_ROWS * FF<NB>::NS * WAVE / 4;
+    constexpr int b = (CH / K3_WAVES) * FF<NB>::NS * WAVE / 4;
     return a > b ? a : b;
 }
 
@@ -289,7 +290,7 @@ __host__ __device__ constexpr int k3_buf_f4() {
 // wave w folds rows [8w, 8w+8) of the chunk; a 2-level tree through LDS
 // (the waves' transpose buffers, idle by then) yields P0 P1 P2 P3.
 // ---------------------------------------------------------------------------
-template <int NB>
+template <int NB, int CH>
 __global__ __launch_bounds__(K1_WAVES *WAVE, 2) void logz_transfer_kernel(
     const float *__restrict__ scores, int T, int N, int C, int Npad, LogzWs ws) {
     using F = FF<NB>;
@@ -300,7 +301,8 @@ __global__ __launch_bounds__(K1_WAVES *WAVE, 2) void logz_transfer_kernel(
     f4 *buf = reinterpret_cast<f4 *>(smem) + wave * (WAVE * F::PIECES);
     const int n0 = blockIdx.x * WAVE;
     const int nvalid = min(WAVE, N - n0) * F::PIECES;
-    const int t0 = c * LOGZ_CH + wave * K1_ROWS, t1 = min(T, t0 + K1_ROWS);
+    constexpr int K1_ROWS = CH / K1_WAVES;
+    const int t0 = c * CH + wave * K1_ROWS, t1 = min(T, t0 + K1_ROWS);
     const size_t rowstride = (size_t)N * F::S;
     const float *base = scores + (size_t)n0 * F::S;
 
@@ -641,25 +643,31 @@ __global__ __launch_bounds__(K2_WAVES *WAVE) void logz_middle_kernel(int N, int 
 // between the waves through LDS; posteriors overwrite the rows in place and
 // are streamed out through the same coalescing transpose.
 // ---------------------------------------------------------------------------
-template <int NB>
-__global__ __launch_bounds__(K3_WAVES *WAVE, 2) void logz_posterior_kernel(
+template <int NB, int CH>
+__global__ __launch_bounds__(K3_WAVES *WAVE, (CH <= 16 ? 4 : 2)) void logz_posterior_kernel(
     const float *__restrict__ scores, float *__restrict__ grad, int T, int N, int Npad,
     LogzWs ws, uint32_t *__restrict__ status) {
     using F = FF<NB>;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int wave = threadIdx.x >> 6, lane = lane_id();
-    constexpr int BUF_F4 = k3_buf_f4<NB>();
+    constexpr int K3_ROWS = CH / K3_WAVES;
+    constexpr int BUF_F4 = k3_buf_f4<NB, CH>();
     f4 *buf = reinterpret_cast<f4 *>(smem) + wave * BUF_F4;
     // between the load phase and the store phase the transpose buffer is idle:
     // it keeps this wave's forward vectors (lane-private slots, no sync needed)
     float *fvb = reinterpret_cast<float *>(buf);            // [K3_ROWS][NS][64]
-    float *chainF = reinterpret_cast<float *>(reinterpret_cast<f4 *>(smem) + K3_WAVES * BUF_F4);
+    // hand-off slots of the two chains: behind the buffers, or (small chunks) in the unused
+    // tail of wave 0's buffer so that two blocks fit in one CU's LDS
+    constexpr bool CHAIN_IN_BUF = (K3_ROWS + 2) * F::NS * WAVE <= BUF_F4 * 4;
+    float *chainF = CHAIN_IN_BUF
+                        ? reinterpret_cast<float *>(smem) + K3_ROWS * F::NS * WAVE
+                        : reinterpret_cast<float *>(reinterpret_cast<f4 *>(smem) + K3_WAVES * BUF_F4);
     float *chainB = chainF + F::NS * WAVE;
     const int c = blockIdx.y;
     const int n0 = blockIdx.x * WAVE;
     const int nvalid = min(WAVE, N - n0) * F::PIECES;
     const size_t rowstride = (size_t)N * F::S;
-    const int tw = c * LOGZ_CH + wave * K3_ROWS;        // first row of this wave
+    const int tw = c * CH + wave * K3_ROWS;             // first row of this wave
     const float *base = scores + (size_t)n0 * F::S;
     const size_t n = (size_t)n0 + lane;
 
@@ -787,11 +795,19 @@ __global__ __launch_bounds__(K3_WAVES *WAVE, 2) void logz_posterior_kernel(
 // ---------------------------------------------------------------------------
 static inline size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
 
+// chunk size: the largest of {32, 16, 8} whose K3 grid still has >= ~2 blocks per CU
+static int logz_pick_ch(size_t T, size_t N) {
+    const size_t ncols = (N + WAVE - 1) / WAVE;
+    for (int ch = 32; ch > 8; ch /= 2)
+        if (ncols * ((T + ch - 1) / ch) >= 384) return ch;
+    return 8;
+}
+
 template <int NB>
 static size_t logz_ws_layout(size_t T, size_t N, void *base, LogzWs *ws) {
     using F = FF<NB>;
     using X = XMat<NB>;
-    const size_t C = (T + LOGZ_CH - 1) / LOGZ_CH, Npad = align_up(N, WAVE);
+    const size_t C = (T + 8 - 1) / 8, Npad = align_up(N, WAVE);     // sized for the smallest chunk
     const size_t NSUP = (C + LOGZ_SUPER - 1) / LOGZ_SUPER;
     size_t off = 0;
     char *p = static_cast<char *>(base);
@@ -809,15 +825,11 @@ static size_t logz_ws_layout(size_t T, size_t N, void *base, LogzWs *ws) {
     return off;
 }
 
-template <int NB>
-static int logz_launch(const float *scores, size_t T, size_t N, float *logz, float *grad,
-                       void *workspace, size_t workspace_bytes, uint32_t *status,
-                       hipStream_t stream) {
+template <int NB, int CH>
+static int logz_launch_ch(const float *scores, size_t T, size_t N, float *logz, float *grad,
+                          LogzWs ws, uint32_t *status, hipStream_t stream) {
     using F = FF<NB>;
-    LogzWs ws;
-    const size_t need = logz_ws_layout<NB>(T, N, workspace, &ws);
-    if (need > workspace_bytes) return 3;
-    const int C = (int)((T + LOGZ_CH - 1) / LOGZ_CH);
+    const int C = (int)((T + CH - 1) / CH);
     const int NSUP = (C + LOGZ_SUPER - 1) / LOGZ_SUPER;
     const int ncols = (int)((N + WAVE - 1) / WAVE), Npad = ncols * WAVE;
     const size_t bufbytes = (size_t)WAVE * F::PIECES * sizeof(f4);
@@ -826,18 +838,18 @@ static int logz_launch(const float *scores, size_t T, size_t N, float *logz, flo
         const size_t lds = matbytes > K1_WAVES * bufbytes ? matbytes : K1_WAVES * bufbytes;
         static bool raised1 = false;
         if (lds > 64 * 1024 && !raised1) {
-            if (hipFuncSetAttribute(reinterpret_cast<const void *>(&logz_transfer_kernel<NB>),
+            if (hipFuncSetAttribute(reinterpret_cast<const void *>(&logz_transfer_kernel<NB, CH>),
                                     hipFuncAttributeMaxDynamicSharedMemorySize,
                                     160 * 1024) != hipSuccess)
                 return 4;
             raised1 = true;
         }
-        hipLaunchKernelGGL(logz_transfer_kernel<NB>, dim3(ncols, C), dim3(K1_WAVES * WAVE), lds,
+        hipLaunchKernelGGL((logz_transfer_kernel<NB, CH>), dim3(ncols, C), dim3(K1_WAVES * WAVE), lds,
                            stream, scores, (int)T, (int)N, C, Npad, ws);
     }
     {
         const size_t lds = ((size_t)(C + NSUP) * 4 * XMat<NB>::NF4 + 2 * (size_t)NSUP * GRP) * sizeof(float);
-        if (lds > 160 * 1024) return 2;         // T > ~16000 blocks: not built
+        if (lds > 160 * 1024) return 2;         // too many chunks for one LDS image
         static bool raised2 = false;
         if (lds > 64 * 1024 && !raised2) {
             if (hipFuncSetAttribute(reinterpret_cast<const void *>(&logz_middle_kernel<NB>),
@@ -851,20 +863,40 @@ static int logz_launch(const float *scores, size_t T, size_t N, float *logz, flo
     }
     if (grad != nullptr) {
         dim3 grid(ncols, C), block(K3_WAVES * WAVE);
-        const size_t lds = K3_WAVES * (size_t)k3_buf_f4<NB>() * sizeof(f4) +
-                           2 * F::NS * WAVE * sizeof(float);
+        constexpr bool chain_in_buf =
+            ((CH / K3_WAVES) + 2) * F::NS * WAVE <= k3_buf_f4<NB, CH>() * 4;
+        const size_t lds = K3_WAVES * (size_t)k3_buf_f4<NB, CH>() * sizeof(f4) +
+                           (chain_in_buf ? 0 : 2 * F::NS * WAVE * sizeof(float));
         static bool raised3 = false;
         if (lds > 64 * 1024 && !raised3) {
-            if (hipFuncSetAttribute(reinterpret_cast<const void *>(&logz_posterior_kernel<NB>),
+            if (hipFuncSetAttribute(reinterpret_cast<const void *>(&logz_posterior_kernel<NB, CH>),
                                     hipFuncAttributeMaxDynamicSharedMemorySize,
                                     160 * 1024) != hipSuccess)
                 return 4;
             raised3 = true;
         }
-        hipLaunchKernelGGL(logz_posterior_kernel<NB>, grid, block, lds, stream, scores, grad,
+        hipLaunchKernelGGL((logz_posterior_kernel<NB, CH>), grid, block, lds, stream, scores, grad,
                            (int)T, (int)N, Npad, ws, status);
     }
     return hipGetLastError() == hipSuccess ? 0 : 4;
+}
+
+template <int NB>
+static int logz_launch(const float *scores, size_t T, size_t N, float *logz, float *grad,
+                       void *workspace, size_t workspace_bytes, uint32_t *status,
+                       hipStream_t stream) {
+    LogzWs ws;
+    const size_t need = logz_ws_layout<NB>(T, N, workspace, &ws);
+    if (need > workspace_bytes) return 3;
+    int ch = logz_pick_ch(T, N);
+    if (const char *e = getenv("TK_LOGZ_CH")) ch = atoi(e);         // tuning override
+    // the middle kernel keeps one read's chunk matrices in LDS: fall back to bigger chunks
+    while (ch < 32 && ((T + ch - 1) / ch) * 4 * XMat<NB>::NF4 * sizeof(float) > 140 * 1024) ch *= 2;
+    switch (ch) {
+        case 8: return logz_launch_ch<NB, 8>(scores, T, N, logz, grad, ws, status, stream);
+        case 16: return logz_launch_ch<NB, 16>(scores, T, N, logz, grad, ws, status, stream);
+        default: return logz_launch_ch<NB, 32>(scores, T, N, logz, grad, ws, status, stream);
+    }
 }
 
 size_t logz_workspace_bytes(size_t T, size_t N, size_t nbase) {

@@ -343,3 +343,15 @@ def test_crf_loss_bounded_by_logz(gpu_device):
     lv = ctc.crf_flipflop_loss(x, torch.from_numpy(inp["seqs"]), torch.from_numpy(inp["seqlens"]), 1.0)
     lv = lv + layers.flipflop_logpartition(x) / 800.0
     assert bool((lv > 0).all())
+
+
+@pytest.mark.parametrize("ch", [8, 16, 32])
+def test_logz_every_chunk_size(oracle_mod, gpu_device, ch, monkeypatch):
+    """The chunk size of the transfer/posterior kernels is picked per problem size;
+    force each instantiation (TK_LOGZ_CH) on a tensor with a ragged tail (T % 32 != 0)."""
+    from taiyaki_amd import synth
+    monkeypatch.setenv("TK_LOGZ_CH", str(ch))
+    sc = synth.scores(333, 70, 40, 45)
+    r = parity.compare_logz(oracle_mod, sc, gpu_device)
+    assert r["finite"] and r["logz_rel"] < LOSS_RTOL and r["grad_abs"] < GRAD_ATOL
+    assert r["rowsum_dev"] < 1e-5

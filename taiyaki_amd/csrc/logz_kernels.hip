@@ -41,6 +41,17 @@ constexpr int K1_WAVES = 4;             // waves per K1 block (one chunk): 4 x C
 constexpr int K3_WAVES = 8;             // waves per K3 block: 8 x CH/8 rows = 1 chunk
 constexpr int ZERO_ROW_EXP = -(1 << 28);    // exponent of an all-zero matrix row
 
+// tuning knobs (tools/logz_lab.hip rebuilds this file with -D overrides)
+#ifndef TK_K1_NT_LOAD
+#define TK_K1_NT_LOAD 0
+#endif
+#ifndef TK_K3_NT_LOAD
+#define TK_K3_NT_LOAD 1
+#endif
+#ifndef TK_K3_NT_STORE
+#define TK_K3_NT_STORE 1
+#endif
+
 // ---------------------------------------------------------------------------
 // XMat: a 2nb x 2nb transfer matrix  value[i][j] = m[i][j] * 2^e[i] * exp(M)
 // stored per read as NF4 float4 (lane = read => [mat][q][Npad] float4 layout,
@@ -326,12 +337,16 @@ __global__ __launch_bounds__(K1_WAVES *WAVE, 2) void logz_transfer_kernel(
             }
             if (((t - t0) & 3) == 3) P.renorm();
         };
-        r0.issue(rowptr(t0), nvalid, lane);
+        auto fetch = [&](RowSet<NB> &r, int t) {
+            if (TK_K1_NT_LOAD) r.issue_nt(rowptr(t), nvalid, lane);
+            else r.issue(rowptr(t), nvalid, lane);
+        };
+        fetch(r0, t0);
         for (int t = t0; t < t1; t += 2) {
-            r1.issue(rowptr(t + 1), nvalid, lane);
+            fetch(r1, t + 1);
             consume(r0, t);
             if (t + 1 >= t1) break;
-            r0.issue(rowptr(t + 2), nvalid, lane);
+            fetch(r0, t + 2);
             consume(r1, t + 1);
         }
         P.renorm();
@@ -423,86 +438,146 @@ __device__ __forceinline__ float grp_bcast(float x, int i) {
 __device__ __forceinline__ int grp_bcast(int x, int i) {
     return __shfl(x, (lane_id() & ~(GRP - 1)) | i, WAVE);
 }
+// 8-lane group maximum: three v_max_*_dpp (the DPP operand is folded into the max; hipcc
+// emits mov + s_nop + mov_dpp + max for the intrinsic form, and these sit on the serial
+// chain of every step).  s_nop 1 = the two wait states a DPP read needs after a VALU write.
 __device__ __forceinline__ int grp_max_i(int x) {
-    x = max(x, __builtin_amdgcn_update_dpp(x, x, 0xB1, 0xF, 0xF, false));
-    x = max(x, __builtin_amdgcn_update_dpp(x, x, 0x4E, 0xF, 0xF, false));
-    x = max(x, __builtin_amdgcn_update_dpp(x, x, 0x141, 0xF, 0xF, false));
-    return x;
+    int r;
+    asm("s_nop 1\n\t"
+        "v_max_i32_dpp %0, %1, %1 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
+        "s_nop 1\n\t"
+        "v_max_i32_dpp %0, %0, %0 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n\t"
+        "s_nop 1\n\t"
+        "v_max_i32_dpp %0, %0, %0 row_half_mirror row_mask:0xf bank_mask:0xf"
+        : "=&v"(r) : "v"(x));
+    return r;
 }
 __device__ __forceinline__ float grp_max_f(float x) {
-    x = fmaxf(x, dpp_f32<0xB1>(x, x));
-    x = fmaxf(x, dpp_f32<0x4E>(x, x));
-    x = fmaxf(x, dpp_f32<0x141>(x, x));
-    return x;
+    float r;
+    asm("s_nop 1\n\t"
+        "v_max_f32_dpp %0, %1, %1 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
+        "s_nop 1\n\t"
+        "v_max_f32_dpp %0, %0, %0 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n\t"
+        "s_nop 1\n\t"
+        "v_max_f32_dpp %0, %0, %0 row_half_mirror row_mask:0xf bank_mask:0xf"
+        : "=&v"(r) : "v"(x));
+    return r;
 }
-// one lane's share of a matrix for v (x) A: column g (NS words) + exponent of row g
+// Shares keep their NS words in "DPP order": the in-group dot product broadcasts lane
+// 4q+k of the lane's own quad q (quad_perm [k,k,k,k]) and lane 7-4q-k of the other quad
+// (the same quad_perm applied to the half-mirrored value), so word k of `a` pairs with
+// state 4q+k and word 4+k with state 7-4q-k.  Eight broadcasts = 1 + 8 DPP movs on the
+// VALU; no ds_bpermute round trip through the LDS crossbar on the serial chain.
+template <int NS>
+__device__ __forceinline__ int dpp_state(int g, int w) {           // state paired with word w
+    const int q4 = (g >> 2) << 2;
+    return (w < 4) ? q4 + w : 7 - q4 - (w - 4);
+}
+// sum_w a[w] * x[state(w)] over the group (x = 0 in lanes >= NS): one mirror + eight
+// multiply-adds whose first operand is the DPP-broadcast lane (v_fmac_f32_dpp)
+__device__ __forceinline__ float grp_dot(const float (&a)[8], float x) {
+    float acc, xm;
+    asm("s_nop 1\n\t"
+        "v_mov_b32_dpp %1, %2 row_half_mirror row_mask:0xf bank_mask:0xf\n\t"
+        "v_mul_f32_dpp %0, %2, %3 quad_perm:[0,0,0,0] row_mask:0xf bank_mask:0xf\n\t"
+        "v_fmac_f32_dpp %0, %2, %4 quad_perm:[1,1,1,1] row_mask:0xf bank_mask:0xf\n\t"
+        "v_fmac_f32_dpp %0, %2, %5 quad_perm:[2,2,2,2] row_mask:0xf bank_mask:0xf\n\t"
+        "v_fmac_f32_dpp %0, %2, %6 quad_perm:[3,3,3,3] row_mask:0xf bank_mask:0xf\n\t"
+        "v_fmac_f32_dpp %0, %1, %7 quad_perm:[0,0,0,0] row_mask:0xf bank_mask:0xf\n\t"
+        "v_fmac_f32_dpp %0, %1, %8 quad_perm:[1,1,1,1] row_mask:0xf bank_mask:0xf\n\t"
+        "v_fmac_f32_dpp %0, %1, %9 quad_perm:[2,2,2,2] row_mask:0xf bank_mask:0xf\n\t"
+        "v_fmac_f32_dpp %0, %1, %10 quad_perm:[3,3,3,3] row_mask:0xf bank_mask:0xf"
+        : "=&v"(acc), "=&v"(xm)
+        : "v"(x), "v"(a[0]), "v"(a[1]), "v"(a[2]), "v"(a[3]), "v"(a[4]), "v"(a[5]), "v"(a[6]), "v"(a[7]));
+    return acc;
+}
+
+// one lane's share of a matrix for v (x) A: column g + exponent of row g
 template <int NB>
 struct ColShare {
-    float a[2 * NB];
+    float a[8];
     int e;
-    double M;
     __device__ __forceinline__ void load(const float *img, int g) {     // img: one read's words
         constexpr int NS = 2 * NB;
         const int gc = min(g, NS - 1);
 #pragma unroll
-        for (int i = 0; i < NS; ++i) a[i] = img[i * NS + gc];
+        for (int w = 0; w < 8; ++w) {
+            const int i = dpp_state<NS>(g, w);
+            const float x = img[min(i, NS - 1) * NS + gc];
+            a[w] = (i < NS) ? x : 0.f;
+        }
         e = (g < NS) ? __float_as_int(img[NS * NS + gc]) : ZERO_ROW_EXP;
-        M = __hiloint2double(__float_as_int(img[NS * NS + NS + 1]), __float_as_int(img[NS * NS + NS]));
     }
 };
 
-// one lane's share for A (x) u: row g (NS words) + exponent of row g
+// one lane's share for A (x) u: row g + exponent of row g
 template <int NB>
 struct RowShare {
-    float a[2 * NB];
+    float a[8];
     int e;
     __device__ __forceinline__ void load(const float *img, int g) {
         constexpr int NS = 2 * NB;
         const int gc = min(g, NS - 1);
 #pragma unroll
-        for (int j = 0; j < NS; ++j) a[j] = img[gc * NS + j];
+        for (int w = 0; w < 8; ++w) {
+            const int j = dpp_state<NS>(g, w);
+            const float x = img[gc * NS + min(j, NS - 1)];
+            a[w] = (j < NS) ? x : 0.f;
+        }
         e = (g < NS) ? __float_as_int(img[NS * NS + gc]) : ZERO_ROW_EXP;
     }
 };
 
-// v (lane g holds v[g]) <- normalise(v (x) A); returns the exponent taken out (group-uniform)
+// the fp64 log-scale M of a matrix image
+template <int NB>
+__device__ __forceinline__ double img_M(const float *img) {
+    constexpr int NS = 2 * NB;
+    return __hiloint2double(__float_as_int(img[NS * NS + NS + 1]), __float_as_int(img[NS * NS + NS]));
+}
+
+// The serial steps below are issued by ONE wave in order, so every instruction in the
+// loop body is latency: bookkeeping that is not on the dependency chain (the fp64 M sums,
+// 64-bit exponent sums, register copies of the prefetched share) is kept out of them.
+//
+// v (lane g holds v[g]) <- v (x) A up to a power of two; returns the exponent taken out
+// (group-uniform).  The rows of A have maxima in [1/2, 1) and the aligned weights have
+// their maximum in [1/2, 1), so the result lies in [2^-2, 2^3): no second normalisation
+// is needed -- the next step aligns on the exponents of whatever v holds.  A zero row
+// (e = ZERO_ROW_EXP) keeps t hugely negative by itself; if every lane is zero the step
+// returns an arbitrary finite exponent with v = 0, which the callers flag.
 template <int NB>
 __device__ __forceinline__ int grp_vec_mat(float &v, const ColShare<NB> &A, int g) {
     constexpr int NS = 2 * NB;
-    const int t = (v > 0.f && A.e != ZERO_ROW_EXP) ? A.e + __builtin_amdgcn_frexp_expf(v) : ZERO_ROW_EXP;
-    int emax = grp_max_i(t);
-    if (emax == ZERO_ROW_EXP) emax = 0;
+    const int t = (v > 0.f) ? A.e + __builtin_amdgcn_frexp_expf(v) : ZERO_ROW_EXP;
+    const int emax = max(grp_max_i(t), -(1 << 20));
     const float vs = __builtin_amdgcn_ldexpf(v, max(A.e - emax, -300));     // row g's scaled weight
-    float acc0 = 0.f, acc1 = 0.f;
-#pragma unroll
-    for (int i = 0; i < NS; i += 2) {
-        acc0 = fmaf(grp_bcast(vs, i), A.a[i], acc0);
-        acc1 = fmaf(grp_bcast(vs, i + 1), A.a[i + 1], acc1);
-    }
-    float acc = acc0 + acc1;
-    if (g >= NS) acc = 0.f;
-    const float mx = grp_max_f(acc);
-    const int ex = (mx > 0.f) ? __builtin_amdgcn_frexp_expf(mx) : 0;
-    v = __builtin_amdgcn_ldexpf(acc, -ex);
-    return emax + ex;
+    const float acc = grp_dot(A.a, vs);
+    v = (g < NS) ? acc : 0.f;
+    return emax;
 }
 
 // u (lane g holds u[g]) <- normalise(A (x) u)
 template <int NB>
 __device__ __forceinline__ void grp_mat_vec(float &u, const RowShare<NB> &A, int g) {
     constexpr int NS = 2 * NB;
-    float acc0 = 0.f, acc1 = 0.f;
-#pragma unroll
-    for (int j = 0; j < NS; j += 2) {
-        acc0 = fmaf(A.a[j], grp_bcast(u, j), acc0);
-        acc1 = fmaf(A.a[j + 1], grp_bcast(u, j + 1), acc1);
-    }
-    float acc = acc0 + acc1;
+    float acc = grp_dot(A.a, u);
     if (g >= NS) acc = 0.f;
-    const int t = (acc > 0.f && A.e != ZERO_ROW_EXP) ? A.e + __builtin_amdgcn_frexp_expf(acc) : ZERO_ROW_EXP;
-    int emax = grp_max_i(t);
-    if (emax == ZERO_ROW_EXP) emax = 0;
+    const int t = (acc > 0.f) ? A.e + __builtin_amdgcn_frexp_expf(acc) : ZERO_ROW_EXP;
+    const int emax = max(grp_max_i(t), -(1 << 20));
     u = __builtin_amdgcn_ldexpf(acc, max(A.e - emax, -300));
+}
+
+__device__ __forceinline__ double wave_sum_f64(double x) {
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) x += __shfl_xor(x, m, WAVE);
+    return x;
+}
+
+// LDS image of the middle kernel: [C] chunk matrices, [NSUP] super totals, 2 x [NSUP][GRP]
+// boundary vectors, and one matrix of slack (the one-ahead prefetches run past the end)
+template <int NB>
+__host__ __device__ constexpr size_t logz_middle_lds_bytes(int C, int NSUP) {
+    return ((size_t)(C + NSUP + 1) * 4 * XMat<NB>::NF4 + 2 * (size_t)NSUP * 8) * sizeof(float);
 }
 
 // ---------------------------------------------------------------------------
@@ -518,6 +593,13 @@ __device__ __forceinline__ void grp_mat_vec(float &u, const RowShare<NB> &A, int
 // grid = N, block = 256.
 // ---------------------------------------------------------------------------
 constexpr int K2_WAVES = 16;
+
+#ifdef TK_LAB_TIMING
+__device__ long long tk_dbg[64];
+#define TK_STAMP(k) do { if (blockIdx.x == 100 && threadIdx.x == 0) tk_dbg[k] = clock64(); } while (0)
+#else
+#define TK_STAMP(k)
+#endif
 
 template <int NB>
 __global__ __launch_bounds__(K2_WAVES *WAVE) void logz_middle_kernel(int N, int C, int NSUP, int Npad,
@@ -537,6 +619,7 @@ __global__ __launch_bounds__(K2_WAVES *WAVE) void logz_middle_kernel(int N, int 
     const int g = lane & (GRP - 1), grp = lane >> 3;
     const size_t n = blockIdx.x;
 
+    TK_STAMP(0);
     // ---- 1. stage the read's chunk matrices: one contiguous run of C*NF4 float4
     {
         const int total = C * X::NF4;
@@ -553,44 +636,64 @@ __global__ __launch_bounds__(K2_WAVES *WAVE) void logz_middle_kernel(int N, int 
         }
     }
     __syncthreads();
+    TK_STAMP(1);
 
-    // ---- 2. combine: group `grp` of the wave carries row `grp` of the super's product
+    // ---- 2. combine: group `grp` of the wave carries row `grp` of the super's product.
+    //         Fully unrolled over the super's chunks: LDS offsets are immediates, the
+    //         shares ping-pong between two register sets one matrix ahead.
     for (int s = wave; s < NSUP; s += K2_WAVES) {
-        const int c0 = s * LOGZ_SUPER, c1 = min(C, c0 + LOGZ_SUPER);
+        const int c0 = s * LOGZ_SUPER, cnt = min(C - c0, LOGZ_SUPER);
+        const float *img0 = pcimg + (size_t)c0 * NFW;
         float v = (g == grp && grp < F::NS) ? 1.f : 0.f;
-        long long eacc = 0;
-        double macc = 0.0;
-        for (int c = c0; c < c1; ++c) {
-            ColShare<NB> A;
-            A.load(pcimg + (size_t)c * NFW, g);
-            eacc += grp_vec_mat<NB>(v, A, g);
-            macc += A.M;
+        int eacc = 0;
+        ColShare<NB> A[2];
+        A[0].load(img0, g);
+#pragma unroll
+        for (int i = 0; i < LOGZ_SUPER; ++i) {
+            if (i < cnt) {
+                A[(i + 1) & 1].load(img0 + (i + 1) * NFW, g);      // may run one matrix past the super
+                eacc += grp_vec_mat<NB>(v, A[i & 1], g);
+            }
         }
+        const double macc = wave_sum_f64((lane < cnt) ? img_M<NB>(img0 + lane * NFW) : 0.0);
         const float mx = grp_max_f(v);
+        {   // rows of the stored totals are normalised like K1's (maximum in [1/2, 1))
+            const int ex = (mx > 0.f) ? __builtin_amdgcn_frexp_expf(mx) : 0;
+            v = __builtin_amdgcn_ldexpf(v, -ex);
+            eacc += ex;
+        }
         float *t = totimg + (size_t)s * NFW;
         if (grp < F::NS && g < F::NS) t[grp * F::NS + g] = v;
-        if (grp < F::NS && g == 0) t[F::NS * F::NS + grp] = __int_as_float((mx > 0.f) ? (int)eacc : ZERO_ROW_EXP);
+        if (grp < F::NS && g == 0) t[F::NS * F::NS + grp] = __int_as_float((mx > 0.f) ? eacc : ZERO_ROW_EXP);
         if (lane == 0) {
             t[F::NS * F::NS + F::NS] = __int_as_float(__double2loint(macc));
             t[F::NS * F::NS + F::NS + 1] = __int_as_float(__double2hiint(macc));
         }
     }
     __syncthreads();
+    TK_STAMP(2);
 
-    // ---- 3. scan over the super totals (one 8-lane group per direction)
+    // ---- 3. scan over the super totals (every group of the wave runs the same chain, so
+    //         the boundary-vector stores need no predicate)
     if (wave == 0) {
         // forward: paths start in any flip state with weight 1 (layers.py:1289-1295,
         // cupy flipflop.py:115-118)
         float v = (g < NB) ? 1.f : 0.f;
-        double macc = 0.0;
-        long long eacc = 0;
-        for (int s = 0; s < NSUP; ++s) {
-            if (grp == 0) vsl[s * GRP + g] = v;
-            ColShare<NB> A;
-            A.load(totimg + (size_t)s * NFW, g);
-            eacc += grp_vec_mat<NB>(v, A, g);
-            macc += A.M;
+        int eacc = 0;
+        ColShare<NB> A[2];
+        A[0].load(totimg, g);
+        for (int s = 0; s < NSUP; s += 2) {
+            A[1].load(totimg + (size_t)(s + 1) * NFW, g);
+            vsl[s * GRP + g] = v;
+            eacc += grp_vec_mat<NB>(v, A[0], g);
+            if (s + 1 >= NSUP) break;
+            A[0].load(totimg + (size_t)(s + 2) * NFW, g);
+            vsl[(s + 1) * GRP + g] = v;
+            eacc += grp_vec_mat<NB>(v, A[1], g);
         }
+        double macc = 0.0;
+        for (int s = lane; s < NSUP; s += WAVE) macc += img_M<NB>(totimg + (size_t)s * NFW);
+        macc = wave_sum_f64(macc);
         float tot = 0.f;
 #pragma unroll
         for (int i = 0; i < F::NS; ++i) tot += grp_bcast(v, i);
@@ -602,15 +705,21 @@ __global__ __launch_bounds__(K2_WAVES *WAVE) void logz_middle_kernel(int N, int 
     } else if (wave == 1 && want_grad) {
         // backward: paths may end in any state (cupy flipflop.py:163-166); scale is free
         float u = (g < F::NS) ? 1.f : 0.f;
-        for (int s = NSUP - 1; s >= 0; --s) {
-            if (grp == 0) usl[s * GRP + g] = u;
-            RowShare<NB> A;
-            A.load(totimg + (size_t)s * NFW, g);
-            grp_mat_vec<NB>(u, A, g);
+        RowShare<NB> A[2];
+        A[0].load(totimg + (size_t)(NSUP - 1) * NFW, g);
+        for (int s = NSUP - 1; s >= 0; s -= 2) {
+            A[1].load(totimg + (size_t)max(s - 1, 0) * NFW, g);
+            usl[s * GRP + g] = u;
+            grp_mat_vec<NB>(u, A[0], g);
+            if (s - 1 < 0) break;
+            A[0].load(totimg + (size_t)max(s - 2, 0) * NFW, g);
+            usl[(s - 1) * GRP + g] = u;
+            grp_mat_vec<NB>(u, A[1], g);
         }
     }
     if (!want_grad) return;
     __syncthreads();
+    TK_STAMP(3);
 
     // ---- 4. expand to chunk granularity: lower half of the waves forward chains, upper
     //         half backward chains; one 8-lane group per chain
@@ -619,22 +728,37 @@ __global__ __launch_bounds__(K2_WAVES *WAVE) void logz_middle_kernel(int N, int 
     const int slot = (wave % HALF) * GRP + grp;
     float *dstbase = (fwd ? ws.Vin : ws.Uout) + n * (size_t)C * F::NS;     // [read][c][NS]
     for (int s = slot; s < NSUP; s += HALF * GRP) {
-        const int c0 = s * LOGZ_SUPER, c1 = min(C, c0 + LOGZ_SUPER);
+        const int c0 = s * LOGZ_SUPER, cnt = min(C - c0, LOGZ_SUPER);
         float v = (fwd ? vsl : usl)[s * GRP + g];
-        for (int i = 0; i < c1 - c0; ++i) {
-            const int c = fwd ? c0 + i : c1 - 1 - i;
-            if (g < F::NS) dstbase[(size_t)c * F::NS + g] = v;
-            if (fwd) {
-                ColShare<NB> A;
-                A.load(pcimg + (size_t)c * NFW, g);
-                (void)grp_vec_mat<NB>(v, A, g);
-            } else {
-                RowShare<NB> A;
-                A.load(pcimg + (size_t)c * NFW, g);
-                grp_mat_vec<NB>(v, A, g);
+        if (fwd) {
+            const float *img0 = pcimg + (size_t)c0 * NFW;
+            float *dst = dstbase + (size_t)c0 * F::NS;
+            ColShare<NB> A[2];
+            A[0].load(img0, g);
+#pragma unroll
+            for (int i = 0; i < LOGZ_SUPER; ++i) {
+                if (i < cnt) {
+                    A[(i + 1) & 1].load(img0 + (i + 1) * NFW, g);
+                    if (g < F::NS) dst[i * F::NS + g] = v;
+                    (void)grp_vec_mat<NB>(v, A[i & 1], g);
+                }
+            }
+        } else {
+            const float *img1 = pcimg + (size_t)(c0 + cnt - 1) * NFW;      // last chunk of the super
+            float *dst = dstbase + (size_t)(c0 + cnt - 1) * F::NS;
+            RowShare<NB> A[2];
+            A[0].load(img1, g);
+#pragma unroll
+            for (int i = 0; i < LOGZ_SUPER; ++i) {
+                if (i < cnt) {
+                    A[(i + 1) & 1].load(img1 - (i + 1 < cnt ? i + 1 : i) * NFW, g);
+                    if (g < F::NS) dst[-i * F::NS + g] = v;
+                    grp_mat_vec<NB>(v, A[i & 1], g);
+                }
             }
         }
     }
+    TK_STAMP(4);
 }
 
 // ---------------------------------------------------------------------------
@@ -675,7 +799,8 @@ __global__ __launch_bounds__(K3_WAVES *WAVE, (CH <= 16 ? 4 : 2)) void logz_poste
     RowSet<NB> w[K3_ROWS];
 #pragma unroll
     for (int j = 0; j < K3_ROWS; ++j)
-        w[j].issue_nt(base + (size_t)min(tw + j, T - 1) * rowstride, nvalid, lane);     // last use
+        if (TK_K3_NT_LOAD) w[j].issue_nt(base + (size_t)min(tw + j, T - 1) * rowstride, nvalid, lane);     // last use
+        else w[j].issue(base + (size_t)min(tw + j, T - 1) * rowstride, nvalid, lane);
     // chain heads (wave 0: forward vector entering the chunk, last wave: backward
     // vector leaving it), loaded while the rows are in flight
     float head[F::NS];
@@ -785,7 +910,8 @@ __global__ __launch_bounds__(K3_WAVES *WAVE, (CH <= 16 ? 4 : 2)) void logz_poste
     for (int j = 0; j < K3_ROWS; ++j) {
         if (tw + j < T) {
             w[j].to_pieces(buf, lane);
-            w[j].store_nt(gbase + (size_t)(tw + j) * rowstride, nvalid, lane);
+            if (TK_K3_NT_STORE) w[j].store_nt(gbase + (size_t)(tw + j) * rowstride, nvalid, lane);
+            else w[j].store(gbase + (size_t)(tw + j) * rowstride, nvalid, lane);
         }
     }
 }
@@ -848,7 +974,7 @@ static int logz_launch_ch(const float *scores, size_t T, size_t N, float *logz, 
                            stream, scores, (int)T, (int)N, C, Npad, ws);
     }
     {
-        const size_t lds = ((size_t)(C + NSUP) * 4 * XMat<NB>::NF4 + 2 * (size_t)NSUP * GRP) * sizeof(float);
+        const size_t lds = logz_middle_lds_bytes<NB>(C, NSUP);
         if (lds > 160 * 1024) return 2;         // too many chunks for one LDS image
         static bool raised2 = false;
         if (lds > 64 * 1024 && !raised2) {
@@ -891,7 +1017,7 @@ static int logz_launch(const float *scores, size_t T, size_t N, float *logz, flo
     int ch = logz_pick_ch(T, N);
     if (const char *e = getenv("TK_LOGZ_CH")) ch = atoi(e);         // tuning override
     // the middle kernel keeps one read's chunk matrices in LDS: fall back to bigger chunks
-    while (ch < 32 && ((T + ch - 1) / ch) * 4 * XMat<NB>::NF4 * sizeof(float) > 140 * 1024) ch *= 2;
+    while (ch < 32 && logz_middle_lds_bytes<NB>((int)((T + ch - 1) / ch), (int)((T + ch - 1) / ch / LOGZ_SUPER + 1)) > 160 * 1024) ch *= 2;
     switch (ch) {
         case 8: return logz_launch_ch<NB, 8>(scores, T, N, logz, grad, ws, status, stream);
         case 16: return logz_launch_ch<NB, 16>(scores, T, N, logz, grad, ws, status, stream);

@@ -1,0 +1,89 @@
+// logz_lab.hip -- per-kernel timing of the logZ pipeline with HIP events, no Python
+// (tools only).  Rebuild with -D knobs to try variants:
+//
+//   hipcc --offload-arch=gfx950 -O3 -Itaiyaki_amd/csrc [-DTK_K3_NT_STORE=0 ...] \
+//         tools/logz_lab.hip -o tools/logz_lab && tools/logz_lab [T N [CH]]
+#include "../taiyaki_amd/csrc/logz_kernels.hip"
+
+#include <algorithm>
+#include <cstdio>
+#include <vector>
+
+#define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("HIP error %s at %d\n", hipGetErrorString(e), __LINE__); exit(1); } } while (0)
+
+using namespace tk;
+
+template <typename F>
+static double timeit(F launch, int reps = 21) {
+    hipEvent_t a, b;
+    CK(hipEventCreate(&a)); CK(hipEventCreate(&b));
+    for (int i = 0; i < 3; ++i) launch();
+    CK(hipDeviceSynchronize());
+    std::vector<float> ms;
+    for (int i = 0; i < reps; ++i) {
+        CK(hipEventRecord(a, 0)); launch(); CK(hipEventRecord(b, 0)); CK(hipEventSynchronize(b));
+        float t; CK(hipEventElapsedTime(&t, a, b)); ms.push_back(t);
+    }
+    std::sort(ms.begin(), ms.end());
+    return ms[reps / 2] * 1e3;
+}
+
+template <int CH>
+static void run(const float *scores, int T, int N, float *logz, float *grad, void *wsmem, uint32_t *status) {
+    constexpr int NB = 4;
+    using F = FF<NB>;
+    LogzWs ws;
+    logz_ws_layout<NB>(T, N, wsmem, &ws);
+    const int C = (T + CH - 1) / CH, NSUP = (C + LOGZ_SUPER - 1) / LOGZ_SUPER;
+    const int ncols = (N + WAVE - 1) / WAVE, Npad = ncols * WAVE;
+    const size_t bufbytes = (size_t)WAVE * F::PIECES * sizeof(f4);
+    const size_t matbytes = (size_t)K1_WAVES * XMat<NB>::NW * WAVE * sizeof(float);
+    const size_t lds1 = std::max(matbytes, K1_WAVES * bufbytes);
+    const size_t lds2 = logz_middle_lds_bytes<NB>(C, NSUP);
+    constexpr bool chain_in_buf = ((CH / K3_WAVES) + 2) * F::NS * WAVE <= k3_buf_f4<NB, CH>() * 4;
+    const size_t lds3 = K3_WAVES * (size_t)k3_buf_f4<NB, CH>() * sizeof(f4) + (chain_in_buf ? 0 : 2 * F::NS * WAVE * sizeof(float));
+    CK(hipFuncSetAttribute(reinterpret_cast<const void *>(&logz_transfer_kernel<NB, CH>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    CK(hipFuncSetAttribute(reinterpret_cast<const void *>(&logz_middle_kernel<NB>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    CK(hipFuncSetAttribute(reinterpret_cast<const void *>(&logz_posterior_kernel<NB, CH>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    auto k1 = [&] { hipLaunchKernelGGL((logz_transfer_kernel<NB, CH>), dim3(ncols, C), dim3(K1_WAVES * WAVE), lds1, 0, scores, T, N, C, Npad, ws); };
+    auto k2 = [&] { hipLaunchKernelGGL(logz_middle_kernel<NB>, dim3(N), dim3(K2_WAVES * WAVE), lds2, 0, N, C, NSUP, Npad, ws, logz, 1, status); };
+    auto k3 = [&] { hipLaunchKernelGGL((logz_posterior_kernel<NB, CH>), dim3(ncols, C), dim3(K3_WAVES * WAVE), lds3, 0, scores, grad, T, N, Npad, ws, status); };
+    k1(); k2(); k3();
+    CK(hipDeviceSynchronize());
+    const double a = timeit(k1), b = timeit(k2), c = timeit(k3), all = timeit([&] { k1(); k2(); k3(); });
+    const double alg = 3.0 * T * N * F::S * 4;
+    float z0;
+    CK(hipMemcpy(&z0, logz, 4, hipMemcpyDeviceToHost));
+    printf("T=%d N=%d CH=%d  transfer %6.1f  middle %6.1f  posterior %6.1f  sum %6.1f | back-to-back %6.1f us -> %5.2f TB/s (%4.1f%% of 8)  logz[0]=%.4f\n",
+           T, N, CH, a, b, c, a + b + c, all, alg / all / 1e6, alg / all / 1e6 / 8 * 100, z0);
+#ifdef TK_LAB_TIMING
+    k2();
+    CK(hipDeviceSynchronize());
+    long long st[8];
+    CK(hipMemcpyFromSymbol(st, HIP_SYMBOL(tk_dbg), sizeof st));
+    printf("   middle phases (block 100, shader clocks): stage %lld  combine %lld  scan %lld  expand %lld\n", st[1] - st[0], st[2] - st[1], st[3] - st[2], st[4] - st[3]);
+#endif
+    fflush(stdout);
+}
+
+int main(int argc, char **argv) {
+    const int T = argc > 1 ? atoi(argv[1]) : 4000, N = argc > 2 ? atoi(argv[2]) : 256;
+    const int ch = argc > 3 ? atoi(argv[3]) : 0;
+    const size_t n = (size_t)T * N * 40;
+    std::vector<float> h(n);
+    uint64_t s = 88172645463325252ull;
+    for (size_t i = 0; i < n; ++i) {
+        s ^= s << 13; s ^= s >> 7; s ^= s << 17;
+        h[i] = (float)((s >> 40) * (1.0 / 16777216.0) * 10.0 - 5.0);
+    }
+    float *scores, *grad, *logz; void *ws; uint32_t *status;
+    CK(hipMalloc(&scores, n * 4)); CK(hipMalloc(&grad, n * 4)); CK(hipMalloc(&logz, N * 4)); CK(hipMalloc(&status, 4));
+    const size_t wsb = logz_workspace_bytes(T, N, 4);
+    CK(hipMalloc(&ws, wsb));
+    CK(hipMemcpy(scores, h.data(), n * 4, hipMemcpyHostToDevice));
+    CK(hipMemset(status, 0, 4));
+    if (ch == 0 || ch == 32) run<32>(scores, T, N, logz, grad, ws, status);
+    if (ch == 0 || ch == 16) run<16>(scores, T, N, logz, grad, ws, status);
+    if (ch == 0 || ch == 8) run<8>(scores, T, N, logz, grad, ws, status);
+    return 0;
+}

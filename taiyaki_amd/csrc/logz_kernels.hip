@@ -36,14 +36,22 @@ namespace tk {
 
 // rows per chunk (CH) is a template parameter of K1 / K3, picked per problem so that
 // the grid fills the chip: 32 for big tensors, 16 / 8 for small ones
-constexpr int LOGZ_SUPER = 8;           // chunks per super-chunk
-constexpr int K1_WAVES = 4;             // waves per K1 block (one chunk): 4 x CH/4 rows
+// chunks per super-chunk (template parameter SUP of the middle kernel): the serial part is
+// SUP + C/SUP + SUP steps, so 8 up to 128 chunks and 16 beyond
+__host__ __device__ constexpr int logz_super(int C) { return C > 128 ? 16 : 8; }
+constexpr int K1_WAVES = 4;             // waves per K1 block = 4 independent chunks
 constexpr int K3_WAVES = 8;             // waves per K3 block: 8 x CH/8 rows = 1 chunk
 constexpr int ZERO_ROW_EXP = -(1 << 28);    // exponent of an all-zero matrix row
 
 // tuning knobs (tools/logz_lab.hip rebuilds this file with -D overrides)
 #ifndef TK_K1_NT_LOAD
 #define TK_K1_NT_LOAD 0
+#endif
+#ifndef TK_K1_DEPTH
+#define TK_K1_DEPTH 2           // row-sets per wave in the K1 prefetch ring
+#endif
+#ifndef TK_K1_MINWAVES
+#define TK_K1_MINWAVES 2
 #endif
 #ifndef TK_K3_NT_LOAD
 #define TK_K3_NT_LOAD 1
@@ -297,12 +305,95 @@ __host__ __device__ constexpr int k3_buf_f4() {
 }
 
 // ---------------------------------------------------------------------------
-// K1: chunk transfer matrices.  grid = (ncols, C), block = 256 = one chunk:
-// wave w folds rows [8w, 8w+8) of the chunk; a 2-level tree through LDS
-// (the waves' transpose buffers, idle by then) yields P0 P1 P2 P3.
+// K1: chunk transfer matrices.  ONE WAVE PER CHUNK: the wave folds all CH rows of its
+// chunk into one 2nb x 2nb matrix in registers, so there is no cross-wave product at
+// all (combining per-wave partial matrices cost 15-25 % of the kernel, LDS-bound) and
+// no block barrier; the four waves of a block are four consecutive chunks of one
+// column.  The stream is HBM-bound: a row costs ~2.5k cycles of issue against the
+// ~4k cycles the memory system needs to deliver it with every SIMD loading.
+// grid = (ncols, ceil(C / 4)), block = 256.
 // ---------------------------------------------------------------------------
 template <int NB, int CH>
-__global__ __launch_bounds__(K1_WAVES *WAVE, 2) void logz_transfer_kernel(
+__global__ __launch_bounds__(K1_WAVES *WAVE, TK_K1_MINWAVES) void logz_transfer_kernel(
+    const float *__restrict__ scores, int T, int N, int C, int Npad, LogzWs ws) {
+    using F = FF<NB>;
+    using X = XMat<NB>;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int wave = threadIdx.x >> 6, lane = lane_id();
+    const int c = blockIdx.y * K1_WAVES + wave;
+    if (c >= C) return;                         // wave-uniform; the kernel has no barriers
+    // wave-private LDS: the row-set transpose buffer, later the matrix image
+    constexpr int IMG_WORDS = (X::NW * WAVE > 4 * WAVE * F::PIECES) ? X::NW * WAVE : 4 * WAVE * F::PIECES;
+    float *img = reinterpret_cast<float *>(smem) + (size_t)wave * IMG_WORDS;
+    f4 *buf = reinterpret_cast<f4 *>(img);
+    const int n0 = blockIdx.x * WAVE;
+    const int nvalid = min(WAVE, N - n0) * F::PIECES;
+    const int t0 = c * CH, t1 = min(T, t0 + CH);
+    const size_t rowstride = (size_t)N * F::S;
+    const float *base = scores + (size_t)n0 * F::S;
+
+    X P;
+    P.set_identity();
+    {
+        // one row-set in flight ahead of the one being consumed; row indices are clamped
+        // (never branched on) so the load stream has no control flow
+        RowSet<NB> ring[TK_K1_DEPTH];
+        auto rowptr = [&](int t) { return base + (size_t)min(t, t1 - 1) * rowstride; };
+        auto consume = [&](RowSet<NB> &cur, int t) {
+            cur.to_rows(buf, lane);
+            P.M += (double)cur.exp_normalise();
+#pragma unroll
+            for (int i = 0; i < F::NS; ++i) {
+                float out[F::NS];
+                ff_fwd_step<NB>(P.m[i], cur, out);
+#pragma unroll
+                for (int j = 0; j < F::NS; ++j) P.m[i][j] = out[j];
+            }
+            if (((t - t0) & 3) == 3) P.renorm();
+        };
+        auto fetch = [&](RowSet<NB> &r, int t) {
+            if (TK_K1_NT_LOAD) r.issue_nt(rowptr(t), nvalid, lane);
+            else r.issue(rowptr(t), nvalid, lane);
+        };
+#pragma unroll
+        for (int d = 0; d < TK_K1_DEPTH - 1; ++d) fetch(ring[d], t0 + d);
+        for (int t = t0; t < t1; t += TK_K1_DEPTH) {
+#pragma unroll
+            for (int d = 0; d < TK_K1_DEPTH; ++d) {
+                if (t + d < t1) {
+                    fetch(ring[(d + TK_K1_DEPTH - 1) % TK_K1_DEPTH], t + d + TK_K1_DEPTH - 1);
+                    consume(ring[d], t + d);
+                }
+            }
+        }
+        P.renorm();
+    }
+    // Pc is READ-major ([read][chunk][NF4] float4): the middle kernel streams one
+    // read's matrices as a single contiguous run (a [chunk][q][read] layout put
+    // all of a read's pieces 16*Npad bytes apart = on ONE L2 channel).  The wave turns
+    // its 64 matrices through the LDS image [word][read]: piece p -> (read p / NF4, q p % NF4).
+    wave_lds_fence();
+    xmat_lds_put<NB>(P, img, lane);
+    wave_lds_fence();
+    f4 *dst = ws.Pc + ((size_t)n0 * C + c) * X::NF4;
+    for (int p = lane; p < WAVE * X::NF4; p += WAVE) {
+        const int r = p / X::NF4, q = p - r * X::NF4;
+        f4 o;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) o[k] = (4 * q + k < X::NW) ? img[(4 * q + k) * WAVE + r] : 0.f;
+        dst[(size_t)r * C * X::NF4 + q] = o;
+    }
+}
+
+// ---------------------------------------------------------------------------
+// K1, cooperative form for SMALL problems (fewer chunks than SIMDs): four waves share
+// one chunk, wave w folds rows [w CH/4, (w+1) CH/4) and the four partial matrices are
+// multiplied row-parallel through LDS.  The products cost 15-25 % of the kernel, but a
+// small tensor has no other way to put more than C * ncols waves on the chip.
+// grid = (ncols, C), block = 256 = one chunk.
+// ---------------------------------------------------------------------------
+template <int NB, int CH>
+__global__ __launch_bounds__(K1_WAVES *WAVE, 2) void logz_transfer_coop_kernel(
     const float *__restrict__ scores, int T, int N, int C, int Npad, LogzWs ws) {
     using F = FF<NB>;
     using X = XMat<NB>;
@@ -601,7 +692,7 @@ __device__ long long tk_dbg[64];
 #define TK_STAMP(k)
 #endif
 
-template <int NB>
+template <int NB, int SUP>
 __global__ __launch_bounds__(K2_WAVES *WAVE) void logz_middle_kernel(int N, int C, int NSUP, int Npad,
                                                                   LogzWs ws,
                                                                   float *__restrict__ logz,
@@ -622,14 +713,17 @@ __global__ __launch_bounds__(K2_WAVES *WAVE) void logz_middle_kernel(int N, int 
     TK_STAMP(0);
     // ---- 1. stage the read's chunk matrices: one contiguous run of C*NF4 float4
     {
+        // every load of a pass is in flight before the first LDS store: one memory latency
+        // for up to 8 * 1024 float4 (C <= 431 chunks), not one per 4 K float4
+        constexpr int PASS = 8;
         const int total = C * X::NF4;
         const f4 *src = ws.Pc + n * (size_t)total;
-        for (int base = 0; base < total; base += 4 * NT) {
-            f4 tmp[4];
+        for (int base = 0; base < total; base += PASS * NT) {
+            f4 tmp[PASS];
 #pragma unroll
-            for (int k = 0; k < 4; ++k) tmp[k] = src[min(base + k * NT + tid, total - 1)];
+            for (int k = 0; k < PASS; ++k) tmp[k] = src[min(base + k * NT + tid, total - 1)];
 #pragma unroll
-            for (int k = 0; k < 4; ++k) {
+            for (int k = 0; k < PASS; ++k) {
                 const int idx = base + k * NT + tid;
                 if (idx < total) *reinterpret_cast<f4 *>(pcimg + (size_t)idx * 4) = tmp[k];
             }
@@ -642,14 +736,20 @@ __global__ __launch_bounds__(K2_WAVES *WAVE) void logz_middle_kernel(int N, int 
     //         Fully unrolled over the super's chunks: LDS offsets are immediates, the
     //         shares ping-pong between two register sets one matrix ahead.
     for (int s = wave; s < NSUP; s += K2_WAVES) {
-        const int c0 = s * LOGZ_SUPER, cnt = min(C - c0, LOGZ_SUPER);
+        const int c0 = s * SUP, cnt = min(C - c0, SUP);
         const float *img0 = pcimg + (size_t)c0 * NFW;
-        float v = (g == grp && grp < F::NS) ? 1.f : 0.f;
-        int eacc = 0;
+        // row `grp` of the first matrix IS the running product after one chunk
+        const int rr = min(grp, F::NS - 1);
+        float v = (g < F::NS && grp < F::NS) ? img0[rr * F::NS + min(g, F::NS - 1)] : 0.f;
+        int eacc = __float_as_int(img0[F::NS * F::NS + rr]);
+        if (eacc == ZERO_ROW_EXP) {
+            v = 0.f;
+            eacc = 0;
+        }
         ColShare<NB> A[2];
-        A[0].load(img0, g);
+        A[1].load(img0 + NFW, g);
 #pragma unroll
-        for (int i = 0; i < LOGZ_SUPER; ++i) {
+        for (int i = 1; i < SUP; ++i) {
             if (i < cnt) {
                 A[(i + 1) & 1].load(img0 + (i + 1) * NFW, g);      // may run one matrix past the super
                 eacc += grp_vec_mat<NB>(v, A[i & 1], g);
@@ -728,7 +828,7 @@ __global__ __launch_bounds__(K2_WAVES *WAVE) void logz_middle_kernel(int N, int 
     const int slot = (wave % HALF) * GRP + grp;
     float *dstbase = (fwd ? ws.Vin : ws.Uout) + n * (size_t)C * F::NS;     // [read][c][NS]
     for (int s = slot; s < NSUP; s += HALF * GRP) {
-        const int c0 = s * LOGZ_SUPER, cnt = min(C - c0, LOGZ_SUPER);
+        const int c0 = s * SUP, cnt = min(C - c0, SUP);
         float v = (fwd ? vsl : usl)[s * GRP + g];
         if (fwd) {
             const float *img0 = pcimg + (size_t)c0 * NFW;
@@ -736,7 +836,7 @@ __global__ __launch_bounds__(K2_WAVES *WAVE) void logz_middle_kernel(int N, int 
             ColShare<NB> A[2];
             A[0].load(img0, g);
 #pragma unroll
-            for (int i = 0; i < LOGZ_SUPER; ++i) {
+            for (int i = 0; i < SUP; ++i) {
                 if (i < cnt) {
                     A[(i + 1) & 1].load(img0 + (i + 1) * NFW, g);
                     if (g < F::NS) dst[i * F::NS + g] = v;
@@ -749,7 +849,7 @@ __global__ __launch_bounds__(K2_WAVES *WAVE) void logz_middle_kernel(int N, int 
             RowShare<NB> A[2];
             A[0].load(img1, g);
 #pragma unroll
-            for (int i = 0; i < LOGZ_SUPER; ++i) {
+            for (int i = 0; i < SUP; ++i) {
                 if (i < cnt) {
                     A[(i + 1) & 1].load(img1 - (i + 1 < cnt ? i + 1 : i) * NFW, g);
                     if (g < F::NS) dst[-i * F::NS + g] = v;
@@ -921,12 +1021,12 @@ __global__ __launch_bounds__(K3_WAVES *WAVE, (CH <= 16 ? 4 : 2)) void logz_poste
 // ---------------------------------------------------------------------------
 static inline size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
 
-// chunk size: the largest of {32, 16, 8} whose K3 grid still has >= ~2 blocks per CU
+// chunk size = rows per K3 block.  16 rows (two per wave) keep K3 at 128 VGPRs = two
+// blocks per CU, so one block's serial chain overlaps the other's loads and stores;
+// 8 when a 16-row grid would leave CUs without a block.  32 is kept for the env override.
 static int logz_pick_ch(size_t T, size_t N) {
     const size_t ncols = (N + WAVE - 1) / WAVE;
-    for (int ch = 32; ch > 8; ch /= 2)
-        if (ncols * ((T + ch - 1) / ch) >= 384) return ch;
-    return 8;
+    return ncols * ((T + 15) / 16) >= 384 ? 16 : 8;
 }
 
 template <int NB>
@@ -934,7 +1034,6 @@ static size_t logz_ws_layout(size_t T, size_t N, void *base, LogzWs *ws) {
     using F = FF<NB>;
     using X = XMat<NB>;
     const size_t C = (T + 8 - 1) / 8, Npad = align_up(N, WAVE);     // sized for the smallest chunk
-    const size_t NSUP = (C + LOGZ_SUPER - 1) / LOGZ_SUPER;
     size_t off = 0;
     char *p = static_cast<char *>(base);
     auto take = [&](size_t bytes) {
@@ -946,7 +1045,6 @@ static size_t logz_ws_layout(size_t T, size_t N, void *base, LogzWs *ws) {
     f4 *Pc = reinterpret_cast<f4 *>(take(C * mbytes));
     float *Vin = reinterpret_cast<float *>(take(C * F::NS * Npad * sizeof(float)));
     float *Uout = reinterpret_cast<float *>(take(C * F::NS * Npad * sizeof(float)));
-    (void)NSUP;
     if (ws) *ws = LogzWs{Pc, Vin, Uout};
     return off;
 }
@@ -956,36 +1054,49 @@ static int logz_launch_ch(const float *scores, size_t T, size_t N, float *logz, 
                           LogzWs ws, uint32_t *status, hipStream_t stream) {
     using F = FF<NB>;
     const int C = (int)((T + CH - 1) / CH);
-    const int NSUP = (C + LOGZ_SUPER - 1) / LOGZ_SUPER;
+    const int SUP = logz_super(C), NSUP = (C + SUP - 1) / SUP;
     const int ncols = (int)((N + WAVE - 1) / WAVE), Npad = ncols * WAVE;
-    const size_t bufbytes = (size_t)WAVE * F::PIECES * sizeof(f4);
     {
-        const size_t matbytes = (size_t)K1_WAVES * XMat<NB>::NW * WAVE * sizeof(float);
-        const size_t lds = matbytes > K1_WAVES * bufbytes ? matbytes : K1_WAVES * bufbytes;
+        const size_t bufwords = 4 * (size_t)WAVE * F::PIECES, imgwords = (size_t)XMat<NB>::NW * WAVE;
+        const size_t lds = K1_WAVES * (imgwords > bufwords ? imgwords : bufwords) * sizeof(float);
         static bool raised1 = false;
         if (lds > 64 * 1024 && !raised1) {
             if (hipFuncSetAttribute(reinterpret_cast<const void *>(&logz_transfer_kernel<NB, CH>),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize,
+                                    160 * 1024) != hipSuccess ||
+                hipFuncSetAttribute(reinterpret_cast<const void *>(&logz_transfer_coop_kernel<NB, CH>),
                                     hipFuncAttributeMaxDynamicSharedMemorySize,
                                     160 * 1024) != hipSuccess)
                 return 4;
             raised1 = true;
         }
-        hipLaunchKernelGGL((logz_transfer_kernel<NB, CH>), dim3(ncols, C), dim3(K1_WAVES * WAVE), lds,
-                           stream, scores, (int)T, (int)N, C, Npad, ws);
+        // one wave per chunk needs about a wave per SIMD to stream at full rate; below that
+        // the cooperative form (4 waves per chunk) is faster
+        if ((size_t)ncols * C >= 640)
+            hipLaunchKernelGGL((logz_transfer_kernel<NB, CH>), dim3(ncols, (C + K1_WAVES - 1) / K1_WAVES),
+                               dim3(K1_WAVES * WAVE), lds, stream, scores, (int)T, (int)N, C, Npad, ws);
+        else
+            hipLaunchKernelGGL((logz_transfer_coop_kernel<NB, CH>), dim3(ncols, C), dim3(K1_WAVES * WAVE),
+                               lds, stream, scores, (int)T, (int)N, C, Npad, ws);
     }
     {
         const size_t lds = logz_middle_lds_bytes<NB>(C, NSUP);
         if (lds > 160 * 1024) return 2;         // too many chunks for one LDS image
         static bool raised2 = false;
-        if (lds > 64 * 1024 && !raised2) {
-            if (hipFuncSetAttribute(reinterpret_cast<const void *>(&logz_middle_kernel<NB>),
-                                    hipFuncAttributeMaxDynamicSharedMemorySize,
-                                    160 * 1024) != hipSuccess)
+        if (!raised2) {
+            if (hipFuncSetAttribute(reinterpret_cast<const void *>(&logz_middle_kernel<NB, 8>),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess ||
+                hipFuncSetAttribute(reinterpret_cast<const void *>(&logz_middle_kernel<NB, 16>),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)
                 return 4;
             raised2 = true;
         }
-        hipLaunchKernelGGL(logz_middle_kernel<NB>, dim3((unsigned)N), dim3(K2_WAVES * WAVE), lds, stream,
-                           (int)N, C, NSUP, Npad, ws, logz, grad != nullptr ? 1 : 0, status);
+        if (SUP == 8)
+            hipLaunchKernelGGL((logz_middle_kernel<NB, 8>), dim3((unsigned)N), dim3(K2_WAVES * WAVE), lds, stream,
+                               (int)N, C, NSUP, Npad, ws, logz, grad != nullptr ? 1 : 0, status);
+        else
+            hipLaunchKernelGGL((logz_middle_kernel<NB, 16>), dim3((unsigned)N), dim3(K2_WAVES * WAVE), lds, stream,
+                               (int)N, C, NSUP, Npad, ws, logz, grad != nullptr ? 1 : 0, status);
     }
     if (grad != nullptr) {
         dim3 grid(ncols, C), block(K3_WAVES * WAVE);
@@ -1017,7 +1128,11 @@ static int logz_launch(const float *scores, size_t T, size_t N, float *logz, flo
     int ch = logz_pick_ch(T, N);
     if (const char *e = getenv("TK_LOGZ_CH")) ch = atoi(e);         // tuning override
     // the middle kernel keeps one read's chunk matrices in LDS: fall back to bigger chunks
-    while (ch < 32 && logz_middle_lds_bytes<NB>((int)((T + ch - 1) / ch), (int)((T + ch - 1) / ch / LOGZ_SUPER + 1)) > 160 * 1024) ch *= 2;
+    auto middle_lds = [&](int c) {
+        const int C = (int)((T + c - 1) / c);
+        return logz_middle_lds_bytes<NB>(C, (C + logz_super(C) - 1) / logz_super(C));
+    };
+    while (ch < 32 && middle_lds(ch) > 160 * 1024) ch *= 2;
     switch (ch) {
         case 8: return logz_launch_ch<NB, 8>(scores, T, N, logz, grad, ws, status, stream);
         case 16: return logz_launch_ch<NB, 16>(scores, T, N, logz, grad, ws, status, stream);

@@ -34,19 +34,25 @@ static void run(const float *scores, int T, int N, float *logz, float *grad, voi
     using F = FF<NB>;
     LogzWs ws;
     logz_ws_layout<NB>(T, N, wsmem, &ws);
-    const int C = (T + CH - 1) / CH, NSUP = (C + LOGZ_SUPER - 1) / LOGZ_SUPER;
+    const int C = (T + CH - 1) / CH, SUP = logz_super(C), NSUP = (C + SUP - 1) / SUP;
     const int ncols = (N + WAVE - 1) / WAVE, Npad = ncols * WAVE;
-    const size_t bufbytes = (size_t)WAVE * F::PIECES * sizeof(f4);
-    const size_t matbytes = (size_t)K1_WAVES * XMat<NB>::NW * WAVE * sizeof(float);
-    const size_t lds1 = std::max(matbytes, K1_WAVES * bufbytes);
+    const size_t lds1 = K1_WAVES * std::max((size_t)XMat<NB>::NW * WAVE, 4 * (size_t)WAVE * F::PIECES) * sizeof(float);
     const size_t lds2 = logz_middle_lds_bytes<NB>(C, NSUP);
     constexpr bool chain_in_buf = ((CH / K3_WAVES) + 2) * F::NS * WAVE <= k3_buf_f4<NB, CH>() * 4;
     const size_t lds3 = K3_WAVES * (size_t)k3_buf_f4<NB, CH>() * sizeof(f4) + (chain_in_buf ? 0 : 2 * F::NS * WAVE * sizeof(float));
     CK(hipFuncSetAttribute(reinterpret_cast<const void *>(&logz_transfer_kernel<NB, CH>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-    CK(hipFuncSetAttribute(reinterpret_cast<const void *>(&logz_middle_kernel<NB>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    CK(hipFuncSetAttribute(reinterpret_cast<const void *>(&logz_middle_kernel<NB, 8>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    CK(hipFuncSetAttribute(reinterpret_cast<const void *>(&logz_middle_kernel<NB, 16>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     CK(hipFuncSetAttribute(reinterpret_cast<const void *>(&logz_posterior_kernel<NB, CH>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-    auto k1 = [&] { hipLaunchKernelGGL((logz_transfer_kernel<NB, CH>), dim3(ncols, C), dim3(K1_WAVES * WAVE), lds1, 0, scores, T, N, C, Npad, ws); };
-    auto k2 = [&] { hipLaunchKernelGGL(logz_middle_kernel<NB>, dim3(N), dim3(K2_WAVES * WAVE), lds2, 0, N, C, NSUP, Npad, ws, logz, 1, status); };
+    CK(hipFuncSetAttribute(reinterpret_cast<const void *>(&logz_transfer_coop_kernel<NB, CH>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    auto k1 = [&] {
+        if ((size_t)ncols * C >= 640) hipLaunchKernelGGL((logz_transfer_kernel<NB, CH>), dim3(ncols, (C + K1_WAVES - 1) / K1_WAVES), dim3(K1_WAVES * WAVE), lds1, 0, scores, T, N, C, Npad, ws);
+        else hipLaunchKernelGGL((logz_transfer_coop_kernel<NB, CH>), dim3(ncols, C), dim3(K1_WAVES * WAVE), lds1, 0, scores, T, N, C, Npad, ws);
+    };
+    auto k2 = [&] {
+        if (SUP == 8) hipLaunchKernelGGL((logz_middle_kernel<NB, 8>), dim3(N), dim3(K2_WAVES * WAVE), lds2, 0, N, C, NSUP, Npad, ws, logz, 1, status);
+        else hipLaunchKernelGGL((logz_middle_kernel<NB, 16>), dim3(N), dim3(K2_WAVES * WAVE), lds2, 0, N, C, NSUP, Npad, ws, logz, 1, status);
+    };
     auto k3 = [&] { hipLaunchKernelGGL((logz_posterior_kernel<NB, CH>), dim3(ncols, C), dim3(K3_WAVES * WAVE), lds3, 0, scores, grad, T, N, Npad, ws, status); };
     k1(); k2(); k3();
     CK(hipDeviceSynchronize());

@@ -218,6 +218,8 @@ __device__ __forceinline__ void ff_fwd_step(const float (&in)[2 * NB], const Row
     }
 }
 
+typedef float f2 __attribute__((ext_vector_type(2)));
+
 // One linear-space backward step:
 //   out[from] = sum_{to<NB} w[to*NS + from] * in[to] + w[FLOP0 + from] * in[flop(from)]
 // with flop(from) = NB + (from mod NB).

@@ -8,23 +8,21 @@
 //   * lane = read: 64 consecutive reads' rows at one time step are ONE contiguous
 //     10 KiB segment of the (T, N, S) tensor, so every HBM access is a fully
 //     coalesced 16-byte-per-lane stream; a wave-private LDS buffer transposes
-//     pieces -> rows.  No cross-lane arithmetic anywhere.
+//     pieces -> rows.
 //   * the time axis is parallelised exactly with (sum,*)-semiring transfer
-//     matrices:
-//       K1  transfer  : one 4-wave block per 32-row chunk; each wave folds 8 rows
-//                       into a 2nb x 2nb matrix in registers, then a 2-level
-//                       LDS tree combines the four into the chunk matrix
-//       K1b combine   : total product of each super-chunk (8 chunks)
-//       K2  scan      : serial scan over the super totals only (16 steps at
-//                       T = 4000), register-ring prefetch -> super boundary
-//                       vectors, logZ
-//       K2b expand    : super boundary vectors -> per-chunk boundary vectors
-//                       (parallel over super-chunks)
-//       K3  posterior : one 512-thread block per chunk, rows held in registers,
-//                       in-chunk forward/backward chained through LDS, normalised
-//                       posterior streamed out.
+//     matrices, three launches:
+//       transfer  : one WAVE per 16-row chunk folds the rows into a 2nb x 2nb matrix
+//                   kept in registers as row pairs (v_pk_fma_f32); no cross-wave
+//                   products, no barriers.  (Small tensors: four waves per chunk.)
+//       middle    : one block per read, eight lanes per chain: super-chunk products,
+//                   serial scan over the supers only, expansion back to chunk
+//                   boundary vectors; logZ.  Everything from one LDS image.
+//       posterior : one 512-thread block per chunk, two rows per wave in registers,
+//                   in-chunk forward/backward chained through LDS, normalised
+//                   posterior streamed out.  128 VGPRs = two blocks per CU, so one
+//                   block's serial chain hides behind the other's loads and stores.
 //     HBM traffic = 2 reads + 1 write of the score tensor = the algorithmic
-//     minimum 3*T*N*S*4 bytes (+ workspace that stays L2/MALL resident).
+//     minimum 3*T*N*S*4 bytes (+ ~12 % workspace that stays L2/MALL resident).
 //   * arithmetic is linear-space fp32 with exact power-of-two renormalisation
 //     (integer exponents are accumulated exactly; row maxima in fp64), so no
 //     transcendental sits on a serial dependency chain.
@@ -47,11 +45,11 @@ constexpr int ZERO_ROW_EXP = -(1 << 28);    // exponent of an all-zero matrix ro
 #ifndef TK_K1_NT_LOAD
 #define TK_K1_NT_LOAD 0
 #endif
-#ifndef TK_K1_DEPTH
-#define TK_K1_DEPTH 2           // row-sets per wave in the K1 prefetch ring
-#endif
-#ifndef TK_K1_MINWAVES
-#define TK_K1_MINWAVES 2
+#ifdef TK_LAB_TIMING
+__device__ long long tk_dbg[64];
+#define TK_STAMP(k) do { if (blockIdx.x == 1 && blockIdx.y == 20 && threadIdx.x == 0) tk_dbg[k] = clock64(); } while (0)
+#else
+#define TK_STAMP(k)
 #endif
 #ifndef TK_K3_NT_LOAD
 #define TK_K3_NT_LOAD 1
@@ -90,26 +88,6 @@ struct XMat {
         if (k == NS * NS + NS + 1) return __int_as_float(__double2hiint(M));
         return 0.f;
     }
-    __device__ __forceinline__ void store(f4 *base, size_t Npad) const {
-#pragma unroll
-        for (int q = 0; q < NF4; ++q)
-            base[(size_t)q * Npad] = f4{word(4 * q), word(4 * q + 1), word(4 * q + 2), word(4 * q + 3)};
-    }
-    __device__ __forceinline__ void load(const f4 *base, size_t Npad) {
-        f4 raw[NF4];
-#pragma unroll
-        for (int q = 0; q < NF4; ++q) raw[q] = base[(size_t)q * Npad];
-        unpack(raw);
-    }
-    __device__ __forceinline__ void unpack(const f4 (&raw)[NF4]) {
-#pragma unroll
-        for (int k = 0; k < NS * NS; ++k) m[k / NS][k % NS] = raw[k >> 2][k & 3];
-#pragma unroll
-        for (int k = 0; k < NS; ++k) e[k] = __float_as_int(raw[(NS * NS + k) >> 2][(NS * NS + k) & 3]);
-        const int lo = __float_as_int(raw[(NS * NS + NS) >> 2][(NS * NS + NS) & 3]);
-        const int hi = __float_as_int(raw[(NS * NS + NS + 1) >> 2][(NS * NS + NS + 1) & 3]);
-        M = __hiloint2double(hi, lo);
-    }
     // exact power-of-two renormalisation of every row
     __device__ __forceinline__ void renorm() {
 #pragma unroll
@@ -128,35 +106,6 @@ struct XMat {
         }
     }
 };
-
-// C = A (x) B.  B's mantissas are rescaled IN PLACE to a common exponent (B is
-// dead afterwards) so only three matrices are ever live.
-template <int NB>
-__device__ __forceinline__ void xmat_mul(const XMat<NB> &A, XMat<NB> &B, XMat<NB> &C) {
-    constexpr int NS = 2 * NB;
-    int ebmax = ZERO_ROW_EXP;
-#pragma unroll
-    for (int k = 0; k < NS; ++k) ebmax = max(ebmax, B.e[k]);
-#pragma unroll
-    for (int k = 0; k < NS; ++k) {
-        const int sh = max(B.e[k] - ebmax, -300);
-#pragma unroll
-        for (int j = 0; j < NS; ++j) B.m[k][j] = __builtin_amdgcn_ldexpf(B.m[k][j], sh);
-    }
-#pragma unroll
-    for (int i = 0; i < NS; ++i) {
-#pragma unroll
-        for (int j = 0; j < NS; ++j) {
-            float acc = A.m[i][0] * B.m[0][j];
-#pragma unroll
-            for (int k = 1; k < NS; ++k) acc = fmaf(A.m[i][k], B.m[k][j], acc);
-            C.m[i][j] = acc;
-        }
-        C.e[i] = (A.e[i] == ZERO_ROW_EXP || ebmax == ZERO_ROW_EXP) ? ZERO_ROW_EXP : A.e[i] + ebmax;
-    }
-    C.M = A.M + B.M;
-    C.renorm();
-}
 
 // out = normalise(v (x) A); returns the binary exponent taken out (v is a row
 // vector of weights with max ~1)
@@ -204,74 +153,6 @@ __device__ __forceinline__ void xmat_vec(const XMat<NB> &A, const float (&u)[2 *
     for (int i = 0; i < NS; ++i) out[i] = __builtin_amdgcn_ldexpf(y[i], max(A.e[i] - emax, -300));
 }
 
-// Streaming forms of the two products for K3's prologue: the matrix is consumed
-// float4 by float4 straight from global memory (no 2nb x 2nb register copy).
-template <int NB>
-__device__ __forceinline__ void xvec_mat_stream(float (&v)[2 * NB], const f4 *base, size_t Npad) {
-    constexpr int NS = 2 * NB, NN = NS * NS;
-    using X = XMat<NB>;
-    int e[NS];
-#pragma unroll
-    for (int q = NN / 4; q < X::NF4; ++q) {
-        const f4 f = base[(size_t)q * Npad];
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const int k = 4 * q + r - NN;
-            if (k >= 0 && k < NS) e[k] = __float_as_int(f[r]);
-        }
-    }
-    int emax = ZERO_ROW_EXP;
-#pragma unroll
-    for (int i = 0; i < NS; ++i)
-        if (v[i] > 0.f && e[i] != ZERO_ROW_EXP) emax = max(emax, e[i] + __builtin_amdgcn_frexp_expf(v[i]));
-    if (emax == ZERO_ROW_EXP) emax = 0;
-    float vs[NS], out[NS];
-#pragma unroll
-    for (int i = 0; i < NS; ++i) {
-        vs[i] = __builtin_amdgcn_ldexpf(v[i], max(e[i] - emax, -300));
-        out[i] = 0.f;
-    }
-#pragma unroll
-    for (int q = 0; q < (NN + 3) / 4; ++q) {
-        const f4 f = base[(size_t)q * Npad];
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const int k = 4 * q + r;
-            if (k < NN) out[k % NS] = fmaf(vs[k / NS], f[r], out[k % NS]);
-        }
-    }
-    (void)pow2_normalise(out);
-#pragma unroll
-    for (int i = 0; i < NS; ++i) v[i] = out[i];
-}
-
-template <int NB>
-__device__ __forceinline__ void xmat_vec_stream(float (&u)[2 * NB], const f4 *base, size_t Npad) {
-    constexpr int NS = 2 * NB, NN = NS * NS;
-    using X = XMat<NB>;
-    float y[NS];
-    int e[NS];
-#pragma unroll
-    for (int i = 0; i < NS; ++i) y[i] = 0.f;
-#pragma unroll
-    for (int q = 0; q < X::NF4; ++q) {
-        const f4 f = base[(size_t)q * Npad];
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const int k = 4 * q + r;
-            if (k < NN) y[k / NS] = fmaf(f[r], u[k % NS], y[k / NS]);
-            else if (k < NN + NS) e[k - NN] = __float_as_int(f[r]);
-        }
-    }
-    int emax = ZERO_ROW_EXP;
-#pragma unroll
-    for (int i = 0; i < NS; ++i)
-        if (y[i] > 0.f && e[i] != ZERO_ROW_EXP) emax = max(emax, e[i] + __builtin_amdgcn_frexp_expf(y[i]));
-    if (emax == ZERO_ROW_EXP) emax = 0;
-#pragma unroll
-    for (int i = 0; i < NS; ++i) u[i] = __builtin_amdgcn_ldexpf(y[i], max(e[i] - emax, -300));
-}
-
 template <int NB>
 __device__ __forceinline__ void xmat_lds_put(const XMat<NB> &A, float *region, int lane) {
 #pragma unroll
@@ -314,7 +195,7 @@ __host__ __device__ constexpr int k3_buf_f4() {
 // grid = (ncols, ceil(C / 4)), block = 256.
 // ---------------------------------------------------------------------------
 template <int NB, int CH>
-__global__ __launch_bounds__(K1_WAVES *WAVE, TK_K1_MINWAVES) void logz_transfer_kernel(
+__global__ __launch_bounds__(K1_WAVES *WAVE, 2) void logz_transfer_kernel(
     const float *__restrict__ scores, int T, int N, int C, int Npad, LogzWs ws) {
     using F = FF<NB>;
     using X = XMat<NB>;
@@ -323,7 +204,7 @@ __global__ __launch_bounds__(K1_WAVES *WAVE, TK_K1_MINWAVES) void logz_transfer_
     const int c = blockIdx.y * K1_WAVES + wave;
     if (c >= C) return;                         // wave-uniform; the kernel has no barriers
     // wave-private LDS: the row-set transpose buffer, later the matrix image
-    constexpr int IMG_WORDS = (X::NW * WAVE > 4 * WAVE * F::PIECES) ? X::NW * WAVE : 4 * WAVE * F::PIECES;
+    constexpr int IMG_WORDS = (X::NF4 > F::PIECES ? X::NF4 : F::PIECES) * 4 * WAVE;
     float *img = reinterpret_cast<float *>(smem) + (size_t)wave * IMG_WORDS;
     f4 *buf = reinterpret_cast<f4 *>(img);
     const int n0 = blockIdx.x * WAVE;
@@ -332,57 +213,137 @@ __global__ __launch_bounds__(K1_WAVES *WAVE, TK_K1_MINWAVES) void logz_transfer_
     const size_t rowstride = (size_t)N * F::S;
     const float *base = scores + (size_t)n0 * F::S;
 
-    X P;
-    P.set_identity();
+    // The running product is kept as PAIRS OF ROWS (Pp[ip][j] = rows 2ip, 2ip+1 at column
+    // j): both rows of a pair take the same step, so every multiply-add is one
+    // v_pk_fma_f32 with the score broadcast, and the outputs land in the same layout --
+    // no operand shuffles between steps (hipcc finds the pairing for a float[NS][NS] too,
+    // but then moves ~130 registers per row to feed it).
+    constexpr int NS = F::NS, NP = NS / 2;
+    f2 Pp[NP][NS], Pq[NP][NS];      // ping-pong: a step reads one set and writes the other
+    int pe[NS];
+    double pM = 0.0;
+#pragma unroll
+    for (int ip = 0; ip < NP; ++ip) {
+        pe[2 * ip] = pe[2 * ip + 1] = 0;
+#pragma unroll
+        for (int j = 0; j < NS; ++j) Pp[ip][j] = f2{(2 * ip == j) ? 1.f : 0.f, (2 * ip + 1 == j) ? 1.f : 0.f};
+    }
+    auto renorm = [&](f2 (&A)[NP][NS]) {           // exact power-of-two renormalisation of every row
+#pragma unroll
+        for (int ip = 0; ip < NP; ++ip) {
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                float mx = A[ip][0][h];
+#pragma unroll
+                for (int j = 1; j < NS; ++j) mx = fmaxf(mx, A[ip][j][h]);
+                if (mx > 0.f) {
+                    const int ex = __builtin_amdgcn_frexp_expf(mx);
+#pragma unroll
+                    for (int j = 0; j < NS; ++j) A[ip][j][h] = __builtin_amdgcn_ldexpf(A[ip][j][h], -ex);
+                    pe[2 * ip + h] += ex;
+                } else {
+                    pe[2 * ip + h] = ZERO_ROW_EXP;
+                }
+            }
+        }
+    };
+    // B = A (x) row: the NP row pairs are NP independent accumulator chains, issued
+    // interleaved (a packed op's result cannot feed the very next instruction)
+    auto step = [&](const f2 (&A)[NP][NS], f2 (&B)[NP][NS], const RowSet<NB> &cur) {
+#pragma unroll
+        for (int to = 0; to < NB; ++to) {
+            f2 acc[NP];
+            const float w0 = cur.get(to * NS);
+#pragma unroll
+            for (int ip = 0; ip < NP; ++ip) acc[ip] = A[ip][0] * f2{w0, w0};
+#pragma unroll
+            for (int from = 1; from < NS; ++from) {
+                const float w = cur.get(to * NS + from);
+#pragma unroll
+                for (int ip = 0; ip < NP; ++ip) acc[ip] = __builtin_elementwise_fma(A[ip][from], f2{w, w}, acc[ip]);
+            }
+#pragma unroll
+            for (int ip = 0; ip < NP; ++ip) B[ip][to] = acc[ip];
+        }
+#pragma unroll
+        for (int b = 0; b < NB; ++b) {
+            const float wst = cur.get(F::FLOP0 + NB + b), wf = cur.get(F::FLOP0 + b);
+#pragma unroll
+            for (int ip = 0; ip < NP; ++ip)
+                B[ip][NB + b] = __builtin_elementwise_fma(A[ip][b], f2{wf, wf}, A[ip][NB + b] * f2{wst, wst});
+        }
+    };
+    TK_STAMP(8);
     {
         // one row-set in flight ahead of the one being consumed; row indices are clamped
         // (never branched on) so the load stream has no control flow
-        RowSet<NB> ring[TK_K1_DEPTH];
+        RowSet<NB> r0, r1;
         auto rowptr = [&](int t) { return base + (size_t)min(t, t1 - 1) * rowstride; };
-        auto consume = [&](RowSet<NB> &cur, int t) {
-            cur.to_rows(buf, lane);
-            P.M += (double)cur.exp_normalise();
-#pragma unroll
-            for (int i = 0; i < F::NS; ++i) {
-                float out[F::NS];
-                ff_fwd_step<NB>(P.m[i], cur, out);
-#pragma unroll
-                for (int j = 0; j < F::NS; ++j) P.m[i][j] = out[j];
-            }
-            if (((t - t0) & 3) == 3) P.renorm();
-        };
         auto fetch = [&](RowSet<NB> &r, int t) {
             if (TK_K1_NT_LOAD) r.issue_nt(rowptr(t), nvalid, lane);
             else r.issue(rowptr(t), nvalid, lane);
         };
+        fetch(r0, t0);
+        for (int t = t0; t < t1; t += 2) {
+            fetch(r1, t + 1);
+            r0.to_rows(buf, lane);
+            pM += (double)r0.exp_normalise();
+            step(Pp, Pq, r0);
+            if (t == t0) TK_STAMP(9);
+            if (t + 1 >= t1) {              // odd tail: the product sits in the other set
 #pragma unroll
-        for (int d = 0; d < TK_K1_DEPTH - 1; ++d) fetch(ring[d], t0 + d);
-        for (int t = t0; t < t1; t += TK_K1_DEPTH) {
+                for (int ip = 0; ip < NP; ++ip)
 #pragma unroll
-            for (int d = 0; d < TK_K1_DEPTH; ++d) {
-                if (t + d < t1) {
-                    fetch(ring[(d + TK_K1_DEPTH - 1) % TK_K1_DEPTH], t + d + TK_K1_DEPTH - 1);
-                    consume(ring[d], t + d);
-                }
+                    for (int j = 0; j < NS; ++j) Pp[ip][j] = Pq[ip][j];
+                break;
             }
+            fetch(r0, t + 2);
+            r1.to_rows(buf, lane);
+            pM += (double)r1.exp_normalise();
+            step(Pq, Pp, r1);
+            if (((t - t0) & 3) == 2) renorm(Pp);
+            if (t == t0 + 8) TK_STAMP(10);
         }
-        P.renorm();
+        renorm(Pp);
     }
+    X P;
+#pragma unroll
+    for (int ip = 0; ip < NP; ++ip) {
+#pragma unroll
+        for (int j = 0; j < NS; ++j) {
+            P.m[2 * ip][j] = Pp[ip][j][0];
+            P.m[2 * ip + 1][j] = Pp[ip][j][1];
+        }
+        P.e[2 * ip] = pe[2 * ip];
+        P.e[2 * ip + 1] = pe[2 * ip + 1];
+    }
+    P.M = pM;
     // Pc is READ-major ([read][chunk][NF4] float4): the middle kernel streams one
     // read's matrices as a single contiguous run (a [chunk][q][read] layout put
     // all of a read's pieces 16*Npad bytes apart = on ONE L2 channel).  The wave turns
-    // its 64 matrices through the LDS image [word][read]: piece p -> (read p / NF4, q p % NF4).
+    // its 64 matrices through LDS in exactly that order: lane r writes its NF4 float4
+    // contiguously (lane stride 304 B = 12 banks mod 64: conflict-free ds_write_b128),
+    // then float4 number p of the image is piece (read p / NF4, q p % NF4): a linear
+    // ds_read_b128.  (A [word][read] image made every gather read ~19-way conflicted.)
+    TK_STAMP(11);
     wave_lds_fence();
-    xmat_lds_put<NB>(P, img, lane);
-    wave_lds_fence();
-    f4 *dst = ws.Pc + ((size_t)n0 * C + c) * X::NF4;
-    for (int p = lane; p < WAVE * X::NF4; p += WAVE) {
-        const int r = p / X::NF4, q = p - r * X::NF4;
+    f4 *img4 = reinterpret_cast<f4 *>(img);
+#pragma unroll
+    for (int q = 0; q < X::NF4; ++q) {
         f4 o;
 #pragma unroll
-        for (int k = 0; k < 4; ++k) o[k] = (4 * q + k < X::NW) ? img[(4 * q + k) * WAVE + r] : 0.f;
-        dst[(size_t)r * C * X::NF4 + q] = o;
+        for (int k = 0; k < 4; ++k) o[k] = P.word(4 * q + k);
+        img4[lane * X::NF4 + q] = o;
     }
+    wave_lds_fence();
+    f4 *dst = ws.Pc + ((size_t)n0 * C + c) * X::NF4;
+#pragma unroll
+    for (int k = 0; k < X::NF4; ++k) {
+        const int p = lane + k * WAVE;
+        const int r = p / X::NF4, q = p - r * X::NF4;
+        dst[(size_t)r * C * X::NF4 + q] = img4[p];
+    }
+    TK_STAMP(12);
 }
 
 // ---------------------------------------------------------------------------
@@ -482,33 +443,33 @@ __global__ __launch_bounds__(K1_WAVES *WAVE, 2) void logz_transfer_coop_kernel(
     }
     if (wave == 0) msum += P.M;         // M of P0 (each wave added P1..P3 once)
     __syncthreads();                    // all reads of `mats` done
-    float *tot = mats;                  // assemble [NW][64]
+    // assemble the chunk matrix in LDS in OUTPUT order: float4 number r * NF4 + q is piece q
+    // of read r, so the store below is a linear, conflict-free ds_read_b128 (a [word][read]
+    // image made the gather ~19-way bank-conflicted)
+    float *tot = mats;
 #pragma unroll
     for (int q = 0; q < RPW; ++q) {
         const int r = wave * RPW + q;
         if (r < F::NS) {
 #pragma unroll
-            for (int k = 0; k < F::NS; ++k) tot[(r * F::NS + k) * WAVE + lane] = rows[q][k];
-            tot[(F::NS * F::NS + r) * WAVE + lane] = __int_as_float(rexp[q]);
+            for (int k = 0; k < F::NS; ++k) tot[lane * (4 * X::NF4) + r * F::NS + k] = rows[q][k];
+            tot[lane * (4 * X::NF4) + F::NS * F::NS + r] = __int_as_float(rexp[q]);
         }
     }
     if (wave == 0) {
-        tot[(F::NS * F::NS + F::NS) * WAVE + lane] = __int_as_float(__double2loint(msum));
-        tot[(F::NS * F::NS + F::NS + 1) * WAVE + lane] = __int_as_float(__double2hiint(msum));
+        tot[lane * (4 * X::NF4) + F::NS * F::NS + F::NS] = __int_as_float(__double2loint(msum));
+        tot[lane * (4 * X::NF4) + F::NS * F::NS + F::NS + 1] = __int_as_float(__double2hiint(msum));
+#pragma unroll
+        for (int k = X::NW; k < 4 * X::NF4; ++k) tot[lane * (4 * X::NF4) + k] = 0.f;
     }
     __syncthreads();
     {
-        // Pc is READ-major ([read][chunk][NF4] float4): the middle kernel streams one
-        // read's matrices as a single contiguous run (a [chunk][q][read] layout put
-        // all of a read's pieces 16*Npad bytes apart = on ONE L2 channel).
-        // 64 reads x NF4 pieces; thread handles piece p -> (read p / NF4, q p % NF4).
+        // Pc is READ-major ([read][chunk][NF4] float4), see logz_transfer_kernel
+        const f4 *tot4 = reinterpret_cast<const f4 *>(tot);
         f4 *dst = ws.Pc + ((size_t)n0 * C + c) * X::NF4;
         for (int p = threadIdx.x; p < WAVE * X::NF4; p += K1_WAVES * WAVE) {
             const int r = p / X::NF4, q = p - r * X::NF4;
-            f4 o;
-#pragma unroll
-            for (int k = 0; k < 4; ++k) o[k] = (4 * q + k < X::NW) ? tot[(4 * q + k) * WAVE + r] : 0.f;
-            dst[(size_t)r * C * X::NF4 + q] = o;
+            dst[(size_t)r * C * X::NF4 + q] = tot4[p];
         }
     }
 }
@@ -685,12 +646,6 @@ __host__ __device__ constexpr size_t logz_middle_lds_bytes(int C, int NSUP) {
 // ---------------------------------------------------------------------------
 constexpr int K2_WAVES = 16;
 
-#ifdef TK_LAB_TIMING
-__device__ long long tk_dbg[64];
-#define TK_STAMP(k) do { if (blockIdx.x == 100 && threadIdx.x == 0) tk_dbg[k] = clock64(); } while (0)
-#else
-#define TK_STAMP(k)
-#endif
 
 template <int NB, int SUP>
 __global__ __launch_bounds__(K2_WAVES *WAVE) void logz_middle_kernel(int N, int C, int NSUP, int Npad,
@@ -710,6 +665,10 @@ __global__ __launch_bounds__(K2_WAVES *WAVE) void logz_middle_kernel(int N, int 
     const int g = lane & (GRP - 1), grp = lane >> 3;
     const size_t n = blockIdx.x;
 
+#ifdef TK_LAB_TIMING
+#undef TK_STAMP
+#define TK_STAMP(k) do { if (blockIdx.x == 100 && threadIdx.x == 0) tk_dbg[k] = clock64(); } while (0)
+#endif
     TK_STAMP(0);
     // ---- 1. stage the read's chunk matrices: one contiguous run of C*NF4 float4
     {
@@ -1057,7 +1016,7 @@ static int logz_launch_ch(const float *scores, size_t T, size_t N, float *logz, 
     const int SUP = logz_super(C), NSUP = (C + SUP - 1) / SUP;
     const int ncols = (int)((N + WAVE - 1) / WAVE), Npad = ncols * WAVE;
     {
-        const size_t bufwords = 4 * (size_t)WAVE * F::PIECES, imgwords = (size_t)XMat<NB>::NW * WAVE;
+        const size_t bufwords = 4 * (size_t)WAVE * F::PIECES, imgwords = 4 * (size_t)XMat<NB>::NF4 * WAVE;
         const size_t lds = K1_WAVES * (imgwords > bufwords ? imgwords : bufwords) * sizeof(float);
         static bool raised1 = false;
         if (lds > 64 * 1024 && !raised1) {

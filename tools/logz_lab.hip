@@ -36,7 +36,7 @@ static void run(const float *scores, int T, int N, float *logz, float *grad, voi
     logz_ws_layout<NB>(T, N, wsmem, &ws);
     const int C = (T + CH - 1) / CH, SUP = logz_super(C), NSUP = (C + SUP - 1) / SUP;
     const int ncols = (N + WAVE - 1) / WAVE, Npad = ncols * WAVE;
-    const size_t lds1 = K1_WAVES * std::max((size_t)XMat<NB>::NW * WAVE, 4 * (size_t)WAVE * F::PIECES) * sizeof(float);
+    const size_t lds1 = K1_WAVES * std::max(4 * (size_t)XMat<NB>::NF4 * WAVE, 4 * (size_t)WAVE * F::PIECES) * sizeof(float);
     const size_t lds2 = logz_middle_lds_bytes<NB>(C, NSUP);
     constexpr bool chain_in_buf = ((CH / K3_WAVES) + 2) * F::NS * WAVE <= k3_buf_f4<NB, CH>() * 4;
     const size_t lds3 = K3_WAVES * (size_t)k3_buf_f4<NB, CH>() * sizeof(f4) + (chain_in_buf ? 0 : 2 * F::NS * WAVE * sizeof(float));
@@ -67,6 +67,11 @@ static void run(const float *scores, int T, int N, float *logz, float *grad, voi
     CK(hipDeviceSynchronize());
     long long st[8];
     CK(hipMemcpyFromSymbol(st, HIP_SYMBOL(tk_dbg), sizeof st));
+    k1();
+    CK(hipDeviceSynchronize());
+    long long s1[16];
+    CK(hipMemcpyFromSymbol(s1, HIP_SYMBOL(tk_dbg), sizeof s1));
+    printf("   transfer (block (1,20) wave 0, shader clocks): first row done %lld  rows 1-8 %lld  rows 9-16 %lld  store %lld\n", s1[9] - s1[8], s1[10] - s1[9], s1[11] - s1[10], s1[12] - s1[11]);
     printf("   middle phases (block 100, shader clocks): stage %lld  combine %lld  scan %lld  expand %lld\n", st[1] - st[0], st[2] - st[1], st[3] - st[2], st[4] - st[3]);
 #endif
     fflush(stdout);

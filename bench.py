@@ -14,10 +14,12 @@ HBM before the timed region), random-init weights.  Weak scaling: per-GPU batch
 is fixed, value = all ranks' chunks / max-over-ranks time.
 
 Rank 0 prints ONE JSON line with the contract fields plus
-  "roofline":     the logZ forward-backward op (5 launches) at the train step's shape,
+  "roofline":     the logZ forward-backward op (3 launches) on the tensor BASELINE.json's
+                  north_star names for the roofline target (T=4000 blocks, N=256 reads),
                   timed with HIP events on its launching stream;
-                  achieved = 3*T*N*S*4 bytes / mean duration
-  "roofline_rowK": the same op at the north_star kernel shape T=4000 / N=256
+                  achieved = 3*T*N*S*4 bytes / mean duration; traffic = HBM
+                  bytes of the committed rocprofv3 PMC passes (profiles/)
+  "roofline_in_step": the same op at the shape the train step itself launches (T=800, N=128)
   "cpu_baseline": the reference C (oracle/_ref) or the oracle port on host cores.
 """
 import argparse
@@ -57,6 +59,20 @@ def make_batches(nbatch, chunk_len, stride, seed, dev, n=4):
                         seqs=torch.from_numpy(seqs).to(device=dev, dtype=torch.int32),
                         seqlens=torch.from_numpy(seqlens).to(device=dev, dtype=torch.int32)))
     return out
+
+
+def pmc_traffic(T, N):
+    """HBM bytes per launch from the committed rocprofv3 PMC passes (FETCH_SIZE, WRITE_SIZE in
+    separate runs, gfx950 corrections applied -- profiles/r1_pmc_logz_*_traffic.json); None when
+    no counters were collected for this shape."""
+    here = os.path.dirname(os.path.abspath(__file__))
+    for name in sorted(os.listdir(os.path.join(here, "profiles"))) if os.path.isdir(os.path.join(here, "profiles")) else []:
+        if name.startswith("r1_pmc_logz_") and name.endswith("_traffic.json"):
+            with open(os.path.join(here, "profiles", name)) as fh:
+                d = json.load(fh)
+            if d["shape"]["T"] == T and d["shape"]["N"] == N:
+                return d["traffic_bytes"]
+    return None
 
 
 def time_logz_op(T, N, dev, reps, seed=1):
@@ -245,17 +261,21 @@ def main():
 
     if rank == 0:
         nglobal = args.batch * world
-        # the loss path's roofline kernel at the train step's own shape, HIP events on
-        # the launching stream, right after the timed steps (the step itself is a
-        # hipGraph replay, so per-launch events cannot be interleaved with it)
-        dur, dmin = time_logz_op(T, args.batch, dev, 30)
-        alg = 3.0 * T * args.batch * 40 * 4
-        roofline = dict(bound="hbm", kernel="logZ forward-backward op (logz_transfer + combine + scan + "
-                        "expand + logz_posterior), T=%d N=%d (the train step's shape)" % (T, args.batch),
-                        achieved=round(alg / dur / 1e9, 1), peak=HBM_PEAK_GBS, unit="GB/s",
-                        frac=round(alg / dur / 1e9 / HBM_PEAK_GBS, 4), traffic=None,
-                        algorithmic_bytes=alg, mean_us=round(dur * 1e6, 2), min_us=round(dmin * 1e6, 2),
-                        launches=30)
+        # Roofline of the loss path's HBM-bound operator (logZ forward-backward), HIP events
+        # on the launching stream, right after the timed steps (the step itself may be a
+        # hipGraph replay, so per-launch events cannot be interleaved with it).
+        #   roofline          : the tensor BASELINE.json's north_star quotes the target on
+        #                       (T=4000 blocks x N=256 reads x 40 transitions)
+        #   roofline_in_step  : the very launch the train step makes (configs[1]: T=800, N=128)
+        def logz_roofline(t, n, reps, label):
+            mean_s, min_s = time_logz_op(t, n, dev, reps)
+            alg = 3.0 * t * n * 40 * 4
+            return dict(bound="hbm", kernel="logZ forward-backward op (logz_transfer + logz_middle + "
+                        "logz_posterior), T=%d N=%d (%s)" % (t, n, label),
+                        achieved=round(alg / mean_s / 1e9, 1), peak=HBM_PEAK_GBS, unit="GB/s",
+                        frac=round(alg / mean_s / 1e9 / HBM_PEAK_GBS, 4), traffic=pmc_traffic(t, n),
+                        algorithmic_bytes=alg, mean_us=round(mean_s * 1e6, 2),
+                        min_us=round(min_s * 1e6, 2), launches=reps)
         out = dict(metric="signal-chunks/sec (T=4000) flip-flop train step", value=round(
                        nglobal * args.steps / elapsed, 2),
                    unit="chunks/s", n_gpus=world, steps=args.steps, warmup=args.warmup,
@@ -266,17 +286,13 @@ def main():
                                % (args.chunk_len, T, args.batch, args.size),
                                global_batch=nglobal, chunk_len=args.chunk_len, launch=mode,
                                conv=args.conv, lstm=args.lstm,
-                               parallelism="dp%d (reads sharded, flat RCCL all-reduce)" % world),
-                   roofline=roofline)
+                               parallelism="dp%d (reads sharded, flat RCCL all-reduce)" % world))
         if not args.no_rowk:
-            mean_s, min_s = time_logz_op(4000, 256, dev, 20)
-            algk = 3.0 * 4000 * 256 * 40 * 4
-            out["roofline_rowK"] = dict(
-                bound="hbm", kernel="logZ forward-backward op, T=4000 N=256 (north_star kernel shape)",
-                achieved=round(algk / mean_s / 1e9, 1), peak=HBM_PEAK_GBS, unit="GB/s",
-                frac=round(algk / mean_s / 1e9 / HBM_PEAK_GBS, 4), traffic=None,
-                algorithmic_bytes=algk, mean_us=round(mean_s * 1e6, 2), min_us=round(min_s * 1e6, 2))
+            out["roofline"] = logz_roofline(4000, 256, 30, "north_star kernel shape")
+            out["roofline_in_step"] = logz_roofline(T, args.batch, 30, "the train step's own launch")
             out["crf_op_ms"] = dict(cfg2=round(time_crf_op(T, args.batch, dev, 5) * 1e3, 3))
+        else:
+            out["roofline"] = logz_roofline(T, args.batch, 30, "the train step's own launch")
         if not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(T, args.batch)
         print(json.dumps(out), flush=True)

@@ -355,3 +355,18 @@ def test_logz_every_chunk_size(oracle_mod, gpu_device, ch, monkeypatch):
     r = parity.compare_logz(oracle_mod, sc, gpu_device)
     assert r["finite"] and r["logz_rel"] < LOSS_RTOL and r["grad_abs"] < GRAD_ATOL
     assert r["rowsum_dev"] < 1e-5
+
+
+@pytest.mark.parametrize("mode_mb", ["0", "6144"])
+@pytest.mark.parametrize("name", ["t7n2_len1", "t50n3_zero_last", "t200n8", "t130n5_long", "t300n3_wide"])
+def test_crf_both_gradient_modes(oracle_mod, gpu_device, name, mode_mb, monkeypatch):
+    """The gradient path has two implementations: lattices in HBM (sweep + posterior kernels)
+    and checkpoint + recompute (one kernel) for batches whose lattices exceed the workspace
+    cap.  TK_CRF_LATTICE_MB=0 forces the second; both must match the oracle."""
+    monkeypatch.setenv("TK_CRF_LATTICE_MB", mode_mb)
+    inp = cases.crf_inputs(cases.CRF_SMALL[name])
+    r = parity.compare_crf(oracle_mod, inp, 1.0, gpu_device)
+    assert r["finite"]
+    assert r["loss_rel"] < LOSS_RTOL, r["loss_rel"]
+    assert r["grad_abs"] < GRAD_ATOL, r["grad_abs"]
+    assert r["rowsum_dev"] < 1e-4

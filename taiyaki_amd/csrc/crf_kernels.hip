@@ -1135,22 +1135,59 @@ size_t crf_workspace_bytes(size_t ntrans, size_t nblk, size_t nbatch, size_t max
     return crf_ckpt_bytes(nblk, nbatch, sh);
 }
 
+// The sweep and the posterior pass only share per-POSITION data (lattices, slots), so each
+// picks its own cells-per-lane x waves split of the same LPAD positions.
 template <int R, int W, bool MOD>
-static int crf_launch_lattice(const CrfArgs &a, hipStream_t stream) {
+static int crf_launch_sweep(const CrfArgs &a, hipStream_t stream) {
     constexpr int KINDS = MOD ? 3 : 2;
-    const size_t lds1 = crf_sweep_lds_bytes(W, a.S, KINDS), lds2 = crf_post_lds_bytes(R, W, a.S, KINDS);
-    if (lds1 > 160 * 1024 || lds2 > 160 * 1024) return 2;
+    const size_t lds = crf_sweep_lds_bytes(W, a.S, KINDS);
+    if (lds > 160 * 1024) return 2;
     static bool raised = false;
     if (!raised) {
         if (hipFuncSetAttribute(reinterpret_cast<const void *>(&crf_sweep_kernel<R, W, MOD>),
-                                hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess ||
-            hipFuncSetAttribute(reinterpret_cast<const void *>(&crf_posterior_kernel<R, W, MOD>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)
+            return 4;
+        raised = true;
+    }
+    hipLaunchKernelGGL((crf_sweep_kernel<R, W, MOD>), dim3(2 * a.N), dim3(W * WAVE), lds, stream, a);
+    return hipGetLastError() == hipSuccess ? 0 : 4;
+}
+
+template <int LPAD, bool MOD>
+static int crf_launch_sweep_lpad(const CrfArgs &a, int R, hipStream_t stream) {
+    if constexpr (LPAD >= 512) {
+        if (R == 8) return crf_launch_sweep<8, LPAD / 512, MOD>(a, stream);
+    }
+    if constexpr (LPAD >= 256) {
+        if (R == 4) return crf_launch_sweep<4, LPAD / 256, MOD>(a, stream);
+    }
+    if constexpr (LPAD >= 128 && LPAD <= 2048) {
+        if (R == 2) return crf_launch_sweep<2, LPAD / 128, MOD>(a, stream);
+    }
+    if constexpr (LPAD == 64) return crf_launch_sweep<1, 1, MOD>(a, stream);
+    return 2;
+}
+
+template <int R, int W, bool MOD>
+static int crf_launch_lattice(const CrfArgs &a, hipStream_t stream) {
+    constexpr int KINDS = MOD ? 3 : 2, LPAD = R * W * WAVE;
+    // sweep split: TK_CRF_SWEEP_R overrides (cells per lane)
+    int Rs = R;
+    if (const char *e = getenv("TK_CRF_SWEEP_R")) Rs = atoi(e);
+    while (Rs > 1 && Rs * WAVE > LPAD) Rs /= 2;
+    if (LPAD > 2048 && Rs < 4) Rs = 4;
+    const int rc = crf_launch_sweep_lpad<LPAD, MOD>(a, Rs, stream);
+    if (rc != 0) return rc;
+    const size_t lds2 = crf_post_lds_bytes(R, W, a.S, KINDS);
+    if (lds2 > 160 * 1024) return 2;
+    static bool raised = false;
+    if (!raised) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void *>(&crf_posterior_kernel<R, W, MOD>),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)
             return 4;
         raised = true;
     }
     const int CKP = crf_ckp(R, W, KINDS);
-    hipLaunchKernelGGL((crf_sweep_kernel<R, W, MOD>), dim3(2 * a.N), dim3(W * WAVE), lds1, stream, a);
     hipLaunchKernelGGL((crf_posterior_kernel<R, W, MOD>), dim3(a.N, (a.T + CKP - 1) / CKP),
                        dim3(W * WAVE), lds2, stream, a);
     return hipGetLastError() == hipSuccess ? 0 : 4;

@@ -839,13 +839,24 @@ __global__ __launch_bounds__(K3_WAVES *WAVE, (CH <= 16 ? 4 : 2)) void logz_poste
     // between the load phase and the store phase the transpose buffer is idle:
     // it keeps this wave's forward vectors (lane-private slots, no sync needed)
     float *fvb = reinterpret_cast<float *>(buf);            // [K3_ROWS][NS][64]
-    // hand-off slots of the two chains: behind the buffers, or (small chunks) in the unused
-    // tail of wave 0's buffer so that two blocks fit in one CU's LDS
+    // Hand-off slots of the two chains.  Big chunks: behind the buffers.  Small chunks (so
+    // that two blocks fit in one CU's LDS): in the unused tail of the PRODUCING wave's own
+    // buffer -- a wave writes its slot only after its own transposes are done, and reads of
+    // it are over (stage barriers) long before that wave transposes its output.  (A slot in
+    // another wave's buffer would race with that wave's load-phase transposes, which no
+    // barrier separates from the first chain stage.)
     constexpr bool CHAIN_IN_BUF = (K3_ROWS + 2) * F::NS * WAVE <= BUF_F4 * 4;
-    float *chainF = CHAIN_IN_BUF
-                        ? reinterpret_cast<float *>(smem) + K3_ROWS * F::NS * WAVE
-                        : reinterpret_cast<float *>(reinterpret_cast<f4 *>(smem) + K3_WAVES * BUF_F4);
-    float *chainB = chainF + F::NS * WAVE;
+    float *const chain_tail = reinterpret_cast<float *>(reinterpret_cast<f4 *>(smem) + K3_WAVES * BUF_F4);
+    auto chainF_of = [&](int w) {       // slot written by wave w for wave w + 1
+        return CHAIN_IN_BUF ? reinterpret_cast<float *>(reinterpret_cast<f4 *>(smem) + w * BUF_F4) +
+                                  K3_ROWS * F::NS * WAVE
+                            : chain_tail;
+    };
+    auto chainB_of = [&](int w) {       // slot written by wave w for wave w - 1
+        return CHAIN_IN_BUF ? reinterpret_cast<float *>(reinterpret_cast<f4 *>(smem) + w * BUF_F4) +
+                                  (K3_ROWS + 1) * F::NS * WAVE
+                            : chain_tail + F::NS * WAVE;
+    };
     const int c = blockIdx.y;
     const int n0 = blockIdx.x * WAVE;
     const int nvalid = min(WAVE, N - n0) * F::PIECES;
@@ -883,7 +894,7 @@ __global__ __launch_bounds__(K3_WAVES *WAVE, (CH <= 16 ? 4 : 2)) void logz_poste
         if (wave == st) {
             float f[F::NS];
 #pragma unroll
-            for (int k = 0; k < F::NS; ++k) f[k] = (st == 0) ? head[k] : chainF[k * WAVE + lane];
+            for (int k = 0; k < F::NS; ++k) f[k] = (st == 0) ? head[k] : chainF_of(st - 1)[k * WAVE + lane];
 #pragma unroll
             for (int j = 0; j < K3_ROWS; ++j) {
 #pragma unroll
@@ -897,12 +908,12 @@ __global__ __launch_bounds__(K3_WAVES *WAVE, (CH <= 16 ? 4 : 2)) void logz_poste
                 }
             }
 #pragma unroll
-            for (int k = 0; k < F::NS; ++k) chainF[k * WAVE + lane] = f[k];
+            for (int k = 0; k < F::NS; ++k) chainF_of(st)[k * WAVE + lane] = f[k];
         }
         if (wave == K3_WAVES - 1 - st) {
             float b[F::NS];
 #pragma unroll
-            for (int k = 0; k < F::NS; ++k) b[k] = (st == 0) ? head[k] : chainB[k * WAVE + lane];
+            for (int k = 0; k < F::NS; ++k) b[k] = (st == 0) ? head[k] : chainB_of(K3_WAVES - st)[k * WAVE + lane];
 #pragma unroll
             for (int k = 0; k < F::NS; ++k) bexit[k] = b[k];
 #pragma unroll
@@ -916,7 +927,7 @@ __global__ __launch_bounds__(K3_WAVES *WAVE, (CH <= 16 ? 4 : 2)) void logz_poste
                 }
             }
 #pragma unroll
-            for (int k = 0; k < F::NS; ++k) chainB[k * WAVE + lane] = b[k];
+            for (int k = 0; k < F::NS; ++k) chainB_of(K3_WAVES - 1 - st)[k * WAVE + lane] = b[k];
         }
         __syncthreads();
     }

@@ -370,3 +370,24 @@ def test_crf_both_gradient_modes(oracle_mod, gpu_device, name, mode_mb, monkeypa
     assert r["loss_rel"] < LOSS_RTOL, r["loss_rel"]
     assert r["grad_abs"] < GRAD_ATOL, r["grad_abs"]
     assert r["rowsum_dev"] < 1e-4
+
+
+@pytest.mark.parametrize("shape", [(4000, 256), (800, 128), (333, 70)])
+def test_logz_and_crf_are_bitwise_reproducible(gpu_device, shape):
+    """No atomics anywhere: repeated launches on the same input must agree bit for bit (this
+    is what exposes an LDS race -- a chain slot shared with another wave's transpose buffer
+    once made 1 run in 3 differ in a single read)."""
+    import torch
+    from taiyaki_amd import ctc, layers, synth
+    T, N = shape
+    inp = synth.crf_case(T, N, 3)
+    x = torch.from_numpy(inp["scores"]).to(gpu_device)
+    seqs, seqlens = torch.from_numpy(inp["seqs"]), torch.from_numpy(inp["seqlens"])
+    lz0, g0 = layers._logz_launch(x, True)
+    c0, cg0 = ctc._run(x, seqs, seqlens, 1.0, 1.0, 1.0, 40, True)
+    for _ in range(8):
+        lz, g = layers._logz_launch(x, True)
+        assert torch.equal(lz, lz0) and torch.equal(g, g0)
+    for _ in range(3):
+        c, cg = ctc._run(x, seqs, seqlens, 1.0, 1.0, 1.0, 40, True)
+        assert torch.equal(c, c0) and torch.equal(cg, cg0)

@@ -9,7 +9,8 @@ One "step" = one optimiser step of the reference's flip-flop trainer
 (bin/train_flipflop.py:544-622) on BASELINE.json configs[1]: mLstm_flipflop
 (size 256, stride 5, winlen 19), chunk_len 4000 (T = 800 blocks), 128 chunks per
 GPU: Conv/LSTM stack in PyTorch-ROCm fp32 -> HIP flip-flop CRF loss + HIP logZ
--> backward -> ONE flat RCCL all-reduce -> AdamW.  Synthetic chunks (resident in
+-> backward -> ONE flat RCCL all-reduce -> AdamW.  Forward + loss and AdamW are
+replayed from hipGraphs, the MIOpen RNN backward (not capturable) is launched eagerly.  Synthetic chunks (resident in
 HBM before the timed region), random-init weights.  Weak scaling: per-GPU batch
 is fixed, value = all ranks' chunks / max-over-ranks time.
 
@@ -164,11 +165,15 @@ def main():
                     help="native = ATen per-timestep LSTM (torch.backends.cudnn.enabled=False), "
                          "capturable into a hipGraph; miopen = fused MIOpen RNN")
     ap.add_argument("--graph", action="store_true",
-                    help="replay the whole step from a captured hipGraph (probed in a child process "
+                    help="replay the WHOLE step from a captured hipGraph (probed in a child process "
                          "first).  Default for --lstm native; with the MIOpen LSTM the RNN backward "
                          "is not capturable on ROCm 7.2 (hipBLASLt call inside capture), so the "
-                         "default there is eager launch")
+                         "default there is the hybrid scheme (--hybrid)")
     ap.add_argument("--no-graph", action="store_true", help="force eager launch")
+    ap.add_argument("--hybrid", action="store_true",
+                    help="(default with the MIOpen LSTM) replay forward + loss and AdamW from "
+                         "hipGraphs, run the uncapturable RNN backward eagerly; probed in a child "
+                         "process first, eager launch if the probe fails; --no-graph disables")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-rowk", action="store_true")
     ap.add_argument("--probe-graph", action="store_true", help=argparse.SUPPRESS)
@@ -199,12 +204,14 @@ def main():
         torch.backends.cuda.preferred_blas_library("cublas")        # = rocBLAS on ROCm
     except Exception:
         pass
-    use_graph = (args.graph or args.lstm == "native") and not args.no_graph
+    hybrid = args.lstm == "miopen" and not args.graph
+    use_graph = (args.graph or args.lstm == "native" or hybrid) and not args.no_graph
     if use_graph and not args.probe_graph:
         # a failed capture aborts the process inside the HIP runtime, so try it in a child first
         # (tiny shapes: what is probed is whether LSTM forward+backward captures at all)
         cmd = [sys.executable, os.path.abspath(__file__), "--probe-graph", "--chunk-len", "200",
                "--batch", "4", "--size", "32", "--conv", args.conv, "--lstm", args.lstm]
+        cmd += ["--hybrid"] if hybrid else ["--graph"]
         env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE")}
         try:
             pr = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900)
@@ -227,10 +234,12 @@ def main():
     stepper = trainer
     if use_graph:
         try:
-            g = train.GraphedTrainer(trainer, batches[0], seq_capacity=args.batch * (T + 1))
+            cls = train.HybridGraphTrainer if hybrid else train.GraphedTrainer
+            g = cls(trainer, batches[0], seq_capacity=args.batch * (T + 1))
             g.load(batches[0])
             g.capture()
-            stepper, mode = g, "hipGraph replay of the whole step"
+            stepper, mode = g, ("hipGraph replay of forward+loss and of AdamW, eager backward"
+                                if hybrid else "hipGraph replay of the whole step")
         except Exception as exc:      # report, never hide
             print("hipGraph capture failed (%s: %s); running eagerly" % (type(exc).__name__, exc),
                   file=sys.stderr)

@@ -51,9 +51,6 @@ __device__ long long tk_dbg[64];
 #else
 #define TK_STAMP(k)
 #endif
-#ifndef TK_K3_NT_LOAD
-#define TK_K3_NT_LOAD 1
-#endif
 #ifndef TK_K3_NT_STORE
 #define TK_K3_NT_STORE 1
 #endif
@@ -829,7 +826,7 @@ __global__ __launch_bounds__(K2_WAVES *WAVE) void logz_middle_kernel(int N, int 
 template <int NB, int CH>
 __global__ __launch_bounds__(K3_WAVES *WAVE, (CH <= 16 ? 4 : 2)) void logz_posterior_kernel(
     const float *__restrict__ scores, float *__restrict__ grad, int T, int N, int Npad,
-    LogzWs ws, uint32_t *__restrict__ status) {
+    LogzWs ws, uint32_t *__restrict__ status, int nt_load) {
     using F = FF<NB>;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int wave = threadIdx.x >> 6, lane = lane_id();
@@ -869,7 +866,10 @@ __global__ __launch_bounds__(K3_WAVES *WAVE, (CH <= 16 ? 4 : 2)) void logz_poste
     RowSet<NB> w[K3_ROWS];
 #pragma unroll
     for (int j = 0; j < K3_ROWS; ++j)
-        if (TK_K3_NT_LOAD) w[j].issue_nt(base + (size_t)min(tw + j, T - 1) * rowstride, nvalid, lane);     // last use
+        // last use of the scores.  Tensors that fit the 256 MB Infinity Cache are read with
+        // plain loads (part of this second read then hits L2 / MALL: 105 -> 100 us at
+        // T=4000 N=256); bigger ones stream past the caches (non-temporal)
+        if (nt_load) w[j].issue_nt(base + (size_t)min(tw + j, T - 1) * rowstride, nvalid, lane);
         else w[j].issue(base + (size_t)min(tw + j, T - 1) * rowstride, nvalid, lane);
     // chain heads (wave 0: forward vector entering the chunk, last wave: backward
     // vector leaving it), loaded while the rows are in flight
@@ -1082,8 +1082,9 @@ static int logz_launch_ch(const float *scores, size_t T, size_t N, float *logz, 
                 return 4;
             raised3 = true;
         }
+        const int nt_load = (size_t)T * N * F::S * sizeof(float) > ((size_t)200 << 20);
         hipLaunchKernelGGL((logz_posterior_kernel<NB, CH>), grid, block, lds, stream, scores, grad,
-                           (int)T, (int)N, Npad, ws, status);
+                           (int)T, (int)N, Npad, ws, status, nt_load);
     }
     return hipGetLastError() == hipSuccess ? 0 : 4;
 }

@@ -53,10 +53,20 @@ static void run(const float *scores, int T, int N, float *logz, float *grad, voi
         if (SUP == 8) hipLaunchKernelGGL((logz_middle_kernel<NB, 8>), dim3(N), dim3(K2_WAVES * WAVE), lds2, 0, N, C, NSUP, Npad, ws, logz, 1, status);
         else hipLaunchKernelGGL((logz_middle_kernel<NB, 16>), dim3(N), dim3(K2_WAVES * WAVE), lds2, 0, N, C, NSUP, Npad, ws, logz, 1, status);
     };
-    auto k3 = [&] { hipLaunchKernelGGL((logz_posterior_kernel<NB, CH>), dim3(ncols, C), dim3(K3_WAVES * WAVE), lds3, 0, scores, grad, T, N, Npad, ws, status); };
+    auto k3 = [&] { hipLaunchKernelGGL((logz_posterior_kernel<NB, CH>), dim3(ncols, C), dim3(K3_WAVES * WAVE), lds3, 0, scores, grad, T, N, Npad, ws, status, (size_t)T * N * 160 > ((size_t)200 << 20)); };
     k1(); k2(); k3();
     CK(hipDeviceSynchronize());
     const double a = timeit(k1), b = timeit(k2), c = timeit(k3), all = timeit([&] { k1(); k2(); k3(); });
+    if (getenv("LAB_SPREAD")) {
+        hipEvent_t e0, e1;
+        CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+        printf("   per-launch us:");
+        for (int i = 0; i < 40; ++i) {
+            CK(hipEventRecord(e0, 0)); k1(); k2(); k3(); CK(hipEventRecord(e1, 0)); CK(hipEventSynchronize(e1));
+            float t; CK(hipEventElapsedTime(&t, e0, e1)); printf(" %.1f", t * 1e3);
+        }
+        printf("\n");
+    }
     const double alg = 3.0 * T * N * F::S * 4;
     float z0;
     CK(hipMemcpy(&z0, logz, 4, hipMemcpyDeviceToHost));

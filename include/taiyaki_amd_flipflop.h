@@ -14,6 +14,7 @@
  *      make_trans/LogZ), taiyaki/layers.py:1277-1299
  *   taiyaki/cupy_extensions/flipflop.py:470-518,            tk_flipflop_viterbi_dev
  *      taiyaki/decode.py:75-115
+ *   taiyaki/qscores.py:88-142 errprobs_from_trans           tk_flipflop_errprobs_dev
  *
  * Conventions
  *  - plain C: pointers and sizes only, no torch / HIP types in the signatures
@@ -122,6 +123,17 @@ int tk_flipflop_viterbi_dev(const float *scores, size_t nblk, size_t nbatch,
                             size_t nbase, float *fwd, int64_t *traceback,
                             int64_t *path, void *workspace,
                             size_t workspace_bytes, void *stream);
+
+/* ------------------------------------------------------------------------- *
+ * Per-block base error probabilities of a decoded path (qscores.py:88-142)
+ *   trans (nblk, nbatch, 2nb(nb+1)) f32 posterior transition weights (what
+ *   tk_flipflop_logz_dev writes as `grad`); path (nblk+1, nbatch) int64 flip-flop
+ *   states; errprobs (nblk+1, nbatch) f32, row 0 = -1.
+ *     p[t+1, n] = sum(trans into base path[t+1, n] % nb) / (sum(trans into any base) + 1e-10)
+ *     errprobs  = 1 - p
+ * ------------------------------------------------------------------------- */
+int tk_flipflop_errprobs_dev(const float *trans, const int64_t *path, size_t nblk,
+                             size_t nbatch, size_t nbase, float *errprobs, void *stream);
 
 /* ------------------------------------------------------------------------- *
  * Exact reference prototypes (HOST pointers; taiyaki/ctc/c_crf_flipflop.h:3-11,

@@ -247,3 +247,48 @@ def flipflop_viterbi(scores):
                                   _ptr(fwd, _f32p), _ptr(tb, _i64p),
                                   _ptr(path, _i64p))
     return fwd, tb, path
+
+
+# ---------------------------------------------------------------------------
+# basecall-side consumers: error probabilities, chunk stitching
+# ---------------------------------------------------------------------------
+def errprobs_from_trans(trans, path):
+    """qscores.errprobs_from_trans (qscores.py:88-142), numpy restatement.
+    baseprobs[b] = sum of the posterior weights of every transition into base b -- the 2nb
+    transitions into b_flip, b_flip -> b_flop, b_flop stay (qscores.py:58-85) -- normalised
+    by (their sum over b + SMALL_VAL = 1e-10, constants.py:7); errprob = 1 - baseprobs at
+    path[t + 1] % nb; row 0 = 1 - 2.0."""
+    trans = np.asarray(trans, dtype=np.float32)
+    path = np.asarray(path)
+    T, N, S = trans.shape
+    nb = nbase_flipflop(S)
+    base = np.zeros((T, N, nb), dtype=np.float32)
+    for b in range(nb):
+        idx = list(range(2 * nb * b, 2 * nb * (b + 1))) + [2 * nb * nb + b, 2 * nb * nb + nb + b]
+        base[:, :, b] = trans[:, :, idx].sum(axis=2, dtype=np.float32)
+    base = base / (base.sum(axis=2, keepdims=True, dtype=np.float32) + np.float32(1e-10))
+    p = np.empty((T + 1, N), dtype=np.float32)
+    p[1:] = np.take_along_axis(base, (path[1:] % nb)[:, :, None], axis=2)[:, :, 0]
+    p[0] = 2.0
+    return (np.float32(1.0) - p).astype(np.float32)
+
+
+def stitch_chunks(out, chunk_starts, chunk_ends, stride, path_stitching=False):
+    """basecall_helpers.stitch_chunks (basecall_helpers.py:46-94), numpy restatement:
+    first / middle / last chunk cut at the midpoints of the overlaps."""
+    out = np.asarray(out)
+    nchunks = out.shape[1]
+    if nchunks == 1:
+        return out[:, 0]
+    one = 1 if path_stitching else 0
+    start = chunk_starts[0] // stride
+    end = (chunk_ends[0] + chunk_starts[1]) // (2 * stride) + one
+    parts = [out[start:end, 0]]
+    for i in range(1, nchunks - 1):
+        start = (chunk_ends[i - 1] - chunk_starts[i]) // (2 * stride) + one
+        end = (chunk_ends[i] + chunk_starts[i + 1] - 2 * chunk_starts[i]) // (2 * stride) + one
+        parts.append(out[start:end, i])
+    start = (chunk_ends[-2] - chunk_starts[-1]) // (2 * stride) + one
+    end = (chunk_ends[-1] - chunk_starts[-1]) // stride + one
+    parts.append(out[start:end, -1])
+    return np.concatenate(parts, 0)

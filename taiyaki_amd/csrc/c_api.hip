@@ -26,6 +26,8 @@ int crf_dispatch(const float *logprob, size_t ntrans, size_t nblk, size_t nbatch
                  size_t max_seqlen, size_t ncan, float sharp_can, float sharp_mod,
                  float out_scale, float *cost, float *grad, void *workspace,
                  size_t workspace_bytes, uint32_t *status, hipStream_t stream);
+int errprobs_dispatch(const float *trans, const int64_t *path, size_t T, size_t N, size_t nbase,
+                      float *out, hipStream_t stream);
 int build_indices_dispatch(const int32_t *seqs, const int32_t *seqlen, size_t nbatch,
                            size_t nbase, const int32_t *mod_cats,
                            const int32_t *can_mods_offsets, const float *mod_cat_weights,
@@ -52,6 +54,15 @@ int tk_flipflop_build_indices_dev(const int32_t *seqs, const int32_t *seqlen, si
     return tk::build_indices_dispatch(seqs, seqlen, nbatch, nbase, mod_cats, can_mods_offsets,
                                       mod_cat_weights, seqoff, stayidx, moveidx, modidx,
                                       modfact, static_cast<hipStream_t>(stream));
+}
+
+int tk_flipflop_errprobs_dev(const float *trans, const int64_t *path, size_t nblk, size_t nbatch,
+                             size_t nbase, float *errprobs, void *stream) {
+    if (!trans || !path || !errprobs || nblk == 0 || nbatch == 0) return TK_ERR_BAD_ARG;
+    if (!aligned16(trans)) return TK_ERR_BAD_ARG;
+    const int rc = tk::errprobs_dispatch(trans, path, nblk, nbatch, nbase, errprobs,
+                                         static_cast<hipStream_t>(stream));
+    return rc == 0 ? TK_OK : (rc == 2 ? TK_ERR_UNSUPPORTED : TK_ERR_LAUNCH);
 }
 
 size_t tk_crf_flipflop_workspace_bytes(size_t ntrans, size_t nblk, size_t nbatch,

@@ -37,6 +37,21 @@ LOGZ_SMALL = {
     "t100n4_nb3": dict(T=100, N=4, nbase=3, seed=46),
 }
 
+# basecall-side consumers: N chunks of T blocks that overlap by `overlap` samples;
+# `ragged` shortens the signal so that the last chunk overlaps its neighbour by more
+BASECALL_SMALL = {
+    "t60n5": dict(T=60, N=5, nbase=4, seed=61, stride=5, overlap=100, ragged=0),
+    "t200n70": dict(T=200, N=70, nbase=4, seed=62, stride=5, overlap=100, ragged=130),
+    "t40n1": dict(T=40, N=1, nbase=4, seed=63, stride=2, overlap=20, ragged=0),
+    "t90n3_nb2": dict(T=90, N=3, nbase=2, seed=64, stride=3, overlap=60, ragged=31),
+}
+
+
+def basecall_scores(spec):
+    nb = spec["nbase"]
+    return synth.scores(spec["T"], spec["N"], 2 * nb * (nb + 1), spec["seed"])
+
+
 # BASELINE.json configs at full size: only per-read scalars + checksums are kept
 FULLSIZE = {
     "cfg2": dict(T=800, N=128, seed=1, mods=None),

@@ -1,0 +1,110 @@
+"""SURVEY 8f.2 -- basecall-side consumers: posterior transition weights, Viterbi path,
+per-block error probabilities (qscores.py:88-142), chunk stitching
+(basecall_helpers.py:46-94), quality strings (qscores.py:145-178).
+
+CPU: the oracle restatements against fixtures produced by the genuine reference
+(tests/golden/make_golden_basecall.py).  GPU: the HIP path against both."""
+import os
+
+import numpy as np
+import pytest
+
+from tests.golden import cases
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+
+
+def gold():
+    return np.load(os.path.join(HERE, "golden", "basecall_small.npz"))
+
+
+@pytest.mark.parametrize("name", list(cases.BASECALL_SMALL))
+def test_oracle_matches_reference_goldens(oracle_mod, name):
+    g, spec = gold(), cases.BASECALL_SMALL[name]
+    scores = cases.basecall_scores(spec)
+    _, trans = oracle_mod.flipflop_logz_grad(scores)
+    _, _, path = oracle_mod.flipflop_viterbi(scores)
+    np.testing.assert_array_equal(path, g[name + "/path"])                    # bit-exact
+    np.testing.assert_allclose(trans.sum(axis=2), g[name + "/trans_sum"], atol=2e-5)
+    err = oracle_mod.errprobs_from_trans(trans, path)
+    np.testing.assert_allclose(err, g[name + "/errprobs"], atol=2e-5)
+    starts, ends = g[name + "/chunk_starts"], g[name + "/chunk_ends"]
+    sp = oracle_mod.stitch_chunks(path, starts, ends, spec["stride"])
+    np.testing.assert_array_equal(sp, g[name + "/stitched_path"])
+    np.testing.assert_array_equal(
+        oracle_mod.stitch_chunks(path, starts, ends, spec["stride"], path_stitching=True),
+        g[name + "/stitched_path_ps"])
+    np.testing.assert_allclose(oracle_mod.stitch_chunks(err, starts, ends, spec["stride"]),
+                               g[name + "/stitched_errprobs"], atol=2e-5)
+
+
+def test_host_string_helpers_match_reference_goldens():
+    """qchar / qstring helpers and stitch_chunks are host code: checked without a GPU on the
+    reference's own error probabilities."""
+    import torch
+    from taiyaki_amd import basecall_helpers, qscores
+    g = gold()
+    for name, spec in cases.BASECALL_SMALL.items():
+        starts, ends = g[name + "/chunk_starts"], g[name + "/chunk_ends"]
+        path, err = torch.from_numpy(g[name + "/path"]), torch.from_numpy(g[name + "/errprobs"])
+        sp = basecall_helpers.stitch_chunks(path, starts, ends, spec["stride"])
+        se = basecall_helpers.stitch_chunks(err, starts, ends, spec["stride"])
+        np.testing.assert_array_equal(sp.numpy(), g[name + "/stitched_path"])
+        np.testing.assert_array_equal(se.numpy(), g[name + "/stitched_errprobs"])
+        np.testing.assert_array_equal(
+            basecall_helpers.stitch_chunks(path, starts, ends, spec["stride"], path_stitching=True).numpy(),
+            g[name + "/stitched_path_ps"])
+        q = qscores.path_errprobs_to_qstring(se, sp.numpy(), 0.9, 0.3)
+        assert q == bytes(g[name + "/qstring"]).decode("ascii")
+    idx = qscores.transitions_into_base(2, 4).numpy()
+    np.testing.assert_array_equal(idx, [16, 17, 18, 19, 20, 21, 22, 23, 34, 38])
+    assert qscores.qchar_from_qscore([0, 1.4, 40]) == '!"I'
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", list(cases.BASECALL_SMALL))
+def test_hip_basecall_chain_matches_reference(oracle_mod, gpu_device, name):
+    """scores -> make_trans -> viterbi -> errprobs -> stitch -> qstring, all on the HIP path."""
+    import torch
+    from taiyaki_amd import basecall_helpers, decode, qscores
+    g, spec = gold(), cases.BASECALL_SMALL[name]
+    scores = torch.from_numpy(cases.basecall_scores(spec)).to(gpu_device)
+    trans = decode.flipflop_make_trans(scores)
+    _, _, path = decode.flipflop_viterbi(scores)
+    np.testing.assert_array_equal(path.cpu().numpy(), g[name + "/path"])      # bit-exact
+    err = qscores.errprobs_from_trans(trans, path)
+    assert err.shape == (spec["T"] + 1, spec["N"]) and err.device == scores.device
+    # HIP kernel vs the oracle on identical inputs, then vs the reference end to end
+    np.testing.assert_allclose(err.cpu().numpy(),
+                               oracle_mod.errprobs_from_trans(trans.cpu().numpy(), path.cpu().numpy()),
+                               atol=1e-6)
+    np.testing.assert_allclose(err.cpu().numpy(), g[name + "/errprobs"], atol=2e-5)
+    starts, ends = g[name + "/chunk_starts"], g[name + "/chunk_ends"]
+    sp = basecall_helpers.stitch_chunks(path, starts, ends, spec["stride"]).cpu().numpy()
+    se = basecall_helpers.stitch_chunks(err, starts, ends, spec["stride"])
+    np.testing.assert_array_equal(sp, g[name + "/stitched_path"])
+    q = qscores.path_errprobs_to_qstring(se, sp, 0.9, 0.3)
+    ref = bytes(g[name + "/qstring"]).decode("ascii")
+    assert len(q) == len(ref)
+    # a quality character is a rounded -10 log10(p): allow one step where p sits on a boundary
+    diff = np.abs(np.frombuffer(q.encode(), np.uint8).astype(int) - np.frombuffer(ref.encode(), np.uint8))
+    assert diff.max(initial=0) <= 1 and (diff > 0).mean() < 0.01
+
+
+@pytest.mark.gpu
+def test_hip_errprobs_fullsize_properties(gpu_device):
+    """At BASELINE size (T=800, N=128): rows are probabilities, row 0 is -1, and the op is
+    invariant to permuting reads."""
+    import torch
+    from taiyaki_amd import decode, qscores, synth
+    sc = torch.from_numpy(synth.scores(800, 128, 40, 5)).to(gpu_device)
+    trans = decode.flipflop_make_trans(sc)
+    _, _, path = decode.flipflop_viterbi(sc)
+    err = qscores.errprobs_from_trans(trans, path)
+    assert torch.all(err[0] == -1.0)
+    assert float(err[1:].min()) >= -1e-6 and float(err[1:].max()) <= 1.0 + 1e-6
+    perm = torch.randperm(128, device=gpu_device)
+    err2 = qscores.errprobs_from_trans(trans[:, perm].contiguous(), path[:, perm].contiguous())
+    assert torch.equal(err2, err[:, perm])
+    with pytest.raises(RuntimeError):
+        qscores.errprobs_from_trans(trans.cpu(), path.cpu())

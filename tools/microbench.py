@@ -14,7 +14,7 @@ import numpy as np
 import torch
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-from taiyaki_amd import _lib, ctc, decode, layers, synth  # noqa: E402
+from taiyaki_amd import _lib, ctc, decode, layers, qscores, synth  # noqa: E402
 
 SHAPES = {"rowK": (4000, 256), "cfg2": (800, 128), "cfg5": (1600, 64), "big": (4000, 1024)}
 
@@ -56,6 +56,10 @@ def main():
             "crf_fwd": (lambda: ctc._run(x, seqs, seqlens, 1.0, 1.0, 1.0, 40, False), 1),
             "viterbi": (lambda: decode.flipflop_viterbi(x), 1),
         }
+        if "errprobs" in args.ops.split(","):
+            trans = decode.flipflop_make_trans(x)
+            path = decode.flipflop_viterbi(x)[2]
+            ops["errprobs"] = (lambda: qscores.errprobs_from_trans(trans, path), 1)
         for name in args.ops.split(","):
             fn, mult = ops[name]
             mean, mn = timed(fn, args.reps)

@@ -6,148 +6,201 @@
 // reproduced exactly, so fwd, traceback and path are bit-identical.
 //
 // EIGHT LANES PER READ: lane (r, j) owns destination state j of read r (8 reads per
-// wave), so one step is one 8-way max chain per lane instead of ten per lane, and
-// N = 128 reads give 16 waves instead of 2.  The max-plus recursion itself stays
-// serial in T by construction (a time-parallel form would re-associate the fp32
-// adds and break bit-exactness).  The running vector is all-gathered inside the
-// 8-lane group after every step; score rows are prefetched VIT_PF steps ahead.
-// The traceback pointers of one (t, read) are packed 4 bits each into one 32-bit
-// word of the workspace so the backward pass streams 4 B/read/step instead of
-// chasing pointers through the int64 traceback tensor.
+// wave).  The max-plus recursion stays serial in T by construction (a time-parallel form
+// would re-associate the fp32 adds and break bit-exactness), so the work is in making one
+// step short:
+//   * every lane evaluates the same eight candidates f[from] + s[from]; a flop lane's
+//     invalid sources are masked to -inf when the row is fetched (off the chain), so there
+//     is no flip / flop divergence;
+//   * the all-gather of the eight state values is folded into the adds: the value of lane
+//     4q+k of the lane's own quad is a quad_perm DPP operand (v_add_f32_dpp), the other
+//     quad comes from one lane^4 exchange (two bank-masked row shifts) -- no ds_bpermute;
+//   * "first index wins" is kept by scanning each quad's four candidates in order and
+//     letting the lower quad win ties;
+//   * the traceback pointers of a step are packed with three ballots (bit b of every
+//     lane's source index) into 3 x 64 bits per wave = 3 bytes per read and step, read
+//     back by the path pass with prefetched loads instead of chasing the int64 tensor.
+// Score rows are prefetched VIT_PF steps ahead.
 #include "ff_common.h"
 
 namespace tk {
 
 constexpr int VIT_GRP = 8;      // lanes per read
 constexpr int VIT_PF = 8;       // score rows in flight per lane
-constexpr int VIT_TB = 16;      // traceback words prefetched per batch
+constexpr int VIT_TB = 16;      // traceback steps prefetched per batch
+constexpr float VIT_NEG_INF = -__builtin_huge_valf();
+
+// lane l <- lane l ^ 4 (inside every 8-lane group): two bank-masked row shifts
+__device__ __forceinline__ float xor4_f32(float x) {
+    int r = __builtin_amdgcn_update_dpp(0, __float_as_int(x), 0x104, 0xF, 0x5, false);   // row_shl:4 -> lanes 0-3, 8-11
+    r = __builtin_amdgcn_update_dpp(r, __float_as_int(x), 0x114, 0xF, 0xA, false);       // row_shr:4 -> lanes 4-7, 12-15
+    return __int_as_float(r);
+}
+
+// c[k] = s[k] + x[lane 4q + k] (k < 4), c[4 + k] = s[4 + k] + xo[lane 4q + k]
+__device__ __forceinline__ void vit_candidates(const float (&s)[8], float x, float xo, float (&c)[8]) {
+    asm("s_nop 1\n\t"
+        "v_add_f32_dpp %0, %8, %10 quad_perm:[0,0,0,0] row_mask:0xf bank_mask:0xf\n\t"
+        "v_add_f32_dpp %1, %8, %11 quad_perm:[1,1,1,1] row_mask:0xf bank_mask:0xf\n\t"
+        "v_add_f32_dpp %2, %8, %12 quad_perm:[2,2,2,2] row_mask:0xf bank_mask:0xf\n\t"
+        "v_add_f32_dpp %3, %8, %13 quad_perm:[3,3,3,3] row_mask:0xf bank_mask:0xf\n\t"
+        "v_add_f32_dpp %4, %9, %14 quad_perm:[0,0,0,0] row_mask:0xf bank_mask:0xf\n\t"
+        "v_add_f32_dpp %5, %9, %15 quad_perm:[1,1,1,1] row_mask:0xf bank_mask:0xf\n\t"
+        "v_add_f32_dpp %6, %9, %16 quad_perm:[2,2,2,2] row_mask:0xf bank_mask:0xf\n\t"
+        "v_add_f32_dpp %7, %9, %17 quad_perm:[3,3,3,3] row_mask:0xf bank_mask:0xf"
+        : "=&v"(c[0]), "=&v"(c[1]), "=&v"(c[2]), "=&v"(c[3]), "=&v"(c[4]), "=&v"(c[5]), "=&v"(c[6]),
+          "=&v"(c[7])
+        : "v"(x), "v"(xo), "v"(s[0]), "v"(s[1]), "v"(s[2]), "v"(s[3]), "v"(s[4]), "v"(s[5]), "v"(s[6]),
+          "v"(s[7]));
+}
 
 template <int NB>
 __global__ __launch_bounds__(WAVE) void viterbi_kernel(const float *__restrict__ scores, int T,
                                                       int N, float *__restrict__ fwd_out,
                                                       int64_t *__restrict__ tb_out,
                                                       int64_t *__restrict__ path_out,
-                                                      uint32_t *__restrict__ packed, int Npad) {
+                                                      unsigned long long *__restrict__ packed) {
     using F = FF<NB>;
-    static_assert(F::NS <= VIT_GRP, "one lane per state, 4-bit packed traceback");
+    static_assert(F::NS <= VIT_GRP, "one lane per state");
     const int lane = lane_id();
-    const int j = lane & (VIT_GRP - 1), rloc = lane >> 3;
+    const int j = lane & (VIT_GRP - 1), rloc = lane >> 3, q = j >> 2;
     const size_t nreal = (size_t)blockIdx.x * VIT_GRP + rloc;
     const bool live = nreal < (size_t)N && j < F::NS;
     const size_t n = min(nreal, (size_t)N - 1);
     const int jc = min(j, F::NS - 1);
     const bool flip = jc < NB;
     const size_t rowstride = (size_t)N * F::S;
-    // every lane reads NS contiguous floats of a score row from its own base (no divergent
-    // branch around the loads): flip lane j its candidate block s[j*NS ..], flop lanes the
-    // flop block s[FLOP0 ..] (= [from-flip scores | flop-stay scores])
-    const float *mine = scores + n * F::S + (flip ? jc * F::NS : F::FLOP0);
+    // every lane reads the NS contiguous floats of its destination's block (no divergent
+    // branch around the loads): flip lane j the block s[j*NS ..], flop lanes the flop block
+    // s[FLOP0 ..] = [from-flip scores | flop-stay scores].  All global accesses are a
+    // wave-uniform row pointer (scalar registers) plus a 32-bit lane offset.
+    const int mine = (int)n * F::S + (flip ? jc * F::NS : F::FLOP0);
+    const int slot = (int)min(nreal, (size_t)N - 1) * F::NS + jc;       // lane's element of an (N, NS) row
+    // register word w pairs with source state src[w]: the lane's own quad first (4q + w),
+    // then the other quad (4 (1 - q) + w - 4)
+    int src[8];
+    bool ok[8];
+#pragma unroll
+    for (int w = 0; w < 8; ++w) {
+        src[w] = (w < 4) ? 4 * q + w : 4 * (1 - q) + (w - 4);
+        // decode.py:99-105: a flip state is reached from every state, flop b only from flip b
+        // and from itself
+        ok[w] = src[w] < F::NS && (flip || src[w] == jc - NB || src[w] == jc);
+    }
 
-    float f[F::NS];                 // the read's full forward vector, replicated in its 8 lanes
-#pragma unroll
-    for (int s = 0; s < F::NS; ++s) f[s] = (s < NB) ? 0.f : NEG_LARGE;      // decode.py:93-95
-    if (fwd_out != nullptr && live) fwd_out[nreal * F::NS + j] = f[jc];
+    float best = (j < NB) ? 0.f : ((j < F::NS) ? NEG_LARGE : VIT_NEG_INF);      // decode.py:93-95
+    if (fwd_out != nullptr && live) fwd_out[slot] = best;
 
-    float sc[VIT_PF][F::NS];
-    auto fetch = [&](int t, float (&dst)[F::NS]) {
-        const float *row = mine + (size_t)min(t, T - 1) * rowstride;       // clamped, unconditional
-        if constexpr (F::NS % 4 == 0) {
-            const f4 *rv = reinterpret_cast<const f4 *>(row);               // 16-byte aligned
+    float sc[VIT_PF][8];
+    // running wave-uniform pointers (scalar adds per step, no index multiplications)
+    const float *frow = scores;                 // row being fetched (stops at row T - 1)
+    int tfetch = 0;
+    auto fetch = [&](float (&dst)[8]) {
+        if constexpr (F::NS == 8) {
+            // the two float4 halves of the block, own quad's sources first
+            const f4 a = *reinterpret_cast<const f4 *>(frow + (mine + 4 * q));
+            const f4 b = *reinterpret_cast<const f4 *>(frow + (mine + 4 * (1 - q)));
 #pragma unroll
-            for (int q = 0; q < F::NS / 4; ++q) {
-                const f4 x = rv[q];
-#pragma unroll
-                for (int r = 0; r < 4; ++r) dst[4 * q + r] = x[r];
+            for (int k = 0; k < 4; ++k) {
+                dst[k] = ok[k] ? a[k] : VIT_NEG_INF;
+                dst[4 + k] = ok[4 + k] ? b[k] : VIT_NEG_INF;
             }
         } else {
 #pragma unroll
-            for (int k = 0; k < F::NS; ++k) dst[k] = row[k];
+            for (int w = 0; w < 8; ++w) {
+                const float v = frow[mine + min(src[w], F::NS - 1)];
+                dst[w] = ok[w] ? v : VIT_NEG_INF;
+            }
         }
+        // clamped, never branched on: past the end the last row is fetched again
+        frow += (tfetch < T - 1) ? rowstride : 0;
+        ++tfetch;
     };
 #pragma unroll
-    for (int k = 0; k < VIT_PF; ++k) fetch(k, sc[k]);
+    for (int k = 0; k < VIT_PF; ++k) fetch(sc[k]);
 
+    const int wave_row = blockIdx.x;            // 8 reads per wave
+    const size_t nwaves = gridDim.x;
+    unsigned long long *prow = packed + (size_t)wave_row * 3;
+    float *fout = fwd_out != nullptr ? fwd_out + (size_t)N * F::NS : nullptr;        // row t + 1
+    int64_t *tout = tb_out;
     for (int t0 = 0; t0 < T; t0 += VIT_PF) {
 #pragma unroll
         for (int k = 0; k < VIT_PF; ++k) {
             const int t = t0 + k;
             if (t < T) {
-                float best;
-                uint32_t arg;
-                if (flip) {
-                    // decode.py:99-101: max over `from`, first index wins
-                    best = f[0] + sc[k][0];
-                    arg = 0;
+                float c[8];
+                vit_candidates(sc[k], best, xor4_f32(best), c);
+                fetch(sc[k]);
+                // first maximum of each quad's four candidates, in source order
+                float bo = c[0], bt = c[4];
+                int ao = 0, at = 0;
 #pragma unroll
-                    for (int from = 1; from < F::NS; ++from) {
-                        const float v = f[from] + sc[k][from];
-                        if (v > best) {
-                            best = v;
-                            arg = from;
-                        }
+                for (int i = 1; i < 4; ++i) {
+                    if (c[i] > bo) {
+                        bo = c[i];
+                        ao = i;
                     }
-                } else {
-                    // decode.py:102-105: index 0 = from flip b, 1 = flop stay; tie -> flip
-                    const int bb = jc - NB;
-                    float fb = f[0], fs = f[NB], su = sc[k][0], sv = sc[k][NB];
-#pragma unroll
-                    for (int q = 1; q < NB; ++q) {
-                        if (bb == q) {
-                            fb = f[q];
-                            fs = f[NB + q];
-                            su = sc[k][q];
-                            sv = sc[k][NB + q];
-                        }
+                    if (c[4 + i] > bt) {
+                        bt = c[4 + i];
+                        at = i;
                     }
-                    const float u = fb + su;
-                    const float v = fs + sv;
-                    const bool stay = v > u;
-                    best = stay ? v : u;
-                    arg = stay ? (uint32_t)jc : (uint32_t)bb;
                 }
-                fetch(t + VIT_PF, sc[k]);
-                // all-gather the new vector inside the 8-lane group
-#pragma unroll
-                for (int s = 0; s < F::NS; ++s) f[s] = __shfl(best, (lane & ~(VIT_GRP - 1)) | s, WAVE);
-                // packed traceback word: OR of (arg << 4 j) over the group
-                uint32_t word = (j < F::NS) ? (arg << (4 * j)) : 0u;
-                word |= (uint32_t)__builtin_amdgcn_update_dpp(0, (int)word, 0xB1, 0xF, 0xF, false);
-                word |= (uint32_t)__builtin_amdgcn_update_dpp(0, (int)word, 0x4E, 0xF, 0xF, false);
-                word |= (uint32_t)__builtin_amdgcn_update_dpp(0, (int)word, 0x141, 0xF, 0xF, false);
-                if (j == 0 && nreal < (size_t)Npad) packed[(size_t)t * Npad + nreal] = word;
-                if (live) {
-                    if (fwd_out != nullptr) fwd_out[((size_t)(t + 1) * N + nreal) * F::NS + j] = best;
-                    if (tb_out != nullptr) tb_out[((size_t)t * N + nreal) * F::NS + j] = (int64_t)arg;
+                // the quad holding the lower source indices wins ties (own quad for q = 0)
+                const bool take_other = (q == 0) ? (bt > bo) : !(bo > bt);
+                best = take_other ? bt : bo;
+                const int arg = take_other ? 4 * (1 - q) + at : 4 * q + ao;
+                // three ballots: bit b of every lane's source index
+                const unsigned long long m0 = __ballot(arg & 1), m1 = __ballot(arg & 2),
+                                         m2 = __ballot(arg & 4);
+                if (lane < 3) prow[lane] = (lane == 0) ? m0 : (lane == 1 ? m1 : m2);
+                prow += nwaves * 3;
+                if (fout != nullptr) {
+                    if (live) fout[slot] = best;
+                    fout += (size_t)N * F::NS;
+                }
+                if (tout != nullptr) {
+                    if (live) tout[slot] = (int64_t)arg;
+                    tout += (size_t)N * F::NS;
                 }
             }
         }
     }
 
-    // traceback (decode.py:108-113); argmax = first maximal index.  One lane per read.
+    // traceback (decode.py:108-113); argmax = first maximal index.  One lane per read; the
+    // group's eight final values are gathered once.
+    float f[F::NS];
+#pragma unroll
+    for (int s = 0; s < F::NS; ++s) f[s] = __shfl(best, (lane & ~(VIT_GRP - 1)) | s, WAVE);
     uint32_t st = 0;
-    float best = f[0];
+    float top = f[0];
 #pragma unroll
     for (int s = 1; s < F::NS; ++s) {
-        if (f[s] > best) {
-            best = f[s];
+        if (f[s] > top) {
+            top = f[s];
             st = s;
         }
     }
     const bool tracer = j == 0 && nreal < (size_t)N;
     if (tracer) path_out[(size_t)T * N + nreal] = (int64_t)st;
-    const size_t np = min(nreal, (size_t)Npad - 1);
+    const int shift0 = rloc * VIT_GRP;
     for (int thi = T; thi > 0; thi -= VIT_TB) {
-        uint32_t wd[VIT_TB];
+        unsigned long long wd[VIT_TB][3];
 #pragma unroll
         for (int k = 0; k < VIT_TB; ++k) {
             const int t = max(thi - 1 - k, 0);      // clamped, never branched: one straight load run
-            wd[k] = packed[(size_t)t * Npad + np];
+            const unsigned long long *p = packed + ((size_t)t * nwaves + wave_row) * 3;
+            wd[k][0] = p[0];
+            wd[k][1] = p[1];
+            wd[k][2] = p[2];
         }
 #pragma unroll
         for (int k = 0; k < VIT_TB; ++k) {
             const int t = thi - 1 - k;
             if (t >= 0) {
-                st = (wd[k] >> (4 * st)) & 0xFu;
+                const int sh = shift0 + (int)st;
+                st = (uint32_t)((wd[k][0] >> sh) & 1ull) | ((uint32_t)((wd[k][1] >> sh) & 1ull) << 1) |
+                     ((uint32_t)((wd[k][2] >> sh) & 1ull) << 2);
                 if (tracer) path_out[(size_t)t * N + nreal] = (int64_t)st;
             }
         }
@@ -156,17 +209,16 @@ __global__ __launch_bounds__(WAVE) void viterbi_kernel(const float *__restrict__
 
 size_t viterbi_workspace_bytes(size_t T, size_t N, size_t nbase) {
     (void)nbase;
-    const size_t Npad = (N + WAVE - 1) / WAVE * WAVE;
-    return (T > 0 ? T : 1) * Npad * sizeof(uint32_t);
+    const size_t nwaves = (N + VIT_GRP - 1) / VIT_GRP;
+    return (T > 0 ? T : 1) * nwaves * 3 * sizeof(unsigned long long);
 }
 
 template <int NB>
 static int viterbi_launch(const float *scores, size_t T, size_t N, float *fwd, int64_t *tb,
                           int64_t *path, void *workspace, hipStream_t stream) {
     const int ngrp = (int)((N + VIT_GRP - 1) / VIT_GRP);
-    const int Npad = (int)((N + WAVE - 1) / WAVE) * WAVE;
     hipLaunchKernelGGL(viterbi_kernel<NB>, dim3(ngrp), dim3(WAVE), 0, stream, scores, (int)T,
-                       (int)N, fwd, tb, path, static_cast<uint32_t *>(workspace), Npad);
+                       (int)N, fwd, tb, path, static_cast<unsigned long long *>(workspace));
     return hipGetLastError() == hipSuccess ? 0 : 4;
 }
 

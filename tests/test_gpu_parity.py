@@ -409,3 +409,20 @@ def test_hybrid_graph_trainer_matches_eager(gpu_device):
     m = re.search(r"loss_rel=(\S+) param_abs=(\S+)", pr.stdout)
     assert m, pr.stdout
     assert float(m.group(1)) < 1e-4 and float(m.group(2)) < 1e-4, pr.stdout
+
+
+@pytest.mark.parametrize("scale", [4.0, 8.0])
+def test_logz_wide_dynamic_range(oracle_mod, gpu_device, scale):
+    """Scores U(-5 scale, 5 scale): per-row ranges up to 80 nats, path weights differing by
+    thousands of nats -- the per-row / per-step power-of-two exponents must carry it."""
+    from taiyaki_amd import synth
+    sc = (synth.scores(600, 70, 40, 77) * np.float32(scale)).astype(np.float32)
+    r = parity.compare_logz(oracle_mod, sc, gpu_device)
+    assert r["finite"] and r["logz_rel"] < LOSS_RTOL, r["logz_rel"]
+    assert r["grad_abs"] < 5e-5, r["grad_abs"]
+    assert r["rowsum_dev"] < 1e-4
+    inp = synth.crf_case(600, 70, 78)
+    inp["scores"] = (inp["scores"] * np.float32(scale)).astype(np.float32)
+    rc = parity.compare_crf(oracle_mod, inp, 1.0, gpu_device)
+    assert rc["finite"] and rc["loss_rel"] < LOSS_RTOL, rc["loss_rel"]
+    assert rc["grad_abs"] < 5e-5, rc["grad_abs"]

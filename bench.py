@@ -207,10 +207,11 @@ def main():
     hybrid = args.lstm == "miopen" and not args.graph
     use_graph = (args.graph or args.lstm == "native" or hybrid) and not args.no_graph
     if use_graph and not args.probe_graph:
-        # a failed capture aborts the process inside the HIP runtime, so try it in a child first
-        # (tiny shapes: what is probed is whether LSTM forward+backward captures at all)
-        cmd = [sys.executable, os.path.abspath(__file__), "--probe-graph", "--chunk-len", "200",
-               "--batch", "4", "--size", "32", "--conv", args.conv, "--lstm", args.lstm]
+        # a failed capture aborts the process inside the HIP runtime, so try it in a child first,
+        # at the real shapes (what is probed is this very capture, workspace sizes included)
+        cmd = [sys.executable, os.path.abspath(__file__), "--probe-graph", "--chunk-len",
+               str(args.chunk_len), "--batch", str(args.batch), "--size", str(args.size),
+               "--conv", args.conv, "--lstm", args.lstm]
         cmd += ["--hybrid"] if hybrid else ["--graph"]
         env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE")}
         try:

@@ -115,7 +115,8 @@ int tk_flipflop_logz_dev(const float *scores, size_t nblk, size_t nbatch,
 /* ------------------------------------------------------------------------- *
  * Viterbi decode (decode.py:75-115: first-index tie rule, bit-exact fp32 adds)
  *   fwd (nblk+1, nbatch, 2nb) f32 ; traceback (nblk, nbatch, 2nb) int64 ;
- *   path (nblk+1, nbatch) int64.   fwd / traceback may be NULL (path only).
+ *   path (nblk+1, nbatch) int64.   fwd and traceback may BOTH be NULL (path only: what
+ *   bin/basecall.py:222 consumes); one without the other is TK_ERR_BAD_ARG.
  * ------------------------------------------------------------------------- */
 size_t tk_flipflop_viterbi_workspace_bytes(size_t nblk, size_t nbatch, size_t nbase);
 

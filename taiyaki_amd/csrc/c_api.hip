@@ -107,6 +107,7 @@ int tk_flipflop_viterbi_dev(const float *scores, size_t nblk, size_t nbatch, siz
                             size_t workspace_bytes, void *stream) {
     if (!scores || !path || !workspace || nbatch == 0) return TK_ERR_BAD_ARG;
     if (!aligned16(scores)) return TK_ERR_BAD_ARG;
+    if ((fwd == nullptr) != (traceback == nullptr)) return TK_ERR_BAD_ARG;      // both or neither
     return tk::viterbi_dispatch(scores, nblk, nbatch, nbase, fwd, traceback, path, workspace,
                                 workspace_bytes, static_cast<hipStream_t>(stream));
 }

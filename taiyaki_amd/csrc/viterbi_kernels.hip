@@ -10,8 +10,8 @@
 // would re-associate the fp32 adds and break bit-exactness), so the work is in making one
 // step short:
 //   * every lane evaluates the same eight candidates f[from] + s[from]; a flop lane's
-//     invalid sources are masked to -inf when the row is fetched (off the chain), so there
-//     is no flip / flop divergence;
+//     invalid sources are masked to -inf (when the row is used, not when it is fetched: the
+//     loads stay in flight for VIT_PF steps), so there is no flip / flop divergence;
 //   * the all-gather of the eight state values is folded into the adds: the value of lane
 //     4q+k of the lane's own quad is a quad_perm DPP operand (v_add_f32_dpp), the other
 //     quad comes from one lane^4 exchange (two bank-masked row shifts) -- no ds_bpermute;
@@ -21,6 +21,8 @@
 //     lane's source index) into 3 x 64 bits per wave = 3 bytes per read and step, read
 //     back by the path pass with prefetched loads instead of chasing the int64 tensor.
 // Score rows are prefetched VIT_PF steps ahead.
+#include <type_traits>
+
 #include "ff_common.h"
 
 namespace tk {
@@ -95,6 +97,8 @@ __global__ __launch_bounds__(WAVE) void viterbi_kernel(const float *__restrict__
     // running wave-uniform pointers (scalar adds per step, no index multiplications)
     const float *frow = scores;                 // row being fetched (stops at row T - 1)
     int tfetch = 0;
+    // the fetch only issues loads: anything computed on the loaded words here would make the
+    // wave wait for the row it has just requested (one L2 round trip per step)
     auto fetch = [&](float (&dst)[8]) {
         if constexpr (F::NS == 8) {
             // the two float4 halves of the block, own quad's sources first
@@ -102,15 +106,12 @@ __global__ __launch_bounds__(WAVE) void viterbi_kernel(const float *__restrict__
             const f4 b = *reinterpret_cast<const f4 *>(frow + (mine + 4 * (1 - q)));
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
-                dst[k] = ok[k] ? a[k] : VIT_NEG_INF;
-                dst[4 + k] = ok[4 + k] ? b[k] : VIT_NEG_INF;
+                dst[k] = a[k];
+                dst[4 + k] = b[k];
             }
         } else {
 #pragma unroll
-            for (int w = 0; w < 8; ++w) {
-                const float v = frow[mine + min(src[w], F::NS - 1)];
-                dst[w] = ok[w] ? v : VIT_NEG_INF;
-            }
+            for (int w = 0; w < 8; ++w) dst[w] = frow[mine + min(src[w], F::NS - 1)];
         }
         // clamped, never branched on: past the end the last row is fetched again
         frow += (tfetch < T - 1) ? rowstride : 0;
@@ -124,47 +125,64 @@ __global__ __launch_bounds__(WAVE) void viterbi_kernel(const float *__restrict__
     unsigned long long *prow = packed + (size_t)wave_row * 3;
     float *fout = fwd_out != nullptr ? fwd_out + (size_t)N * F::NS : nullptr;        // row t + 1
     int64_t *tout = tb_out;
-    for (int t0 = 0; t0 < T; t0 += VIT_PF) {
+    // The loop body is instantiated per (outputs wanted, every lane live): the per-step
+    // "is this pointer null / is this lane live" tests are loop invariants, but left inside
+    // they cost a scalar compare + branch + exec-mask round trip each, every step.
+    auto steps = [&](auto want_full, auto all_live) {
+        constexpr bool FULLOUT = decltype(want_full)::value, ALLLIVE = decltype(all_live)::value;
+        for (int t0 = 0; t0 < T; t0 += VIT_PF) {
 #pragma unroll
-        for (int k = 0; k < VIT_PF; ++k) {
-            const int t = t0 + k;
-            if (t < T) {
-                float c[8];
-                vit_candidates(sc[k], best, xor4_f32(best), c);
-                fetch(sc[k]);
-                // first maximum of each quad's four candidates, in source order
-                float bo = c[0], bt = c[4];
-                int ao = 0, at = 0;
+            for (int k = 0; k < VIT_PF; ++k) {
+                const int t = t0 + k;
+                if (t < T) {
+                    // a flop lane's invalid sources are masked when the row is USED, VIT_PF
+                    // steps after it was requested
+                    float sm[8], c[8];
 #pragma unroll
-                for (int i = 1; i < 4; ++i) {
-                    if (c[i] > bo) {
-                        bo = c[i];
-                        ao = i;
+                    for (int w = 0; w < 8; ++w) sm[w] = ok[w] ? sc[k][w] : VIT_NEG_INF;
+                    vit_candidates(sm, best, xor4_f32(best), c);
+                    fetch(sc[k]);
+                    // first maximum of each quad's four candidates, in source order
+                    float bo = c[0], bt = c[4];
+                    int ao = 0, at = 0;
+#pragma unroll
+                    for (int i = 1; i < 4; ++i) {
+                        if (c[i] > bo) {
+                            bo = c[i];
+                            ao = i;
+                        }
+                        if (c[4 + i] > bt) {
+                            bt = c[4 + i];
+                            at = i;
+                        }
                     }
-                    if (c[4 + i] > bt) {
-                        bt = c[4 + i];
-                        at = i;
+                    // the quad holding the lower source indices wins ties (own quad for q = 0)
+                    const bool take_other = (q == 0) ? (bt > bo) : !(bo > bt);
+                    best = take_other ? bt : bo;
+                    const int arg = take_other ? 4 * (1 - q) + at : 4 * q + ao;
+                    // three ballots: bit b of every lane's source index
+                    const unsigned long long m0 = __ballot(arg & 1), m1 = __ballot(arg & 2),
+                                             m2 = __ballot(arg & 4);
+                    if (lane < 3) prow[lane] = (lane == 0) ? m0 : (lane == 1 ? m1 : m2);
+                    prow += nwaves * 3;
+                    if constexpr (FULLOUT) {
+                        if (ALLLIVE || live) {
+                            fout[slot] = best;
+                            tout[slot] = (int64_t)arg;
+                        }
+                        fout += (size_t)N * F::NS;
+                        tout += (size_t)N * F::NS;
                     }
-                }
-                // the quad holding the lower source indices wins ties (own quad for q = 0)
-                const bool take_other = (q == 0) ? (bt > bo) : !(bo > bt);
-                best = take_other ? bt : bo;
-                const int arg = take_other ? 4 * (1 - q) + at : 4 * q + ao;
-                // three ballots: bit b of every lane's source index
-                const unsigned long long m0 = __ballot(arg & 1), m1 = __ballot(arg & 2),
-                                         m2 = __ballot(arg & 4);
-                if (lane < 3) prow[lane] = (lane == 0) ? m0 : (lane == 1 ? m1 : m2);
-                prow += nwaves * 3;
-                if (fout != nullptr) {
-                    if (live) fout[slot] = best;
-                    fout += (size_t)N * F::NS;
-                }
-                if (tout != nullptr) {
-                    if (live) tout[slot] = (int64_t)arg;
-                    tout += (size_t)N * F::NS;
                 }
             }
         }
+    };
+    const bool every_lane_live = __all(live);
+    if (fwd_out != nullptr && tb_out != nullptr) {
+        if (every_lane_live) steps(std::true_type{}, std::true_type{});
+        else steps(std::true_type{}, std::false_type{});
+    } else {
+        steps(std::false_type{}, std::true_type{});
     }
 
     // traceback (decode.py:108-113); argmax = first maximal index.  One lane per read; the

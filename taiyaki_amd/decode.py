@@ -27,6 +27,26 @@ def flipflop_viterbi(scores, _never_use_cupy=False):
     return fwd, tb, path
 
 
+def flipflop_viterbi_path(scores):
+    """Path-only Viterbi: what bin/basecall.py:222 keeps of `flipflop_viterbi` (the forward
+    scores and the int64 traceback tensor, five times the size of the input, are not
+    written)."""
+    _lib.require_gpu(scores, "flipflop_viterbi_path")
+    L = _lib.lib()
+    sc = scores.detach().float().contiguous()
+    T, N, S = sc.shape
+    nbase = flipflopfings.nbase_flipflop(S)
+    dev = sc.device
+    with torch.cuda.device(dev):
+        path = torch.empty(T + 1, N, dtype=torch.int64, device=dev)
+        wsb = L.tk_flipflop_viterbi_workspace_bytes(T, N, nbase)
+        ws = torch.empty(wsb, dtype=torch.uint8, device=dev)
+        rc = L.tk_flipflop_viterbi_dev(_lib.ptr(sc), T, N, nbase, None, None, _lib.ptr(path),
+                                       _lib.ptr(ws), wsb, _lib.stream_ptr())
+        _lib.check(rc, "tk_flipflop_viterbi_dev")
+    return path
+
+
 def flipflop_make_trans(scores, _never_use_cupy=False):
     """decode.py:42-72: posterior transition probabilities (not logs) =
     d logZ / d scores; always detached, like the reference."""

@@ -72,6 +72,7 @@ def test_hip_basecall_chain_matches_reference(oracle_mod, gpu_device, name):
     trans = decode.flipflop_make_trans(scores)
     _, _, path = decode.flipflop_viterbi(scores)
     np.testing.assert_array_equal(path.cpu().numpy(), g[name + "/path"])      # bit-exact
+    assert torch.equal(decode.flipflop_viterbi_path(scores), path)            # path-only variant
     err = qscores.errprobs_from_trans(trans, path)
     assert err.shape == (spec["T"] + 1, spec["N"]) and err.device == scores.device
     # HIP kernel vs the oracle on identical inputs, then vs the reference end to end

@@ -55,6 +55,7 @@ def main():
             "crf": (lambda: ctc._run(x, seqs, seqlens, 1.0, 1.0, 1.0, 40, True), 3),
             "crf_fwd": (lambda: ctc._run(x, seqs, seqlens, 1.0, 1.0, 1.0, 40, False), 1),
             "viterbi": (lambda: decode.flipflop_viterbi(x), 1),
+            "viterbi_path": (lambda: decode.flipflop_viterbi_path(x), 1),
         }
         if "errprobs" in args.ops.split(","):
             trans = decode.flipflop_make_trans(x)

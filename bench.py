@@ -36,6 +36,12 @@ os.environ.setdefault("DISABLE_ADDMM_CUDA_LT", "1")
 os.environ.setdefault("TORCH_BLAS_PREFER_HIPBLASLT", "0")
 os.environ.setdefault("ROCBLAS_USE_HIPBLASLT", "0")            # rocBLAS -> its own Tensile kernels
 os.environ.setdefault("MIOPEN_GEMM_ENFORCE_BACKEND", "1")      # MIOpen RNN GEMMs -> rocBLAS
+# HIP spreads streams and hipGraph branches over several hardware queues and pays a
+# cross-queue signal (~10 us) whenever the ~16,000 tiny dependent launches of a step hop
+# between them.  One queue keeps the whole step in order on the hardware: 167 -> 110 ms per
+# step on one GPU (127 ms with two queues).  With RCCL in the process (N > 1) the collective
+# kernels get the second queue, the setting AMD's own RCCL recipes use.
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "1" if int(os.environ.get("WORLD_SIZE", "1")) <= 1 else "2")
 
 import numpy as np
 import torch
@@ -295,6 +301,7 @@ def main():
                                "blocks), %d chunks/GPU, size %d, HIP flip-flop CRF loss + logZ, AdamW"
                                % (args.chunk_len, T, args.batch, args.size),
                                global_batch=nglobal, chunk_len=args.chunk_len, launch=mode,
+                               hw_queues=int(os.environ.get("GPU_MAX_HW_QUEUES", "0")),
                                conv=args.conv, lstm=args.lstm,
                                parallelism="dp%d (reads sharded, flat RCCL all-reduce)" % world))
         if not args.no_rowk:

@@ -259,18 +259,18 @@ def main():
 
     for i in range(args.warmup):
         stepper.step(batches[i % len(batches)])
-    if world > 1:
+    if dist.is_initialized():
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for i in range(args.steps):
         stepper.step(batches[i % len(batches)])
-    if world > 1:
+    if dist.is_initialized():
         dist.barrier()
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
     _lib.raise_if_nonfinite()
-    if world > 1:
+    if dist.is_initialized():
         tmax = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         elapsed = float(tmax.item())
@@ -312,10 +312,21 @@ def main():
             out["roofline"] = logz_roofline(T, args.batch, 30, "the train step's own launch")
         if not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(T, args.batch)
-        print(json.dumps(out), flush=True)
-    if world > 1:
+    else:
+        out = None
+    if dist.is_initialized():
         dist.barrier()
         dist.destroy_process_group()
+    if out is not None:
+        # RCCL writes a version banner through C stdio (fully buffered when stdout is a pipe):
+        # flush it first so that the JSON line is the LAST thing rank 0 prints
+        sys.stdout.flush()
+        try:
+            import ctypes
+            ctypes.CDLL(None).fflush(None)
+        except Exception:
+            pass
+        print(json.dumps(out), flush=True)
 
 
 if __name__ == "__main__":

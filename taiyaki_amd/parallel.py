@@ -21,7 +21,10 @@ def init_from_env(backend=None):
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
-    if world > 1 and not dist.is_initialized():
+    # TK_FORCE_PROCESS_GROUP=1: build the (single-rank) RCCL communicator anyway -- lets a 1-GPU
+    # box exercise the collective path, its streams and the NCCL watchdog thread
+    forced = bool(os.environ.get("TK_FORCE_PROCESS_GROUP"))
+    if (world > 1 or forced) and not dist.is_initialized():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29500")
         if backend is None:
@@ -47,6 +50,7 @@ class FlatGradArena:
             p.grad = self.flat[off:off + p.numel()].view_as(p)
             off += p.numel()
         self.world = dist.get_world_size() if dist.is_initialized() else 1
+        self._always = dist.is_initialized() and bool(os.environ.get("TK_FORCE_PROCESS_GROUP"))
         self._work = None
 
     def zero(self):
@@ -55,7 +59,7 @@ class FlatGradArena:
     def allreduce_async(self):
         """SUM over ranks (the reference's DDP averages; the 1/world factor is
         applied by `finish`)."""
-        if self.world > 1:
+        if self.world > 1 or self._always:
             self._work = dist.all_reduce(self.flat, op=dist.ReduceOp.SUM, async_op=True)
 
     def finish(self):

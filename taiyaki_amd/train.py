@@ -49,6 +49,11 @@ class Trainer:
         return loss
 
 
+# Other threads of the process (the NCCL/RCCL watchdog polls events) must not invalidate a
+# capture in progress: capture errors are scoped to the capturing thread.
+_CAPTURE = dict(capture_error_mode="thread_local")
+
+
 class GraphedTrainer:
     """The whole optimiser step captured ONCE into a hipGraph and replayed.
 
@@ -86,7 +91,7 @@ class GraphedTrainer:
         torch.cuda.current_stream().wait_stream(side)
         torch.cuda.synchronize()
         self.graph = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(self.graph):
+        with torch.cuda.graph(self.graph, **_CAPTURE):
             self.loss = self.trainer.step(self.static)
         torch.cuda.synchronize()
 
@@ -144,7 +149,7 @@ class HybridGraphTrainer(GraphedTrainer):
         torch.cuda.current_stream().wait_stream(side)
         torch.cuda.synchronize()
         self.graph = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(self.graph):
+        with torch.cuda.graph(self.graph, **_CAPTURE):
             tr.arena.zero()
             self.loss, _ = calculate_loss(tr.net, **self.static)
         torch.cuda.synchronize()
@@ -154,7 +159,7 @@ class HybridGraphTrainer(GraphedTrainer):
         self._tail_eager()
         torch.cuda.synchronize()
         self.opt_graph = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(self.opt_graph):
+        with torch.cuda.graph(self.opt_graph, **_CAPTURE):
             self._clip_and_step()
         torch.cuda.synchronize()
 

@@ -426,3 +426,28 @@ def test_logz_wide_dynamic_range(oracle_mod, gpu_device, scale):
     rc = parity.compare_crf(oracle_mod, inp, 1.0, gpu_device)
     assert rc["finite"] and rc["loss_rel"] < LOSS_RTOL, rc["loss_rel"]
     assert rc["grad_abs"] < 5e-5, rc["grad_abs"]
+
+
+def test_bench_contract_with_live_rccl_group(gpu_device):
+    """bench.py at toy shapes with a (single-rank) RCCL process group forced on: the hybrid
+    hipGraph step must coexist with the collective path and its watchdog thread, and the LAST
+    line rank 0 prints must be the contract JSON."""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29547", RANK="0", LOCAL_RANK="0",
+               WORLD_SIZE="1", TK_FORCE_PROCESS_GROUP="1")
+    pr = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--chunk-len", "400",
+                         "--batch", "8", "--size", "32", "--steps", "2", "--warmup", "1",
+                         "--no-cpu-baseline", "--no-rowk"],
+                        env=env, capture_output=True, text=True, timeout=900)
+    assert pr.returncode == 0, pr.stderr[-800:]
+    line = pr.stdout.strip().splitlines()[-1]
+    out = json.loads(line)
+    for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step",
+                "higher_is_better", "scaling", "vs_baseline", "dtype", "data", "config", "roofline"):
+        assert key in out, key
+    assert out["value"] > 0 and out["n_gpus"] == 1 and out["scaling"] == "weak"
+    assert {"bound", "achieved", "peak", "unit", "frac", "traffic"} <= set(out["roofline"])

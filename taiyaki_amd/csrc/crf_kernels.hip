@@ -53,7 +53,6 @@ struct CrfArgs {
     float *ckpt;                // workspace: checkpoint columns
     double *ckoff;              // workspace: checkpoint offsets
     uint32_t *status;
-    int debug;                  // profiling switches (TK_CRF_DEBUG): 1 no atomics, 2 no posterior, 4 no recompute
     // lattice mode (crf_sweep_kernel + crf_posterior_kernel): both lattices live in HBM
     float *latF, *latB;         // [N][T][LP] forward column before step t / backward column after it
     int LP;                     // lattice row pitch: max_seqlen rounded up to 256 (<= LPAD)
@@ -381,7 +380,7 @@ __global__ __launch_bounds__(W *WAVE) void crf_kernel(CrfArgs a) {
             for (int j = 0; j < R; ++j) f[j] = ck_n[((size_t)k * R + j) * NT + tid];
             offF = ckoff_n[k];
             fwd_edge_init(f, t0);       // barrier: tile and edges are visible
-            for (int i = 0; i < ((a.debug & 4) ? 0 : nrows); ++i) {
+            for (int i = 0; i < nrows; ++i) {
                 const int t = t0 + i;
                 // The checkpoint holds the column BEFORE the fold that was pending at
                 // the tile boundary (CK % 4 == 0): re-post its column max so the step
@@ -414,15 +413,11 @@ __global__ __launch_bounds__(W *WAVE) void crf_kernel(CrfArgs a) {
                     float am = fmaf(lm, c, br);
                     if (MOD) am = fmaf(row[md[j]], fw[j], am);
                     const float fc = Fblk[((size_t)i * R + j) * NT + tid] - ct;
-                    if (!(a.debug & 2)) {
-                        const float ps = fast_exp2(fc + as);
-                        const float pm = fast_exp2(fc + am);
-                        if (!(a.debug & 1)) {
-                            prow[slot[0][j]] = ps;
-                            prow[LPAD + slot[1][j]] = pm;
-                            if (MOD) prow[2 * LPAD + slot[MOD ? 2 : 0][j]] = pm * (fw[j] * inv_cmod);
-                        }
-                    }
+                    const float ps = fast_exp2(fc + as);
+                    const float pm = fast_exp2(fc + am);
+                    prow[slot[0][j]] = ps;
+                    prow[LPAD + slot[1][j]] = pm;
+                    if (MOD) prow[2 * LPAD + slot[MOD ? 2 : 0][j]] = pm * (fw[j] * inv_cmod);
                     b[j] = lse2(as, am);
                 }
                 if (W > 1 && lane == 0) edgeB[(nbwd & 1) * W + wave] = b[0];
@@ -1286,10 +1281,6 @@ int crf_dispatch(const float *logprob, size_t ntrans, size_t nblk, size_t nbatch
         a.slotws = a.segws = nullptr;
     }
     a.status = status;
-    {
-        const char *dbg = getenv("TK_CRF_DEBUG");
-        a.debug = dbg ? atoi(dbg) : 0;
-    }
     return modidx != nullptr ? crf_launch_mod<true>(sh, a, lattice, stream)
                              : crf_launch_mod<false>(sh, a, lattice, stream);
 }

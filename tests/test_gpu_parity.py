@@ -451,3 +451,16 @@ def test_bench_contract_with_live_rccl_group(gpu_device):
         assert key in out, key
     assert out["value"] > 0 and out["n_gpus"] == 1 and out["scaling"] == "weak"
     assert {"bound", "achieved", "peak", "unit", "frac", "traffic"} <= set(out["roofline"])
+
+
+def test_logz_very_long_chunks(oracle_mod, gpu_device):
+    """T = 9000: more 16-row chunks than one LDS image of the middle kernel holds -> the
+    launcher falls back to 32-row chunks; T = 21000 exceeds the build and must say so."""
+    import torch
+    from taiyaki_amd import layers, synth
+    sc = synth.scores(9000, 3, 40, 91)
+    r = parity.compare_logz(oracle_mod, sc, gpu_device)
+    assert r["finite"] and r["logz_rel"] < LOSS_RTOL and r["grad_abs"] < GRAD_ATOL
+    big = torch.zeros(21000, 1, 40, device=gpu_device)
+    with pytest.raises(RuntimeError):
+        layers.flipflop_logpartition(big)

@@ -464,3 +464,18 @@ def test_logz_very_long_chunks(oracle_mod, gpu_device):
     big = torch.zeros(21000, 1, 40, device=gpu_device)
     with pytest.raises(RuntimeError):
         layers.flipflop_logpartition(big)
+
+
+@pytest.mark.parametrize("nbase", [2, 3])
+@pytest.mark.parametrize("mode_mb", ["0", "6144"])
+def test_crf_other_alphabet_sizes(oracle_mod, gpu_device, nbase, mode_mb, monkeypatch):
+    """2- and 3-letter alphabets (S = 12, 24) through both gradient modes; the kernels take
+    the transition count at run time, the reference's tests use nbase 2
+    (test_ctc_loss.py:80-135)."""
+    from taiyaki_amd import synth
+    monkeypatch.setenv("TK_CRF_LATTICE_MB", mode_mb)
+    inp = synth.crf_case(120, 9, 300 + nbase, nbase=nbase)
+    r = parity.compare_crf(oracle_mod, inp, 1.0, gpu_device)
+    assert r["finite"] and r["loss_rel"] < LOSS_RTOL, r["loss_rel"]
+    assert r["grad_abs"] < GRAD_ATOL, r["grad_abs"]
+    assert r["rowsum_dev"] < 1e-4

@@ -479,3 +479,27 @@ def test_crf_other_alphabet_sizes(oracle_mod, gpu_device, nbase, mode_mb, monkey
     assert r["finite"] and r["loss_rel"] < LOSS_RTOL, r["loss_rel"]
     assert r["grad_abs"] < GRAD_ATOL, r["grad_abs"]
     assert r["rowsum_dev"] < 1e-4
+
+
+def test_config1_mgru_abinitio_lossvector(oracle_mod, gpu_device):
+    """BASELINE configs[0] (the reference's own CPU-runnable case): mGru_flipflop size 96
+    stride 2 on chunk_len 2000 -> T = 1000, N = 64, realistic sequence lengths.  The network
+    output goes through the HIP loss assembly (train_abinitio.py:213-217) and through the CPU
+    oracle; the per-read loss vector and the score gradient must agree."""
+    from taiyaki_amd import models, synth, train
+    torch.manual_seed(3)
+    chunk_len, N = 2000, 64
+    net = models.mGru_flipflop(size=96, stride=2).to(gpu_device)
+    seqlens = synth.realistic_seqlens(1000, N, 9, chunk_len)
+    seqs, _ = synth.sequences(seqlens, 9)
+    indata = torch.from_numpy(synth.signal_chunks(chunk_len, N, 9)).to(gpu_device)
+    outputs = net(indata).detach().requires_grad_(True)
+    assert outputs.shape == (1000, N, 40)
+    _, lossvector = train.calculate_loss(lambda _x: outputs, indata, torch.from_numpy(seqs),
+                                         torch.from_numpy(seqlens))
+    lossvector.mean().backward()
+    sc = outputs.detach().cpu().numpy()
+    oloss, ograd = oracle_mod.crf_flipflop_loss(sc, seqs, seqlens, 1.0)
+    olz, olgrad = oracle_mod.flipflop_logz_grad(sc)
+    np.testing.assert_allclose(lossvector.detach().cpu().numpy(), oloss + olz / 1000, rtol=LOSS_RTOL)
+    np.testing.assert_allclose(outputs.grad.cpu().numpy(), (ograd + olgrad / 1000) / N, atol=1e-6)

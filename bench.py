@@ -234,7 +234,9 @@ def main():
             m.use_gemm = args.conv == "gemm"
     parallel.broadcast_parameters(net)
     arena = parallel.FlatGradArena(net)
-    trainer = train.Trainer(net, arena)
+    # the reference's default adaptive clipping (--gradient_clip_num_mads 0, window 1000):
+    # gradient maxima every step, clamp once 1000 steps have been seen
+    trainer = train.Trainer(net, arena, clip_num_mads=0)
     batches = make_batches(args.batch, args.chunk_len, stride, 17 + rank, dev,
                            n=2 if args.probe_graph else 4)
     mode = "eager"
@@ -298,7 +300,7 @@ def main():
                    ms_per_step=round(elapsed / args.steps * 1e3, 3), higher_is_better=True,
                    scaling="weak", vs_baseline=None, dtype="f32", data="synthetic",
                    config=dict(workload="configs[1]: mLstm_flipflop r9.4.1 DNA, chunk_len=%d (T=%d "
-                               "blocks), %d chunks/GPU, size %d, HIP flip-flop CRF loss + logZ, AdamW"
+                               "blocks), %d chunks/GPU, size %d, HIP flip-flop CRF loss + logZ, gradient maxima/clipping, AdamW"
                                % (args.chunk_len, T, args.batch, args.size),
                                global_batch=nglobal, chunk_len=args.chunk_len, launch=mode,
                                hw_queues=int(os.environ.get("GPU_MAX_HW_QUEUES", "0")),

@@ -15,6 +15,7 @@
  *   taiyaki/cupy_extensions/flipflop.py:470-518,            tk_flipflop_viterbi_dev
  *      taiyaki/decode.py:75-115
  *   taiyaki/qscores.py:88-142 errprobs_from_trans           tk_flipflop_errprobs_dev
+ *   bin/train_flipflop.py:201-212 apply_clipping            tk_grad_maxabs_clip_dev
  *
  * Conventions
  *  - plain C: pointers and sizes only, no torch / HIP types in the signatures
@@ -135,6 +136,19 @@ int tk_flipflop_viterbi_dev(const float *scores, size_t nblk, size_t nbatch,
  * ------------------------------------------------------------------------- */
 int tk_flipflop_errprobs_dev(const float *trans, const int64_t *path, size_t nblk,
                              size_t nbatch, size_t nbase, float *errprobs, void *stream);
+
+/* ------------------------------------------------------------------------- *
+ * Gradient maxima + clip by value over a flat gradient arena
+ * (bin/train_flipflop.py:201-212 apply_clipping, without its per-tensor host syncs)
+ *   grads: all trainable gradients, contiguous; seg_off (nseg+1) int64 element offsets of
+ *   the parameter tensors; max_seg_len = longest segment (grid sizing);
+ *   maxs[s] = max |grads[seg s]| BEFORE clipping (NaN if the segment holds a NaN);
+ *   thresh (nseg) nullable: where given (finite, >= 0) segment s is clamped to
+ *   [-thresh[s], thresh[s]] -- identical to the reference's "clamp if max > thresh".
+ * ------------------------------------------------------------------------- */
+int tk_grad_maxabs_clip_dev(float *grads, const int64_t *seg_off, size_t nseg,
+                            size_t max_seg_len, const float *thresh, float *maxs,
+                            void *stream);
 
 /* ------------------------------------------------------------------------- *
  * Exact reference prototypes (HOST pointers; taiyaki/ctc/c_crf_flipflop.h:3-11,

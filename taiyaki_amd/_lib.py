@@ -33,6 +33,7 @@ SIGNATURES = {
     "tk_flipflop_viterbi_workspace_bytes": (_sz, [_sz, _sz, _sz]),
     "tk_flipflop_viterbi_dev": (_i, [_vp, _sz, _sz, _sz, _vp, _vp, _vp, _vp, _sz, _vp]),
     "tk_flipflop_errprobs_dev": (_i, [_vp, _vp, _sz, _sz, _sz, _vp, _vp]),
+    "tk_grad_maxabs_clip_dev": (_i, [_vp, _vp, _sz, _sz, _vp, _vp, _vp]),
     # exact reference prototypes (host pointers)
     "crf_flipflop_grad": (None, [_vp, _sz, _sz, _sz, _vp, _vp, _vp, _vp, _vp]),
     "crf_flipflop_cost": (None, [_vp, _sz, _sz, _sz, _vp, _vp, _vp, _vp]),

@@ -26,6 +26,8 @@ int crf_dispatch(const float *logprob, size_t ntrans, size_t nblk, size_t nbatch
                  size_t max_seqlen, size_t ncan, float sharp_can, float sharp_mod,
                  float out_scale, float *cost, float *grad, void *workspace,
                  size_t workspace_bytes, uint32_t *status, hipStream_t stream);
+int grad_clip_dispatch(float *grads, const int64_t *seg_off, size_t nseg, size_t max_seg_len,
+                       const float *thresh, float *maxs, hipStream_t stream);
 int errprobs_dispatch(const float *trans, const int64_t *path, size_t T, size_t N, size_t nbase,
                       float *out, hipStream_t stream);
 int build_indices_dispatch(const int32_t *seqs, const int32_t *seqlen, size_t nbatch,
@@ -54,6 +56,14 @@ int tk_flipflop_build_indices_dev(const int32_t *seqs, const int32_t *seqlen, si
     return tk::build_indices_dispatch(seqs, seqlen, nbatch, nbase, mod_cats, can_mods_offsets,
                                       mod_cat_weights, seqoff, stayidx, moveidx, modidx,
                                       modfact, static_cast<hipStream_t>(stream));
+}
+
+int tk_grad_maxabs_clip_dev(float *grads, const int64_t *seg_off, size_t nseg, size_t max_seg_len,
+                            const float *thresh, float *maxs, void *stream) {
+    if (!grads || !seg_off || !maxs) return TK_ERR_BAD_ARG;
+    const int rc = tk::grad_clip_dispatch(grads, seg_off, nseg, max_seg_len, thresh, maxs,
+                                          static_cast<hipStream_t>(stream));
+    return rc == 0 ? TK_OK : TK_ERR_LAUNCH;
 }
 
 int tk_flipflop_errprobs_dev(const float *trans, const int64_t *path, size_t nblk, size_t nbatch,

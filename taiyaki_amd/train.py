@@ -27,9 +27,19 @@ class Trainer:
     """One optimiser step = forward, loss, backward, flat all-reduce, clip, AdamW.
     Defaults follow bin/_bin_argparse.py:16-193 (AdamW lr 4e-3, wd 0.01, eps 1e-6)."""
 
-    def __init__(self, net, arena, lr=4e-3, weight_decay=0.01, eps=1e-6, grad_clip=None):
+    def __init__(self, net, arena, lr=4e-3, weight_decay=0.01, eps=1e-6, grad_clip=None,
+                 clip_num_mads=None, clip_window=1000):
+        """`clip_num_mads` (reference default 0, `--gradient_clip_num_mads`; None = off) turns on
+        the reference's adaptive clipping: per-parameter gradient maxima every step, clamp at
+        median + num_mads * MAD of the last `clip_window` maxima once that many were seen
+        (bin/train_flipflop.py:201-212, 575-578) -- on the device, see clipping.DeviceClipper.
+        `grad_clip` is a fixed clip-by-value bound."""
         self.net = net
         self.arena = arena
+        self.clipper = None
+        if clip_num_mads is not None and arena.flat.is_cuda:
+            from taiyaki_amd import clipping
+            self.clipper = clipping.DeviceClipper(arena, clip_num_mads, clip_window)
         self.opt = torch.optim.AdamW(arena.params, lr=lr, weight_decay=weight_decay, eps=eps,
                                      betas=(0.9, 0.999),
                                      capturable=arena.flat.is_cuda)  # no host sync in step()
@@ -41,12 +51,19 @@ class Trainer:
         loss.backward()
         self.arena.allreduce_async()
         self.arena.finish()
-        if self.grad_clip is not None:
-            # device-side clip (the reference's apply_clipping syncs once per
-            # parameter tensor, bin/train_flipflop.py:201-212)
-            self.arena.flat.clamp_(min=-self.grad_clip, max=self.grad_clip)
+        self.clip()
         self.opt.step()
         return loss
+
+    def clip(self):
+        """Gradient maxima / clipping between the all-reduce and the optimiser step."""
+        if self.clipper is not None:
+            if torch.cuda.is_current_stream_capturing():
+                self.clipper.launch_kernels()       # whole-step capture: no host traffic inside
+            else:
+                self.clipper.step()
+        if self.grad_clip is not None:
+            self.arena.flat.clamp_(min=-self.grad_clip, max=self.grad_clip)
 
 
 # Other threads of the process (the NCCL/RCCL watchdog polls events) must not invalidate a
@@ -160,13 +177,11 @@ class HybridGraphTrainer(GraphedTrainer):
         torch.cuda.synchronize()
         self.opt_graph = torch.cuda.CUDAGraph()
         with torch.cuda.graph(self.opt_graph, **_CAPTURE):
-            self._clip_and_step()
+            self.opt.step()
         torch.cuda.synchronize()
 
     def _clip_and_step(self):
-        tr = self.trainer
-        if tr.grad_clip is not None:
-            tr.arena.flat.clamp_(min=-tr.grad_clip, max=tr.grad_clip)
+        self.trainer.clip()
         self.opt.step()
 
     def _tail_eager(self):
@@ -181,5 +196,6 @@ class HybridGraphTrainer(GraphedTrainer):
         self.loss.backward(retain_graph=True)
         self.trainer.arena.allreduce_async()
         self.trainer.arena.finish()
+        self.trainer.clip()         # eager: two tiny launches + an async copy of the maxima
         self.opt_graph.replay()
         return self.loss

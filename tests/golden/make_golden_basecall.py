@@ -51,6 +51,18 @@ def main():
             path, starts, ends, stride, path_stitching=True).numpy()
         q = qscores.path_errprobs_to_qstring(serr, spath.numpy(), 0.9, 0.3)
         out[name + "/qstring"] = np.frombuffer(q.encode("ascii"), dtype=np.uint8)
+    # rolling median + MAD thresholds of the gradient clipper (maths.py:138-195)
+    from taiyaki import maths
+    rng = np.random.RandomState(7)
+    vals = np.abs(rng.standard_normal((14, 5))).astype(np.float32) * np.float32(3.0)
+    out["rollingmad/vals"] = vals
+    for tag, n_mads in (("m0", 0), ("m15", 1.5)):
+        rm = maths.RollingMAD(5, n_mads=n_mads, window=6)
+        ths = []
+        for v in vals:
+            th = rm.update(list(v))
+            ths.append(np.full(5, np.nan, dtype=np.float64) if th is None else np.asarray(th, dtype=np.float64))
+        out["rollingmad/thresh_" + tag] = np.stack(ths)
     np.savez_compressed(os.path.join(HERE, "basecall_small.npz"), **out)
     print("wrote basecall_small.npz:", sorted(out)[:6], "...")
 

@@ -24,8 +24,9 @@ def main():
     net_a = models.mLstm_flipflop(size=size, stride=stride).to(dev)
     net_b = copy.deepcopy(net_a)
     batches = bench.make_batches(nbatch, chunk_len, stride, 5, dev, n=3)
-    tr_a = train.Trainer(net_a, parallel.FlatGradArena(net_a))
-    tr_b = train.Trainer(net_b, parallel.FlatGradArena(net_b))
+    # adaptive clipping on, with a 3-step window so that the clamp is active inside the test
+    tr_a = train.Trainer(net_a, parallel.FlatGradArena(net_a), clip_num_mads=0, clip_window=3)
+    tr_b = train.Trainer(net_b, parallel.FlatGradArena(net_b), clip_num_mads=0, clip_window=3)
     hy = train.HybridGraphTrainer(tr_b, batches[0], seq_capacity=nbatch * (T + 1))
     hy.load(batches[0])
     hy.capture(warmup=1)        # one eager step + the capture's own tail step, both on batch 0

@@ -109,3 +109,62 @@ def test_hip_errprobs_fullsize_properties(gpu_device):
     assert torch.equal(err2, err[:, perm])
     with pytest.raises(RuntimeError):
         qscores.errprobs_from_trans(trans.cpu(), path.cpu())
+
+
+# ------------------------------------------------------------------------------------------
+# SURVEY 8f.1 -- on-device gradient maxima / clipping (bin/train_flipflop.py:201-212)
+# ------------------------------------------------------------------------------------------
+def test_rolling_mad_matches_reference_goldens():
+    from taiyaki_amd import clipping
+    g = gold()
+    vals = g["rollingmad/vals"]
+    for tag, n_mads in (("m0", 0), ("m15", 1.5)):
+        rm = clipping.RollingMAD(5, n_mads=n_mads, window=6)
+        for v, want in zip(vals, g["rollingmad/thresh_" + tag]):
+            th = rm.update(list(v))
+            if np.isnan(want).all():
+                assert th is None
+            else:
+                np.testing.assert_allclose(th, want, rtol=1e-6)
+    with pytest.raises(AssertionError):
+        clipping.RollingMAD(5).update([1.0, 2.0])
+
+
+@pytest.mark.gpu
+def test_device_clipper_matches_apply_clipping(gpu_device):
+    """Kernel maxima == per-tensor max|grad| (the reference's grad_maxs), clamp == the
+    reference's clamp-if-exceeds, thresholds follow the rolling MAD one step behind."""
+    import torch
+    from taiyaki_amd import clipping, models, parallel
+    torch.manual_seed(5)
+    net = models.mLstm_flipflop(size=32, stride=5).to(gpu_device)
+    arena = parallel.FlatGradArena(net)
+    clip = clipping.DeviceClipper(arena, n_mads=0, window=3)
+    ref_roll = clipping.RollingMAD(len(arena.params), n_mads=0, window=3)
+    thresh = None
+    for it in range(6):
+        arena.flat.copy_(torch.randn_like(arena.flat) * (1.0 + it))
+        before = arena.flat.clone()
+        want_maxs = np.array([float(p.grad.abs().max()) for p in arena.params], dtype=np.float32)
+        prev = clip.step()
+        torch.cuda.synchronize()
+        np.testing.assert_array_equal(clip.maxs.cpu().numpy(), want_maxs)
+        # reference order: clip with the thresholds known before this step, then update them
+        expect = before.clone()
+        if thresh is not None:
+            off = 0
+            for p, th in zip(arena.params, thresh):
+                seg = expect[off:off + p.numel()]
+                if float(seg.abs().max()) > th:
+                    seg.clamp_(min=-float(th), max=float(th))
+                off += p.numel()
+        assert torch.equal(arena.flat, expect), it
+        if it > 0:
+            np.testing.assert_array_equal(prev, last_maxs)
+        last_maxs = want_maxs
+        thresh = ref_roll.update(want_maxs)
+    # a NaN gradient surfaces as a NaN maximum, like float(torch.max(...))
+    arena.flat[5] = float("nan")
+    clip.step()
+    torch.cuda.synchronize()
+    assert np.isnan(clip.maxs.cpu().numpy()[0])

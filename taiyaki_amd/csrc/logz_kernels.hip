@@ -38,7 +38,10 @@ namespace tk {
 // SUP + C/SUP + SUP steps, so 8 up to 128 chunks and 16 beyond
 __host__ __device__ constexpr int logz_super(int C) { return C > 128 ? 16 : 8; }
 constexpr int K1_WAVES = 4;             // waves per K1 block = 4 independent chunks
-constexpr int K3_WAVES = 8;             // waves per K3 block: 8 x CH/8 rows = 1 chunk
+#ifndef TK_K3_WAVES
+#define TK_K3_WAVES 8
+#endif
+constexpr int K3_WAVES = TK_K3_WAVES;   // waves per K3 block: 8 x CH/8 rows = 1 chunk
 constexpr int ZERO_ROW_EXP = -(1 << 28);    // exponent of an all-zero matrix row
 
 // tuning knobs (tools/logz_lab.hip rebuilds this file with -D overrides)
@@ -824,7 +827,7 @@ __global__ __launch_bounds__(K2_WAVES *WAVE) void logz_middle_kernel(int N, int 
 // are streamed out through the same coalescing transpose.
 // ---------------------------------------------------------------------------
 template <int NB, int CH>
-__global__ __launch_bounds__(K3_WAVES *WAVE, (CH <= 16 ? 4 : 2)) void logz_posterior_kernel(
+__global__ __launch_bounds__(K3_WAVES *WAVE, (CH / K3_WAVES <= 2 ? 4 : 2)) void logz_posterior_kernel(
     const float *__restrict__ scores, float *__restrict__ grad, int T, int N, int Npad,
     LogzWs ws, uint32_t *__restrict__ status, int nt_load) {
     using F = FF<NB>;

@@ -127,3 +127,23 @@ def test_convolution_gemm_form_equals_conv1d(cin, cout, k, stride):
     for a, b in zip(*outs):
         assert a.shape == b.shape
         torch.testing.assert_close(a, b, rtol=1e-4, atol=1e-6)
+
+
+def test_c_abi_rejects_bad_arguments_before_touching_the_gpu():
+    """Argument validation happens before any HIP call: NULL pointers, zero sizes and a
+    one-sided fwd/traceback pair return TK_ERR_BAD_ARG (1) on a box without a GPU too."""
+    from taiyaki_amd import _lib
+    L = _lib.lib()
+    BAD = 1
+    one = 16        # any non-NULL, 16-byte aligned value: never dereferenced on these paths
+    assert L.tk_flipflop_logz_dev(None, 10, 2, 4, None, None, None, 0, None, None) == BAD
+    assert L.tk_flipflop_viterbi_dev(None, 10, 2, 4, None, None, None, None, 0, None) == BAD
+    # fwd without traceback (or the reverse) is refused
+    assert L.tk_flipflop_viterbi_dev(one, 10, 2, 4, one, None, one, one, 1 << 20, None) == BAD
+    assert L.tk_flipflop_errprobs_dev(None, None, 10, 2, 4, None, None) == BAD
+    assert L.tk_flipflop_errprobs_dev(one, one, 0, 2, 4, one, None) == BAD
+    assert L.tk_grad_maxabs_clip_dev(None, None, 3, 10, None, None, None) == BAD
+    assert L.tk_crf_flipflop_dev(None, 40, 10, 2, None, None, None, None, None, None, 0, 40,
+                                 1.0, 1.0, 1.0, None, None, None, 0, None, None) == BAD
+    assert L.tk_flipflop_build_indices_dev(None, None, 0, 0, 4, None, None, None, None, None, None,
+                                           None, None, None) == BAD

@@ -629,7 +629,8 @@ __device__ __forceinline__ double wave_sum_f64(double x) {
 // boundary vectors, and one matrix of slack (the one-ahead prefetches run past the end)
 template <int NB>
 __host__ __device__ constexpr size_t logz_middle_lds_bytes(int C, int NSUP) {
-    return ((size_t)(C + NSUP + 1) * 4 * XMat<NB>::NF4 + 2 * (size_t)NSUP * 8) * sizeof(float);
+    constexpr size_t NFW = XMat<NB>::NW + (XMat<NB>::NW & 1);
+    return ((size_t)(C + NSUP + 1) * NFW + 2 * (size_t)NSUP * 8) * sizeof(float);
 }
 
 // ---------------------------------------------------------------------------
@@ -648,14 +649,17 @@ constexpr int K2_WAVES = 16;
 
 
 template <int NB, int SUP>
-__global__ __launch_bounds__(K2_WAVES *WAVE) void logz_middle_kernel(int N, int C, int NSUP, int Npad,
+__global__ __launch_bounds__(K2_WAVES *WAVE, 8) void logz_middle_kernel(int N, int C, int NSUP, int Npad,
                                                                   LogzWs ws,
                                                                   float *__restrict__ logz,
                                                                   int want_grad,
                                                                   uint32_t *__restrict__ status) {
     using F = FF<NB>;
     using X = XMat<NB>;
-    constexpr int NFW = 4 * X::NF4, NT = K2_WAVES * WAVE;
+    // LDS stride of one matrix image: the NW payload words, not the NF4 padded float4s -- at
+    // 250 chunks that is what lets TWO blocks share a CU's 160 KB (2 x 80 KB), so one
+    // read's serial scan overlaps another's work-bound combine (<= 64 VGPRs for the same)
+    constexpr int NFW = X::NW + (X::NW & 1), NT = K2_WAVES * WAVE;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     float *pcimg = reinterpret_cast<float *>(smem);             // [C][NFW]
     float *totimg = pcimg + (size_t)C * NFW;                    // [NSUP][NFW]
@@ -673,8 +677,9 @@ __global__ __launch_bounds__(K2_WAVES *WAVE) void logz_middle_kernel(int N, int 
     // ---- 1. stage the read's chunk matrices: one contiguous run of C*NF4 float4
     {
         // every load of a pass is in flight before the first LDS store: one memory latency
-        // for up to 8 * 1024 float4 (C <= 431 chunks), not one per 4 K float4
-        constexpr int PASS = 8;
+        // per 4 K float4.  The image is repacked from 4 NF4 to NFW words per matrix (8-byte
+        // aligned: two 64-bit LDS stores per float4, the padding words are dropped).
+        constexpr int PASS = 4;
         const int total = C * X::NF4;
         const f4 *src = ws.Pc + n * (size_t)total;
         for (int base = 0; base < total; base += PASS * NT) {
@@ -684,7 +689,12 @@ __global__ __launch_bounds__(K2_WAVES *WAVE) void logz_middle_kernel(int N, int 
 #pragma unroll
             for (int k = 0; k < PASS; ++k) {
                 const int idx = base + k * NT + tid;
-                if (idx < total) *reinterpret_cast<f4 *>(pcimg + (size_t)idx * 4) = tmp[k];
+                if (idx < total) {
+                    const int c = idx / X::NF4, q = idx - c * X::NF4;
+                    float *dst = pcimg + (size_t)c * NFW + 4 * q;
+                    *reinterpret_cast<f2 *>(dst) = f2{tmp[k][0], tmp[k][1]};
+                    if (4 * q + 2 < NFW) *reinterpret_cast<f2 *>(dst + 2) = f2{tmp[k][2], tmp[k][3]};
+                }
             }
         }
     }

@@ -58,7 +58,7 @@ struct CrfArgs {
     int LP;                     // lattice row pitch: max_seqlen rounded up to 256 (<= LPAD)
     double *offF, *offB;        // [N][T]       their log2 offsets
     double *scoreF, *scoreB;    // [N]          log2 scores of the two sweeps
-    int *slotws;                // [N][KINDS][LPAD] sorted posterior slots
+    int *slotws;                // [N][LPAD] x (2 or 3) words: ids and sorted posterior slots, packed per position
     int *segws;                 // [N][KINDS][S + 3] segment starts per transition id
 };
 
@@ -653,13 +653,29 @@ __global__ __launch_bounds__(W *WAVE) void crf_sweep_kernel(CrfArgs a) {
             }
         }
         __syncthreads();
+        // One record per position for the posterior pass: [stay id:8 | move id:8 | stay slot:16]
+        // [move slot:16 | -] (+ [mod slot:16 | mod id:8] for cat-mod) -- 8 (12) bytes instead of
+        // the 16 (24) of separate id and slot arrays; every tile of the posterior pass reloads them.
+        {
+            int fin[KINDS][R];
 #pragma unroll
-        for (int kind = 0; kind < KINDS; ++kind) {
-            int *sl = a.slotws + ((size_t)n * KINDS + kind) * LPAD + p0;
+            for (int kind = 0; kind < KINDS; ++kind)
 #pragma unroll
-            for (int j = 0; j < R; ++j) {
-                const int key = (kind == 0) ? st[j] : ((kind == 1) ? mv[j] : md[MOD ? j : 0]);
-                sl[j] = slot[kind][j] + wcnt[(kind * W + wave) * K + key];
+                for (int j = 0; j < R; ++j) {
+                    const int key = (kind == 0) ? st[j] : ((kind == 1) ? mv[j] : md[MOD ? j : 0]);
+                    fin[kind][j] = slot[kind][j] + wcnt[(kind * W + wave) * K + key];
+                }
+            uint2 *rec = reinterpret_cast<uint2 *>(a.slotws) + (size_t)n * LPAD + p0;
+#pragma unroll
+            for (int j = 0; j < R; ++j)
+                rec[j] = uint2{(unsigned)st[j] | ((unsigned)mv[j] << 8) | ((unsigned)fin[0][j] << 16),
+                               (unsigned)fin[1][j]};
+            if (MOD) {
+                unsigned *rec2 = reinterpret_cast<unsigned *>(reinterpret_cast<uint2 *>(a.slotws) + (size_t)a.N * LPAD) +
+                                 (size_t)n * LPAD + p0;
+#pragma unroll
+                for (int j = 0; j < R; ++j)
+                    rec2[j] = (unsigned)fin[MOD ? 2 : 0][j] | ((unsigned)md[MOD ? j : 0] << 16);
             }
         }
     }
@@ -854,18 +870,30 @@ __global__ __launch_bounds__(W *WAVE) void crf_posterior_kernel(CrfArgs a) {
     const int p0 = tid * R;
     int st[R], mv[R], md[MOD ? R : 1], slot[KINDS][R];
     float fw[MOD ? R : 1];
+    {
+        // the sweep kernel left one packed record per position (ids with their sentinels
+        // already resolved, sorted slots)
+        const uint2 *rec = reinterpret_cast<const uint2 *>(a.slotws) + (size_t)n * LPAD + p0;
 #pragma unroll
-    for (int j = 0; j < R; ++j) {
-        const int p = p0 + j;
-        st[j] = (p < L) ? a.stay[off + p] : S;
-        mv[j] = (p < L - 1) ? a.move[off + p] : S;
-        if (MOD) {
-            md[j] = (p < L - 1) ? a.mod[off + p] : S + 1;
-            fw[j] = (p < L - 1) ? a.modfact[off + p] * a.c_mod : 0.f;
+        for (int j = 0; j < R; ++j) {
+            const uint2 r = rec[j];
+            st[j] = (int)(r.x & 0xffu);
+            mv[j] = (int)((r.x >> 8) & 0xffu);
+            slot[0][j] = (int)(r.x >> 16);
+            slot[1][j] = (int)(r.y & 0xffffu);
         }
+        if (MOD) {
+            const unsigned *rec2 = reinterpret_cast<const unsigned *>(reinterpret_cast<const uint2 *>(a.slotws) +
+                                                                      (size_t)a.N * LPAD) + (size_t)n * LPAD + p0;
 #pragma unroll
-        for (int kind = 0; kind < KINDS; ++kind)
-            slot[kind][j] = a.slotws[((size_t)n * KINDS + kind) * LPAD + p];
+            for (int j = 0; j < R; ++j) {
+                const unsigned r = rec2[j];
+                const int p = p0 + j;
+                slot[MOD ? 2 : 0][j] = (int)(r & 0xffffu);
+                md[MOD ? j : 0] = (int)(r >> 16);
+                fw[MOD ? j : 0] = (p < L - 1) ? a.modfact[off + p] * a.c_mod : 0.f;
+            }
+        }
     }
     for (int e = tid; e < KINDS * (SP + 1); e += NT)
         segstart[e] = a.segws[(size_t)n * KINDS * (SP + 1) + e];

@@ -89,6 +89,10 @@ def time_logz_op(T, N, dev, reps, seed=1):
     for _ in range(20):         # steady state: clocks and caches settle over the first ~15 launches
         layers._logz_launch(x, True)
     torch.cuda.synchronize()
+    # Keep the GPU busy while the host enqueues the timed launches: the ~40 us of Python between
+    # an event record and the first kernel launch must not show up as GPU idle time inside the
+    # event window (the events then bracket exactly the three kernels, back to back).
+    torch.cuda._sleep(int(2.0e6 * max(1, reps // 10)))
     evs = []
     for _ in range(reps):
         a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)

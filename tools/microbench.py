@@ -58,6 +58,12 @@ def main():
             "viterbi": (lambda: decode.flipflop_viterbi(x), 1),
             "viterbi_path": (lambda: decode.flipflop_viterbi_path(x), 1),
         }
+        if "catmod" in args.ops.split(","):
+            cm = synth.crf_case(T, N, 2, nmods_per_base=(1, 1, 0, 0))
+            xm = torch.from_numpy(cm["scores"]).to(dev)
+            ms, ml, mc = (torch.from_numpy(cm[k]) for k in ("seqs", "seqlens", "mod_cats"))
+            ops["catmod"] = (lambda: ctc._run(xm, ms, ml, 1.0, 1.0, 1.0, 40, True, mc,
+                                              cm["can_mods_offsets"], cm["mod_cat_weights"]), 3)
         if "errprobs" in args.ops.split(","):
             trans = decode.flipflop_make_trans(x)
             path = decode.flipflop_viterbi(x)[2]

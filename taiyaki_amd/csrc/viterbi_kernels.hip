@@ -17,9 +17,9 @@
 //     quad comes from one lane^4 exchange (two bank-masked row shifts) -- no ds_bpermute;
 //   * "first index wins" is kept by scanning each quad's four candidates in order and
 //     letting the lower quad win ties;
-//   * the traceback pointers of a step are packed with three ballots (bit b of every
-//     lane's source index) into 3 x 64 bits per wave = 3 bytes per read and step, read
-//     back by the path pass with prefetched loads instead of chasing the int64 tensor.
+//   * every lane drops its source index as ONE BYTE (a single 64-byte store per wave and
+//     step); the eight bytes of a read are one 64-bit word, so the path pass reads them
+//     with prefetched, address-independent loads instead of chasing the int64 tensor.
 // Score rows are prefetched VIT_PF steps ahead.
 #include <type_traits>
 
@@ -61,7 +61,7 @@ __global__ __launch_bounds__(WAVE) void viterbi_kernel(const float *__restrict__
                                                       int N, float *__restrict__ fwd_out,
                                                       int64_t *__restrict__ tb_out,
                                                       int64_t *__restrict__ path_out,
-                                                      unsigned long long *__restrict__ packed) {
+                                                      unsigned char *__restrict__ packed) {
     using F = FF<NB>;
     static_assert(F::NS <= VIT_GRP, "one lane per state");
     const int lane = lane_id();
@@ -90,6 +90,7 @@ __global__ __launch_bounds__(WAVE) void viterbi_kernel(const float *__restrict__
         ok[w] = src[w] < F::NS && (flip || src[w] == jc - NB || src[w] == jc);
     }
 
+    const int base_own = 4 * q, base_other = 4 * (1 - q);
     float best = (j < NB) ? 0.f : ((j < F::NS) ? NEG_LARGE : VIT_NEG_INF);      // decode.py:93-95
     if (fwd_out != nullptr && live) fwd_out[slot] = best;
 
@@ -122,7 +123,8 @@ __global__ __launch_bounds__(WAVE) void viterbi_kernel(const float *__restrict__
 
     const int wave_row = blockIdx.x;            // 8 reads per wave
     const size_t nwaves = gridDim.x;
-    unsigned long long *prow = packed + (size_t)wave_row * 3;
+    // traceback bytes: one per lane (= destination state) and step, [t][wave][64]
+    unsigned char *prow = packed + (size_t)wave_row * WAVE;
     float *fout = fwd_out != nullptr ? fwd_out + (size_t)N * F::NS : nullptr;        // row t + 1
     int64_t *tout = tb_out;
     // The loop body is instantiated per (outputs wanted, every lane live): the per-step
@@ -159,12 +161,9 @@ __global__ __launch_bounds__(WAVE) void viterbi_kernel(const float *__restrict__
                     // the quad holding the lower source indices wins ties (own quad for q = 0)
                     const bool take_other = (q == 0) ? (bt > bo) : !(bo > bt);
                     best = take_other ? bt : bo;
-                    const int arg = take_other ? 4 * (1 - q) + at : 4 * q + ao;
-                    // three ballots: bit b of every lane's source index
-                    const unsigned long long m0 = __ballot(arg & 1), m1 = __ballot(arg & 2),
-                                             m2 = __ballot(arg & 4);
-                    if (lane < 3) prow[lane] = (lane == 0) ? m0 : (lane == 1 ? m1 : m2);
-                    prow += nwaves * 3;
+                    const int arg = (take_other ? at : ao) + (take_other ? base_other : base_own);
+                    prow[lane] = (unsigned char)arg;        // one 64-byte store per wave and step
+                    prow += nwaves * WAVE;
                     if constexpr (FULLOUT) {
                         if (ALLLIVE || live) {
                             fout[slot] = best;
@@ -201,24 +200,22 @@ __global__ __launch_bounds__(WAVE) void viterbi_kernel(const float *__restrict__
     }
     const bool tracer = j == 0 && nreal < (size_t)N;
     if (tracer) path_out[(size_t)T * N + nreal] = (int64_t)st;
-    const int shift0 = rloc * VIT_GRP;
+    // the eight bytes of this read's group at a step are one 64-bit word: no dependent address
+    const unsigned long long *words = reinterpret_cast<const unsigned long long *>(packed) +
+                                      (size_t)wave_row * VIT_GRP + rloc;
+    const size_t wstride = nwaves * VIT_GRP;
     for (int thi = T; thi > 0; thi -= VIT_TB) {
-        unsigned long long wd[VIT_TB][3];
+        unsigned long long wd[VIT_TB];
 #pragma unroll
         for (int k = 0; k < VIT_TB; ++k) {
             const int t = max(thi - 1 - k, 0);      // clamped, never branched: one straight load run
-            const unsigned long long *p = packed + ((size_t)t * nwaves + wave_row) * 3;
-            wd[k][0] = p[0];
-            wd[k][1] = p[1];
-            wd[k][2] = p[2];
+            wd[k] = words[(size_t)t * wstride];
         }
 #pragma unroll
         for (int k = 0; k < VIT_TB; ++k) {
             const int t = thi - 1 - k;
             if (t >= 0) {
-                const int sh = shift0 + (int)st;
-                st = (uint32_t)((wd[k][0] >> sh) & 1ull) | ((uint32_t)((wd[k][1] >> sh) & 1ull) << 1) |
-                     ((uint32_t)((wd[k][2] >> sh) & 1ull) << 2);
+                st = (uint32_t)(wd[k] >> (8 * st)) & 7u;
                 if (tracer) path_out[(size_t)t * N + nreal] = (int64_t)st;
             }
         }
@@ -228,7 +225,7 @@ __global__ __launch_bounds__(WAVE) void viterbi_kernel(const float *__restrict__
 size_t viterbi_workspace_bytes(size_t T, size_t N, size_t nbase) {
     (void)nbase;
     const size_t nwaves = (N + VIT_GRP - 1) / VIT_GRP;
-    return (T > 0 ? T : 1) * nwaves * 3 * sizeof(unsigned long long);
+    return (T > 0 ? T : 1) * nwaves * WAVE;         // one byte per lane and step
 }
 
 template <int NB>
@@ -236,7 +233,7 @@ static int viterbi_launch(const float *scores, size_t T, size_t N, float *fwd, i
                           int64_t *path, void *workspace, hipStream_t stream) {
     const int ngrp = (int)((N + VIT_GRP - 1) / VIT_GRP);
     hipLaunchKernelGGL(viterbi_kernel<NB>, dim3(ngrp), dim3(WAVE), 0, stream, scores, (int)T,
-                       (int)N, fwd, tb, path, static_cast<unsigned long long *>(workspace));
+                       (int)N, fwd, tb, path, static_cast<unsigned char *>(workspace));
     return hipGetLastError() == hipSuccess ? 0 : 4;
 }
 

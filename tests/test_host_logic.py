@@ -35,8 +35,8 @@ def test_workspace_queries_need_no_gpu():
     assert L.tk_flipflop_logz_workspace_bytes(4000, 256, 9) == 0      # nbase not built
     assert L.tk_crf_flipflop_workspace_bytes(40, 800, 128, 480, 1) > \
         L.tk_crf_flipflop_workspace_bytes(40, 800, 128, 480, 0)
-    # three 64-bit ballots per step and wave of eight reads
-    assert L.tk_flipflop_viterbi_workspace_bytes(800, 128, 4) == 800 * (128 // 8) * 3 * 8
+    # one traceback byte per lane (8 lanes per read) and step
+    assert L.tk_flipflop_viterbi_workspace_bytes(800, 128, 4) == 800 * (128 // 8) * 64
 
 
 def test_flipflopfings_reference_docstring_examples(oracle_mod):

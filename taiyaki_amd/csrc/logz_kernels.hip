@@ -221,13 +221,12 @@ __global__ __launch_bounds__(K1_WAVES *WAVE, 2) void logz_transfer_kernel(
     constexpr int NS = F::NS, NP = NS / 2;
     f2 Pp[NP][NS], Pq[NP][NS];      // ping-pong: a step reads one set and writes the other
     int pe[NS];
-    double pM = 0.0;
-#pragma unroll
-    for (int ip = 0; ip < NP; ++ip) {
-        pe[2 * ip] = pe[2 * ip + 1] = 0;
-#pragma unroll
-        for (int j = 0; j < NS; ++j) Pp[ip][j] = f2{(2 * ip == j) ? 1.f : 0.f, (2 * ip + 1 == j) ? 1.f : 0.f};
-    }
+    double pM;
+    // Rows are renormalised every fourth step; a row whose maximum fell below 2^-60 in
+    // between (per-step score ranges of tens of nats -- no tanh-bounded network output does
+    // that) has lost low-order entries to underflow: `shrunk` makes the wave redo its chunk
+    // renormalising after every step.
+    bool shrunk = false;
     auto renorm = [&](f2 (&A)[NP][NS]) {           // exact power-of-two renormalisation of every row
 #pragma unroll
         for (int ip = 0; ip < NP; ++ip) {
@@ -236,6 +235,7 @@ __global__ __launch_bounds__(K1_WAVES *WAVE, 2) void logz_transfer_kernel(
                 float mx = A[ip][0][h];
 #pragma unroll
                 for (int j = 1; j < NS; ++j) mx = fmaxf(mx, A[ip][j][h]);
+                shrunk |= mx < 0x1p-60f;
                 if (mx > 0.f) {
                     const int ex = __builtin_amdgcn_frexp_expf(mx);
 #pragma unroll
@@ -273,12 +273,19 @@ __global__ __launch_bounds__(K1_WAVES *WAVE, 2) void logz_transfer_kernel(
                 B[ip][NB + b] = __builtin_elementwise_fma(A[ip][b], f2{wf, wf}, A[ip][NB + b] * f2{wst, wst});
         }
     };
+    pM = 0.0;
+#pragma unroll
+    for (int ip = 0; ip < NP; ++ip) {
+        pe[2 * ip] = pe[2 * ip + 1] = 0;
+#pragma unroll
+        for (int j = 0; j < NS; ++j) Pp[ip][j] = f2{(2 * ip == j) ? 1.f : 0.f, (2 * ip + 1 == j) ? 1.f : 0.f};
+    }
     TK_STAMP(8);
+    auto rowptr = [&](int t) { return base + (size_t)min(t, t1 - 1) * rowstride; };
     {
         // one row-set in flight ahead of the one being consumed; row indices are clamped
         // (never branched on) so the load stream has no control flow
         RowSet<NB> r0, r1;
-        auto rowptr = [&](int t) { return base + (size_t)min(t, t1 - 1) * rowstride; };
         auto fetch = [&](RowSet<NB> &r, int t) {
             if (TK_K1_NT_LOAD) r.issue_nt(rowptr(t), nvalid, lane);
             else r.issue(rowptr(t), nvalid, lane);
@@ -318,6 +325,23 @@ __global__ __launch_bounds__(K1_WAVES *WAVE, 2) void logz_transfer_kernel(
         P.e[2 * ip + 1] = pe[2 * ip + 1];
     }
     P.M = pM;
+    if (__any(shrunk)) {            // wave-uniform, rare: redo the chunk one careful step at a time
+        P.set_identity();
+        RowSet<NB> r;
+        for (int t = t0; t < t1; ++t) {
+            r.issue(rowptr(t), nvalid, lane);
+            r.to_rows(buf, lane);
+            P.M += (double)r.exp_normalise();
+#pragma unroll
+            for (int i = 0; i < NS; ++i) {
+                float out[NS];
+                ff_fwd_step<NB>(P.m[i], r, out);
+#pragma unroll
+                for (int j = 0; j < NS; ++j) P.m[i][j] = out[j];
+            }
+            P.renorm();
+        }
+    }
     // Pc is READ-major ([read][chunk][NF4] float4): the middle kernel streams one
     // read's matrices as a single contiguous run (a [chunk][q][read] layout put
     // all of a read's pieces 16*Npad bytes apart = on ONE L2 channel).  The wave turns
@@ -387,7 +411,7 @@ __global__ __launch_bounds__(K1_WAVES *WAVE, 2) void logz_transfer_coop_kernel(
 #pragma unroll
                 for (int j = 0; j < F::NS; ++j) P.m[i][j] = out[j];
             }
-            if (((t - t0) & 3) == 3) P.renorm();
+            P.renorm();         // every step: this form serves small problems, the cost is noise
         };
         auto fetch = [&](RowSet<NB> &r, int t) {
             if (TK_K1_NT_LOAD) r.issue_nt(rowptr(t), nvalid, lane);
@@ -401,7 +425,7 @@ __global__ __launch_bounds__(K1_WAVES *WAVE, 2) void logz_transfer_coop_kernel(
             fetch(r0, t + 2);
             consume(r1, t + 1);
         }
-        P.renorm();
+        if (t0 >= t1) P.renorm();       // no rows (ragged last chunk): the identity, normalised like the rest
     }
     // combine P0 P1 P2 P3 row-parallel: row r of the product is (row r of P0) (x) P1
     // (x) P2 (x) P3, three cheap mat-vecs, and the rows are spread over the 4 waves

@@ -411,12 +411,15 @@ def test_hybrid_graph_trainer_matches_eager(gpu_device):
     assert float(m.group(1)) < 1e-4 and float(m.group(2)) < 1e-4, pr.stdout
 
 
-@pytest.mark.parametrize("scale", [4.0, 8.0])
-def test_logz_wide_dynamic_range(oracle_mod, gpu_device, scale):
+@pytest.mark.parametrize("scale,T,N", [(4.0, 600, 70), (8.0, 600, 70),
+                                        (1.0, 2100, 320), (3.0, 2100, 320), (8.0, 2100, 320)])
+def test_logz_wide_dynamic_range(oracle_mod, gpu_device, scale, T, N):
     """Scores U(-5 scale, 5 scale): per-row ranges up to 80 nats, path weights differing by
-    thousands of nats -- the per-row / per-step power-of-two exponents must carry it."""
+    thousands of nats -- the per-row / per-step power-of-two exponents must carry it.  The
+    larger shape takes the wave-per-chunk transfer kernel, whose matrices are stored with a
+    common row exponent where their rows lie within 2^40 of each other (else per-row exponents)."""
     from taiyaki_amd import synth
-    sc = (synth.scores(600, 70, 40, 77) * np.float32(scale)).astype(np.float32)
+    sc = (synth.scores(T, N, 40, 77) * np.float32(scale)).astype(np.float32)
     r = parity.compare_logz(oracle_mod, sc, gpu_device)
     assert r["finite"] and r["logz_rel"] < LOSS_RTOL, r["logz_rel"]
     assert r["grad_abs"] < 5e-5, r["grad_abs"]

@@ -16,6 +16,9 @@
  *      taiyaki/decode.py:75-115
  *   taiyaki/qscores.py:88-142 errprobs_from_trans           tk_flipflop_errprobs_dev
  *   bin/train_flipflop.py:201-212 apply_clipping            tk_grad_maxabs_clip_dev
+ *   taiyaki/signal_mapping.py:515-557,676-716 + chunk_selection.py:29-95 +
+ *   bin/train_flipflop.py:103-140 (chunk extraction, filters,
+ *   batch stacking, flip-flop coding)                       tk_chunks_{locate,select,gather}_dev
  *
  * Conventions
  *  - plain C: pointers and sizes only, no torch / HIP types in the signatures
@@ -54,6 +57,7 @@ extern "C" {
 /* bits of the device-side status word */
 #define TK_STATUS_NONFINITE_SCORE 1u
 #define TK_STATUS_NONFINITE_GRAD 2u
+#define TK_STATUS_SEQS_OVERFLOW 4u      /* tk_chunks_gather_dev: seqs buffer too small */
 
 /* library / build identification: returns e.g. "taiyaki_amd flipflop gfx950 r1" */
 const char *tk_version(void);
@@ -149,6 +153,67 @@ int tk_flipflop_errprobs_dev(const float *trans, const int64_t *path, size_t nbl
 int tk_grad_maxabs_clip_dev(float *grads, const int64_t *seg_off, size_t nseg,
                             size_t max_seg_len, const float *thresh, float *maxs,
                             void *stream);
+
+/* ------------------------------------------------------------------------- *
+ * Training-chunk extraction from a mapped-signal set RESIDENT in device memory.
+ * The arrays are the per-read datasets of the reference's mapped-signal format
+ * (signal_mapping.py:26-33, docs/FILE_FORMATS.md:43-75), concatenated over reads.
+ * ------------------------------------------------------------------------- */
+typedef struct tk_mapped_store {
+    const int16_t *dacs;            /* Dacs of all reads                                      */
+    const int64_t *dacs_off;        /* (nreads + 1) element offsets into dacs                 */
+    const int32_t *ref_to_signal;   /* Ref_to_signal of all reads (reflen_r + 1 entries each) */
+    const int64_t *rts_off;         /* (nreads + 1) element offsets into ref_to_signal        */
+    const int16_t *reference;       /* Reference of all reads; read r starts at rts_off[r] - r */
+    const double *scaling;          /* nreads x 5: offset, range, digitisation, shift_frompA,
+                                       scale_frompA                                           */
+    const int32_t *mapped;          /* nreads x 2: get_mapped_dacs_region (signal_mapping.py:366-380) */
+    size_t nreads;
+} tk_mapped_store;
+
+/* chunk_selection.py:9-26 FILTER_PARAMETERS; enabled = 0 is the reference's "median/mad/stride/
+ * path_buffer is None" short circuit (signal_mapping.py:688-695) */
+typedef struct tk_chunk_filter {
+    int enabled;
+    int model_stride;
+    double filter_mean_dwell, filter_max_dwell, median_meandwell, mad_meandwell, path_buffer;
+} tk_chunk_filter;
+
+#define TK_CHUNK_NREASON 8  /* pass, emptysequence, emptysignal, tooshort, nullmapping, pathbuffer,
+                               meandwell, maxdwell (signal_mapping.py:611-623)               */
+
+/* SignalMapping.get_chunk_with_sample_length + Chunk.apply_filters for ncand candidates
+ * (cand_read[c], start): start = cand_start[c] samples into the mapped region, or -- when
+ * cand_start is NULL -- floor(cand_frac[c] * spare_length), cand_frac uniform in [0, 1)
+ * (np.random.randint(spare_length), signal_mapping.py:541-542).  Outputs per candidate:
+ * reason code, first sample of the chunk within the read, first base and number of bases of its
+ * reference slice (0 unless accepted), maximum dwell.  All pointers are device pointers. */
+int tk_chunks_locate_dev(const tk_mapped_store *store, const int32_t *cand_read,
+                         const int32_t *cand_start, const double *cand_frac, size_t ncand,
+                         size_t chunk_len, const tk_chunk_filter *filter, uint8_t *reason,
+                         int32_t *dacstart, int32_t *seqstart, int32_t *seqlen,
+                         int32_t *maxdwell, void *stream);
+
+/* chunk_selection.sample_chunks' accept loop: sel[k] = index of the k-th accepted candidate in
+ * draw order (k < nwant; -1 when fewer pass), seqoff (nwant + 1) = offsets of the chunks'
+ * sequences in the concatenated sequence array, counts (TK_CHUNK_NREASON + 2) = rejection
+ * histogram over the attempts the reference's loop makes, then number accepted, attempts. */
+int tk_chunks_select_dev(const uint8_t *reason, const int32_t *seqlen, size_t ncand, size_t nwant,
+                         int32_t *sel, int64_t *seqoff, int32_t *counts, void *stream);
+
+/* bin/train_flipflop.py:103-140: indata (chunk_len, nwant, 1) float32 (columns beyond the
+ * accepted count are zero), seqs = concatenated flip-flop coded sequences (int32, capacity
+ * seqs_cap; TK_STATUS_SEQS_OVERFLOW in *status if that is too small), seqlens (nwant; 0 beyond
+ * the accepted count).  reverse = the network reads the signal backwards (np.flip of signal
+ * and labels).  can_labels / mod_labels (nullable, together with mod_cats) are the cat-mod
+ * label maps of layers.py:1441-1460; ncan = number of canonical bases. */
+int tk_chunks_gather_dev(const tk_mapped_store *store, const int32_t *cand_read,
+                         const int32_t *dacstart, const int32_t *seqstart, const int32_t *seqlen,
+                         const int32_t *sel, const int64_t *seqoff, const int32_t *counts,
+                         size_t nwant, size_t chunk_len, int reverse, int standardize, size_t ncan,
+                         const int32_t *can_labels, const int32_t *mod_labels, float *indata,
+                         int32_t *seqs, size_t seqs_cap, int32_t *seqlens, int32_t *mod_cats,
+                         uint32_t *status, void *stream);
 
 /* ------------------------------------------------------------------------- *
  * Exact reference prototypes (HOST pointers; taiyaki/ctc/c_crf_flipflop.h:3-11,

@@ -35,6 +35,18 @@ int build_indices_dispatch(const int32_t *seqs, const int32_t *seqlen, size_t nb
                            const int32_t *can_mods_offsets, const float *mod_cat_weights,
                            int64_t *seqoff, int32_t *stay, int32_t *move, int32_t *mod,
                            float *fact, hipStream_t stream);
+int chunks_locate_dispatch(const tk_mapped_store *st, const int32_t *cand_read, const int32_t *cand_start,
+                           const double *cand_frac, size_t ncand, size_t chunk_len,
+                           const tk_chunk_filter *fp, uint8_t *reason, int32_t *dacstart,
+                           int32_t *seqstart, int32_t *seqlen, int32_t *maxdwell, hipStream_t stream);
+int chunks_select_dispatch(const uint8_t *reason, const int32_t *seqlen, size_t ncand, size_t nwant,
+                           int32_t *sel, int64_t *seqoff, int32_t *counts, hipStream_t stream);
+int chunks_gather_dispatch(const tk_mapped_store *st, const int32_t *cand_read, const int32_t *dacstart,
+                           const int32_t *seqstart, const int32_t *seqlen, const int32_t *sel,
+                           const int64_t *seqoff, const int32_t *counts, size_t nwant, size_t chunk_len,
+                           int reverse, int standardize, size_t ncan, const int32_t *can_labels,
+                           const int32_t *mod_labels, float *indata, int32_t *seqs, size_t seqs_cap,
+                           int32_t *seqlens_out, int32_t *mod_cats, uint32_t *status, hipStream_t stream);
 }  // namespace tk
 
 static inline bool aligned16(const void *p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
@@ -64,6 +76,50 @@ int tk_grad_maxabs_clip_dev(float *grads, const int64_t *seg_off, size_t nseg, s
     const int rc = tk::grad_clip_dispatch(grads, seg_off, nseg, max_seg_len, thresh, maxs,
                                           static_cast<hipStream_t>(stream));
     return rc == 0 ? TK_OK : TK_ERR_LAUNCH;
+}
+
+static bool store_ok(const tk_mapped_store *s) {
+    return s && s->dacs && s->dacs_off && s->ref_to_signal && s->rts_off && s->reference && s->scaling &&
+           s->mapped && s->nreads > 0;
+}
+
+int tk_chunks_locate_dev(const tk_mapped_store *store, const int32_t *cand_read, const int32_t *cand_start,
+                         const double *cand_frac, size_t ncand, size_t chunk_len,
+                         const tk_chunk_filter *filter, uint8_t *reason, int32_t *dacstart,
+                         int32_t *seqstart, int32_t *seqlen, int32_t *maxdwell, void *stream) {
+    if (!store_ok(store) || !filter || !cand_read || (!cand_start && !cand_frac) || !reason || !dacstart ||
+        !seqstart || !seqlen || !maxdwell)
+        return TK_ERR_BAD_ARG;
+    if (ncand == 0) return TK_OK;
+    if (ncand > (size_t)INT32_MAX || chunk_len > (size_t)INT32_MAX) return TK_ERR_UNSUPPORTED;
+    return tk::chunks_locate_dispatch(store, cand_read, cand_start, cand_frac, ncand, chunk_len, filter, reason,
+                                      dacstart, seqstart, seqlen, maxdwell, static_cast<hipStream_t>(stream));
+}
+
+int tk_chunks_select_dev(const uint8_t *reason, const int32_t *seqlen, size_t ncand, size_t nwant,
+                         int32_t *sel, int64_t *seqoff, int32_t *counts, void *stream) {
+    if (!seqoff || !counts || (nwant > 0 && !sel) || (ncand > 0 && (!reason || !seqlen))) return TK_ERR_BAD_ARG;
+    if (ncand > (size_t)INT32_MAX || nwant > (size_t)INT32_MAX) return TK_ERR_UNSUPPORTED;
+    return tk::chunks_select_dispatch(reason, seqlen, ncand, nwant, sel, seqoff, counts,
+                                      static_cast<hipStream_t>(stream));
+}
+
+int tk_chunks_gather_dev(const tk_mapped_store *store, const int32_t *cand_read, const int32_t *dacstart,
+                         const int32_t *seqstart, const int32_t *seqlen, const int32_t *sel,
+                         const int64_t *seqoff, const int32_t *counts, size_t nwant, size_t chunk_len,
+                         int reverse, int standardize, size_t ncan, const int32_t *can_labels,
+                         const int32_t *mod_labels, float *indata, int32_t *seqs, size_t seqs_cap,
+                         int32_t *seqlens, int32_t *mod_cats, uint32_t *status, void *stream) {
+    if (!store_ok(store) || !cand_read || !dacstart || !seqstart || !seqlen || !sel || !seqoff || !counts ||
+        !indata || !seqs || !seqlens || ncan == 0)
+        return TK_ERR_BAD_ARG;
+    if ((can_labels == nullptr) != (mod_labels == nullptr) || (mod_cats && !mod_labels)) return TK_ERR_BAD_ARG;
+    if (nwant == 0 || chunk_len == 0) return TK_OK;
+    if (nwant > 65535u * 64u || chunk_len > (size_t)INT32_MAX) return TK_ERR_UNSUPPORTED;
+    return tk::chunks_gather_dispatch(store, cand_read, dacstart, seqstart, seqlen, sel, seqoff, counts, nwant,
+                                      chunk_len, reverse, standardize, ncan, can_labels, mod_labels, indata,
+                                      seqs, seqs_cap, seqlens, mod_cats, status,
+                                      static_cast<hipStream_t>(stream));
 }
 
 int tk_flipflop_errprobs_dev(const float *trans, const int64_t *path, size_t nblk, size_t nbatch,

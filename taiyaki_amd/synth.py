@@ -145,3 +145,52 @@ def crf_case(T, N, seed, nbase=4, nmods_per_base=None, seqlens=None):
         out["mod_cat_weights"] = np.full(nbase + int(np.sum(nmods_per_base)), 8.0,
                                          dtype=np.float32)
     return out
+
+
+def mapped_reads(nreads, seed, nlabel=4, mean_reflen=400, mean_dwell=9, clip_prob=0.5,
+                 slip_prob=0.03, long_dwell_prob=0.01):
+    """Synthetic per-read dictionaries with the fields of the reference's mapped-signal
+    format (signal_mapping.py:26-33, docs/FILE_FORMATS.md:43-75): int16 Dacs, int32
+    Ref_to_signal (reflen + 1, non-decreasing; -1 = reference start not mapped, siglen + 1 =
+    reference end not mapped), int16 Reference, and the five scaling floats.  Dwells are
+    1 + geometric-like around `mean_dwell`, with a few zero-dwell ("slip") bases and a few very
+    long ones so that every chunk filter has something to reject; reads of very different
+    lengths so that some are too short for a chunk."""
+    reads = []
+    for r in range(nreads):
+        s = seed * 1000003 + r
+        reflen = int(8 + randint(s, 11, 1, 2 * mean_reflen)[0] * (0.05 if r % 7 == 3 else 1.0))
+        u = uniform01(s, 12, reflen)
+        dw = (1 + np.floor(-np.log(np.maximum(u, 1e-6)) * (mean_dwell - 1))).astype(np.int64)
+        kind = uniform01(s, 13, reflen)
+        dw[kind < slip_prob] = 0
+        dw[kind > 1.0 - long_dwell_prob] *= 12
+        head_ref, tail_ref = 0, 0
+        cu = uniform01(s, 14, 4)
+        if cu[0] < clip_prob:
+            head_ref = int(cu[1] * min(20, reflen // 4))
+        if cu[2] < clip_prob:
+            tail_ref = int(cu[3] * min(20, reflen // 4))
+        pad = randint(s, 15, 2, 50)
+        mapped_dw = dw[head_ref:reflen - tail_ref]
+        sig0 = int(pad[0])
+        pos = sig0 + np.concatenate([[0], np.cumsum(mapped_dw)])
+        siglen = int(pos[-1] + pad[1])
+        rts = np.empty(reflen + 1, dtype=np.int32)
+        rts[:head_ref] = -1
+        rts[head_ref:head_ref + len(pos)] = pos
+        rts[head_ref + len(pos):] = siglen + 1
+        lab = randint(s, 16, reflen, nlabel)
+        rep = uniform01(s, 17, reflen) < 0.3            # homopolymer runs exercise the flop states
+        for p in range(1, reflen):
+            if rep[p]:
+                lab[p] = lab[p - 1]
+        fl = uniform01(s, 18, 5)
+        reads.append(dict(
+            read_id="synth-%d-%d" % (seed, r),
+            Dacs=(randint(s, 19, siglen, 1200) + 200).astype(np.int16),
+            Ref_to_signal=rts, Reference=lab.astype(np.int16),
+            offset=float(np.float32(-20 + 40 * fl[0])), range=float(np.float32(1000 + 800 * fl[1])),
+            digitisation=8192.0, shift_frompA=float(np.float32(60 + 60 * fl[2])),
+            scale_frompA=float(np.float32(8 + 10 * fl[3]))))
+    return reads

@@ -83,3 +83,26 @@ def grad_checksums(grad):
     idx = np.arange(0, flat.size, max(1, flat.size // 4096))[:4096]
     return dict(sum=g.sum(axis=(0, 2)), sumsq=(g * g).sum(axis=(0, 2)),
                 sample_idx=idx, sample=flat[idx].copy())
+
+
+# training-chunk extraction: reads from synth.mapped_reads, the reference's
+# sample_filter_parameters + sample_chunks on them
+_CH = dict(filter_mean_dwell=3.0, filter_max_dwell=10.0, min_pass=0.5, stride=5, path_buffer=1.1,
+           standardize=True, mod=False, ncan=4, nlabel=4, can_labels=None, mod_labels=None)
+CHUNKS_SMALL = {
+    "r40c600": dict(_CH, nreads=40, seed=71, chunk_len=600, nsample=60, nwant=32),
+    "r25c2000": dict(_CH, nreads=25, seed=72, chunk_len=2000, nsample=40, nwant=16),
+    "r30c300_tight": dict(_CH, nreads=30, seed=73, chunk_len=300, nsample=50, nwant=48, stride=8,
+                          filter_mean_dwell=1.0, filter_max_dwell=4.0, min_pass=0.2),
+    "r20c500_raw": dict(_CH, nreads=20, seed=74, chunk_len=500, nsample=30, nwant=20,
+                        standardize=False),
+    # ACGTZY: labels 4 (6mA) and 5 (5mC) are modified A and C
+    "r30c800_mod": dict(_CH, nreads=30, seed=75, chunk_len=800, nsample=40, nwant=24, mod=True,
+                        nlabel=6, can_labels=[0, 1, 2, 3, 0, 1], mod_labels=[0, 0, 0, 0, 1, 1]),
+    "r6c700_starved": dict(_CH, nreads=6, seed=76, chunk_len=700, nsample=12, nwant=64,
+                            filter_max_dwell=6.0, min_pass=0.25),
+}
+
+
+def chunk_reads(spec):
+    return synth.mapped_reads(spec["nreads"], spec["seed"], nlabel=spec["nlabel"])

@@ -115,7 +115,7 @@ int tk_chunks_gather_dev(const tk_mapped_store *store, const int32_t *cand_read,
         return TK_ERR_BAD_ARG;
     if ((can_labels == nullptr) != (mod_labels == nullptr) || (mod_cats && !mod_labels)) return TK_ERR_BAD_ARG;
     if (nwant == 0 || chunk_len == 0) return TK_OK;
-    if (nwant > 65535u * 64u || chunk_len > (size_t)INT32_MAX) return TK_ERR_UNSUPPORTED;
+    if (nwant > 65535u * 16u || chunk_len > (size_t)INT32_MAX) return TK_ERR_UNSUPPORTED;
     return tk::chunks_gather_dispatch(store, cand_read, dacstart, seqstart, seqlen, sel, seqoff, counts, nwant,
                                       chunk_len, reverse, standardize, ncan, can_labels, mod_labels, indata,
                                       seqs, seqs_cap, seqlens, mod_cats, status,

@@ -16,7 +16,7 @@
 //   2. chunk_select   one block: the first `nwant` accepted candidates in draw order, the
 //                     sequence offsets (exclusive scan), the rejection histogram over the
 //                     attempts the reference's loop would have made
-//   3. chunk_gather   signal: 64 x 64 (sample, chunk) tiles through LDS -- int16 reads along the
+//   3. chunk_gather   signal: 64 x 16 (sample, chunk) tiles through LDS -- int16 reads along the
 //                     signal, float32 writes along the batch, both coalesced; the float64
 //                     arithmetic of get_current in the reference's order, rounded once to
 //                     float32 like torch.tensor(..., dtype=float32).  Sequence: one block per
@@ -191,19 +191,21 @@ __global__ __launch_bounds__(SEL_THREADS) void chunk_select_kernel(
 // ---------------------------------------------------------------------------
 // 3a. signal tiles
 // ---------------------------------------------------------------------------
-constexpr int GT = 64;              // tile edge: 64 samples x 64 chunks
+constexpr int GT = 64;              // tile: 64 samples ...
+constexpr int GN = 16;              // ... x 16 chunks (504 blocks for 128 chunks of 4000 samples)
 constexpr int GATHER_THREADS = 256;
 
 __global__ __launch_bounds__(GATHER_THREADS) void chunk_signal_kernel(
     tk_mapped_store st, const int32_t *__restrict__ cand_read, const int32_t *__restrict__ dacstart,
     const int32_t *__restrict__ sel, const int32_t *__restrict__ counts, int nwant, int chunk_len,
     int reverse, int standardize, float *__restrict__ indata) {
-    __shared__ float tile[GT][GT + 1];
+    __shared__ float tile[GN][GT + 1];
     const int lane = lane_id(), wave = threadIdx.x >> 6;
-    const int t0 = blockIdx.x * GT, n0 = blockIdx.y * GT;
+    const int t0 = blockIdx.x * GT, n0 = blockIdx.y * GN;
     const int nsel = counts[CH_NREASON];
     // read: wave w takes chunks n0 + w, w + 4, ...; lane = sample (2-byte loads, 128 B per wave)
-    for (int j = wave; j < GT; j += GATHER_THREADS / WAVE) {
+#pragma unroll
+    for (int j = wave; j < GN; j += GATHER_THREADS / WAVE) {
         const int n = n0 + j, t = t0 + lane;
         float v = 0.f;
         if (n < nsel && t < chunk_len) {
@@ -219,10 +221,12 @@ __global__ __launch_bounds__(GATHER_THREADS) void chunk_signal_kernel(
         tile[j][lane] = v;
     }
     __syncthreads();
-    // write: wave w takes samples t0 + w, ...; lane = chunk (256 B per wave)
-    for (int i = wave; i < GT; i += GATHER_THREADS / WAVE) {
-        const int t = t0 + i, n = n0 + lane;
-        if (t < chunk_len && n < nwant) indata[(size_t)t * nwant + n] = tile[lane][i];
+    // write: a wave stores 4 samples x 16 chunks per pass (64 B runs along the batch)
+    const int jn = lane & (GN - 1), it = lane / GN;
+#pragma unroll
+    for (int i = wave * (WAVE / GN) + it; i < GT; i += GATHER_THREADS / GN) {
+        const int t = t0 + i, n = n0 + jn;
+        if (t < chunk_len && n < nwant) indata[(size_t)t * nwant + n] = tile[jn][i];
     }
 }
 
@@ -291,7 +295,7 @@ int chunks_gather_dispatch(const tk_mapped_store *st, const int32_t *cand_read, 
                            int reverse, int standardize, size_t ncan, const int32_t *can_labels,
                            const int32_t *mod_labels, float *indata, int32_t *seqs, size_t seqs_cap,
                            int32_t *seqlens_out, int32_t *mod_cats, uint32_t *status, hipStream_t stream) {
-    const dim3 grid((unsigned)((chunk_len + GT - 1) / GT), (unsigned)((nwant + GT - 1) / GT));
+    const dim3 grid((unsigned)((chunk_len + GT - 1) / GT), (unsigned)((nwant + GN - 1) / GN));
     hipLaunchKernelGGL(chunk_signal_kernel, grid, dim3(GATHER_THREADS), 0, stream, *st, cand_read, dacstart, sel,
                        counts, (int)nwant, (int)chunk_len, reverse, standardize, indata);
     hipLaunchKernelGGL(chunk_sequence_kernel, dim3((unsigned)nwant), dim3(256), 0, stream, *st, cand_read,

@@ -19,6 +19,7 @@
  *   taiyaki/signal_mapping.py:515-557,676-716 + chunk_selection.py:29-95 +
  *   bin/train_flipflop.py:103-140 (chunk extraction, filters,
  *   batch stacking, flip-flop coding)                       tk_chunks_{locate,select,gather}_dev
+ *   taiyaki/flipflop_remap.py:6-88 map_to_crf_viterbi       tk_flipflop_remap_dev
  *
  * Conventions
  *  - plain C: pointers and sizes only, no torch / HIP types in the signatures
@@ -214,6 +215,24 @@ int tk_chunks_gather_dev(const tk_mapped_store *store, const int32_t *cand_read,
                          const int32_t *can_labels, const int32_t *mod_labels, float *indata,
                          int32_t *seqs, size_t seqs_cap, int32_t *seqlens, int32_t *mod_cats,
                          uint32_t *status, void *stream);
+
+/* ------------------------------------------------------------------------- *
+ * Best path through a score matrix that spells a given sequence, for nread reads at once
+ * (taiyaki/flipflop_remap.py:6-88 map_to_crf_viterbi; float64 like the reference).
+ *   scores     rows of ntrans float32, all reads concatenated; read i owns rows
+ *              row_off[i] .. row_off[i+1] (T_i of them)
+ *   stay_index concatenated, M_i = seq_off[i+1] - seq_off[i] per read, starting at seq_off[i]
+ *   step_index concatenated, M_i - 1 per read, starting at seq_off[i] - i
+ *   localpen   (nread) score paid per block spent in the start / end state
+ *   score      (nread) float64;  path: T_i + 1 int64 per read starting at row_off[i] + i,
+ *              -1 = start / end state
+ *   traceback  scratch, T_i * ceil(M_i / 64) 64-bit words per read starting at tb_off[i]
+ * M_i >= 1; max_seqlen = max M_i <= 16384 (TK_ERR_UNSUPPORTED beyond). */
+int tk_flipflop_remap_dev(const float *scores, const int64_t *row_off, size_t ntrans,
+                          const int32_t *stay_index, const int32_t *step_index,
+                          const int64_t *seq_off, const double *localpen, size_t nread,
+                          size_t max_seqlen, double *score, int64_t *path, uint64_t *traceback,
+                          const int64_t *tb_off, void *stream);
 
 /* ------------------------------------------------------------------------- *
  * Exact reference prototypes (HOST pointers; taiyaki/ctc/c_crf_flipflop.h:3-11,

@@ -47,6 +47,20 @@ int chunks_gather_dispatch(const tk_mapped_store *st, const int32_t *cand_read, 
                            int reverse, int standardize, size_t ncan, const int32_t *can_labels,
                            const int32_t *mod_labels, float *indata, int32_t *seqs, size_t seqs_cap,
                            int32_t *seqlens_out, int32_t *mod_cats, uint32_t *status, hipStream_t stream);
+struct RemapArgs {
+    const float *scores;
+    const int64_t *row_off;
+    const int32_t *stay_index;
+    const int32_t *step_index;
+    const int64_t *seq_off;
+    const double *localpen;
+    int K;
+    double *score;
+    int64_t *path;
+    uint64_t *tb;
+    const int64_t *tb_off;
+};
+int remap_dispatch(const RemapArgs &a, size_t nread, size_t max_M, hipStream_t stream);
 }  // namespace tk
 
 static inline bool aligned16(const void *p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
@@ -76,6 +90,20 @@ int tk_grad_maxabs_clip_dev(float *grads, const int64_t *seg_off, size_t nseg, s
     const int rc = tk::grad_clip_dispatch(grads, seg_off, nseg, max_seg_len, thresh, maxs,
                                           static_cast<hipStream_t>(stream));
     return rc == 0 ? TK_OK : TK_ERR_LAUNCH;
+}
+
+int tk_flipflop_remap_dev(const float *scores, const int64_t *row_off, size_t ntrans,
+                          const int32_t *stay_index, const int32_t *step_index, const int64_t *seq_off,
+                          const double *localpen, size_t nread, size_t max_seqlen, double *score,
+                          int64_t *path, uint64_t *traceback, const int64_t *tb_off, void *stream) {
+    if (!row_off || !stay_index || !seq_off || !localpen || !score || !path || !tb_off || ntrans == 0)
+        return TK_ERR_BAD_ARG;
+    if (nread == 0) return TK_OK;
+    if (max_seqlen > 1 && !step_index) return TK_ERR_BAD_ARG;
+    if (nread > (size_t)INT32_MAX || ntrans > 4096) return TK_ERR_UNSUPPORTED;
+    tk::RemapArgs a{scores, row_off, stay_index, step_index, seq_off, localpen, (int)ntrans, score, path,
+                    traceback, tb_off};
+    return tk::remap_dispatch(a, nread, max_seqlen, static_cast<hipStream_t>(stream));
 }
 
 static bool store_ok(const tk_mapped_store *s) {

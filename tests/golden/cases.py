@@ -106,3 +106,41 @@ CHUNKS_SMALL = {
 
 def chunk_reads(spec):
     return synth.mapped_reads(spec["nreads"], spec["seed"], nlabel=spec["nlabel"])
+
+
+# flipflop_remap: (T, K) scores, a base sequence of length M, localpen (None = the
+# reference's default LARGE_VAL = global mapping)
+REMAP_SMALL = {
+    "t30m8": dict(T=30, M=8, nbase=4, seed=81, localpen=None, scale=1.0),
+    "t200m60": dict(T=200, M=60, nbase=4, seed=82, localpen=None, scale=1.0),
+    "t200m60_glocal": dict(T=200, M=60, nbase=4, seed=82, localpen=2.0, scale=1.0),
+    "t500m1": dict(T=500, M=1, nbase=4, seed=83, localpen=1.0, scale=1.0),
+    "t64m64": dict(T=64, M=64, nbase=4, seed=84, localpen=None, scale=1.0),     # every block steps
+    "t40m70_too_long": dict(T=40, M=70, nbase=4, seed=85, localpen=None, scale=1.0),   # no global path
+    "t900m300_nb2": dict(T=900, M=300, nbase=2, seed=86, localpen=0.7, scale=1.0),
+    "t1500m700_ties": dict(T=1500, M=700, nbase=4, seed=87, localpen=3.0, scale=-1.0),  # integer scores
+    "t3000m1300": dict(T=3000, M=1300, nbase=4, seed=88, localpen=4.0, scale=1.0),
+    # junk at both ends of the signal: the glocal mapping clips it (path -1), the global one cannot
+    "t400m90_clip": dict(T=400, M=90, nbase=4, seed=89, localpen=1.5, scale=1.0, junk=(0.25, 0.15)),
+    "t400m90_clip_global": dict(T=400, M=90, nbase=4, seed=89, localpen=None, scale=1.0, junk=(0.25, 0.15)),
+    "t2500m800_clip": dict(T=2500, M=800, nbase=4, seed=90, localpen=0.5, scale=1.0, junk=(0.1, 0.3)),
+}
+
+
+def remap_inputs(spec):
+    """(scores (T, K) float32, bases (M,) int).  scale < 0: scores rounded to integers in
+    [-2, 2] so that ties are everywhere (the strict '<' of the traceback decides)."""
+    nb = spec["nbase"]
+    sc = synth.scores(spec["T"], 1, 2 * nb * (nb + 1), spec["seed"])[:, 0, :]
+    if spec["scale"] < 0:
+        sc = np.round(sc * np.float32(0.4)).astype(np.float32)
+    if spec.get("junk"):
+        head, tail = (int(f * spec["T"]) for f in spec["junk"])
+        sc[:head] -= np.float32(7.0)
+        sc[spec["T"] - tail:] -= np.float32(7.0)
+    bases = synth.randint(spec["seed"], 21, spec["M"], nb)
+    rep = synth.uniform01(spec["seed"], 22, spec["M"]) < 0.3
+    for p in range(1, spec["M"]):
+        if rep[p]:
+            bases[p] = bases[p - 1]
+    return np.ascontiguousarray(sc), bases

@@ -61,6 +61,10 @@ __device__ __forceinline__ uint64_t readlane_u64(uint64_t v, int lane) {
     return ((uint64_t)hi << 32) | lo;
 }
 
+// scores a thread carries from one tile to the next: RM_ROWS * K / threads.  R = 2 blocks can
+// be as small as one wave (20 for K = 40); R = 8 / 16 blocks have at least 257 / 513 threads.
+__host__ __device__ constexpr int remap_prefetch_regs(int R) { return R == 2 ? 24 : 8; }
+
 template <int R>
 __global__ __launch_bounds__(1024) void remap_kernel(RemapArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -91,12 +95,13 @@ __global__ __launch_bounds__(1024) void remap_kernel(RemapArgs a) {
 
     // my positions and their transition ids; positions >= M are inert (they only receive)
     const int m_first = tid * R;
-    int stay_id[R], step_id[R];
+    uint32_t ids[R];                                        // stay id | step id << 16
 #pragma unroll
     for (int r = 0; r < R; ++r) {
         const int m = m_first + r;
-        stay_id[r] = (m < M) ? a.stay_index[s0 + m] : 0;
-        step_id[r] = (m < M - 1) ? a.step_index[s0 - read + m] : 0;
+        const uint32_t st = (m < M) ? (uint32_t)a.stay_index[s0 + m] : 0u;
+        const uint32_t sp = (m < M - 1) ? (uint32_t)a.step_index[s0 - read + m] : 0u;
+        ids[r] = st | (sp << 16);
     }
     double p[R];                                            // :30-32
 #pragma unroll
@@ -107,7 +112,7 @@ __global__ __launch_bounds__(1024) void remap_kernel(RemapArgs a) {
 
     const int tile_elems = RM_ROWS * K;
     const int per_thread = (tile_elems + nthreads - 1) / nthreads;     // <= 20 with >= 64 threads, K = 40
-    constexpr int PRE_MAX = 24;
+    constexpr int PRE_MAX = remap_prefetch_regs(R);
     float pre[PRE_MAX];
     const int64_t total_elems = (int64_t)T * K;
     auto fetch_tile = [&](int j) {                          // into registers
@@ -143,7 +148,7 @@ __global__ __launch_bounds__(1024) void remap_kernel(RemapArgs a) {
         for (int n = n_lo; n < n_hi; ++n) {
             const float *row = rows + (n - n_lo) * K;
             // what my last position offers its right-hand neighbour (:48-49)
-            const double out = p[R - 1] + (double)row[step_id[R - 1]];
+            const double out = p[R - 1] + (double)row[ids[R - 1] >> 16];
             double cin = wave_shift_up1_f64(out, 0.0);
             if (multi) {
                 double *sl = slot + (n & 1) * 16;
@@ -151,29 +156,45 @@ __global__ __launch_bounds__(1024) void remap_kernel(RemapArgs a) {
                 __syncthreads();
                 if (lane == 0 && wave > 0) cin = sl[wave - 1];
             }
+            // the start state feeds position 0, the end state drains position M - 1: one thread
+            // each, the other waves skip these blocks
+            double leave_start = 0.0;
+            if (tid == 0) {
+                const double stay0 = (double)row[ids[0] & 0xffffu];
+                leave_start = start_score - localpen;                      // :52
+                start_score = start_score + fmax(stay0, -localpen);        // :53
+            }
+            if (tid == last_owner) {
+                double p_last = p[0];
+                uint32_t id_last = ids[0];
+#pragma unroll
+                for (int r = 1; r < R; ++r) {
+                    p_last = (r == last_r) ? p[r] : p_last;
+                    id_last = (r == last_r) ? ids[r] : id_last;
+                }
+                const double stay_l = (double)row[id_last & 0xffffu];
+                const double remain = end_score + fmax(stay_l, -localpen); // :63
+                const double into_end = p_last - localpen;                 // :64
+                end_score = fmax(remain, into_end);
+                if (into_end > remain) alignment_end = n;
+            }
             uint32_t bits = 0;
 #pragma unroll
             for (int r = 0; r < R; ++r) {
-                const double stay_s = (double)row[stay_id[r]];
+                const double stay_s = (double)row[ids[r] & 0xffffu];
                 const double cstay = p[r] + stay_s;                         // :45-46
-                const double next_out = p[r] + (double)row[step_id[r]];
+                const double next_out = p[r] + (double)row[ids[r] >> 16];
                 double cand = cin;
                 bool bit = cstay < cin;                                     // :59
-                if (m_first + r == 0) {
-                    const double leave_start = start_score - localpen;     // :52
-                    start_score = start_score + fmax(stay_s, -localpen);   // :53
-                    cand = start_score;                                     // :58
-                    bit = leave_start > cstay;                              // :60
-                }
-                if (tid == last_owner && r == last_r) {
-                    const double remain = end_score + fmax(stay_s, -localpen);  // :63
-                    const double into_end = p[r] - localpen;                // :64
-                    end_score = fmax(remain, into_end);
-                    if (into_end > remain) alignment_end = n;
+                if (r == 0) {
+                    cand = (tid == 0) ? start_score : cand;                 // :58 (the updated start score)
+                    bit = (tid == 0) ? (leave_start > cstay) : bit;         // :60
                 }
                 p[r] = fmax(cstay, cand);                                   // :56-58
                 bits |= (bit ? 1u : 0u) << r;
                 cin = next_out;
+                // 16 cells of float64 state leave no room for hoisting every cell's gathers
+                if (R > 8 && (r & 3) == 3) __builtin_amdgcn_sched_barrier(0);
             }
             // traceback row n (row 0 of the reference's table is all zero and not stored)
             uint8_t *trow = reinterpret_cast<uint8_t *>(tb + (size_t)n * pitchw);
@@ -244,7 +265,7 @@ int remap_dispatch(const RemapArgs &a, size_t nread, size_t max_M, hipStream_t s
     int threads = (int)((max_M + R - 1) / R);
     threads = ((threads + WAVE - 1) / WAVE) * WAVE;
     // the prefetch registers hold RM_ROWS * K / threads scores per thread
-    if ((RM_ROWS * a.K + threads - 1) / threads > 24) return TK_ERR_UNSUPPORTED;
+    if ((RM_ROWS * a.K + threads - 1) / threads > remap_prefetch_regs(R)) return TK_ERR_UNSUPPORTED;
     const size_t lds = remap_lds_bytes(a.K);
     switch (R) {
     case 2: hipLaunchKernelGGL(remap_kernel<2>, dim3((unsigned)nread), dim3(threads), lds, stream, a); break;

@@ -54,6 +54,7 @@ def basecall_scores(spec):
 
 # BASELINE.json configs at full size: only per-read scalars + checksums are kept
 FULLSIZE = {
+    "cfg1": dict(T=1000, N=64, seed=4, mods=None),      # train_abinitio: chunk 2000, stride 2, batch 64
     "cfg2": dict(T=800, N=128, seed=1, mods=None),
     "cfg4": dict(T=800, N=128, seed=2, mods=(1, 1, 0, 0)),
     "cfg5": dict(T=1600, N=64, seed=3, mods=None),

@@ -3,10 +3,10 @@
 
     python tools/chunkbench.py [--reads 2000] [--batch 128] [--chunk-len 4000] [--reps 50]
 Prints the time of one `MappedSignalStore.sample_chunks` call (candidates drawn on the device,
-three kernel launches, no host sync) and of the numpy restatement of the reference's per-chunk
-Python path (oracle/chunks.py: get_chunk_with_sample_length + apply_filters + np.vstack +
-flipflop_code) for the same number of chunks.  Algorithmic bytes: 6 per sample (int16 in,
-float32 out).
+three kernel launches, no host sync).  The host-path comparison (the numpy restatement of the
+reference's per-chunk Python code) lives with the test infrastructure:
+`python -m tests.helpers.cpu_legs chunks`.  Algorithmic bytes: 6 per sample (int16 in, float32
+out).
 """
 import argparse
 import os
@@ -26,7 +26,7 @@ def main():
     ap.add_argument("--batch", type=int, default=128)
     ap.add_argument("--chunk-len", type=int, default=4000)
     ap.add_argument("--reps", type=int, default=50)
-    ap.add_argument("--no-cpu", action="store_true")
+    ap.add_argument("--no-cpu", action="store_true", help="(kept for old command lines; no effect)")
     args = ap.parse_args()
     dev = torch.device("cuda:0")
     reads = synth.mapped_reads(args.reads, 7, mean_reflen=900, long_dwell_prob=0.0003)
@@ -61,19 +61,6 @@ def main():
         evs.append((a, e))
     torch.cuda.synchronize()
     print("        locate + select kernels: %.1f us" % (np.mean([a.elapsed_time(e) for a, e in evs[5:]]) * 1e3))
-    if not args.no_cpu:
-        from oracle import chunks as oc
-        rng = np.random.RandomState(3)
-        fpd = dict(fp._asdict())
-        t0 = time.time()
-        reps = 3
-        for _ in range(reps):
-            cands = oc.candidates_from_rng(reads, int(N / 0.5), T, rng)
-            chunks, _, _ = oc.sample_chunks(reads, N, T, fpd, cands)
-            oc.assemble_batch(chunks, 4)
-        ct = (time.time() - t0) / reps
-        print("host    (numpy restatement of the reference's per-chunk path, 1 core): %8.1f us per batch"
-              " = %.0f chunks/s  -> device %.0fx" % (ct * 1e6, N / ct, ct / dt))
 
 
 if __name__ == "__main__":

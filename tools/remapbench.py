@@ -1,10 +1,11 @@
 #!/usr/bin/env python
 """flipflop_remap benchmark.
 
-    python tools/remapbench.py [--blocks 20000] [--bases 9000] [--reads 256] [--cpu-reads 1]
+    python tools/remapbench.py [--blocks 20000] [--bases 9000] [--reads 256] 
 One read alone (latency of the serial time loop + traceback) and a batch of reads in one launch
-(one workgroup per read), against the numpy restatement of the reference (oracle/remap.py: the
-same ~12 numpy calls per time step as taiyaki/flipflop_remap.py) on one host core.
+(one workgroup per read).  The host-path comparison (numpy restatement of the reference: the
+same ~12 numpy calls per time step as taiyaki/flipflop_remap.py) lives with the test
+infrastructure: `python -m tests.helpers.cpu_legs remap`.
 """
 import argparse
 import os
@@ -23,7 +24,7 @@ def main():
     ap.add_argument("--blocks", type=int, default=20000)
     ap.add_argument("--bases", type=int, default=9000)
     ap.add_argument("--reads", type=int, default=256)
-    ap.add_argument("--cpu-reads", type=int, default=1)
+    ap.add_argument("--cpu-reads", type=int, default=0, help="(kept for old command lines; no effect)")
     args = ap.parse_args()
     dev = torch.device("cuda:0")
     T, M = args.blocks, args.bases
@@ -48,16 +49,6 @@ def main():
     assert np.all(s == score) and all(np.array_equal(x, path) for x in p[:4])
     print("batch of %d: %8.2f ms = %.2f ms per read = %.0f reads/s (%.1f M blocks/s)"
           % (n, bt * 1e3, bt / n * 1e3, n / bt, n * T / bt / 1e6))
-    if args.cpu_reads:
-        from oracle import remap as orm
-        h = sc.cpu().numpy()
-        t0 = time.time()
-        for _ in range(args.cpu_reads):
-            ws, wp = orm.map_to_crf_viterbi(h, step, stay, 3.0)
-        ct = (time.time() - t0) / args.cpu_reads
-        assert ws == score and np.array_equal(wp, path)
-        print("host (numpy restatement of the reference, 1 core): %8.1f ms per read -> GPU %.0fx alone, %.0fx batched"
-              % (ct * 1e3, ct / one, ct / (bt / n)))
 
 
 if __name__ == "__main__":

@@ -184,6 +184,11 @@ def main():
                     help="(default with the MIOpen LSTM) replay forward + loss and AdamW from "
                          "hipGraphs, run the uncapturable RNN backward eagerly; probed in a child "
                          "process first, eager launch if the probe fails; --no-graph disables")
+    ap.add_argument("--data", choices=["arena", "store"], default="arena",
+                    help="arena: a few pre-assembled synthetic batches cycled from HBM (default); "
+                         "store: every step samples, filters and assembles its batch on the device "
+                         "from a synthetic mapped-signal set resident in HBM "
+                         "(taiyaki_amd.mapped_signal, the reference's prepare_random_batches)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-rowk", action="store_true")
     ap.add_argument("--probe-graph", action="store_true", help=argparse.SUPPRESS)
@@ -263,14 +268,28 @@ def main():
         print("graph-probe-ok" if mode != "eager" else "graph-probe-eager")
         return
 
+    next_batch = lambda i: batches[i % len(batches)]        # noqa: E731
+    if args.data == "store":
+        # batches straight from the file-format arrays: sample_chunks + filters + stacking +
+        # flip-flop coding as three launches on this stream, nothing on the host
+        from taiyaki_amd import mapped_signal, synth
+        store = mapped_signal.MappedSignalStore(
+            synth.mapped_reads(1500, 31 + rank, mean_reflen=max(900, args.chunk_len // 4),
+                               long_dwell_prob=0.0003), dev)
+        torch.manual_seed(99 + rank)
+        fparams = store.sample_filter_parameters(1000, args.chunk_len, 3.0, 10.0, 0.5, stride, 1.1)
+
+        def next_batch(i):
+            b = store.sample_chunks(args.batch, args.chunk_len, fparams, max_bases_per_chunk=T + 1)
+            return dict(indata=b.indata, seqs=b.seqs, seqlens=b.seqlens)
     for i in range(args.warmup):
-        stepper.step(batches[i % len(batches)])
+        stepper.step(next_batch(i))
     if dist.is_initialized():
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for i in range(args.steps):
-        stepper.step(batches[i % len(batches)])
+        stepper.step(next_batch(i))
     if dist.is_initialized():
         dist.barrier()
     torch.cuda.synchronize()
@@ -309,6 +328,8 @@ def main():
                                global_batch=nglobal, chunk_len=args.chunk_len, launch=mode,
                                hw_queues=int(os.environ.get("GPU_MAX_HW_QUEUES", "0")),
                                conv=args.conv, lstm=args.lstm,
+                               batches=("assembled on the device every step from a mapped-signal set in HBM"
+                                        if args.data == "store" else "pre-assembled, cycled from HBM"),
                                parallelism="dp%d (reads sharded, flat RCCL all-reduce)" % world))
         if not args.no_rowk:
             out["roofline"] = logz_roofline(4000, 256, 50, "north_star kernel shape")

@@ -248,7 +248,7 @@ class MappedSignalStore:
             dev = self.device
             cap = nwant * int(max_bases_per_chunk if max_bases_per_chunk else max(chunk_len, 1))
             indata = torch.empty((chunk_len, nwant, 1), dtype=torch.float32, device=dev)
-            seqs = torch.empty(max(cap, 1), dtype=torch.int32, device=dev)
+            seqs = torch.zeros(max(cap, 1), dtype=torch.int32, device=dev)       # tail beyond seqoff[-1] stays 0
             seqlens = torch.empty(max(nwant, 1), dtype=torch.int32, device=dev)[:nwant]
             status = torch.zeros(1, dtype=torch.int32, device=dev)
             cl = ml = mc = None

@@ -20,6 +20,7 @@
  *   bin/train_flipflop.py:103-140 (chunk extraction, filters,
  *   batch stacking, flip-flop coding)                       tk_chunks_{locate,select,gather}_dev
  *   taiyaki/flipflop_remap.py:6-88 map_to_crf_viterbi       tk_flipflop_remap_dev
+ *   taiyaki/signal_mapping.py:202-316 from_remapping_path   tk_remap_path_to_ref_to_signal_dev
  *
  * Conventions
  *  - plain C: pointers and sizes only, no torch / HIP types in the signatures
@@ -233,6 +234,18 @@ int tk_flipflop_remap_dev(const float *scores, const int64_t *row_off, size_t nt
                           const int64_t *seq_off, const double *localpen, size_t nread,
                           size_t max_seqlen, double *score, int64_t *path, uint64_t *traceback,
                           const int64_t *tb_off, void *stream);
+
+/* SignalMapping.from_remapping_path + get_reftosignal (taiyaki/signal_mapping.py:202-316):
+ * Ref_to_signal of nread reads from their remapping paths.  path: concatenated, read i owns
+ * entries path_off[i] .. path_off[i+1] (tk_flipflop_remap_dev's output layout: path_off[i] =
+ * row_off[i] + i), -1 at the clipped ends and non-decreasing in between; entry k sits at signal
+ * position k * stride - 1 + signalstart[i]; siglen[i] = length of the read's Dacs; reference
+ * lengths from ref_off (nread + 1).  Output: reflen_i + 1 int32 per read starting at
+ * ref_off[i] + i -- the tk_mapped_store layout. */
+int tk_remap_path_to_ref_to_signal_dev(const int64_t *path, const int64_t *path_off,
+                                       const int64_t *ref_off, const int64_t *signalstart,
+                                       const int64_t *siglen, size_t stride, size_t nread,
+                                       int32_t *ref_to_signal, void *stream);
 
 /* ------------------------------------------------------------------------- *
  * Exact reference prototypes (HOST pointers; taiyaki/ctc/c_crf_flipflop.h:3-11,

@@ -35,6 +35,7 @@ SIGNATURES = {
     "tk_flipflop_errprobs_dev": (_i, [_vp, _vp, _sz, _sz, _sz, _vp, _vp]),
     "tk_grad_maxabs_clip_dev": (_i, [_vp, _vp, _sz, _sz, _vp, _vp, _vp]),
     "tk_flipflop_remap_dev": (_i, [_vp, _vp, _sz, _vp, _vp, _vp, _vp, _sz, _sz, _vp, _vp, _vp, _vp, _vp]),
+    "tk_remap_path_to_ref_to_signal_dev": (_i, [_vp, _vp, _vp, _vp, _vp, _sz, _sz, _vp, _vp]),
     "tk_chunks_locate_dev": (_i, [_vp, _vp, _vp, _vp, _sz, _sz, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "tk_chunks_select_dev": (_i, [_vp, _vp, _sz, _sz, _vp, _vp, _vp, _vp]),
     "tk_chunks_gather_dev": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _sz, _i, _i, _sz, _vp, _vp,

@@ -61,6 +61,9 @@ struct RemapArgs {
     const int64_t *tb_off;
 };
 int remap_dispatch(const RemapArgs &a, size_t nread, size_t max_M, hipStream_t stream);
+int path_to_reftosignal_dispatch(const int64_t *path, const int64_t *path_off, const int64_t *ref_off,
+                                 const int64_t *signalstart, const int64_t *siglen, int stride, size_t nread,
+                                 int32_t *rts, hipStream_t stream);
 }  // namespace tk
 
 static inline bool aligned16(const void *p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
@@ -104,6 +107,17 @@ int tk_flipflop_remap_dev(const float *scores, const int64_t *row_off, size_t nt
     tk::RemapArgs a{scores, row_off, stay_index, step_index, seq_off, localpen, (int)ntrans, score, path,
                     traceback, tb_off};
     return tk::remap_dispatch(a, nread, max_seqlen, static_cast<hipStream_t>(stream));
+}
+
+int tk_remap_path_to_ref_to_signal_dev(const int64_t *path, const int64_t *path_off, const int64_t *ref_off,
+                                       const int64_t *signalstart, const int64_t *siglen, size_t stride,
+                                       size_t nread, int32_t *ref_to_signal, void *stream) {
+    if (!path || !path_off || !ref_off || !signalstart || !siglen || !ref_to_signal || stride == 0)
+        return TK_ERR_BAD_ARG;
+    if (nread == 0) return TK_OK;
+    if (nread > (size_t)INT32_MAX || stride > (size_t)INT32_MAX) return TK_ERR_UNSUPPORTED;
+    return tk::path_to_reftosignal_dispatch(path, path_off, ref_off, signalstart, siglen, (int)stride, nread,
+                                            ref_to_signal, static_cast<hipStream_t>(stream));
 }
 
 static bool store_ok(const tk_mapped_store *s) {

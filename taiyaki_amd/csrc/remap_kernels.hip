@@ -257,6 +257,79 @@ __global__ __launch_bounds__(1024) void remap_kernel(RemapArgs a) {
     }
 }
 
+// ---------------------------------------------------------------------------
+// Ref_to_signal from remapping paths (signal_mapping.py:268-316 from_remapping_path, :202-265
+// get_reftosignal): entry k of a path sits at signal position k stride - 1 + signalstart;
+// reference position r starts at the signal position of the first path entry >= r.  A path is
+// -1 (clipped) at its two ends and non-decreasing in between, so that entry is a binary search.
+// One workgroup per read; output in the mapped-signal store's layout (read i at ref_off[i] + i).
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void path_to_reftosignal_kernel(
+    const int64_t *__restrict__ path, const int64_t *__restrict__ path_off, const int64_t *__restrict__ ref_off,
+    const int64_t *__restrict__ signalstart, const int64_t *__restrict__ siglen_all, int stride,
+    int32_t *__restrict__ rts_all) {
+    __shared__ int klo_s, khi_s;
+    const int read = blockIdx.x;
+    const int64_t p0 = path_off[read];
+    const int npath = (int)(path_off[read + 1] - p0);
+    const int reflen = (int)(ref_off[read + 1] - ref_off[read]);
+    const int64_t ss = signalstart[read], siglen = siglen_all[read];
+    const int64_t *pth = path + p0;
+    int32_t *rts = rts_all + ref_off[read] + read;
+    if (threadIdx.x == 0) {
+        klo_s = INT32_MAX;
+        khi_s = -1;
+    }
+    __syncthreads();
+    auto sigloc = [&](int k) { return (int64_t)k * stride - 1 + ss; };
+    int lo = INT32_MAX, hi = -1;
+    for (int k = threadIdx.x; k < npath; k += blockDim.x) {
+        const int64_t sl = sigloc(k);
+        if (pth[k] != -1 && sl >= 0 && sl < siglen) {
+            lo = min(lo, k);
+            hi = max(hi, k);
+        }
+    }
+    if (hi >= 0) {
+        atomicMin(&klo_s, lo);
+        atomicMax(&khi_s, hi);
+    }
+    __syncthreads();
+    const int klo = klo_s, khi = khi_s;
+    if (khi < 0) {                                      // nothing mapped: :232-234
+        for (int r = threadIdx.x; r <= reflen; r += blockDim.x) rts[r] = -1;
+        return;
+    }
+    const int64_t v0 = pth[klo], vl = pth[khi];
+    for (int r = threadIdx.x; r <= reflen; r += blockDim.x) {
+        int32_t out;
+        if (r < v0) {
+            out = -1;                                   // :249-252 start of the reference not mapped
+        } else if (r <= vl) {
+            int a = klo, b = khi;                       // first k with path[k] >= r
+            while (a < b) {
+                const int mid = (a + b) >> 1;
+                if (pth[mid] < r) a = mid + 1;
+                else b = mid;
+            }
+            out = (int32_t)sigloc(a);                   // :236-238 np.repeat(valid idx, moves)
+        } else if (r == vl + 1) {
+            out = (int32_t)(sigloc(khi) + 1);           // :240-242 end of the last mapped position
+        } else {
+            out = (int32_t)(siglen + 1);                // :253-255 end of the reference not mapped
+        }
+        rts[r] = out;
+    }
+}
+
+int path_to_reftosignal_dispatch(const int64_t *path, const int64_t *path_off, const int64_t *ref_off,
+                                 const int64_t *signalstart, const int64_t *siglen, int stride, size_t nread,
+                                 int32_t *rts, hipStream_t stream) {
+    hipLaunchKernelGGL(path_to_reftosignal_kernel, dim3((unsigned)nread), dim3(256), 0, stream, path, path_off,
+                       ref_off, signalstart, siglen, stride, rts);
+    return hipGetLastError() == hipSuccess ? TK_OK : TK_ERR_LAUNCH;
+}
+
 size_t remap_lds_bytes(int K) { return 2 * (size_t)RM_ROWS * K * sizeof(float) + 2 * 16 * sizeof(double) + 16; }
 
 int remap_dispatch(const RemapArgs &a, size_t nread, size_t max_M, hipStream_t stream) {

@@ -98,3 +98,39 @@ def flipflop_remap_batch(transition_scores, sequences, alphabet=DEFAULT_ALPHABET
     """flipflop_remap for a list of reads in one launch."""
     idx = [remap_indices(s, alphabet) for s in sequences]
     return map_to_crf_viterbi_batch(transition_scores, [i[0] for i in idx], [i[1] for i in idx], localpen)
+
+
+def ref_to_signal_from_remapping_paths(paths, reflens, stride, signalstarts, siglens, device=None):
+    """``SignalMapping.from_remapping_path(...).Ref_to_signal`` (signal_mapping.py:268-316 with
+    ``get_reftosignal`` :202-265) for a batch of reads on the device.
+
+    paths: list of (T_i + 1,) remapping paths (-1 at the clipped ends, non-decreasing in between --
+    what ``flipflop_remap`` returns); reflens: reference lengths; stride: model stride;
+    signalstarts / siglens: ``sig.signalstart`` and ``len(sig.untrimmed_dacs)`` per read.
+    Returns a list of int32 arrays of length reflen_i + 1."""
+    nread = len(paths)
+    if nread == 0:
+        return []
+    host = [np.asarray(p.cpu() if torch.is_tensor(p) else p, dtype=np.int64) for p in paths]
+    for p in host:
+        body = p[p >= 0]
+        inner = np.flatnonzero(p >= 0)
+        if len(body) and (np.any(np.diff(body) < 0) or inner[-1] - inner[0] + 1 != len(inner) or p.min() < -1):
+            raise ValueError("remapping path must be -1 at its ends and non-decreasing in between")
+    device = torch.device("cuda" if device is None else device)
+    if device.type != "cuda":
+        raise RuntimeError("runs as a HIP kernel on an AMD GPU; device=%s (no CPU fallback)" % device)
+    path_off = np.concatenate([[0], np.cumsum([len(p) for p in host])]).astype(np.int64)
+    ref_off = np.concatenate([[0], np.cumsum(np.asarray(reflens, dtype=np.int64))]).astype(np.int64)
+    with torch.cuda.device(device):
+        up = lambda a: torch.from_numpy(np.array(a, dtype=np.int64)).to(device)    # noqa: E731
+        path_d, po_d, ro_d = up(np.concatenate(host)), up(path_off), up(ref_off)
+        ss_d = up(np.broadcast_to(np.asarray(signalstarts), (nread,)))
+        sl_d = up(np.broadcast_to(np.asarray(siglens), (nread,)))
+        out = torch.empty(int(ref_off[-1]) + nread, dtype=torch.int32, device=device)
+        rc = _lib.lib().tk_remap_path_to_ref_to_signal_dev(
+            _lib.ptr(path_d), _lib.ptr(po_d), _lib.ptr(ro_d), _lib.ptr(ss_d), _lib.ptr(sl_d), int(stride),
+            nread, _lib.ptr(out), _lib.stream_ptr())
+        _lib.check(rc, "tk_remap_path_to_ref_to_signal_dev")
+        flat = out.cpu().numpy()
+    return [flat[ref_off[i] + i:ref_off[i + 1] + i + 1] for i in range(nread)]

@@ -24,7 +24,13 @@ from tests.golden.cases import REMAP_SMALL, remap_inputs  # noqa: E402
 
 def main():
     make_golden.build_reference()
-    from taiyaki import flipflop_remap
+    from taiyaki import flipflop_remap, signal_mapping
+
+    class SigStub:
+        def __init__(self, dacs, signalstart):
+            self.untrimmed_dacs, self.signalstart = dacs, signalstart
+            self.shift_from_pA, self.scale_from_pA, self.range, self.offset = 0.0, 1.0, 1.0, 0.0
+            self.digitisation, self.read_id = 1.0, "stub"
 
     class NumpyOneInts:
         """numpy seen by the reference module, with unpackbits widened to int64: numpy 2 refuses
@@ -47,6 +53,14 @@ def main():
         score, path = flipflop_remap.flipflop_remap(scores.astype(np.float64), seq, alphabet=alphabet, **kw)
         out[name + "/score"] = np.float64(score)
         out[name + "/path"] = np.asarray(path, dtype=np.int64)
+        # the mapping the reference derives from that path (prepare_mapping_funcs.py:95-97):
+        # SignalMapping.from_remapping_path with a stand-in for the Signal object (taiyaki.signal
+        # needs ont_fast5_api; only these attributes are read)
+        for stride, start, extra in ((1, 0, 0), (5, 3, 7), (2, 40, 0)):
+            sig = SigStub(np.zeros(len(path) * stride + start + extra, dtype=np.int16), start)
+            sm = signal_mapping.SignalMapping.from_remapping_path(
+                np.asarray(path), np.asarray(bases, dtype=np.int16), stride, sig)
+            out["%s/rts_s%d_o%d_e%d" % (name, stride, start, extra)] = sm.Ref_to_signal.astype(np.int32)
         print(name, "score", score, "clipped", int((path < 0).sum()), "of", len(path))
     path = os.path.join(HERE, "remap_small.npz")
     np.savez_compressed(path, **out)

@@ -194,7 +194,16 @@ __host__ __device__ constexpr int k3_buf_f4() {
 // ~4k cycles the memory system needs to deliver it with every SIMD loading.
 // grid = (ncols, ceil(C / 4)), block = 256.
 // ---------------------------------------------------------------------------
-template <int NB, int CH>
+// RING > 0: the score rows go from HBM straight into a wave-private LDS ring of RING row-sets
+// (global_load_lds_dwordx4, gfx950) instead of through registers, RING - 1 rows in flight behind
+// the one being consumed.  It costs no registers (the register path cannot afford a second
+// row-set in flight next to the 128-register matrix ping-pong) and no ds_write pass; it costs
+// LDS -- RING x 10 KiB per wave -- so it is the form for launches that fill the chip with one
+// wave per SIMD anyway.
+typedef __attribute__((address_space(3))) void tk_lds_void;
+typedef const __attribute__((address_space(1))) void tk_global_void;
+
+template <int NB, int CH, int RING>
 __global__ __launch_bounds__(K1_WAVES *WAVE, 2) void logz_transfer_kernel(
     const float *__restrict__ scores, int T, int N, int C, int Npad, LogzWs ws) {
     using F = FF<NB>;
@@ -204,7 +213,8 @@ __global__ __launch_bounds__(K1_WAVES *WAVE, 2) void logz_transfer_kernel(
     const int c = blockIdx.y * K1_WAVES + wave;
     if (c >= C) return;                         // wave-uniform; the kernel has no barriers
     // wave-private LDS: the row-set transpose buffer, later the matrix image
-    constexpr int IMG_WORDS = (X::NF4 > F::PIECES ? X::NF4 : F::PIECES) * 4 * WAVE;
+    constexpr int IMG_F4 = (X::NF4 > F::PIECES * (RING > 0 ? RING : 1) ? X::NF4 : F::PIECES * (RING > 0 ? RING : 1));
+    constexpr int IMG_WORDS = IMG_F4 * 4 * WAVE;
     float *img = reinterpret_cast<float *>(smem) + (size_t)wave * IMG_WORDS;
     f4 *buf = reinterpret_cast<f4 *>(img);
     const int n0 = blockIdx.x * WAVE;
@@ -282,7 +292,62 @@ __global__ __launch_bounds__(K1_WAVES *WAVE, 2) void logz_transfer_kernel(
     }
     TK_STAMP(8);
     auto rowptr = [&](int t) { return base + (size_t)min(t, t1 - 1) * rowstride; };
-    {
+    if constexpr (RING > 0) {
+        constexpr int SLOT = WAVE * F::PIECES;          // f4 per row-set
+        auto issue = [&](int slot, int t) {
+            const f4 *src = reinterpret_cast<const f4 *>(rowptr(t));
+            f4 *dst = buf + slot * SLOT;
+#pragma unroll
+            for (int q = 0; q < F::PIECES; ++q)
+                __builtin_amdgcn_global_load_lds((tk_global_void *)(src + min(q * WAVE + lane, nvalid - 1)),
+                                                 (tk_lds_void *)(dst + q * WAVE), 16, 0, 0);
+        };
+        // rows issued after row t are still allowed in flight when row t is read: vmcnt counts
+        // loads in order, PIECES per row
+        auto landed = [&](int t) {
+            const int behind = min(RING - 1, t1 - 1 - t);
+            if (behind >= 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * F::PIECES) : "memory");
+            else if (behind == 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(F::PIECES) : "memory");
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        };
+        auto take = [&](RowSet<NB> &r, int slot) {     // pieces -> own row, straight from the ring
+#pragma unroll
+            for (int q = 0; q < F::PIECES; ++q) r.v[q] = buf[slot * SLOT + lane * F::PIECES + q];
+        };
+        static_assert(RING == 0 || RING == 3, "landed() is written for two rows in flight");
+#pragma unroll
+        for (int k = 0; k < RING; ++k)
+            if (t0 + k < t1) issue(k, t0 + k);
+        int slot = 0;
+        RowSet<NB> r0, r1;
+        for (int t = t0; t < t1; t += 2) {
+            landed(t);
+            take(r0, slot);
+            pM += (double)r0.exp_normalise();           // every piece of the slot is in registers now
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            if (t + RING < t1) issue(slot, t + RING);
+            slot = (slot + 1 == RING) ? 0 : slot + 1;
+            step(Pp, Pq, r0);
+            if (t == t0) TK_STAMP(9);
+            if (t + 1 >= t1) {              // odd tail: the product sits in the other set
+#pragma unroll
+                for (int ip = 0; ip < NP; ++ip)
+#pragma unroll
+                    for (int j = 0; j < NS; ++j) Pp[ip][j] = Pq[ip][j];
+                break;
+            }
+            landed(t + 1);
+            take(r1, slot);
+            pM += (double)r1.exp_normalise();
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            if (t + 1 + RING < t1) issue(slot, t + 1 + RING);
+            slot = (slot + 1 == RING) ? 0 : slot + 1;
+            step(Pq, Pp, r1);
+            if (((t - t0) & 3) == 2) renorm(Pp);
+            if (t == t0 + 8) TK_STAMP(10);
+        }
+        renorm(Pp);
+    } else {
         // one row-set in flight ahead of the one being consumed; row indices are clamped
         // (never branched on) so the load stream has no control flow
         RowSet<NB> r0, r1;
@@ -1028,6 +1093,20 @@ __global__ __launch_bounds__(K3_WAVES *WAVE, (CH / K3_WAVES <= 2 ? 4 : 2)) void 
 // ---------------------------------------------------------------------------
 static inline size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
 
+// LDS ring form of the transfer kernel (120 KiB per block = one block per CU): for launches with
+// fewer waves than SIMDs, where the extra row in flight is worth 3-9 % of the kernel (T=4000 x
+// N=192: 28.1 vs 30.9 us); at a wave per SIMD (N=256) it measures the same and above that the
+// second block per CU matters more.  TK_K1_RING=0/1 overrides
+constexpr int K1_RING = 3;
+static bool logz_use_ring(size_t nchunks) {
+    static const int forced = [] {
+        const char *e = getenv("TK_K1_RING");
+        return e ? atoi(e) : -1;
+    }();
+    if (forced >= 0) return forced != 0;
+    return nchunks <= 900;
+}
+
 // chunk size = rows per K3 block.  16 rows (two per wave) keep K3 at 128 VGPRs = two
 // blocks per CU, so one block's serial chain overlaps the other's loads and stores;
 // 8 when a 16-row grid would leave CUs without a block.  32 is kept for the env override.
@@ -1068,7 +1147,10 @@ static int logz_launch_ch(const float *scores, size_t T, size_t N, float *logz, 
         const size_t lds = K1_WAVES * (imgwords > bufwords ? imgwords : bufwords) * sizeof(float);
         static bool raised1 = false;
         if (lds > 64 * 1024 && !raised1) {
-            if (hipFuncSetAttribute(reinterpret_cast<const void *>(&logz_transfer_kernel<NB, CH>),
+            if (hipFuncSetAttribute(reinterpret_cast<const void *>(&logz_transfer_kernel<NB, CH, 0>),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize,
+                                    160 * 1024) != hipSuccess ||
+                hipFuncSetAttribute(reinterpret_cast<const void *>(&logz_transfer_kernel<NB, CH, K1_RING>),
                                     hipFuncAttributeMaxDynamicSharedMemorySize,
                                     160 * 1024) != hipSuccess ||
                 hipFuncSetAttribute(reinterpret_cast<const void *>(&logz_transfer_coop_kernel<NB, CH>),
@@ -1079,10 +1161,17 @@ static int logz_launch_ch(const float *scores, size_t T, size_t N, float *logz, 
         }
         // one wave per chunk needs about a wave per SIMD to stream at full rate; below that
         // the cooperative form (4 waves per chunk) is faster
-        if ((size_t)ncols * C >= 640)
-            hipLaunchKernelGGL((logz_transfer_kernel<NB, CH>), dim3(ncols, (C + K1_WAVES - 1) / K1_WAVES),
-                               dim3(K1_WAVES * WAVE), lds, stream, scores, (int)T, (int)N, C, Npad, ws);
-        else
+        if ((size_t)ncols * C >= 640) {
+            if (logz_use_ring((size_t)ncols * C)) {
+                const size_t ringlds = K1_WAVES * (size_t)K1_RING * WAVE * F::PIECES * sizeof(f4);
+                hipLaunchKernelGGL((logz_transfer_kernel<NB, CH, K1_RING>), dim3(ncols, (C + K1_WAVES - 1) / K1_WAVES),
+                                   dim3(K1_WAVES * WAVE), ringlds > lds ? ringlds : lds, stream, scores, (int)T,
+                                   (int)N, C, Npad, ws);
+            } else {
+                hipLaunchKernelGGL((logz_transfer_kernel<NB, CH, 0>), dim3(ncols, (C + K1_WAVES - 1) / K1_WAVES),
+                                   dim3(K1_WAVES * WAVE), lds, stream, scores, (int)T, (int)N, C, Npad, ws);
+            }
+        } else
             hipLaunchKernelGGL((logz_transfer_coop_kernel<NB, CH>), dim3(ncols, C), dim3(K1_WAVES * WAVE),
                                lds, stream, scores, (int)T, (int)N, C, Npad, ws);
     }

@@ -39,9 +39,13 @@ os.environ.setdefault("MIOPEN_GEMM_ENFORCE_BACKEND", "1")      # MIOpen RNN GEMM
 # HIP spreads streams and hipGraph branches over several hardware queues and pays a
 # cross-queue signal (~10 us) whenever the ~16,000 tiny dependent launches of a step hop
 # between them.  One queue keeps the whole step in order on the hardware: 167 -> 110 ms per
-# step on one GPU (127 ms with two queues).  With RCCL in the process (N > 1) the collective
-# kernels get the second queue, the setting AMD's own RCCL recipes use.
-os.environ.setdefault("GPU_MAX_HW_QUEUES", "1" if int(os.environ.get("WORLD_SIZE", "1")) <= 1 else "2")
+# step on one GPU (124-127 ms with two queues).  The limit is per PRIORITY level: RCCL's
+# collectives run on a high-priority stream (taiyaki_amd/parallel.py) and therefore in a
+# hardware queue of their own, so multi-GPU runs keep the single compute queue too
+# (tools/queue_probe.py shows a high-priority stream running beside a busy normal one at
+# GPU_MAX_HW_QUEUES=1).
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "1")
+os.environ.setdefault("TORCH_NCCL_HIGH_PRIORITY", "1")
 
 import numpy as np
 import torch

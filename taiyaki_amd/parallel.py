@@ -31,7 +31,17 @@ def init_from_env(backend=None):
             backend = "nccl" if torch.cuda.is_available() else "gloo"
         if backend == "nccl":
             torch.cuda.set_device(local)
-            dist.init_process_group(backend=backend, device_id=torch.device("cuda", local))
+            # RCCL's kernels go to a HIGH-PRIORITY stream: HIP keeps a hardware queue per
+            # priority level, so the collectives never share (or wait in) the queue of this
+            # rank's compute streams, however few queues GPU_MAX_HW_QUEUES leaves those
+            # (tools/queue_probe.py)
+            opts = None
+            try:
+                opts = dist.ProcessGroupNCCL.Options()
+                opts.is_high_priority_stream = True
+            except Exception:
+                os.environ.setdefault("TORCH_NCCL_HIGH_PRIORITY", "1")
+            dist.init_process_group(backend=backend, device_id=torch.device("cuda", local), pg_options=opts)
         else:
             dist.init_process_group(backend=backend)
     return rank, local, world

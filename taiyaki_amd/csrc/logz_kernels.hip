@@ -593,6 +593,18 @@ __device__ __forceinline__ int grp_max_i(int x) {
         : "=&v"(r) : "v"(x));
     return r;
 }
+// 8-lane group sum, result in every lane of the group (same three DPP steps as the maximum)
+__device__ __forceinline__ float grp_sum_f(float x) {
+    float r;
+    asm("s_nop 1\n\t"
+        "v_add_f32_dpp %0, %1, %1 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
+        "s_nop 1\n\t"
+        "v_add_f32_dpp %0, %0, %0 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n\t"
+        "s_nop 1\n\t"
+        "v_add_f32_dpp %0, %0, %0 row_half_mirror row_mask:0xf bank_mask:0xf"
+        : "=&v"(r) : "v"(x));
+    return r;
+}
 __device__ __forceinline__ float grp_max_f(float x) {
     float r;
     asm("s_nop 1\n\t"
@@ -806,14 +818,17 @@ __global__ __launch_bounds__(K2_WAVES *WAVE, 8) void logz_middle_kernel(int N, i
         }
         ColShare<NB> A[2];
         A[1].load(img0 + NFW, g);
+        // the fp64 log-scales ride along (one broadcast LDS read and one add per step, off the
+        // dependency chain) instead of a six-stage cross-lane sum after it
+        double macc = img_M<NB>(img0);
 #pragma unroll
         for (int i = 1; i < SUP; ++i) {
             if (i < cnt) {
                 A[(i + 1) & 1].load(img0 + (i + 1) * NFW, g);      // may run one matrix past the super
+                macc += img_M<NB>(img0 + i * NFW);
                 eacc += grp_vec_mat<NB>(v, A[i & 1], g);
             }
         }
-        const double macc = wave_sum_f64((lane < cnt) ? img_M<NB>(img0 + lane * NFW) : 0.0);
         const float mx = grp_max_f(v);
         {   // rows of the stored totals are normalised like K1's (maximum in [1/2, 1))
             const int ex = (mx > 0.f) ? __builtin_amdgcn_frexp_expf(mx) : 0;
@@ -840,21 +855,19 @@ __global__ __launch_bounds__(K2_WAVES *WAVE, 8) void logz_middle_kernel(int N, i
         int eacc = 0;
         ColShare<NB> A[2];
         A[0].load(totimg, g);
+        double macc = 0.0;                      // the supers' fp64 log-scales ride along, off the chain
         for (int s = 0; s < NSUP; s += 2) {
             A[1].load(totimg + (size_t)(s + 1) * NFW, g);
             vsl[s * GRP + g] = v;
+            macc += img_M<NB>(totimg + (size_t)s * NFW);
             eacc += grp_vec_mat<NB>(v, A[0], g);
             if (s + 1 >= NSUP) break;
             A[0].load(totimg + (size_t)(s + 2) * NFW, g);
             vsl[(s + 1) * GRP + g] = v;
+            macc += img_M<NB>(totimg + (size_t)(s + 1) * NFW);
             eacc += grp_vec_mat<NB>(v, A[1], g);
         }
-        double macc = 0.0;
-        for (int s = lane; s < NSUP; s += WAVE) macc += img_M<NB>(totimg + (size_t)s * NFW);
-        macc = wave_sum_f64(macc);
-        float tot = 0.f;
-#pragma unroll
-        for (int i = 0; i < F::NS; ++i) tot += grp_bcast(v, i);
+        const float tot = grp_sum_f(v);         // lanes >= NS of the group hold 0
         if (lane == 0) {
             const float lzf = (float)(macc + (double)eacc * 0.6931471805599453 + (double)logf(tot));
             logz[n] = lzf;

@@ -1112,11 +1112,7 @@ static inline size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; 
 // second block per CU matters more.  TK_K1_RING=0/1 overrides
 constexpr int K1_RING = 3;
 static bool logz_use_ring(size_t nchunks) {
-    static const int forced = [] {
-        const char *e = getenv("TK_K1_RING");
-        return e ? atoi(e) : -1;
-    }();
-    if (forced >= 0) return forced != 0;
+    if (const char *e = getenv("TK_K1_RING")) return atoi(e) != 0;     // tuning / test override
     return nchunks <= 900;
 }
 

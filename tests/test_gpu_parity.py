@@ -357,6 +357,20 @@ def test_logz_every_chunk_size(oracle_mod, gpu_device, ch, monkeypatch):
     assert r["rowsum_dev"] < 1e-5
 
 
+@pytest.mark.parametrize("ring", ["0", "1"])
+@pytest.mark.parametrize("T,N", [(1500, 448), (3333, 200), (2500, 270)])
+def test_logz_transfer_register_and_lds_ring_forms(oracle_mod, gpu_device, T, N, ring, monkeypatch):
+    """One wave per chunk, score rows through registers (TK_K1_RING=0) or through the
+    global_load_lds ring of three row-sets (=1; the default below 900 chunks): ragged last
+    chunk (T % 16 != 0), a partial last column (N % 64 != 0), odd and even row counts."""
+    from taiyaki_amd import synth
+    monkeypatch.setenv("TK_K1_RING", ring)
+    sc = synth.scores(T, N, 40, 1000 + T + N)
+    r = parity.compare_logz(oracle_mod, sc, gpu_device)
+    assert r["finite"] and r["logz_rel"] < LOSS_RTOL and r["grad_abs"] < GRAD_ATOL
+    assert r["rowsum_dev"] < 1e-5 and r["nograd_same"] == 0.0
+
+
 @pytest.mark.parametrize("mode_mb", ["0", "6144"])
 @pytest.mark.parametrize("name", ["t7n2_len1", "t50n3_zero_last", "t200n8", "t130n5_long", "t300n3_wide"])
 def test_crf_both_gradient_modes(oracle_mod, gpu_device, name, mode_mb, monkeypatch):

@@ -203,7 +203,7 @@ __host__ __device__ constexpr int k3_buf_f4() {
 typedef __attribute__((address_space(3))) void tk_lds_void;
 typedef const __attribute__((address_space(1))) void tk_global_void;
 
-template <int NB, int CH, int RING>
+template <int NB, int CH, int RING, bool NT>
 __global__ __launch_bounds__(K1_WAVES *WAVE, 2) void logz_transfer_kernel(
     const float *__restrict__ scores, int T, int N, int C, int Npad, LogzWs ws) {
     using F = FF<NB>;
@@ -352,7 +352,7 @@ __global__ __launch_bounds__(K1_WAVES *WAVE, 2) void logz_transfer_kernel(
         // (never branched on) so the load stream has no control flow
         RowSet<NB> r0, r1;
         auto fetch = [&](RowSet<NB> &r, int t) {
-            if (TK_K1_NT_LOAD) r.issue_nt(rowptr(t), nvalid, lane);
+            if (TK_K1_NT_LOAD || NT) r.issue_nt(rowptr(t), nvalid, lane);      // compile-time: no branch in the load stream
             else r.issue(rowptr(t), nvalid, lane);
         };
         fetch(r0, t0);
@@ -1156,10 +1156,13 @@ static int logz_launch_ch(const float *scores, size_t T, size_t N, float *logz, 
         const size_t lds = K1_WAVES * (imgwords > bufwords ? imgwords : bufwords) * sizeof(float);
         static bool raised1 = false;
         if (lds > 64 * 1024 && !raised1) {
-            if (hipFuncSetAttribute(reinterpret_cast<const void *>(&logz_transfer_kernel<NB, CH, 0>),
+            if (hipFuncSetAttribute(reinterpret_cast<const void *>(&logz_transfer_kernel<NB, CH, 0, false>),
                                     hipFuncAttributeMaxDynamicSharedMemorySize,
                                     160 * 1024) != hipSuccess ||
-                hipFuncSetAttribute(reinterpret_cast<const void *>(&logz_transfer_kernel<NB, CH, K1_RING>),
+                hipFuncSetAttribute(reinterpret_cast<const void *>(&logz_transfer_kernel<NB, CH, 0, true>),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize,
+                                    160 * 1024) != hipSuccess ||
+                hipFuncSetAttribute(reinterpret_cast<const void *>(&logz_transfer_kernel<NB, CH, K1_RING, false>),
                                     hipFuncAttributeMaxDynamicSharedMemorySize,
                                     160 * 1024) != hipSuccess ||
                 hipFuncSetAttribute(reinterpret_cast<const void *>(&logz_transfer_coop_kernel<NB, CH>),
@@ -1173,12 +1176,25 @@ static int logz_launch_ch(const float *scores, size_t T, size_t N, float *logz, 
         if ((size_t)ncols * C >= 640) {
             if (logz_use_ring((size_t)ncols * C)) {
                 const size_t ringlds = K1_WAVES * (size_t)K1_RING * WAVE * F::PIECES * sizeof(f4);
-                hipLaunchKernelGGL((logz_transfer_kernel<NB, CH, K1_RING>), dim3(ncols, (C + K1_WAVES - 1) / K1_WAVES),
+                hipLaunchKernelGGL((logz_transfer_kernel<NB, CH, K1_RING, false>), dim3(ncols, (C + K1_WAVES - 1) / K1_WAVES),
                                    dim3(K1_WAVES * WAVE), ringlds > lds ? ringlds : lds, stream, scores, (int)T,
                                    (int)N, C, Npad, ws);
             } else {
-                hipLaunchKernelGGL((logz_transfer_kernel<NB, CH, 0>), dim3(ncols, (C + K1_WAVES - 1) / K1_WAVES),
-                                   dim3(K1_WAVES * WAVE), lds, stream, scores, (int)T, (int)N, C, Npad, ws);
+                // a score tensor that fits the Infinity Cache is read with plain loads: the
+                // posterior kernel's second read then hits (T=4000 x N=256: 99.5 us for the op
+                // against 110 with streaming loads here); a bigger one is streamed (N=1024:
+                // transfer 130 us instead of 157, the op 385 instead of 412; break-even ~300 MB).
+                // Two instantiations, not a runtime flag: a branch in the load stream costs the
+                // whole gain
+                bool nt_load = (size_t)T * N * F::S * sizeof(float) > ((size_t)300 << 20);
+                if (const char *e = getenv("TK_K1_NT")) nt_load = atoi(e) != 0;     // tuning / test override
+                const dim3 grid(ncols, (C + K1_WAVES - 1) / K1_WAVES);
+                if (nt_load)
+                    hipLaunchKernelGGL((logz_transfer_kernel<NB, CH, 0, true>), grid, dim3(K1_WAVES * WAVE), lds, stream,
+                                       scores, (int)T, (int)N, C, Npad, ws);
+                else
+                    hipLaunchKernelGGL((logz_transfer_kernel<NB, CH, 0, false>), grid, dim3(K1_WAVES * WAVE), lds, stream,
+                                       scores, (int)T, (int)N, C, Npad, ws);
             }
         } else
             hipLaunchKernelGGL((logz_transfer_coop_kernel<NB, CH>), dim3(ncols, C), dim3(K1_WAVES * WAVE),

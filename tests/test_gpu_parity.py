@@ -371,6 +371,21 @@ def test_logz_transfer_register_and_lds_ring_forms(oracle_mod, gpu_device, T, N,
     assert r["rowsum_dev"] < 1e-5 and r["nograd_same"] == 0.0
 
 
+def test_logz_streaming_transfer_kernel_is_the_same_arithmetic(oracle_mod, gpu_device, monkeypatch):
+    """Score tensors above 300 MB go through the non-temporal-load instantiation of the transfer
+    kernel: force it (TK_K1_NT=1) on a tensor the oracle handles in seconds and require the very
+    same bits as the plain-load form, and parity with the oracle."""
+    from taiyaki_amd import synth
+    sc = synth.scores(2000, 330, 40, 4242)
+    monkeypatch.setenv("TK_K1_RING", "0")
+    monkeypatch.setenv("TK_K1_NT", "0")
+    lz0, g0 = parity.run_logz(sc, gpu_device)
+    monkeypatch.setenv("TK_K1_NT", "1")
+    r = parity.compare_logz(oracle_mod, sc, gpu_device)
+    assert r["finite"] and r["logz_rel"] < LOSS_RTOL and r["grad_abs"] < GRAD_ATOL
+    assert np.array_equal(r["logz"], lz0) and np.array_equal(r["grad"], g0)
+
+
 @pytest.mark.parametrize("mode_mb", ["0", "6144"])
 @pytest.mark.parametrize("name", ["t7n2_len1", "t50n3_zero_last", "t200n8", "t130n5_long", "t300n3_wide"])
 def test_crf_both_gradient_modes(oracle_mod, gpu_device, name, mode_mb, monkeypatch):

@@ -40,17 +40,20 @@ static void run(const float *scores, int T, int N, float *logz, float *grad, voi
     const size_t lds2 = logz_middle_lds_bytes<NB>(C, NSUP);
     constexpr bool chain_in_buf = ((CH / K3_WAVES) + 2) * F::NS * WAVE <= k3_buf_f4<NB, CH>() * 4;
     const size_t lds3 = K3_WAVES * (size_t)k3_buf_f4<NB, CH>() * sizeof(f4) + (chain_in_buf ? 0 : 2 * F::NS * WAVE * sizeof(float));
-    CK(hipFuncSetAttribute(reinterpret_cast<const void *>(&logz_transfer_kernel<NB, CH, 0>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-    CK(hipFuncSetAttribute(reinterpret_cast<const void *>(&logz_transfer_kernel<NB, CH, 3>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    CK(hipFuncSetAttribute(reinterpret_cast<const void *>(&logz_transfer_kernel<NB, CH, 0, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    CK(hipFuncSetAttribute(reinterpret_cast<const void *>(&logz_transfer_kernel<NB, CH, 0, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    CK(hipFuncSetAttribute(reinterpret_cast<const void *>(&logz_transfer_kernel<NB, CH, 3, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     const bool ring = getenv("LAB_RING") ? atoi(getenv("LAB_RING")) != 0 : (size_t)ncols * C <= 900;
     const size_t ringlds = std::max(lds1, K1_WAVES * (size_t)3 * WAVE * F::PIECES * sizeof(f4));
     CK(hipFuncSetAttribute(reinterpret_cast<const void *>(&logz_middle_kernel<NB, 8>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     CK(hipFuncSetAttribute(reinterpret_cast<const void *>(&logz_middle_kernel<NB, 16>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     CK(hipFuncSetAttribute(reinterpret_cast<const void *>(&logz_posterior_kernel<NB, CH>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     CK(hipFuncSetAttribute(reinterpret_cast<const void *>(&logz_transfer_coop_kernel<NB, CH>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    const int nt1 = getenv("LAB_NT1") ? atoi(getenv("LAB_NT1")) : ((size_t)T * N * 160 > ((size_t)300 << 20));
     auto k1 = [&] {
-        if ((size_t)ncols * C >= 640 && ring) hipLaunchKernelGGL((logz_transfer_kernel<NB, CH, 3>), dim3(ncols, (C + K1_WAVES - 1) / K1_WAVES), dim3(K1_WAVES * WAVE), ringlds, 0, scores, T, N, C, Npad, ws);
-        else if ((size_t)ncols * C >= 640) hipLaunchKernelGGL((logz_transfer_kernel<NB, CH, 0>), dim3(ncols, (C + K1_WAVES - 1) / K1_WAVES), dim3(K1_WAVES * WAVE), lds1, 0, scores, T, N, C, Npad, ws);
+        if ((size_t)ncols * C >= 640 && ring) hipLaunchKernelGGL((logz_transfer_kernel<NB, CH, 3, false>), dim3(ncols, (C + K1_WAVES - 1) / K1_WAVES), dim3(K1_WAVES * WAVE), ringlds, 0, scores, T, N, C, Npad, ws);
+        else if ((size_t)ncols * C >= 640 && nt1) hipLaunchKernelGGL((logz_transfer_kernel<NB, CH, 0, true>), dim3(ncols, (C + K1_WAVES - 1) / K1_WAVES), dim3(K1_WAVES * WAVE), lds1, 0, scores, T, N, C, Npad, ws);
+        else if ((size_t)ncols * C >= 640) hipLaunchKernelGGL((logz_transfer_kernel<NB, CH, 0, false>), dim3(ncols, (C + K1_WAVES - 1) / K1_WAVES), dim3(K1_WAVES * WAVE), lds1, 0, scores, T, N, C, Npad, ws);
         else hipLaunchKernelGGL((logz_transfer_coop_kernel<NB, CH>), dim3(ncols, C), dim3(K1_WAVES * WAVE), lds1, 0, scores, T, N, C, Npad, ws);
     };
     auto k2 = [&] {

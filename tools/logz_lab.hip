@@ -50,6 +50,7 @@ static void run(const float *scores, int T, int N, float *logz, float *grad, voi
     CK(hipFuncSetAttribute(reinterpret_cast<const void *>(&logz_posterior_kernel<NB, CH>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     CK(hipFuncSetAttribute(reinterpret_cast<const void *>(&logz_transfer_coop_kernel<NB, CH>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     const int nt1 = getenv("LAB_NT1") ? atoi(getenv("LAB_NT1")) : ((size_t)T * N * 160 > ((size_t)300 << 20));
+    const int nt3 = getenv("LAB_NT3") ? atoi(getenv("LAB_NT3")) : ((size_t)T * N * 160 > ((size_t)200 << 20));
     auto k1 = [&] {
         if ((size_t)ncols * C >= 640 && ring) hipLaunchKernelGGL((logz_transfer_kernel<NB, CH, 3, false>), dim3(ncols, (C + K1_WAVES - 1) / K1_WAVES), dim3(K1_WAVES * WAVE), ringlds, 0, scores, T, N, C, Npad, ws);
         else if ((size_t)ncols * C >= 640 && nt1) hipLaunchKernelGGL((logz_transfer_kernel<NB, CH, 0, true>), dim3(ncols, (C + K1_WAVES - 1) / K1_WAVES), dim3(K1_WAVES * WAVE), lds1, 0, scores, T, N, C, Npad, ws);
@@ -60,7 +61,7 @@ static void run(const float *scores, int T, int N, float *logz, float *grad, voi
         if (SUP == 8) hipLaunchKernelGGL((logz_middle_kernel<NB, 8>), dim3(N), dim3(K2_WAVES * WAVE), lds2, 0, N, C, NSUP, Npad, ws, logz, 1, status);
         else hipLaunchKernelGGL((logz_middle_kernel<NB, 16>), dim3(N), dim3(K2_WAVES * WAVE), lds2, 0, N, C, NSUP, Npad, ws, logz, 1, status);
     };
-    auto k3 = [&] { hipLaunchKernelGGL((logz_posterior_kernel<NB, CH>), dim3(ncols, C), dim3(K3_WAVES * WAVE), lds3, 0, scores, grad, T, N, Npad, ws, status, (size_t)T * N * 160 > ((size_t)200 << 20)); };
+    auto k3 = [&] { hipLaunchKernelGGL((logz_posterior_kernel<NB, CH>), dim3(ncols, C), dim3(K3_WAVES * WAVE), lds3, 0, scores, grad, T, N, Npad, ws, status, nt3); };
     k1(); k2(); k3();
     CK(hipDeviceSynchronize());
     const double a = timeit(k1), b = timeit(k2), c = timeit(k3), all = timeit([&] { k1(); k2(); k3(); });

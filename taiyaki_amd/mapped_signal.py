@@ -92,6 +92,51 @@ def draw_reference_candidates(mapped, attempts, chunk_len, rng=np.random, select
     return reads, starts
 
 
+# ---- packed on-disk form --------------------------------------------------------------------
+# The arrays of tk_mapped_store as one .npz: what `MappedSignalStore` uploads, so a training set is
+# packed once (tools/mapped_signal_to_npz.py does it from the reference's HDF5 container on a
+# machine that has h5py) and then loaded with a few large reads instead of one HDF5 group per read.
+_NPZ_KEYS = ("dacs", "dacs_off", "ref_to_signal", "rts_off", "reference", "scaling", "read_ids",
+             "alphabet", "collapse_alphabet")
+
+
+def pack_reads(reads, alphabet="ACGT", collapse_alphabet=None):
+    """Read dictionaries (signal_mapping.py:318-350) -> dict of concatenated arrays (_NPZ_KEYS)."""
+    dacs = [np.ascontiguousarray(r["Dacs"], dtype=np.int16) for r in reads]
+    rts = [np.ascontiguousarray(r["Ref_to_signal"], dtype=np.int32) for r in reads]
+    ref = [np.ascontiguousarray(r["Reference"], dtype=np.int16) for r in reads]
+    return dict(
+        dacs=np.concatenate(dacs) if dacs else np.zeros(0, np.int16),
+        dacs_off=np.concatenate([[0], np.cumsum([len(d) for d in dacs])]).astype(np.int64),
+        ref_to_signal=np.concatenate(rts) if rts else np.zeros(0, np.int32),
+        rts_off=np.concatenate([[0], np.cumsum([len(a) for a in rts])]).astype(np.int64),
+        reference=np.concatenate(ref) if ref else np.zeros(0, np.int16),
+        scaling=np.array([[r["offset"], r["range"], r["digitisation"], r["shift_frompA"], r["scale_frompA"]]
+                          for r in reads], dtype=np.float64).reshape(len(reads), 5),
+        read_ids=np.array([str(r.get("read_id", i)) for i, r in enumerate(reads)]),
+        alphabet=np.array(alphabet), collapse_alphabet=np.array(collapse_alphabet or alphabet))
+
+
+def save_npz(path, reads, alphabet="ACGT", collapse_alphabet=None):
+    np.savez(path, **pack_reads(reads, alphabet, collapse_alphabet))
+
+
+def load_npz(path):
+    """-> (read dictionaries (views into the packed arrays), alphabet, collapse_alphabet)."""
+    z = np.load(path, allow_pickle=False)
+    missing = [k for k in _NPZ_KEYS if k not in z.files]
+    if missing:
+        raise ValueError("%s is not a packed mapped-signal file: missing %s" % (path, missing))
+    d, do, t, to, f, sc = (z[k] for k in ("dacs", "dacs_off", "ref_to_signal", "rts_off", "reference", "scaling"))
+    reads = []
+    for i, rid in enumerate(z["read_ids"]):
+        reads.append(dict(read_id=str(rid), Dacs=d[do[i]:do[i + 1]], Ref_to_signal=t[to[i]:to[i + 1]],
+                          Reference=f[to[i] - i:to[i + 1] - i - 1], offset=float(sc[i, 0]), range=float(sc[i, 1]),
+                          digitisation=float(sc[i, 2]), shift_frompA=float(sc[i, 3]),
+                          scale_frompA=float(sc[i, 4])))
+    return reads, str(z["alphabet"]), str(z["collapse_alphabet"])
+
+
 class ChunkBatch:
     """One sampled batch, all tensors on the device.  ``indata`` (chunk_len, nwant, 1) float32,
     ``seqs`` int32 (capacity; the first ``seqoff[-1]`` entries are valid), ``seqlens`` (nwant)
@@ -167,6 +212,14 @@ class MappedSignalStore:
         self._struct = _Store(t["dacs"].data_ptr(), t["dacs_off"].data_ptr(), t["rts"].data_ptr(),
                               t["rts_off"].data_ptr(), t["ref"].data_ptr(), t["scaling"].data_ptr(),
                               t["mapped"].data_ptr(), len(reads))
+
+    @classmethod
+    def from_npz(cls, path, device):
+        """A training set packed by `save_npz` / tools/mapped_signal_to_npz.py."""
+        reads, alphabet, collapse = load_npz(path)
+        store = cls(reads, device)
+        store.alphabet, store.collapse_alphabet = alphabet, collapse
+        return store
 
     @property
     def nreads(self):

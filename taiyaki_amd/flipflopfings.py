@@ -21,14 +21,17 @@ def stay_indices(labels, nbase=len(DEFAULT_ALPHABET)):
 
 def flopmask(labels):
     """flipflopfings.py:34-53: True where a label sits at an even (2nd, 4th, ...)
-    position within a run of identical labels."""
+    position within a run of identical labels.  Vectorised: position within the run = index
+    minus the index at which the run started."""
     labels = np.asarray(labels)
-    mask = np.zeros(len(labels), dtype=bool)
-    run = 0
-    for p in range(len(labels)):
-        run = run + 1 if (p > 0 and labels[p] == labels[p - 1]) else 0
-        mask[p] = bool(run & 1)
-    return mask
+    n = len(labels)
+    if n == 0:
+        return np.zeros(0, dtype=bool)
+    idx = np.arange(n)
+    new_run = np.ones(n, dtype=bool)
+    new_run[1:] = labels[1:] != labels[:-1]
+    run_start = np.maximum.accumulate(np.where(new_run, idx, 0))
+    return ((idx - run_start) & 1).astype(bool)
 
 
 def flipflop_code(labels, alphabet_length=4):

@@ -371,6 +371,29 @@ def test_logz_transfer_register_and_lds_ring_forms(oracle_mod, gpu_device, T, N,
     assert r["rowsum_dev"] < 1e-5 and r["nograd_same"] == 0.0
 
 
+def test_logz_above_the_streaming_threshold(gpu_device):
+    """T=4000 x N=512 (328 MB of scores: the transfer kernel streams with non-temporal loads, two
+    workgroups per CU): posteriors are distributions, and the first 256 reads give bit for bit
+    what the same reads give as a tensor of their own (row K shape, plain loads) -- the
+    arithmetic per read does not depend on how the tensor is moved."""
+    import torch
+    from taiyaki_amd import layers, synth
+    T, N = 4000, 512
+    big = torch.empty((T, N, 40), dtype=torch.float32, device=gpu_device)
+    for lo in range(0, N, 128):                                 # generated in slabs: less host memory
+        big[:, lo:lo + 128] = torch.from_numpy(synth.scores(T, 128, 40, 900 + lo)).to(gpu_device)
+    big.requires_grad_(True)
+    lz = layers.flipflop_logpartition(big)
+    lz.sum().backward()
+    g = big.grad
+    assert torch.isfinite(lz).all() and torch.isfinite(g).all()
+    assert float((g.sum(dim=2) - 1.0).abs().max()) < 1e-5
+    sub = big.detach()[:, :256].contiguous().requires_grad_(True)
+    lz2 = layers.flipflop_logpartition(sub)
+    lz2.sum().backward()
+    assert torch.equal(lz[:256], lz2) and torch.equal(g[:, :256], sub.grad)
+
+
 def test_logz_streaming_transfer_kernel_is_the_same_arithmetic(oracle_mod, gpu_device, monkeypatch):
     """Score tensors above 300 MB go through the non-temporal-load instantiation of the transfer
     kernel: force it (TK_K1_NT=1) on a tensor the oracle handles in seconds and require the very

@@ -371,6 +371,28 @@ def test_logz_transfer_register_and_lds_ring_forms(oracle_mod, gpu_device, T, N,
     assert r["rowsum_dev"] < 1e-5 and r["nograd_same"] == 0.0
 
 
+def test_parity_on_saturated_network_outputs(oracle_mod, gpu_device):
+    """Scores shaped like GlobalNormFlipFlop's output (5 tanh(y), layers.py:1402-1411) with a wide
+    pre-activation: most entries saturate at exactly +-5, so equal scores -- and exact ties in the
+    Viterbi recursion -- are everywhere.  All three operators against the oracle; the path must
+    still be the reference's (first index wins)."""
+    from taiyaki_amd import synth
+    T, N = 300, 70
+    u1 = synth.uniform01(71, 1, T * N * 40).astype(np.float64)
+    u2 = synth.uniform01(71, 2, T * N * 40).astype(np.float64)
+    y = np.sqrt(-2.0 * np.log(np.maximum(u1, 2.0 ** -24))) * np.cos(2 * np.pi * u2) * 20.0
+    sc = (5.0 * np.tanh(y)).astype(np.float32).reshape(T, N, 40)
+    assert (np.abs(sc) == 5.0).mean() > 0.3
+    r = parity.compare_logz(oracle_mod, sc, gpu_device)
+    assert r["finite"] and r["logz_rel"] < LOSS_RTOL and r["grad_abs"] < GRAD_ATOL
+    v = parity.compare_viterbi(oracle_mod, sc, gpu_device)
+    assert v["path_mismatch"] == 0 and v["tb_mismatch"] == 0 and v["fwd_bit_mismatch"] == 0
+    inp = synth.crf_case(T, N, 72)
+    inp["scores"] = sc
+    rc = parity.compare_crf(oracle_mod, inp, 1.0, gpu_device)
+    assert rc["finite"] and rc["loss_rel"] < LOSS_RTOL and rc["grad_abs"] < GRAD_ATOL
+
+
 def test_logz_above_the_streaming_threshold(gpu_device):
     """T=4000 x N=512 (328 MB of scores: the transfer kernel streams with non-temporal loads, two
     workgroups per CU): posteriors are distributions, and the first 256 reads give bit for bit

@@ -1,0 +1,64 @@
+#!/usr/bin/env python
+"""Random-shape sweep of the three lattice operators against the oracle (GPU box; test
+infrastructure).  Shapes straddle the launcher's regime switches: cooperative / one-wave / LDS-ring
+transfer kernels (ncols x chunks around 640 and 900), 8- vs 16-row chunks (around 384), partial
+columns (N % 64), ragged last chunks, single rows.
+
+    python -m tests.helpers.fuzz_shapes [--cases 40] [--seed 1]
+"""
+import argparse
+import os
+import sys
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, ROOT)
+import oracle  # noqa: E402
+from taiyaki_amd import synth  # noqa: E402
+from tests import parity  # noqa: E402
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--cases", type=int, default=40)
+    ap.add_argument("--seed", type=int, default=1)
+    args = ap.parse_args()
+    rng = np.random.RandomState(args.seed)
+    dev = torch.device("cuda:0")
+    bad = 0
+    edges = [(1, 1), (15, 64), (16, 65), (17, 63), (639 * 16 // 10, 640), (2048, 300), (2049, 300),
+             (1536, 384), (1535, 385), (2400, 320), (3601, 256), (100, 1000), (9, 2048)]
+    for k in range(args.cases):
+        if k < len(edges):
+            T, N = edges[k]
+        else:
+            T, N = int(rng.randint(1, 2600)), int(rng.randint(1, 420))
+        sc = synth.scores(T, N, 40, 7000 + k)
+        r = parity.compare_logz(oracle, sc, dev)
+        v = parity.compare_viterbi(oracle, sc, dev)
+        L = max(1, min(T - 1, int(T * rng.uniform(0.05, 0.85)))) if T > 1 else 1
+        # a zero-length read is only put LAST: the reference's move-index layout gives every read
+        # L - 1 slots (c_crf_flipflop.c:479-480), i.e. minus one for an empty read, so an empty read
+        # in the middle makes its neighbours' slots overlap -- in the reference and in its oracle
+        seqlens = np.clip(rng.randint(1, L + 1, size=N), 1, max(T, 1)).astype(np.int32)
+        if k % 3 == 0:
+            seqlens[-1] = 0
+        inp = synth.crf_case(T, N, 7100 + k, seqlens=seqlens)
+        inp["scores"] = sc
+        c = parity.compare_crf(oracle, inp, 1.0, dev)
+        ok = (r["finite"] and r["logz_rel"] < 1e-5 and r["grad_abs"] < 2e-5 and r["nograd_same"] == 0.0 and
+              v["path_mismatch"] == 0 and v["fwd_bit_mismatch"] == 0 and
+              c["finite"] and c["loss_rel"] < 1e-4 and c["grad_abs"] < 2e-5)     # 1e-4: north_star; the fp32
+              # reference itself carries ~1e-5 at T ~ 2000 for one-base sequences
+        bad += not ok
+        print("%s T=%4d N=%4d  logz %.1e / %.1e  viterbi %d  crf %.1e / %.1e" % (
+            "ok  " if ok else "FAIL", T, N, r["logz_rel"], r["grad_abs"], v["path_mismatch"], c["loss_rel"],
+            c["grad_abs"]), flush=True)
+    print("fuzz: %d cases, %d failures" % (args.cases, bad))
+    sys.exit(1 if bad else 0)
+
+
+if __name__ == "__main__":
+    main()

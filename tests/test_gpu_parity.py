@@ -371,6 +371,31 @@ def test_logz_transfer_register_and_lds_ring_forms(oracle_mod, gpu_device, T, N,
     assert r["rowsum_dev"] < 1e-5 and r["nograd_same"] == 0.0
 
 
+def test_crf_reads_do_not_depend_on_their_batch(gpu_device):
+    """Every read of a ragged batch -- empty reads in the middle, single-base reads, one read as
+    long as the block allows -- gives bit for bit the loss and gradient it gives alone.  (The
+    oracle cannot be asked: the reference's move-index layout gives a read L - 1 slots, minus one
+    for an empty read, so an empty read in the middle makes its neighbours' slots overlap.)"""
+    from taiyaki_amd import synth
+    T, N = 40, 70
+    rng = np.random.RandomState(5)
+    seqlens = rng.randint(0, 30, size=N).astype(np.int32)
+    seqlens[[3, 4, 17, 40, 69]] = 0
+    seqlens[[5, 41]] = 1
+    seqlens[10] = 36
+    inp = synth.crf_case(T, N, 91, seqlens=seqlens)
+    loss, grad = parity.run_crf(inp, 1.0, gpu_device)
+    assert np.isfinite(loss).all() and np.isfinite(grad).all()
+    off = np.concatenate([[0], np.cumsum(seqlens)])
+    for n in (2, 3, 5, 9, 10, 16, 17, 18, 39, 40, 41, 68, 69):
+        one = dict(scores=np.ascontiguousarray(inp["scores"][:, n:n + 1]), seqs=inp["seqs"][off[n]:off[n + 1]],
+                   seqlens=seqlens[n:n + 1])
+        l1, g1 = parity.run_crf(one, 1.0, gpu_device)
+        assert np.array_equal(l1[0], loss[n]) and np.array_equal(g1[:, 0], grad[:, n]), n
+        if seqlens[n] == 0:
+            assert loss[n] == 0.0 and not grad[:, n].any()
+
+
 def test_parity_on_saturated_network_outputs(oracle_mod, gpu_device):
     """Scores shaped like GlobalNormFlipFlop's output (5 tanh(y), layers.py:1402-1411) with a wide
     pre-activation: most entries saturate at exactly +-5, so equal scores -- and exact ties in the

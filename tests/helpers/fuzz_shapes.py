@@ -48,14 +48,20 @@ def main():
         inp = synth.crf_case(T, N, 7100 + k, seqlens=seqlens)
         inp["scores"] = sc
         c = parity.compare_crf(oracle, inp, 1.0, dev)
-        ok = (r["finite"] and r["logz_rel"] < 1e-5 and r["grad_abs"] < 2e-5 and r["nograd_same"] == 0.0 and
+        # the cat-mod variant of the same kernels on every third case (46 columns, own scores)
+        cm_ok, cm = True, None
+        if k % 3 == 1 and T > 1:
+            minp = synth.crf_case(T, N, 7200 + k, nmods_per_base=(1, 1, 0, 0), seqlens=seqlens)
+            cm = parity.compare_crf(oracle, minp, 1.0, dev)
+            cm_ok = cm["finite"] and cm["loss_rel"] < 1e-4 and cm["grad_abs"] < 5e-5
+        ok = cm_ok and (r["finite"] and r["logz_rel"] < 1e-5 and r["grad_abs"] < 2e-5 and r["nograd_same"] == 0.0 and
               v["path_mismatch"] == 0 and v["fwd_bit_mismatch"] == 0 and
               c["finite"] and c["loss_rel"] < 1e-4 and c["grad_abs"] < 2e-5)     # 1e-4: north_star; the fp32
               # reference itself carries ~1e-5 at T ~ 2000 for one-base sequences
         bad += not ok
         print("%s T=%4d N=%4d  logz %.1e / %.1e  viterbi %d  crf %.1e / %.1e" % (
             "ok  " if ok else "FAIL", T, N, r["logz_rel"], r["grad_abs"], v["path_mismatch"], c["loss_rel"],
-            c["grad_abs"]), flush=True)
+            c["grad_abs"]) + ("  catmod %.1e / %.1e" % (cm["loss_rel"], cm["grad_abs"]) if cm else ""), flush=True)
     print("fuzz: %d cases, %d failures" % (args.cases, bad))
     sys.exit(1 if bad else 0)
 

@@ -250,15 +250,18 @@ bool host_seq_call(float const *logprob, size_t ntrans, size_t nblk, size_t nbat
         mod.assign(total ? total : 1, 0);
         fact.assign(total ? total : 1, 0.f);
     }
+    // read b's moves start at off[b] - b (c_crf_flipflop.c:479-480: L - 1 slots per read).  With
+    // empty reads in front that can point before the array in the reference; clamp instead
+    auto mbase = [&](size_t b) { return (size_t)off[b] >= b ? (size_t)off[b] - b : (size_t)0; };
     for (size_t b = 0; b < nbatch; ++b) {
         const size_t L = (size_t)seqlen[b];
         for (size_t p = 0; p < L; ++p) {
             stay[off[b] + p] = (int32_t)stayidxs[off[b] + p];
             if (p + 1 < L) {
-                move[off[b] + p] = (int32_t)moveidxs[off[b] - b + p];
+                move[off[b] + p] = (int32_t)moveidxs[mbase(b) + p];
                 if (modmoveidxs) {
-                    mod[off[b] + p] = (int32_t)modmoveidxs[off[b] - b + p];
-                    fact[off[b] + p] = modmovefacts[off[b] - b + p];
+                    mod[off[b] + p] = (int32_t)modmoveidxs[mbase(b) + p];
+                    fact[off[b] + p] = modmovefacts[mbase(b) + p];
                 }
             } else {
                 move[off[b] + p] = 0;
@@ -293,7 +296,7 @@ bool host_seq_call(float const *logprob, size_t ntrans, size_t nblk, size_t nbat
     if (modmoveidxs) {
         for (size_t b = 0; b < nbatch; ++b)
             for (size_t p = 0; p + 1 < (size_t)seqlen[b]; ++p)
-                if (modmoveidxs[off[b] - b + p] < ncan) ncan = modmoveidxs[off[b] - b + p];
+                if (modmoveidxs[mbase(b) + p] < ncan) ncan = modmoveidxs[mbase(b) + p];
     }
     const int rc = tk::crf_dispatch(
         static_cast<const float *>(d_lp.p), ntrans, nblk, nbatch,

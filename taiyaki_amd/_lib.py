@@ -13,7 +13,7 @@ import torch
 _HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(_HERE, "csrc")
 LIBNAME = "libtaiyaki_amd_flipflop.so"
-LIBPATH = os.path.join(CSRC, LIBNAME)
+LIBPATH = os.environ.get("TAIYAKI_AMD_LIB") or os.path.join(CSRC, LIBNAME)   # (override: lab builds)
 
 _vp = ctypes.c_void_p
 _sz = ctypes.c_size_t

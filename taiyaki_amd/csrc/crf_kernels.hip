@@ -31,6 +31,7 @@
 //     c_crf_flipflop.c:400-401) and streams it out once.
 #include <stdlib.h>
 
+#include "crf_band.h"
 #include "ff_common.h"
 
 namespace tk {
@@ -1143,9 +1144,31 @@ static CrfLatLayout crf_lattice_layout(size_t ntrans, size_t nblk, size_t nbatch
 // Lattice mode when both lattices fit under the cap (default 24 GiB of the 288 GB,
 // TK_CRF_LATTICE_MB overrides; 0 forces the checkpoint kernel)
 static bool crf_use_lattice(size_t ntrans, size_t nblk, size_t nbatch, size_t max_seqlen, CrfShape sh) {
-    size_t cap_mb = 24576;
+    size_t cap_mb = 40960;
     if (const char *e = getenv("TK_CRF_LATTICE_MB")) cap_mb = (size_t)atoll(e);
     return crf_lattice_layout(ntrans, nblk, nbatch, max_seqlen, sh).total <= cap_mb * 1024 * 1024;
+}
+
+// Which form of kernel A runs (TK_CRF_MODE overrides: band | lattice | ckpt):
+//   band     crf_band.hip -- banded skewed sweep + row-parallel posterior pass (default whenever
+//            the sequences fit 16 waves x 256 cells and the two lattices fit the workspace cap)
+//   lattice  the per-step-barrier sweep + tile posterior of this file (kept for A/B runs)
+//   ckpt     single-launch checkpoint/recompute kernel, no lattice in HBM (workspace-bound batches)
+enum CrfMode { CRF_BAND, CRF_LATTICE, CRF_CKPT };
+static size_t crf_lattice_cap_bytes() {
+    size_t cap_mb = 40960;          // 40 GiB of the 288 GB
+    if (const char *e = getenv("TK_CRF_LATTICE_MB")) cap_mb = (size_t)atoll(e);
+    return cap_mb * 1024 * 1024;
+}
+static CrfMode crf_pick_mode(size_t ntrans, size_t nblk, size_t nbatch, size_t max_seqlen, bool want_grad,
+                             bool mod, CrfShape sh) {
+    const char *e = getenv("TK_CRF_MODE");
+    const bool force_ckpt = e && e[0] == 'c', force_lat = e && e[0] == 'l';
+    if (!force_ckpt && !force_lat && crf_band_fits(max_seqlen) &&
+        (!want_grad || crf_band_layout(ntrans, nblk, nbatch, max_seqlen, mod).total <= crf_lattice_cap_bytes()))
+        return CRF_BAND;
+    if (!want_grad || force_ckpt) return CRF_CKPT;
+    return crf_use_lattice(ntrans, nblk, nbatch, max_seqlen, sh) ? CRF_LATTICE : CRF_CKPT;
 }
 
 size_t crf_workspace_bytes(size_t ntrans, size_t nblk, size_t nbatch, size_t max_seqlen,
@@ -1153,9 +1176,12 @@ size_t crf_workspace_bytes(size_t ntrans, size_t nblk, size_t nbatch, size_t max
     if (!want_grad) return 256;
     if (max_seqlen == 0) max_seqlen = nblk + 1;
     const CrfShape sh = crf_pick_shape(max_seqlen);
-    if (crf_use_lattice(ntrans, nblk, nbatch, max_seqlen, sh))
-        return crf_lattice_layout(ntrans, nblk, nbatch, max_seqlen, sh).total;
-    return crf_ckpt_bytes(nblk, nbatch, sh);
+    // (the cat-mod layout is the larger one: an upper bound for both)
+    switch (crf_pick_mode(ntrans, nblk, nbatch, max_seqlen, true, true, sh)) {
+        case CRF_BAND: return crf_band_layout(ntrans, nblk, nbatch, max_seqlen, true).total;
+        case CRF_LATTICE: return crf_lattice_layout(ntrans, nblk, nbatch, max_seqlen, sh).total;
+        default: return crf_ckpt_bytes(nblk, nbatch, sh);
+    }
 }
 
 // The sweep and the posterior pass only share per-POSITION data (lattices, slots), so each
@@ -1282,7 +1308,44 @@ int crf_dispatch(const float *logprob, size_t ntrans, size_t nblk, size_t nbatch
     a.out_scale = out_scale;
     a.cost = cost;
     a.grad = grad;
-    const bool lattice = grad != nullptr && crf_use_lattice(ntrans, nblk, nbatch, max_seqlen, sh);
+    const bool mod = modidx != nullptr;
+    const CrfMode mode = crf_pick_mode(ntrans, nblk, nbatch, max_seqlen, grad != nullptr, true, sh);
+    if (mode == CRF_BAND) {
+        const BandLayout l = crf_band_layout(ntrans, nblk, nbatch, max_seqlen, mod);
+        char *wb = static_cast<char *>(workspace);
+        BandArgs b;
+        b.lp = logprob;
+        b.T = (int)nblk;
+        b.N = (int)nbatch;
+        b.S = (int)ntrans;
+        b.ncan = (int)ncan;
+        b.stay = stayidx;
+        b.move = moveidx;
+        b.mod = modidx;
+        b.modfact = modfact;
+        b.seqlen = seqlen;
+        b.seqoff = seqoff;
+        b.c_can = sharp_can * LOG2E;
+        b.c_mod = sharp_mod * LOG2E;
+        b.out_scale = out_scale;
+        b.cost = cost;
+        b.grad = grad;
+        b.status = status;
+        b.W = l.W;
+        b.LP = (int)l.LP;
+        const bool g = grad != nullptr;
+        b.latF = g ? reinterpret_cast<float *>(wb + l.latF) : nullptr;
+        b.latB = g ? reinterpret_cast<float *>(wb + l.latB) : nullptr;
+        b.offF = g ? reinterpret_cast<int *>(wb + l.offF) : nullptr;
+        b.offB = g ? reinterpret_cast<int *>(wb + l.offB) : nullptr;
+        b.scoreF = g ? reinterpret_cast<double *>(wb + l.scoreF) : nullptr;
+        b.scoreB = g ? reinterpret_cast<double *>(wb + l.scoreB) : nullptr;
+        b.rec = g ? reinterpret_cast<uint32_t *>(wb + l.rec) : nullptr;
+        b.recw = g ? reinterpret_cast<float *>(wb + l.recw) : nullptr;
+        b.segend = g ? reinterpret_cast<int *>(wb + l.segend) : nullptr;
+        return crf_band_dispatch(b, l.R, mod, stream);
+    }
+    const bool lattice = mode == CRF_LATTICE;
     char *wsb = static_cast<char *>(workspace);
     if (lattice) {
         const CrfLatLayout l = crf_lattice_layout(ntrans, nblk, nbatch, max_seqlen, sh);

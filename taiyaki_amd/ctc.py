@@ -39,6 +39,9 @@ def _indices(seqs, seqlen, nbase, device, mod_cats=None, can_mods_offsets=None,
     return seqlen_d, seqoff, stay, move, mod, fact, (seqs_d, mc, cmo, mcw)
 
 
+_KEEP_WS = None      # debugging aid: set to a list to keep the kernels' workspaces alive
+
+
 def _max_seqlen(seqlen):
     """Exact bound without a device sync when seqlen lives on the host
     (bin/train_flipflop.py:133-138); 0 (= unknown) otherwise."""
@@ -63,6 +66,8 @@ def _run(logprob, seqs, seqlen, sharp_can, sharp_mod, out_scale, ncan, want_grad
         grad = torch.empty_like(lp) if want_grad else None
         wsb = L.tk_crf_flipflop_workspace_bytes(ntrans, nblk, nbatch, maxlen, int(want_grad))
         ws = torch.empty(wsb, dtype=torch.uint8, device=dev)
+        if _KEEP_WS is not None:
+            ws.zero_()
         status = _lib.status_word(dev)
         rc = L.tk_crf_flipflop_dev(
             _lib.ptr(lp), ntrans, nblk, nbatch, _lib.ptr(stay), _lib.ptr(move), _lib.ptr(mod),
@@ -72,6 +77,8 @@ def _run(logprob, seqs, seqlen, sharp_can, sharp_mod, out_scale, ncan, want_grad
         _lib.check(rc, "tk_crf_flipflop_dev")
         _lib.finish(status)
     del keep
+    if _KEEP_WS is not None:
+        _KEEP_WS.append(ws)
     return cost, grad
 
 

@@ -31,6 +31,7 @@ struct BandArgs {
     uint32_t *rec;              // [N][W][EPL][64]  sorted transition instances of every chunk
     float *recw;                // (cat-mod) their mod weights
     int *segend;                // [N][W][64]  end of every transition id's segment
+    unsigned long long *dbg;    // lab builds only (TK_LAB_STAMPS): s_memtime stamps of workgroup 0, wave 0
 };
 
 struct BandLayout {

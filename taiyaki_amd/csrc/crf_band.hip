@@ -15,7 +15,7 @@
 //     Inside a block a step is R cells per lane, one DPP wave shift and 2R ds_bpermute
 //     gathers from the score row, which the wave holds in ONE VGPR (lane = transition id):
 //     no LDS tile, no cross-wave dependency, rows are prefetched two blocks ahead.
-//   * Every chunk carries its own INTEGER log2 offset and renormalises every BNORM = 4 steps
+//   * Every chunk carries its own INTEGER log2 offset and renormalises every BNORM = 8 steps
 //     by floor(max(own cells, incoming boundary cells)): subtracting an integer is exact in
 //     fp32 and the offsets add exactly in int32 -- no fp64 on the path.  (The reference
 //     subtracts the column maximum every step, c_crf_flipflop.c:73-77; any common offset is
@@ -30,6 +30,7 @@
 //     (c_crf_flipflop.c:403-412) are differences of ONE prefix scan held in registers (DPP
 //     scan + ds_bpermute look-ups): no atomics, no cross-wave reduction, no barrier, and the
 //     summation order is fixed -> bitwise reproducible.
+#include <stdio.h>
 #include <stdlib.h>
 
 #include "crf_band.h"
@@ -38,7 +39,7 @@
 namespace tk {
 
 constexpr int BK = 8;               // time steps per block (= per workgroup barrier)
-constexpr int BNORM = 4;            // steps between renormalisations
+constexpr int BNORM = 8;            // steps between renormalisations (a multiple of 4 that divides BK)
 constexpr int BSUB = BK / BNORM;
 constexpr int BAND_MAXW = 16;       // waves per workgroup
 constexpr int POST_WAVES = 8;       // waves per posterior workgroup
@@ -64,17 +65,11 @@ __device__ __forceinline__ bool want_grad_launch(const BandArgs &a) { return a.g
 
 __device__ __forceinline__ void band_barrier() {
     // LDS traffic only: the lattice stores stay in flight across the barrier
-#ifndef TK_LAB_NOBARRIER
     asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
-#endif
 }
 
 __device__ __forceinline__ float bperm(int byteaddr, float v) {
-#ifdef TK_LAB_NOGATHER
-    return v + __int_as_float(byteaddr);
-#else
     return __int_as_float(__builtin_amdgcn_ds_bpermute(byteaddr, __float_as_int(v)));
-#endif
 }
 
 template <int CTRL, int ROWMASK>
@@ -114,18 +109,9 @@ __device__ __forceinline__ float band_row(const float *lpn, size_t rowstride, in
 // row_bcast 15 / 31) leave it in lane 63.  hipcc's own expansion of the same reduction is ~25
 // instructions (v_mov_dpp + two v_max per stage); the sweep is issue-bound, so this matters.
 __device__ __forceinline__ float wave_max_scalar(float x) {
-#if defined(TK_LAB_NORENORM)
-    return x;
-#elif defined(TK_LAB_OLDMAX)
-    return wave_allmax_dpp(x);
-#else
     // one statement per instruction (each carries its own DPP-hazard wait states) so that the
     // scheduler may interleave the reduction with the steps it runs beside
-#ifdef TK_LAB_VOLMAX
-#define TK_ASM asm volatile
-#else
 #define TK_ASM asm
-#endif
     TK_ASM("s_nop 1\n\tv_max_f32_dpp %0, %0, %0 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf" : "+v"(x));
     TK_ASM("s_nop 1\n\tv_max_f32_dpp %0, %0, %0 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf" : "+v"(x));
     TK_ASM("s_nop 1\n\tv_max_f32_dpp %0, %0, %0 row_half_mirror row_mask:0xf bank_mask:0xf" : "+v"(x));
@@ -134,7 +120,6 @@ __device__ __forceinline__ float wave_max_scalar(float x) {
     TK_ASM("s_nop 1\n\tv_max_f32_dpp %0, %0, %0 row_bcast:31 row_mask:0xc bank_mask:0xf" : "+v"(x));
 #undef TK_ASM
     return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(x), 63));
-#endif
 }
 
 constexpr int BUF_WORD3 = 0x00027000;       // raw buffer descriptor, 32-bit data (gfx9 family)
@@ -225,68 +210,85 @@ __device__ __forceinline__ void band_sweep(const BandArgs &a, int n, int L, floa
         const int last = T - 1 - j * BK;                        // rows past the end re-read the last one
 #pragma unroll
         for (int i = 0; i < BK; ++i) {
-#ifdef TK_LAB_NOLOAD
-            dst[i] = (float)(j * BK + i) * 1e-3f;
-#else
             dst[i] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rs, col4, rs4 * (unsigned)min(i, last), 0));
-#endif
         }
     };
 
-    // Gathered, sharpened scores of ONE time step: everything of a cell update that does not
-    // depend on the cells.  The boundary cell coming in from the neighbouring chunk is folded into
-    // the boundary lane's move term (that lane's DPP source is out of range and reads 0).
+    // Scores of ONE time step gathered by transition id (raw): issued a step ahead of their use.
     struct Gath {
-        float sc[R], mc[R];     // stay term, move term (+ mod term, + boundary cell)
+        float ls[R], lm[R], ld[MOD ? R : 1];
     };
-    const bool edge_in = lane == (FWD ? 0 : WAVE - 1);
-    auto gather = [&](float rowraw, float edge) {
+    auto gather = [&](float rowraw) {
         const float row = is_col ? rowraw : sent;
         Gath g;
 #pragma unroll
         for (int jj = 0; jj < R; ++jj) {
-            g.sc[jj] = bperm(st4[jj], row) * c;
-            float m = bperm(mv4[jj], row) * c;
-            if (MOD) m = fmaf(bperm(md4[MOD ? jj : 0], row), fw[MOD ? jj : 0], m);
-            if (jj == (FWD ? 0 : R - 1)) m += edge_in ? edge : 0.f;
-            g.mc[jj] = m;
+            g.ls[jj] = bperm(st4[jj], row);
+            g.lm[jj] = bperm(mv4[jj], row);
+            if (MOD) g.ld[MOD ? jj : 0] = bperm(md4[MOD ? jj : 0], row);
         }
         return g;
     };
-    // one time step on the cells: forward consumes row t (column t -> t+1), backward t+1 -> t.
-    // On the serial chain: v_add_f32_dpp (neighbour cell + move term), sub, exp, add, log, add.
-    auto advance = [&](const Gath &g) {
+    const bool edge_in = lane == (FWD ? 0 : WAVE - 1);
+    // One time step on the cells: forward consumes row t (column t -> t+1), backward t+1 -> t.
+    // Everything that does not depend on the cells is computed first (sharpened stay / move terms;
+    // the boundary cell coming in from the neighbouring chunk is folded into the boundary lane's
+    // move term, whose DPP source is out of range and reads 0).  On the serial chain:
+    // v_add_f32_dpp (neighbour cell + move term), sub, exp, add, log, add.
+    const float emask = edge_in ? 1.f : 0.f;
+    auto advance = [&](const Gath &g, float ein_i, float dmask) {
+        // (ein_i + delta) on the boundary lane, 0 elsewhere: fma(ein_i, emask, delta * emask)
+        const float eterm = fmaf(ein_i, emask, dmask);
+        float sc[R], mc[R];
+#pragma unroll
+        for (int jj = 0; jj < R; ++jj) {
+            sc[jj] = g.ls[jj] * c;
+            float m = (jj == (FWD ? 0 : R - 1)) ? fmaf(g.lm[jj], c, eterm) : g.lm[jj] * c;
+            if (MOD) m = fmaf(g.ld[MOD ? jj : 0], fw[MOD ? jj : 0], m);
+            mc[jj] = m;
+        }
+        float nb;       // the neighbouring lane's boundary cell + this lane's boundary move term
+        if constexpr (FWD)
+            asm("s_nop 1\n\tv_add_f32_dpp %0, %1, %2 wave_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:1"
+                : "=v"(nb) : "v"(x[R - 1]), "v"(mc[0]));
+        else
+            asm("s_nop 1\n\tv_add_f32_dpp %0, %1, %2 wave_shl:1 row_mask:0xf bank_mask:0xf bound_ctrl:1"
+                : "=v"(nb) : "v"(x[0]), "v"(mc[R - 1]));
         if constexpr (FWD) {
-            // lane l <- cell R-1 of lane l-1; lane 0 reads 0 (bound_ctrl) and has the boundary cell in mc
-            const float left0 = __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x[R - 1]), 0x138, 0xF, 0xF, true));
 #pragma unroll
             for (int jj = R - 1; jj >= 0; --jj) {
-                const float left = (jj == 0) ? left0 : x[jj > 0 ? jj - 1 : 0];
-                x[jj] = lse2(x[jj] + g.sc[jj], left + g.mc[jj]);
+                const float bv = (jj == 0) ? nb : x[jj > 0 ? jj - 1 : 0] + mc[jj];
+                x[jj] = lse2(x[jj] + sc[jj], bv);
             }
         } else {
-            const float right0 = __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x[0]), 0x130, 0xF, 0xF, true));
 #pragma unroll
             for (int jj = 0; jj < R; ++jj) {
-                const float right = (jj == R - 1) ? right0 : x[jj < R - 1 ? jj + 1 : 0];
-                x[jj] = lse2(x[jj] + g.sc[jj], right + g.mc[jj]);
+                const float bv = (jj == R - 1) ? nb : x[jj < R - 1 ? jj + 1 : 0] + mc[jj];
+                x[jj] = lse2(x[jj] + sc[jj], bv);
             }
         }
     };
 
-    float mpend = 0.f;      // renormalisation decided at the previous group of rows, not yet applied
+    int stamp_k = 0;
+#ifdef TK_LAB_STAMPS
+#define STAMP(q)                                                                            \
+    if (a.dbg && blockIdx.x == (GRAD ? a.N : 0) && w == 0 && lane == 0 && stamp_k < 64)        \
+        a.dbg[stamp_k * 8 + (q)] = __builtin_amdgcn_s_memtime();
+#else
+#define STAMP(q)
+#endif
+    (void)stamp_k;
 
     // One live phase = one time block of this chunk.  The sweep is bound by instruction ISSUE on
     // the read's CU (all of a read's waves share one CU) and, per wave, by the dependent chain
     // dpp -> fma -> sub -> exp -> add -> log -> add of a step (~105 cycles, tools/latlab.hip).
     // Everything that does not depend on the cells is kept off that chain:
     //   * the gathers of step i+1 are issued before the arithmetic of step i;
-    //   * the renormalisation is LAGGED: floor(max(...)) of the column at the start of a group of
-    //     BNORM rows is computed beside that group's steps and subtracted at the start of the
-    //     next group (any integer offset is exact, so when it is applied is free);
+    //   * one renormalisation per block (BNORM = BK): a six-instruction DPP maximum;
     //   * the incoming boundary cells and offsets of the whole block are read at its start;
     //   * a full block is straight-line code (no exec-mask or scalar branch between the steps).
     auto body = [&](int j, const float (&cur)[BK], float (&fill)[BK]) {
+        STAMP(0);
         load_block(FWD ? j + 2 : j - 2, fill);
         const bool pl = j >= wsrc.j0 && j <= wsrc.j1;           // the neighbour ran this block one phase ago
         const int slot = j & 1;
@@ -296,57 +298,58 @@ __device__ __forceinline__ void band_sweep(const BandArgs &a, int n, int L, floa
         float *Ew = (lane == edge_lane) ? E + (w * 2 + slot) * BK : Escratch + w * (WAVE + BK) + lane;
         float ein[BK];
         int osrc[BSUB], omine[BSUB];
-        {
+#pragma unroll
+        for (int i = 0; i < BK; ++i) ein[i] = neg;
+#pragma unroll
+        for (int ss = 0; ss < BSUB; ++ss) osrc[ss] = omine[ss] = 0;
+        if (pl) {
             const f4 *Ein = reinterpret_cast<const f4 *>(E + (srcc * 2 + slot) * BK);
 #pragma unroll
-            for (int ss = 0; ss < BSUB; ++ss) {
-                const f4 e = Ein[ss];
-                osrc[ss] = Eoff[(srcc * 2 + slot) * BSUB + ss];
-                omine[ss] = 0;
+            for (int ss = 0; ss < BSUB; ++ss) osrc[ss] = Eoff[(srcc * 2 + slot) * BSUB + ss];
 #pragma unroll
-                for (int q = 0; q < BNORM; ++q) ein[ss * BNORM + q] = pl ? e[q] : neg;
+            for (int q4 = 0; q4 < BK / 4; ++q4) {
+                const f4 e = Ein[q4];
+#pragma unroll
+                for (int q = 0; q < 4; ++q) ein[q4 * 4 + q] = e[q];
             }
         }
         __amdgpu_buffer_rsrc_t lat_rs = __builtin_amdgcn_make_buffer_rsrc(
             GRAD ? latn + (size_t)(j * BK) * a.LP : nullptr, 0, 0x7fffffff, BUF_WORD3);
         const int nvalid = min(BK, T - j * BK);                 // rows of this block that exist
+        STAMP(1);
         float delta = 0.f;
         auto group_start = [&](int sub, int qlo, int qhi) {
-            // apply the pending renormalisation, then decide the next one from this column
-            // and the boundary cells that will come in during the group [qlo, qhi]
-#pragma unroll
-            for (int jj = 0; jj < R; ++jj) x[jj] -= mpend;
-            offacc += (int)mpend;
-            omine[sub] = offacc;
-            delta = (float)((pl ? osrc[sub] : offacc) - offacc);
+            // renormalise by floor(max(this column, the boundary cells that will come in during the
+            // group [qlo, qhi])): an integer, so the subtraction is exact and the offsets add exactly
             float mx = x[0];
 #pragma unroll
             for (int jj = 1; jj < R; ++jj) mx = fmaxf(mx, x[jj]);
             mx = wave_max_scalar(mx);
+            const int d0 = (pl ? osrc[sub] : offacc) - offacc;
+            const float delta0 = (float)d0;
 #pragma unroll
             for (int q = 0; q < BNORM; ++q)
-                if (q >= qlo && q <= qhi) mx = fmaxf(mx, ein[sub * BNORM + q] + delta);
-#ifdef TK_LAB_NORENORM
-            mpend = 0.f * mx;
-#else
-            mpend = (mx > -1e29f) ? floorf(mx) : 0.f;
-#endif
+                if (q >= qlo && q <= qhi) mx = fmaxf(mx, ein[sub * BNORM + q] + delta0);
+            const float m = (mx > -1e29f) ? floorf(mx) : 0.f;
+#pragma unroll
+            for (int jj = 0; jj < R; ++jj) x[jj] -= m;
+            const int mi = (int)m;
+            offacc += mi;
+            omine[sub] = offacc;
+            delta = (float)(d0 - mi);
         };
         if (nvalid == BK) {
-            Gath g;
+            Gath g = gather(cur[FWD ? 0 : BK - 1]);
 #pragma unroll
             for (int ii = 0; ii < BK; ++ii) {
                 const int i = FWD ? ii : BK - 1 - ii;
-                if ((ii % BNORM) == 0) {
-                    group_start(i / BNORM, 0, BNORM - 1);
-                    g = gather(cur[i], ein[i] + delta);         // (delta changes with the group)
-                }
+                if ((ii % BNORM) == 0) group_start(i / BNORM, 0, BNORM - 1);
                 Gath gn = g;
-                if ((ii + 1) % BNORM != 0) gn = gather(cur[FWD ? i + 1 : i - 1], ein[FWD ? i + 1 : i - 1] + delta);
+                if (ii + 1 < BK) gn = gather(cur[FWD ? i + 1 : i - 1]);
                 // forward: column t (before row t is consumed); backward: column t+1
                 if (GRAD) band_buffer_store<R>(lat_rs, lane_cell4, lp4 * (unsigned)i, x);
                 Ew[i] = FWD ? x[R - 1] : x[0];                 // the boundary lane's word is the real one
-                advance(g);
+                advance(g, ein[i], delta * emask);
                 g = gn;
             }
         } else {
@@ -369,12 +372,13 @@ __device__ __forceinline__ void band_sweep(const BandArgs &a, int n, int L, floa
                         rowraw = cur[k];
                         e = ein[k];
                     }
-                const Gath g = gather(rowraw, e + delta);
+                const Gath g = gather(rowraw);
                 if (GRAD) band_buffer_store<R>(lat_rs, lane_cell4, lp4 * (unsigned)i, x);
                 Ew[i] = FWD ? x[R - 1] : x[0];
-                advance(g);
+                advance(g, e, delta * emask);
             }
         }
+        STAMP(2);
         // this block's offsets: to the ring (the neighbour reads them next phase) and to HBM
         if (lane < BSUB) {
             int o = omine[0];
@@ -384,7 +388,10 @@ __device__ __forceinline__ void band_sweep(const BandArgs &a, int n, int L, floa
             Eoff[(w * 2 + slot) * BSUB + lane] = o;
             if (GRAD && j * BK + lane * BNORM < T) offn[(size_t)(j * BSUB + lane) * W] = o;
         }
+        STAMP(3);
         band_barrier();
+        STAMP(4);
+        ++stamp_k;
     };
 
     // phases: chunk w runs block j in phase j + w (forward) / (NB-1-j) + (W-1-w) (backward);
@@ -707,13 +714,15 @@ __global__ __launch_bounds__(POST_WAVES *WAVE) void crf_band_posterior_kernel(Ba
 // ---------------------------------------------------------------------------
 // host side
 // ---------------------------------------------------------------------------
+// Cells per lane: the smallest R whose chunks fit the 16 waves of a workgroup.  The sweep is
+// bound by instruction issue (one VALU instruction per ~5 cycles and wave, tools/latlab.hip), a
+// read's live chunks sit on one CU, and the band keeps about half of them live at a time: small
+// chunks spread those over the CU's four SIMDs (cfg 2: R=1 108 us, R=2 115 us, R=4 158 us).
 int crf_band_pick_R(size_t max_seqlen) {
     int R = 1;
     if (const char *e = getenv("TK_CRF_BAND_R")) {
         R = atoi(e);
         if (R != 1 && R != 2 && R != 4) R = 1;
-    } else {
-        R = max_seqlen <= 256 ? 1 : (max_seqlen <= 2048 ? 2 : 4);
     }
     while (R < 4 && (size_t)R * WAVE * BAND_MAXW < max_seqlen) R *= 2;
     return R;
@@ -776,7 +785,30 @@ static int band_launch(const BandArgs &a, hipStream_t stream) {
     return hipGetLastError() == hipSuccess ? 0 : 4;
 }
 
-int crf_band_dispatch(const BandArgs &a, int R, bool mod, hipStream_t stream) {
+int crf_band_dispatch(const BandArgs &a0, int R, bool mod, hipStream_t stream) {
+    BandArgs a = a0;
+#ifdef TK_LAB_STAMPS
+    static unsigned long long *dbg = nullptr;
+    if (getenv("TK_CRF_STAMPS")) {
+        if (!dbg) (void)hipMalloc(&dbg, 64 * 8 * 8);
+        (void)hipMemsetAsync(dbg, 0, 64 * 8 * 8, stream);
+        a.dbg = dbg;
+    }
+    struct Printer {
+        unsigned long long *d;
+        hipStream_t s;
+        ~Printer() {
+            if (!d) return;
+            static unsigned long long h[64 * 8];
+            (void)hipStreamSynchronize(s);
+            (void)hipMemcpy(h, d, sizeof(h), hipMemcpyDeviceToHost);
+            for (int k = 2; k < 12; ++k)
+                fprintf(stderr, "phase %2d: loads+ring %5llu  steps %5llu  offsets %5llu  barrier %5llu  next-phase-gap %5llu\n", k,
+                        h[k * 8 + 1] - h[k * 8 + 0], h[k * 8 + 2] - h[k * 8 + 1], h[k * 8 + 3] - h[k * 8 + 2],
+                        h[k * 8 + 4] - h[k * 8 + 3], h[(k + 1) * 8 + 0] - h[k * 8 + 4]);
+        }
+    } printer{a.dbg, stream};
+#endif
     if (a.W < 1 || a.W > BAND_MAXW) return 2;
     switch (R * 2 + (mod ? 1 : 0)) {
         case 2: return band_launch<1, false>(a, stream);

@@ -5,30 +5,18 @@
 // (forward, backward, posterior scatter) and the index algebra of
 // taiyaki/flipflopfings.py:6-31 / ctc.pyx:127-134,282-292.
 //
-// Design (see DESIGN.md "Kernel A"):
-//   * one workgroup of W wavefronts per read, position-parallel: thread g owns
-//     the R consecutive lattice positions [g*R, (g+1)*R) in registers.  One time
-//     step = R independent cells per lane, ONE neighbour exchange (a DPP
-//     wave_shr/wave_shl inside a wave, a double-buffered LDS word between
-//     waves) and ONE s_barrier.  (R, W) are picked from the longest sequence so
-//     that a cfg-2 read (L ~ 450) runs on 4 waves x 2 cells.
-//   * arithmetic is log2-space (v_exp_f32 / v_log_f32 are base-2 natively):
-//     cell = max(a,b) + log2(1 + 2^-|a-b|), the reference's logaddexp.  The
-//     per-column max-subtraction of the reference (c_crf_flipflop.c:73-77) is
-//     applied every 4th column (a common offset is exact to account for; it is
-//     tracked in fp64); the block-wide max rides on the step barrier.
-//   * score rows are staged CK rows at a time in LDS and gathered by
-//     transition id; stay / move / mod ids live in registers.
-//   * the (T+1) x L forward lattice is never written out: the forward sweep
-//     stores one checkpoint column every CK steps; the backward sweep
-//     recomputes each CK-column tile into LDS ("LDS-tiled"), walks it backwards
-//     fused with the backward recursion and writes every posterior to a slot
-//     that was PRE-SORTED by transition id (positions are ranked once per read
-//     with ballots, deterministically).  At tile flush a wave turns a row into
-//     per-id sums with a DPP prefix scan and boundary differences -- no atomics
-//     (ds_add_f32 costs ~10 cycles per lane and was half of the kernel) -- then
-//     normalises the row (the reference's per-column softmax,
-//     c_crf_flipflop.c:400-401) and streams it out once.
+// Two forms (see DESIGN.md "Kernel A"):
+//   * crf_band.hip (default): banded skewed sweep + row-parallel posterior pass, both lattices
+//     of the band in HBM.  This file holds its launcher, the index construction and
+//   * crf_kernel below, the single-launch CHECKPOINT form for batches whose lattices would not
+//     fit the workspace cap: one workgroup of W wavefronts per read, position-parallel (thread
+//     g owns R consecutive lattice positions in registers, one DPP / LDS neighbour exchange and
+//     one s_barrier per time step, log2-space LSE, column max every 4th step tracked in fp64);
+//     the forward sweep stores one checkpoint column every CK steps, the backward sweep
+//     recomputes each CK-column tile into LDS, walks it backwards fused with the backward
+//     recursion and writes every posterior to a slot PRE-SORTED by transition id; at tile flush
+//     a wave turns a row into per-id sums with a DPP prefix scan and boundary differences (no
+//     atomics), normalises the row (c_crf_flipflop.c:400-401) and streams it out once.
 #include <stdlib.h>
 
 #include "crf_band.h"
@@ -54,13 +42,6 @@ struct CrfArgs {
     float *ckpt;                // workspace: checkpoint columns
     double *ckoff;              // workspace: checkpoint offsets
     uint32_t *status;
-    // lattice mode (crf_sweep_kernel + crf_posterior_kernel): both lattices live in HBM
-    float *latF, *latB;         // [N][T][LP] forward column before step t / backward column after it
-    int LP;                     // lattice row pitch: max_seqlen rounded up to 256 (<= LPAD)
-    double *offF, *offB;        // [N][T]       their log2 offsets
-    double *scoreF, *scoreB;    // [N]          log2 scores of the two sweeps
-    int *slotws;                // [N][LPAD] x (2 or 3) words: ids and sorted posterior slots, packed per position
-    int *segws;                 // [N][KINDS][S + 3] segment starts per transition id
 };
 
 __host__ __device__ inline int crf_ck(int R, int W, int kinds) {
@@ -497,517 +478,6 @@ __global__ __launch_bounds__(W *WAVE) void crf_kernel(CrfArgs a) {
     if (a.status && bad) atomicOr(a.status, 2u);
 }
 
-// ===========================================================================
-// LATTICE MODE.  With 288 GB of HBM both lattices of a batch fit in memory (cfg 2:
-// 2 x 210 MB), so nothing is recomputed and nothing serial is left in the posterior:
-//   crf_sweep_kernel      grid 2N: block n runs the forward recursion of read n, block
-//                         N + n its backward recursion, CONCURRENTLY on different CUs;
-//                         every column goes to HBM with its log2 offset (a coalesced
-//                         8-16 B per lane per step).  The forward block also ranks the
-//                         read's positions by transition id (sorted posterior slots).
-//   crf_posterior_kernel  grid (N, T / CKP): every tile of rows is independent -- load
-//                         the two lattice rows, form the 2L-1 posteriors, write them to
-//                         their sorted slots, segment-sum per transition id (DPP prefix
-//                         scan, no atomics), normalise, store the gradient row.
-// The serial chain per read drops from 3T steps (forward, recompute, backward fused with
-// the posterior) to T steps; the checkpoint kernel above remains for batches whose
-// lattices would not fit the workspace cap.
-// ===========================================================================
-__host__ __device__ inline int crf_ckp(int R, int W, int kinds) {
-    const int rowbytes = kinds * R * W * WAVE * 4;
-    return rowbytes * 8 <= 72 * 1024 ? 8 : (rowbytes * 4 <= 72 * 1024 ? 4 : 2);
-}
-constexpr int CRF_CKS = 16;         // score rows staged per tile in the sweep kernel
-
-__host__ __device__ inline size_t crf_sweep_lds_bytes(int W, int S, int kinds) {
-    const int SP = S + 2;
-    size_t f = (size_t)CRF_CKS * SP + (size_t)kinds * W * SP + (size_t)kinds * SP +
-               (size_t)kinds * (SP + 1) + 2 * W + W + 8;
-    return (f * 4 + 15) / 16 * 16;
-}
-__host__ __device__ inline size_t crf_post_lds_bytes(int R, int W, int S, int kinds) {
-    const int SP = S + 2, CKP = crf_ckp(R, W, kinds);
-    size_t f = (size_t)CKP * SP + (size_t)CKP * kinds * R * W * WAVE + (size_t)kinds * (SP + 1) +
-               (size_t)W * WAVE + CKP + 8;
-    return (f * 4 + 15) / 16 * 16;
-}
-
-template <int R>
-__device__ __forceinline__ void crf_store_cells(float *dst, const float (&x)[R]) {
-    if constexpr (R == 4) {
-        *reinterpret_cast<f4 *>(dst) = f4{x[0], x[1], x[2], x[3]};
-    } else if constexpr (R == 2) {
-        *reinterpret_cast<f2 *>(dst) = f2{x[0], x[1]};
-    } else {
-#pragma unroll
-        for (int j = 0; j < R; ++j) dst[j] = x[j];
-    }
-}
-
-template <int R, int W, bool MOD>
-__global__ __launch_bounds__(W *WAVE) void crf_sweep_kernel(CrfArgs a) {
-    using Cfg = CrfCfg<R, W, MOD>;
-    constexpr int NT = Cfg::NT, LPAD = Cfg::LPAD, KINDS = Cfg::KINDS;
-    constexpr int CK = CRF_CKS, MAXK = (CK + W - 1) / W;
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & (WAVE - 1);
-    const bool fwd_role = blockIdx.x < (unsigned)a.N;
-    const int n = fwd_role ? (int)blockIdx.x : (int)blockIdx.x - a.N;
-    const int T = a.T, N = a.N, S = a.S, SP = S + 2;
-    const int L = a.seqlen[n];
-    if (L == 0 || L > R * NT) return;           // the posterior kernel reports these reads
-
-    float *tile = reinterpret_cast<float *>(smem);              // [CK][SP]
-    int *wcnt = reinterpret_cast<int *>(tile + CK * SP);        // [KINDS][W][SP]
-    int *ktot = wcnt + KINDS * W * SP;                          // [KINDS][SP]
-    int *segl = ktot + KINDS * SP;                              // [KINDS][SP + 1]
-    float *edge = reinterpret_cast<float *>(segl + KINDS * (SP + 1));   // [2][W]
-    float *red = edge + 2 * W;                                  // [W]
-
-    const size_t rowstride = (size_t)N * S;
-    const float *lpn = a.lp + (size_t)n * S;
-    auto tile_fetch = [&](int t0, float (&pre)[MAXK]) {
-        const int nrows = min(CK, T - t0);
-        const int col = min(lane, S - 1);
-#pragma unroll
-        for (int k = 0; k < MAXK; ++k) {
-            const int row = min(wave + W * k, nrows - 1);
-            pre[k] = lpn[(size_t)(t0 + row) * rowstride + col];
-        }
-    };
-    auto tile_commit = [&](int t0, const float (&pre)[MAXK]) {
-        const int nrows = min(CK, T - t0);
-#pragma unroll
-        for (int k = 0; k < MAXK; ++k) {
-            const int row = wave + W * k;
-            if (row < nrows && lane < S) tile[row * SP + lane] = pre[k];
-        }
-    };
-
-    const int64_t off = a.seqoff[n];
-    const int p0 = tid * R;
-    int st[R], mv[R], md[MOD ? R : 1];
-    float fw[MOD ? R : 1];
-#pragma unroll
-    for (int j = 0; j < R; ++j) {
-        const int p = p0 + j;
-        st[j] = (p < L) ? a.stay[off + p] : S;
-        mv[j] = (p < L - 1) ? a.move[off + p] : S;
-        if (MOD) {
-            md[j] = (p < L - 1) ? a.mod[off + p] : S + 1;
-            fw[j] = (p < L - 1) ? a.modfact[off + p] * a.c_mod : 0.f;
-        }
-    }
-    const bool has_in = (p0 >= 1) && (p0 - 1 < L - 1);
-    const int mvin0 = has_in ? a.move[off + p0 - 1] : S;
-    const int mdin0 = (MOD && has_in) ? a.mod[off + p0 - 1] : S + 1;
-    const float fwin0 = (MOD && has_in) ? a.modfact[off + p0 - 1] * a.c_mod : 0.f;
-    for (int r = tid; r < CK; r += NT) {
-        tile[r * SP + S] = NEG_LARGE;
-        tile[r * SP + S + 1] = 0.f;
-    }
-    const float c = a.c_can;
-    const float neg = NEG_LARGE * LOG2E;
-
-    // ---- sorted posterior slots (same deterministic ballot ranking as crf_kernel) -> HBM
-    if (fwd_role) {
-        const int K = SP;
-        int slot[KINDS][R];
-#pragma unroll
-        for (int kind = 0; kind < KINDS; ++kind) {
-            int cnt = 0;
-#pragma unroll
-            for (int j = 0; j < R; ++j) {
-                const int key = (kind == 0) ? st[j] : ((kind == 1) ? mv[j] : md[MOD ? j : 0]);
-                int rank = 0;
-                for (int b = 0; b < K; ++b) {
-                    const unsigned long long mask = __ballot(key == b);
-                    if (key == b)
-                        rank = __builtin_amdgcn_readlane(cnt, b) +
-                               __popcll(mask & ((1ull << lane) - 1ull));
-                    if (lane == b) cnt += __popcll(mask);
-                }
-                slot[kind][j] = rank;
-            }
-            if (lane < K) wcnt[(kind * W + wave) * K + lane] = cnt;
-        }
-        __syncthreads();
-        for (int e = tid; e < KINDS * K; e += NT) {
-            const int kind = e / K, b = e - kind * K;
-            int tot = 0;
-            for (int w = 0; w < W; ++w) tot += wcnt[(kind * W + w) * K + b];
-            ktot[e] = tot;
-        }
-        __syncthreads();
-        int *segn = a.segws + (size_t)n * KINDS * (SP + 1);
-        for (int e = tid; e < KINDS * K; e += NT) {
-            const int kind = e / K, b = e - kind * K;
-            int start = 0;
-            for (int bb = 0; bb < b; ++bb) start += ktot[kind * K + bb];
-            segn[kind * (SP + 1) + b] = start;
-            if (b == K - 1) segn[kind * (SP + 1) + K] = start + ktot[e];
-            int run = start;
-            for (int w = 0; w < W; ++w) {
-                const int cwb = wcnt[(kind * W + w) * K + b];
-                wcnt[(kind * W + w) * K + b] = run;
-                run += cwb;
-            }
-        }
-        __syncthreads();
-        // One record per position for the posterior pass: [stay id:8 | move id:8 | stay slot:16]
-        // [move slot:16 | -] (+ [mod slot:16 | mod id:8] for cat-mod) -- 8 (12) bytes instead of
-        // the 16 (24) of separate id and slot arrays; every tile of the posterior pass reloads them.
-        {
-            int fin[KINDS][R];
-#pragma unroll
-            for (int kind = 0; kind < KINDS; ++kind)
-#pragma unroll
-                for (int j = 0; j < R; ++j) {
-                    const int key = (kind == 0) ? st[j] : ((kind == 1) ? mv[j] : md[MOD ? j : 0]);
-                    fin[kind][j] = slot[kind][j] + wcnt[(kind * W + wave) * K + key];
-                }
-            uint2 *rec = reinterpret_cast<uint2 *>(a.slotws) + (size_t)n * LPAD + p0;
-#pragma unroll
-            for (int j = 0; j < R; ++j)
-                rec[j] = uint2{(unsigned)st[j] | ((unsigned)mv[j] << 8) | ((unsigned)fin[0][j] << 16),
-                               (unsigned)fin[1][j]};
-            if (MOD) {
-                unsigned *rec2 = reinterpret_cast<unsigned *>(reinterpret_cast<uint2 *>(a.slotws) + (size_t)a.N * LPAD) +
-                                 (size_t)n * LPAD + p0;
-#pragma unroll
-                for (int j = 0; j < R; ++j)
-                    rec2[j] = (unsigned)fin[MOD ? 2 : 0][j] | ((unsigned)md[MOD ? j : 0] << 16);
-            }
-        }
-    }
-
-    auto fold_norm = [&](float (&x)[R], float &edge_val, double &offacc) {
-        float mx = red[0];
-#pragma unroll
-        for (int w = 1; w < W; ++w) mx = fmaxf(mx, red[w]);
-        if (!(mx > -1e29f)) mx = 0.f;
-#pragma unroll
-        for (int j = 0; j < R; ++j) x[j] -= mx;
-        edge_val -= mx;
-        offacc += (double)mx;
-    };
-    auto post_max = [&](const float (&x)[R]) {
-        float mx = x[0];
-#pragma unroll
-        for (int j = 1; j < R; ++j) mx = fmaxf(mx, x[j]);
-        mx = wave_allmax_dpp(mx);
-        if (lane == 0) red[wave] = mx;
-    };
-    const int NK = (T + CK - 1) / CK;
-
-    if (fwd_role) {
-        // ================= forward sweep (c_crf_flipflop.c:43-133) =================
-        const int LP = a.LP;
-        const bool stored = p0 < LP;                // positions past the pitch are never live
-        float *Fn = a.latF + (size_t)n * T * LP + p0;
-        double *offn = a.offF + (size_t)n * T;
-        float f[R];
-#pragma unroll
-        for (int j = 0; j < R; ++j) f[j] = (p0 + j == 0) ? 0.f : neg;
-        double offF = 0.0;
-        if (W > 1 && lane == WAVE - 1) edge[1 * W + wave] = f[R - 1];       // slot (t-1)&1, t = 0
-        float pre[MAXK];
-        tile_fetch(0, pre);
-        for (int k = 0; k < NK; ++k) {
-            const int t0 = k * CK, nrows = min(CK, T - t0);
-            tile_commit(t0, pre);
-            __syncthreads();
-            if (k + 1 < NK) tile_fetch(t0 + CK, pre);
-            for (int i = 0; i < nrows; ++i) {
-                const int t = t0 + i;
-                const float *row = tile + i * SP;
-                // (column, offset) before the fold that may be pending: a consistent pair
-                if (stored) crf_store_cells<R>(Fn + (size_t)t * LP, f);
-                if (tid == 0) offn[t] = offF;
-                float ein = (W > 1 && wave > 0) ? edge[((t - 1) & 1) * W + wave - 1] : neg;
-                if (t > 0 && (t & 3) == 0) fold_norm(f, ein, offF);
-                float left0 = wave_shift_up1(f[R - 1], neg);
-                if (W > 1 && lane == 0) left0 = ein;
-#pragma unroll
-                for (int j = R - 1; j >= 0; --j) {
-                    const float ls = row[st[j]];
-                    const int mi = (j == 0) ? mvin0 : mv[j > 0 ? j - 1 : 0];
-                    const float lm = row[mi];
-                    const float left = (j == 0) ? left0 : f[j > 0 ? j - 1 : 0];
-                    const float av = fmaf(ls, c, f[j]);
-                    float bv = fmaf(lm, c, left);
-                    if (MOD) {
-                        const int di = (j == 0) ? mdin0 : md[j > 0 ? j - 1 : 0];
-                        const float dw = (j == 0) ? fwin0 : fw[j > 0 ? j - 1 : 0];
-                        bv = fmaf(row[di], dw, bv);
-                    }
-                    f[j] = lse2(av, bv);
-                }
-                if (W > 1 && lane == WAVE - 1) edge[(t & 1) * W + wave] = f[R - 1];
-                if (((t + 1) & 3) == 0) post_max(f);
-                __syncthreads();
-            }
-        }
-        if (tid == (L - 1) / R) {
-            const int jj = (L - 1) % R;
-            float last = 0.f;
-#pragma unroll
-            for (int j = 0; j < R; ++j)
-                if (j == jj) last = f[j];
-            a.scoreF[n] = offF + (double)last;          // c_crf_flipflop.c:131
-        }
-    } else {
-        // ================= backward sweep (c_crf_flipflop.c:150-235) ================
-        const int LP = a.LP;
-        const bool stored = p0 < LP;
-        float *Bn = a.latB + (size_t)n * T * LP + p0;
-        double *offn = a.offB + (size_t)n * T;
-        float b[R];
-#pragma unroll
-        for (int j = 0; j < R; ++j) b[j] = (p0 + j == L - 1) ? 0.f : neg;
-        double offB = 0.0;
-        int nbwd = 0;
-        bool bnorm_pending = false;
-        if (W > 1 && lane == 0) edge[1 * W + wave] = b[0];
-        float pre[MAXK];
-        tile_fetch((NK - 1) * CK, pre);
-        for (int k = NK - 1; k >= 0; --k) {
-            const int t0 = k * CK, nrows = min(CK, T - t0);
-            tile_commit(t0, pre);
-            __syncthreads();
-            if (k > 0) tile_fetch(t0 - CK, pre);
-            for (int i = nrows - 1; i >= 0; --i) {
-                const int t = t0 + i;
-                const float *row = tile + i * SP;
-                float ein = (W > 1 && wave < W - 1) ? edge[((nbwd - 1) & 1) * W + wave + 1] : neg;
-                if (bnorm_pending) fold_norm(b, ein, offB);
-                // the column the posterior of row t combines with (bwd[t+1]) and its offset
-                if (stored) crf_store_cells<R>(Bn + (size_t)t * LP, b);
-                if (tid == 0) offn[t] = offB;
-                float right0 = wave_shift_down1(b[0], neg);
-                if (W > 1 && lane == WAVE - 1) right0 = ein;
-#pragma unroll
-                for (int j = 0; j < R; ++j) {
-                    const float ls = row[st[j]];
-                    const float lm = row[mv[j]];
-                    const float br = (j == R - 1) ? right0 : b[j < R - 1 ? j + 1 : 0];
-                    const float as = fmaf(ls, c, b[j]);
-                    float am = fmaf(lm, c, br);
-                    if (MOD) am = fmaf(row[md[j]], fw[j], am);
-                    b[j] = lse2(as, am);
-                }
-                if (W > 1 && lane == 0) edge[(nbwd & 1) * W + wave] = b[0];
-                ++nbwd;
-                bnorm_pending = (nbwd & 3) == 0;
-                if (bnorm_pending) post_max(b);
-                __syncthreads();
-            }
-        }
-        if (bnorm_pending) {
-            float ein = 0.f;
-            fold_norm(b, ein, offB);
-        }
-        if (tid == 0) a.scoreB[n] = offB + (double)b[0];       // c_crf_flipflop.c:234
-    }
-}
-
-template <int R, int W, bool MOD>
-__global__ __launch_bounds__(W *WAVE) void crf_posterior_kernel(CrfArgs a) {
-    using Cfg = CrfCfg<R, W, MOD>;
-    constexpr int NT = Cfg::NT, LPAD = Cfg::LPAD, KINDS = Cfg::KINDS, EPL = Cfg::EPL;
-    constexpr int CKP = KINDS * LPAD * 4 * 8 <= 72 * 1024 ? 8 : (KINDS * LPAD * 4 * 4 <= 72 * 1024 ? 4 : 2);
-    constexpr int MAXK = (CKP + W - 1) / W;
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & (WAVE - 1);
-    const int n = blockIdx.x, k = blockIdx.y;
-    const int T = a.T, N = a.N, S = a.S, SP = S + 2;
-    const int L = a.seqlen[n];
-    const int t0 = k * CKP, nrows = min(CKP, T - t0);
-    const size_t rowstride = (size_t)N * S;
-
-    if (L == 0) {
-        // c_crf_flipflop.c:269-272 / 458-464: cost 0, zero gradient rows
-        if (k == 0 && tid == 0) a.cost[n] = 0.f;
-        if (lane < S)
-            for (int i = wave; i < nrows; i += W)
-                a.grad[(size_t)(t0 + i) * rowstride + (size_t)n * S + lane] = 0.f;
-        return;
-    }
-    if (L > R * NT) {
-        if (k == 0 && tid == 0) {
-            a.cost[n] = __builtin_nanf("");
-            if (a.status) atomicOr(a.status, 4u);
-        }
-        return;
-    }
-
-    float *tile = reinterpret_cast<float *>(smem);                      // [CKP][SP]
-    float *Psort = tile + CKP * SP;                                     // [CKP][KINDS][LPAD]
-    int *segstart = reinterpret_cast<int *>(Psort + (size_t)CKP * KINDS * LPAD);   // [KINDS][SP + 1]
-    float *lanebase = reinterpret_cast<float *>(segstart + KINDS * (SP + 1));      // [W][64]
-    float *ctl = lanebase + W * WAVE;                                   // [CKP]
-
-    // score rows of the tile: wave = row, lane = column; sentinels S (-LARGE), S+1 (0)
-    {
-        const float *lpn = a.lp + (size_t)n * S;
-        const int col = min(lane, S - 1);
-        float pre[MAXK];
-#pragma unroll
-        for (int q = 0; q < MAXK; ++q) {
-            const int row = min(wave + W * q, nrows - 1);
-            pre[q] = lpn[(size_t)(t0 + row) * rowstride + col];
-        }
-#pragma unroll
-        for (int q = 0; q < MAXK; ++q) {
-            const int row = wave + W * q;
-            if (row < nrows && lane < S) tile[row * SP + lane] = pre[q];
-        }
-        for (int r = tid; r < CKP; r += NT) {
-            tile[r * SP + S] = NEG_LARGE;
-            tile[r * SP + S + 1] = 0.f;
-        }
-    }
-    const int64_t off = a.seqoff[n];
-    const int p0 = tid * R;
-    int st[R], mv[R], md[MOD ? R : 1], slot[KINDS][R];
-    float fw[MOD ? R : 1];
-    {
-        // the sweep kernel left one packed record per position (ids with their sentinels
-        // already resolved, sorted slots)
-        const uint2 *rec = reinterpret_cast<const uint2 *>(a.slotws) + (size_t)n * LPAD + p0;
-#pragma unroll
-        for (int j = 0; j < R; ++j) {
-            const uint2 r = rec[j];
-            st[j] = (int)(r.x & 0xffu);
-            mv[j] = (int)((r.x >> 8) & 0xffu);
-            slot[0][j] = (int)(r.x >> 16);
-            slot[1][j] = (int)(r.y & 0xffffu);
-        }
-        if (MOD) {
-            const unsigned *rec2 = reinterpret_cast<const unsigned *>(reinterpret_cast<const uint2 *>(a.slotws) +
-                                                                      (size_t)a.N * LPAD) + (size_t)n * LPAD + p0;
-#pragma unroll
-            for (int j = 0; j < R; ++j) {
-                const unsigned r = rec2[j];
-                const int p = p0 + j;
-                slot[MOD ? 2 : 0][j] = (int)(r & 0xffffu);
-                md[MOD ? j : 0] = (int)(r >> 16);
-                fw[MOD ? j : 0] = (p < L - 1) ? a.modfact[off + p] * a.c_mod : 0.f;
-            }
-        }
-    }
-    for (int e = tid; e < KINDS * (SP + 1); e += NT)
-        segstart[e] = a.segws[(size_t)n * KINDS * (SP + 1) + e];
-    const double fwd_score2 = a.scoreF[n];
-    if (tid < nrows) {
-        const size_t ti = (size_t)n * T + t0 + tid;
-        ctl[tid] = (float)(fwd_score2 - a.offF[ti] - a.offB[ti]);
-    }
-    // both lattice rows of every row of the tile, issued before anything is consumed
-    const float neg = NEG_LARGE * LOG2E;
-    float Fv[CKP][R], Bv[CKP][R + 1];
-    {
-        const int LP = a.LP;
-        const bool inside = p0 < LP, has_right = p0 + R < LP;
-        const int pc = inside ? p0 : 0;             // clamped: the loads stay unconditional
-        const float *Fn = a.latF + ((size_t)n * T + t0) * LP + pc;
-        const float *Bn = a.latB + ((size_t)n * T + t0) * LP + pc;
-#pragma unroll
-        for (int i = 0; i < CKP; ++i) {
-            const size_t ro = (size_t)min(i, nrows - 1) * LP;
-#pragma unroll
-            for (int j = 0; j < R; ++j) {
-                const float fv = Fn[ro + j], bv = Bn[ro + j];
-                Fv[i][j] = inside ? fv : neg;
-                Bv[i][j] = inside ? bv : neg;
-            }
-            const float br = Bn[ro + (has_right ? R : 0)];
-            Bv[i][R] = has_right ? br : neg;
-        }
-    }
-    __syncthreads();
-
-    const float c = a.c_can;
-    const float inv_cmod = MOD ? (1.0f / a.c_mod) : 0.f;
-#pragma unroll
-    for (int i = 0; i < CKP; ++i) {
-        if (i < nrows) {
-            const float *row = tile + i * SP;
-            float *prow = Psort + (size_t)i * KINDS * LPAD;
-            const float ct = ctl[i];
-#pragma unroll
-            for (int j = 0; j < R; ++j) {
-                const float as = fmaf(row[st[j]], c, Bv[i][j]);
-                float am = fmaf(row[mv[j]], c, Bv[i][j + 1]);
-                if (MOD) am = fmaf(row[md[j]], fw[j], am);
-                const float fc = Fv[i][j] - ct;
-                const float ps = fast_exp2(fc + as);
-                const float pm = fast_exp2(fc + am);
-                prow[slot[0][j]] = ps;
-                prow[LPAD + slot[1][j]] = pm;
-                if (MOD) prow[2 * LPAD + slot[MOD ? 2 : 0][j]] = pm * (fw[j] * inv_cmod);
-            }
-        }
-    }
-    __syncthreads();
-
-    // flush: one wave per row (see crf_kernel)
-    bool bad = false;
-    for (int row = wave; row < nrows; row += W) {
-        float colval = 0.f, total = 0.f;
-        float *lb = lanebase + wave * WAVE;
-#pragma unroll
-        for (int kind = 0; kind < KINDS; ++kind) {
-            float *arr = Psort + ((size_t)row * KINDS + kind) * LPAD;
-            float run = 0.f;
-            if constexpr (EPL % 4 == 0) {
-                f4 *av = reinterpret_cast<f4 *>(arr + lane * EPL);
-#pragma unroll
-                for (int e = 0; e < EPL / 4; ++e) {
-                    f4 x = av[e];
-                    x[0] += run;
-                    x[1] += x[0];
-                    x[2] += x[1];
-                    x[3] += x[2];
-                    run = x[3];
-                    av[e] = x;
-                }
-            } else {
-#pragma unroll
-                for (int e = 0; e < EPL; ++e) {
-                    run += arr[lane * EPL + e];
-                    arr[lane * EPL + e] = run;
-                }
-            }
-            const float inc = wave_inclusive_scan_dpp(run);
-            lb[lane] = inc - run;
-            wave_lds_fence();
-            if (kind < 2) total += __int_as_float(__builtin_amdgcn_readlane(__float_as_int(inc), 63));
-            if (lane < S) {
-                const int s0 = segstart[kind * (SP + 1) + lane];
-                const int s1 = segstart[kind * (SP + 1) + lane + 1];
-                const float p1 = (s1 > 0) ? arr[s1 - 1] + lb[(s1 - 1) / EPL] : 0.f;
-                const float p0s = (s0 > 0) ? arr[s0 - 1] + lb[(s0 - 1) / EPL] : 0.f;
-                colval += (s1 > s0) ? (p1 - p0s) : 0.f;
-            }
-            wave_lds_fence();
-        }
-        const float g = colval * (-1.0f / (total * (float)T));
-        if (lane < S) {
-            bad |= !isfinite(g);
-            a.grad[(size_t)(t0 + row) * rowstride + (size_t)n * S + lane] = g;
-        }
-    }
-    if (k == 0 && tid == 0) {
-        // score = mean of the two sweeps (c_crf_flipflop.c:482-491), cost = -score / T
-        const double score2 = 0.5 * (fwd_score2 + a.scoreB[n]);
-        const float cst = (float)(-(score2 * 0.6931471805599453) / (double)T) * a.out_scale;
-        a.cost[n] = cst;
-        if (a.status && !isfinite(cst)) atomicOr(a.status, 1u);
-    }
-    if (a.status && bad) atomicOr(a.status, 2u);
-}
-
 // ---------------------------------------------------------------------------
 // index construction (flipflopfings.py:6-31, ctc.pyx:127-134, 282-292)
 // ---------------------------------------------------------------------------
@@ -1110,51 +580,12 @@ static size_t crf_ckpt_bytes(size_t nblk, size_t nbatch, CrfShape sh) {
     return (ck + 255) / 256 * 256 + (co + 255) / 256 * 256 + 256;
 }
 
-// lattice-mode workspace: two lattices, their offsets, the sweep scores, the sorted slots
-struct CrfLatLayout {
-    size_t latF, latB, offF, offB, scoreF, scoreB, slot, seg, total;
-};
-static size_t crf_lattice_pitch(size_t max_seqlen, CrfShape sh) {
-    const size_t LPAD = (size_t)sh.R * sh.W * WAVE, lp = (max_seqlen + 255) / 256 * 256;
-    return lp < LPAD ? lp : LPAD;
-}
-static CrfLatLayout crf_lattice_layout(size_t ntrans, size_t nblk, size_t nbatch, size_t max_seqlen,
-                                       CrfShape sh) {
-    const size_t LPAD = (size_t)sh.R * sh.W * WAVE, SP = ntrans + 2;
-    const size_t LP = crf_lattice_pitch(max_seqlen, sh);
-    CrfLatLayout l;
-    size_t off = 0;
-    auto take = [&](size_t bytes) {
-        const size_t r = off;
-        off += (bytes + 255) / 256 * 256;
-        return r;
-    };
-    l.latF = take(nbatch * nblk * LP * sizeof(float));
-    l.latB = take(nbatch * nblk * LP * sizeof(float));
-    l.offF = take(nbatch * nblk * sizeof(double));
-    l.offB = take(nbatch * nblk * sizeof(double));
-    l.scoreF = take(nbatch * sizeof(double));
-    l.scoreB = take(nbatch * sizeof(double));
-    l.slot = take(nbatch * 3 * LPAD * sizeof(int));
-    l.seg = take(nbatch * 3 * (SP + 1) * sizeof(int));
-    l.total = off + 256;
-    return l;
-}
-
-// Lattice mode when both lattices fit under the cap (default 24 GiB of the 288 GB,
-// TK_CRF_LATTICE_MB overrides; 0 forces the checkpoint kernel)
-static bool crf_use_lattice(size_t ntrans, size_t nblk, size_t nbatch, size_t max_seqlen, CrfShape sh) {
-    size_t cap_mb = 40960;
-    if (const char *e = getenv("TK_CRF_LATTICE_MB")) cap_mb = (size_t)atoll(e);
-    return crf_lattice_layout(ntrans, nblk, nbatch, max_seqlen, sh).total <= cap_mb * 1024 * 1024;
-}
-
-// Which form of kernel A runs (TK_CRF_MODE overrides: band | lattice | ckpt):
+// Which form of kernel A runs (TK_CRF_MODE overrides: band | ckpt):
 //   band     crf_band.hip -- banded skewed sweep + row-parallel posterior pass (default whenever
 //            the sequences fit 16 waves x 256 cells and the two lattices fit the workspace cap)
-//   lattice  the per-step-barrier sweep + tile posterior of this file (kept for A/B runs)
-//   ckpt     single-launch checkpoint/recompute kernel, no lattice in HBM (workspace-bound batches)
-enum CrfMode { CRF_BAND, CRF_LATTICE, CRF_CKPT };
+//   ckpt     the single-launch checkpoint/recompute kernel of this file: no lattice in HBM, three
+//            serial passes per read (workspace-bound batches)
+enum CrfMode { CRF_BAND, CRF_CKPT };
 static size_t crf_lattice_cap_bytes() {
     size_t cap_mb = 40960;          // 40 GiB of the 288 GB
     if (const char *e = getenv("TK_CRF_LATTICE_MB")) cap_mb = (size_t)atoll(e);
@@ -1163,12 +594,12 @@ static size_t crf_lattice_cap_bytes() {
 static CrfMode crf_pick_mode(size_t ntrans, size_t nblk, size_t nbatch, size_t max_seqlen, bool want_grad,
                              bool mod, CrfShape sh) {
     const char *e = getenv("TK_CRF_MODE");
-    const bool force_ckpt = e && e[0] == 'c', force_lat = e && e[0] == 'l';
-    if (!force_ckpt && !force_lat && crf_band_fits(max_seqlen) &&
+    (void)sh;
+    const bool force_ckpt = e && e[0] == 'c';
+    if (!force_ckpt && crf_band_fits(max_seqlen) &&
         (!want_grad || crf_band_layout(ntrans, nblk, nbatch, max_seqlen, mod).total <= crf_lattice_cap_bytes()))
         return CRF_BAND;
-    if (!want_grad || force_ckpt) return CRF_CKPT;
-    return crf_use_lattice(ntrans, nblk, nbatch, max_seqlen, sh) ? CRF_LATTICE : CRF_CKPT;
+    return CRF_CKPT;
 }
 
 size_t crf_workspace_bytes(size_t ntrans, size_t nblk, size_t nbatch, size_t max_seqlen,
@@ -1179,67 +610,8 @@ size_t crf_workspace_bytes(size_t ntrans, size_t nblk, size_t nbatch, size_t max
     // (the cat-mod layout is the larger one: an upper bound for both)
     switch (crf_pick_mode(ntrans, nblk, nbatch, max_seqlen, true, true, sh)) {
         case CRF_BAND: return crf_band_layout(ntrans, nblk, nbatch, max_seqlen, true).total;
-        case CRF_LATTICE: return crf_lattice_layout(ntrans, nblk, nbatch, max_seqlen, sh).total;
         default: return crf_ckpt_bytes(nblk, nbatch, sh);
     }
-}
-
-// The sweep and the posterior pass only share per-POSITION data (lattices, slots), so each
-// picks its own cells-per-lane x waves split of the same LPAD positions.
-template <int R, int W, bool MOD>
-static int crf_launch_sweep(const CrfArgs &a, hipStream_t stream) {
-    constexpr int KINDS = MOD ? 3 : 2;
-    const size_t lds = crf_sweep_lds_bytes(W, a.S, KINDS);
-    if (lds > 160 * 1024) return 2;
-    static bool raised = false;
-    if (!raised) {
-        if (hipFuncSetAttribute(reinterpret_cast<const void *>(&crf_sweep_kernel<R, W, MOD>),
-                                hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)
-            return 4;
-        raised = true;
-    }
-    hipLaunchKernelGGL((crf_sweep_kernel<R, W, MOD>), dim3(2 * a.N), dim3(W * WAVE), lds, stream, a);
-    return hipGetLastError() == hipSuccess ? 0 : 4;
-}
-
-template <int LPAD, bool MOD>
-static int crf_launch_sweep_lpad(const CrfArgs &a, int R, hipStream_t stream) {
-    if constexpr (LPAD >= 512) {
-        if (R == 8) return crf_launch_sweep<8, LPAD / 512, MOD>(a, stream);
-    }
-    if constexpr (LPAD >= 256) {
-        if (R == 4) return crf_launch_sweep<4, LPAD / 256, MOD>(a, stream);
-    }
-    if constexpr (LPAD >= 128 && LPAD <= 2048) {
-        if (R == 2) return crf_launch_sweep<2, LPAD / 128, MOD>(a, stream);
-    }
-    if constexpr (LPAD == 64) return crf_launch_sweep<1, 1, MOD>(a, stream);
-    return 2;
-}
-
-template <int R, int W, bool MOD>
-static int crf_launch_lattice(const CrfArgs &a, hipStream_t stream) {
-    constexpr int KINDS = MOD ? 3 : 2, LPAD = R * W * WAVE;
-    // sweep split: TK_CRF_SWEEP_R overrides (cells per lane)
-    int Rs = R;
-    if (const char *e = getenv("TK_CRF_SWEEP_R")) Rs = atoi(e);
-    while (Rs > 1 && Rs * WAVE > LPAD) Rs /= 2;
-    if (LPAD > 2048 && Rs < 4) Rs = 4;
-    const int rc = crf_launch_sweep_lpad<LPAD, MOD>(a, Rs, stream);
-    if (rc != 0) return rc;
-    const size_t lds2 = crf_post_lds_bytes(R, W, a.S, KINDS);
-    if (lds2 > 160 * 1024) return 2;
-    static bool raised = false;
-    if (!raised) {
-        if (hipFuncSetAttribute(reinterpret_cast<const void *>(&crf_posterior_kernel<R, W, MOD>),
-                                hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)
-            return 4;
-        raised = true;
-    }
-    const int CKP = crf_ckp(R, W, KINDS);
-    hipLaunchKernelGGL((crf_posterior_kernel<R, W, MOD>), dim3(a.N, (a.T + CKP - 1) / CKP),
-                       dim3(W * WAVE), lds2, stream, a);
-    return hipGetLastError() == hipSuccess ? 0 : 4;
 }
 
 template <int R, int W, bool MOD>
@@ -1261,11 +633,11 @@ static int crf_launch_one(const CrfArgs &a, hipStream_t stream) {
 }
 
 template <bool MOD>
-static int crf_launch_mod(CrfShape sh, const CrfArgs &a, bool lattice, hipStream_t stream) {
+static int crf_launch_mod(CrfShape sh, const CrfArgs &a, hipStream_t stream) {
     const int key = sh.R * 100 + sh.W;
 #define TK_CRF_CASE(R_, W_)                                                           \
     case R_ * 100 + W_:                                                               \
-        return lattice ? crf_launch_lattice<R_, W_, MOD>(a, stream) : crf_launch_one<R_, W_, MOD>(a, stream);
+        return crf_launch_one<R_, W_, MOD>(a, stream);
     switch (key) {
         TK_CRF_CASE(1, 1)
         TK_CRF_CASE(2, 1)
@@ -1343,37 +715,19 @@ int crf_dispatch(const float *logprob, size_t ntrans, size_t nblk, size_t nbatch
         b.rec = g ? reinterpret_cast<uint32_t *>(wb + l.rec) : nullptr;
         b.recw = g ? reinterpret_cast<float *>(wb + l.recw) : nullptr;
         b.segend = g ? reinterpret_cast<int *>(wb + l.segend) : nullptr;
+        b.dbg = nullptr;
         return crf_band_dispatch(b, l.R, mod, stream);
     }
-    const bool lattice = mode == CRF_LATTICE;
-    char *wsb = static_cast<char *>(workspace);
-    if (lattice) {
-        const CrfLatLayout l = crf_lattice_layout(ntrans, nblk, nbatch, max_seqlen, sh);
-        a.LP = (int)crf_lattice_pitch(max_seqlen, sh);
-        a.latF = reinterpret_cast<float *>(wsb + l.latF);
-        a.latB = reinterpret_cast<float *>(wsb + l.latB);
-        a.offF = reinterpret_cast<double *>(wsb + l.offF);
-        a.offB = reinterpret_cast<double *>(wsb + l.offB);
-        a.scoreF = reinterpret_cast<double *>(wsb + l.scoreF);
-        a.scoreB = reinterpret_cast<double *>(wsb + l.scoreB);
-        a.slotws = reinterpret_cast<int *>(wsb + l.slot);
-        a.segws = reinterpret_cast<int *>(wsb + l.seg);
-        a.ckpt = nullptr;
-        a.ckoff = nullptr;
-    } else {
+    {
         const int CK = crf_ck(sh.R, sh.W, modidx != nullptr ? 3 : 2);
         const size_t NK = (nblk + CK - 1) / CK;
         const size_t ckb = (nbatch * NK * (size_t)sh.R * sh.W * WAVE * sizeof(float) + 255) / 256 * 256;
+        char *wsb = static_cast<char *>(workspace);
         a.ckpt = reinterpret_cast<float *>(wsb);
         a.ckoff = reinterpret_cast<double *>(wsb + (grad ? ckb : 0));
-        a.latF = a.latB = nullptr;
-        a.LP = 0;
-        a.offF = a.offB = a.scoreF = a.scoreB = nullptr;
-        a.slotws = a.segws = nullptr;
     }
     a.status = status;
-    return modidx != nullptr ? crf_launch_mod<true>(sh, a, lattice, stream)
-                             : crf_launch_mod<false>(sh, a, lattice, stream);
+    return modidx != nullptr ? crf_launch_mod<true>(sh, a, stream) : crf_launch_mod<false>(sh, a, stream);
 }
 
 }  // namespace tk

@@ -459,9 +459,10 @@ def test_logz_streaming_transfer_kernel_is_the_same_arithmetic(oracle_mod, gpu_d
 @pytest.mark.parametrize("mode_mb", ["0", "6144"])
 @pytest.mark.parametrize("name", ["t7n2_len1", "t50n3_zero_last", "t200n8", "t130n5_long", "t300n3_wide"])
 def test_crf_both_gradient_modes(oracle_mod, gpu_device, name, mode_mb, monkeypatch):
-    """The gradient path has two implementations: lattices in HBM (sweep + posterior kernels)
-    and checkpoint + recompute (one kernel) for batches whose lattices exceed the workspace
-    cap.  TK_CRF_LATTICE_MB=0 forces the second; both must match the oracle."""
+    """The gradient path has two implementations: the band of both lattices in HBM (banded
+    skewed sweep + row-parallel posterior pass, csrc/crf_band.hip) and checkpoint + recompute
+    (one kernel) for batches whose lattices exceed the workspace cap.  TK_CRF_LATTICE_MB=0
+    forces the second; both must match the oracle."""
     monkeypatch.setenv("TK_CRF_LATTICE_MB", mode_mb)
     inp = cases.crf_inputs(cases.CRF_SMALL[name])
     r = parity.compare_crf(oracle_mod, inp, 1.0, gpu_device)
@@ -469,6 +470,62 @@ def test_crf_both_gradient_modes(oracle_mod, gpu_device, name, mode_mb, monkeypa
     assert r["loss_rel"] < LOSS_RTOL, r["loss_rel"]
     assert r["grad_abs"] < GRAD_ATOL, r["grad_abs"]
     assert r["rowsum_dev"] < 1e-4
+
+
+@pytest.mark.parametrize("R", ["1", "2", "4"])
+def test_crf_band_shapes_against_oracle(oracle_mod, gpu_device, R, monkeypatch):
+    """Band mode at every cells-per-lane setting: chunk counts from 1 to several, a last chunk
+    with one or two live cells, L = T + 1, T not a multiple of the 8-step time block, an empty
+    read in the middle of the batch."""
+    from taiyaki_amd import synth
+    monkeypatch.setenv("TK_CRF_MODE", "band")
+    monkeypatch.setenv("TK_CRF_BAND_R", R)
+    PW = 64 * int(R)
+    for T, Ls in ((203, [1, PW, PW + 1, PW + 2, 2 * PW, 0, 150, 204, 97]),
+                  (61, [62, 30, 5, 61]),
+                  (520, [3 * PW + 3 if 3 * PW + 3 <= 521 else 500, 2 * PW + 1, 333])):
+        Ls = [min(L, T + 1) for L in Ls]
+        inp = synth.crf_case(T, len(Ls), 77 + T, seqlens=np.array(Ls, dtype=np.int32))
+        # (the reference cannot index an empty read that is not last: compare the others singly)
+        off = np.concatenate([[0], np.cumsum(Ls)])
+        loss, grad = parity.run_crf(inp, 1.0, gpu_device)
+        for n, L in enumerate(Ls):
+            if L == 0:
+                assert loss[n] == 0.0 and np.all(grad[:, n] == 0.0)
+                continue
+            one = dict(scores=np.ascontiguousarray(inp["scores"][:, n:n + 1]), seqs=inp["seqs"][off[n]:off[n + 1]],
+                       seqlens=np.array([L], dtype=np.int32))
+            oloss, ograd = parity.oracle_crf(oracle_mod, one, 1.0)
+            # (a loss that is itself ~0 is a cancelled sum: bound its absolute error instead)
+            assert (parity.rel_err(loss[n:n + 1], oloss) < LOSS_RTOL
+                    or parity.abs_err(loss[n:n + 1], oloss) < 2e-6), (T, L, loss[n], oloss)
+            assert parity.abs_err(grad[:, n:n + 1], ograd) < GRAD_ATOL, (T, L)
+
+
+@pytest.mark.parametrize("R", ["1", "2", "4"])
+def test_crf_band_does_not_read_what_it_did_not_write(gpu_device, R, monkeypatch):
+    """The posterior pass reads only the band the sweeps stored, and every store lands whole:
+    the same batch must give the same bits whether the workspace it is handed was full of NaN or
+    of zeros (a 16-byte column store whose data registers the next instruction overwrote once
+    replaced one dword of a column by that instruction's result -- only visible this way)."""
+    import torch
+    from taiyaki_amd import ctc, synth
+    monkeypatch.setenv("TK_CRF_MODE", "band")
+    monkeypatch.setenv("TK_CRF_BAND_R", R)
+    T, N = 800, 96
+    seqlens = synth.realistic_seqlens(T, N, 17000, 4000, 9.0)
+    inp = synth.crf_case(T, N, 1, seqlens=seqlens)
+    x = torch.from_numpy(inp["scores"]).to(gpu_device)
+    seqs, sl = torch.from_numpy(inp["seqs"]), torch.from_numpy(inp["seqlens"])
+    outs = []
+    for fill in (float("nan"), 0.0, 1e30, float("nan")):
+        junk = torch.full((160 * 1024 * 1024,), fill, device=gpu_device)
+        del junk                        # back to the caching allocator: the next workspace reuses it
+        c, g = ctc._run(x, seqs, sl, 1.0, 1.0, 1.0, 40, True)
+        outs.append((c.clone(), g.clone()))
+    for c, g in outs[1:]:
+        assert torch.equal(c, outs[0][0]) and torch.equal(g, outs[0][1])
+    assert bool(torch.isfinite(outs[0][1]).all())
 
 
 @pytest.mark.parametrize("shape", [(4000, 256), (800, 128), (333, 70)])

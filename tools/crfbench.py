@@ -2,7 +2,7 @@
 """Kernel A (sequence CRF) timing by mode and shape (run it under rocprofv3 --kernel-trace
 --stats for the per-kernel split).
 
-    python tools/crfbench.py [--reps 10] [--shapes cfg2,cfg2r,cfg5,rowK] [--modes band1,band2,lattice]
+    python tools/crfbench.py [--reps 10] [--shapes cfg2,cfg2r,cfg5,rowK] [--modes band1,band2,ckpt]
 Shapes: cfg2 = T 800 x N 128 with the reference's SPEED_TEST lengths (0.45-0.55 T);
 cfg2r = the same with realistic chunk lengths (what the train step launches); cfg5 = T 1600 x
 N 64; rowK = T 4000 x N 256.  Algorithmic bytes = 3 T N S 4."""
@@ -21,7 +21,7 @@ SHAPES = {"cfg2": (800, 128, None), "cfg2r": (800, 128, 4000), "cfg5": (1600, 64
           "one": (800, 1, 4000), "short": (800, 128, 450), "short1": (800, 1, 450), "mid": (800, 128, 1100)}
 MODES = {"band1": dict(TK_CRF_MODE="band", TK_CRF_BAND_R="1"), "band2": dict(TK_CRF_MODE="band", TK_CRF_BAND_R="2"),
          "band4": dict(TK_CRF_MODE="band", TK_CRF_BAND_R="4"), "band": dict(TK_CRF_MODE="band"),
-         "lattice": dict(TK_CRF_MODE="lattice"), "ckpt": dict(TK_CRF_MODE="ckpt")}
+         "ckpt": dict(TK_CRF_MODE="ckpt")}
 
 
 def timed(fn, reps):
@@ -45,7 +45,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--reps", type=int, default=10)
     ap.add_argument("--shapes", default="cfg2,cfg2r,rowK")
-    ap.add_argument("--modes", default="band1,band2,lattice")
+    ap.add_argument("--modes", default="band,ckpt")
     ap.add_argument("--fwd", action="store_true", help="also time the cost-only call")
     args = ap.parse_args()
     dev = torch.device("cuda:0")

@@ -67,6 +67,32 @@ __global__ void lat(int mode, float *out, long long *cyc, float seed) {
             const float s = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(x), 17));
             x = x * 0.5f + s;
         }
+    } else if (mode == 12) {
+        float a = x, b = x + 1, c2 = x + 2, d = x + 3;
+#pragma unroll 4
+        for (int i = 0; i < ITER; i += 4) {
+            a = fmaf(a, 0.999f, y); b = fmaf(b, 0.999f, y); c2 = fmaf(c2, 0.999f, y); d = fmaf(d, 0.999f, y);
+        }
+        x = a + b + c2 + d;
+    } else if (mode == 13) {
+        float a = x, b = x + 1, c2 = x + 2, d = x + 3;
+#pragma unroll 4
+        for (int i = 0; i < ITER; i += 4) {
+            a = __builtin_amdgcn_exp2f(a) - 1.0f; b = __builtin_amdgcn_exp2f(b) - 1.0f;
+            c2 = __builtin_amdgcn_exp2f(c2) - 1.0f; d = __builtin_amdgcn_exp2f(d) - 1.0f;
+        }
+        x = a + b + c2 + d;
+    } else if (mode == 14) {
+        int a0 = (lane * 4 + 4) & 255;
+        float a = x, b = x + 1, c2 = x + 2, d = x + 3;
+#pragma unroll 4
+        for (int i = 0; i < ITER; i += 4) {
+            a = __int_as_float(__builtin_amdgcn_ds_bpermute(a0, __float_as_int(a)));
+            b = __int_as_float(__builtin_amdgcn_ds_bpermute(a0, __float_as_int(b)));
+            c2 = __int_as_float(__builtin_amdgcn_ds_bpermute(a0, __float_as_int(c2)));
+            d = __int_as_float(__builtin_amdgcn_ds_bpermute(a0, __float_as_int(d)));
+        }
+        x = a + b + c2 + d;
     } else if (mode == 10) {
         int idx = lane;
 #pragma unroll 16
@@ -85,12 +111,12 @@ int main() {
     CHECK(hipMalloc(&cyc, 4096 * 8));
     const char *names[] = {"fma chain", "exp2 chain (+sub)", "log2 chain (+add)", "ds_bpermute chain", "dpp wave_shr chain",
                            "dpp row_shr chain", "lse step (dpp+2fma+lse)", "s_barrier", "lse step + barrier/8", "readlane+fma chain",
-                           "ds_read_b32 chain", "lse step + 2 bpermute gathers"};
+                           "ds_read_b32 chain", "lse step + 2 bpermute gathers", "4 independent fma chains (per instr)", "4 independent exp2+sub chains (per pair)", "4 independent bpermute chains (per instr)"};
     hipEvent_t e0, e1;
     CHECK(hipEventCreate(&e0));
     CHECK(hipEventCreate(&e1));
-    for (int waves = 1; waves <= 9; waves += 4) {
-        for (int mode = 0; mode < 12; ++mode) {
+    for (int waves = 1; waves <= 1; waves += 4) {
+        for (int mode = 0; mode < 15; ++mode) {
             for (int blocks : {1, 256}) {
                 hipLaunchKernelGGL(lat, dim3(blocks), dim3(64 * waves), 0, 0, mode, out, cyc, 1.5f);
                 CHECK(hipDeviceSynchronize());

@@ -1,31 +1,50 @@
 #!/usr/bin/env python
-"""bench.py -- flip-flop train-step throughput + loss-kernel roofline on MI355X.
+"""bench.py -- flip-flop train-step throughput + loss-kernel rooflines on MI355X.
 
-    python bench.py --gpus N --steps K --warmup W
+    python bench.py --gpus N --steps K --warmup W [--config {1,2,3,4,5}]
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
         --master-port P bench.py --gpus N --steps K --warmup W
 
+`--gpus N` (N > 1) without a torchrun environment LAUNCHES the N ranks itself (the same
+torch.distributed.run command, one rank per GPU, like the reference's workflow/test_multiGPU.sh:47-55)
+and fails loudly when fewer than N devices are visible.
+
 One "step" = one optimiser step of the reference's flip-flop trainer
-(bin/train_flipflop.py:544-622) on BASELINE.json configs[1]: mLstm_flipflop
-(size 256, stride 5, winlen 19), chunk_len 4000 (T = 800 blocks), 128 chunks per
-GPU: Conv/LSTM stack in PyTorch-ROCm fp32 -> HIP flip-flop CRF loss + HIP logZ
--> backward -> ONE flat RCCL all-reduce -> AdamW.  Forward + loss and AdamW are
-replayed from hipGraphs, the MIOpen RNN backward (not capturable) is launched eagerly.  Synthetic chunks (resident in
-HBM before the timed region), random-init weights.  Weak scaling: per-GPU batch
-is fixed, value = all ranks' chunks / max-over-ranks time.
+(bin/train_flipflop.py:544-622).  `--config` selects the BASELINE.json configuration in SURVEY.md
+section 8's numbering (BASELINE.json configs[k-1]); the default 2 is the one the metric is quoted on:
+  1  mGru_flipflop size 96 stride 2, chunk_len 2000 (T = 1000), 64 chunks   (configs[0], the
+     train_abinitio.py plumbing case; here on the GPU with the HIP loss)
+  2  mLstm_flipflop size 256 stride 5, chunk_len 4000 (T = 800), 128 chunks per GPU  (configs[1])
+  3  = 2 with --gpus 8: global batch 1024, RCCL all-reduce over xGMI                  (configs[2])
+  4  mLstm_cat_mod_flipflop (5mC + 6mA, 46 outputs), cat-mod loss, mod_factor 8       (configs[3])
+  5  mLstm_flipflop, chunk_len 8000 (T = 1600), 64 chunks per GPU                     (configs[4])
+Conv/RNN stack in PyTorch-ROCm fp32 -> HIP flip-flop CRF (or cat-mod) loss + HIP logZ -> backward
+-> bucketed RCCL all-reduce overlapped with backward -> gradient maxima / clipping -> AdamW.
+Forward + loss and AdamW are replayed from hipGraphs, the MIOpen RNN backward (not capturable) is
+launched eagerly.  Synthetic chunks (resident in HBM before the timed region), random-init weights.
+Weak scaling: per-GPU batch is fixed, value = all ranks' chunks / max-over-ranks time.
 
 Rank 0 prints ONE JSON line with the contract fields plus
-  "roofline":     the logZ forward-backward op (3 launches) on the tensor BASELINE.json's
-                  north_star names for the roofline target (T=4000 blocks, N=256 reads),
-                  timed with HIP events on its launching stream;
-                  achieved = 3*T*N*S*4 bytes / mean duration; traffic = HBM
-                  bytes of the committed rocprofv3 PMC passes (profiles/)
-  "roofline_in_step": the same op at the shape the train step itself launches (T=800, N=128)
-  "cpu_baseline": the reference C (oracle/_ref) or the oracle port on host cores.
+  "roofline"        the logZ forward-backward op on the tensor BASELINE.json's north_star names
+                    for the roofline target (T=4000 blocks, N=256 reads): HIP events on the
+                    launching stream; achieved = 3*T*N*S*4 bytes / mean duration;
+                    traffic = HBM bytes from rocprofv3 PMC passes (measured in this run when
+                    rocprofv3 is on PATH, else the committed profile with its kernel hash)
+  "roofline_in_step" the same op at the shape the train step itself launches
+  "roofline_crf"    kernel A (sequence CRF, sweep + posterior) at the step's shape with realistic
+                    sequence lengths and at the north_star shape
+  "loss_path"       the whole loss path (A + B) in chunks/s on the GPU, on the host cores, and
+                    on the host cores including the D->H / H->D copies of the score and gradient
+                    tensors the reference design incurs (ctc.pyx:119, 139-141)
+  "rccl"            (N > 1) ranks, bytes and event-timed duration of the gradient all-reduce
+  "cpu_baseline"    the reference C (oracle/_ref) or the oracle port on host cores.
 """
 import argparse
+import hashlib
 import json
 import os
+import shutil
+import socket
 import subprocess
 import sys
 import time
@@ -46,6 +65,7 @@ os.environ.setdefault("MIOPEN_GEMM_ENFORCE_BACKEND", "1")      # MIOpen RNN GEMM
 # GPU_MAX_HW_QUEUES=1).
 os.environ.setdefault("GPU_MAX_HW_QUEUES", "1")
 os.environ.setdefault("TORCH_NCCL_HIGH_PRIORITY", "1")
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")       # dmabuf IPC (RCCL across processes)
 
 import numpy as np
 import torch
@@ -56,52 +76,89 @@ sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0       # MI355X_MICROARCH.md: HBM3E 8 TB/s peak (6.3 TB/s achievable)
 
+# SURVEY.md section 8 table (model, chunk_len, stride, chunks per GPU, size, samples per base)
+CONFIGS = {
+    1: dict(model="mGru_flipflop", chunk_len=2000, stride=2, batch=64, size=96, spb=9.0,
+            label="configs[0]: mGru_flipflop r9 DNA (train_abinitio.py defaults)"),
+    2: dict(model="mLstm_flipflop", chunk_len=4000, stride=5, batch=128, size=256, spb=9.0,
+            label="configs[1]: mLstm_flipflop r9.4.1 DNA"),
+    3: dict(model="mLstm_flipflop", chunk_len=4000, stride=5, batch=128, size=256, spb=9.0,
+            label="configs[2]: mLstm_flipflop r9.4.1 DNA, global batch 1024 over 8 GPUs"),
+    4: dict(model="mLstm_cat_mod_flipflop", chunk_len=4000, stride=5, batch=128, size=256, spb=9.0,
+            label="configs[3]: mLstm_cat_mod_flipflop (5mC+6mA) r9.4.1, cat-mod loss"),
+    5: dict(model="mLstm_flipflop", chunk_len=8000, stride=5, batch=64, size=256, spb=9.5,
+            label="configs[4]: mLstm_flipflop r10.3 DNA, long chunks"),
+}
+CAN_NMODS = (1, 1, 0, 0)        # alphabet ACGTZY: 6mA on A, 5mC on C (layers.py:1441-1460)
+MOD_FACTOR = 8.0                # --mod_factor start value (bin/_bin_argparse.py:178)
 
-def make_batches(nbatch, chunk_len, stride, seed, dev, n=4):
+
+def make_batches(nbatch, chunk_len, stride, seed, dev, n=4, spb=9.0, cat_mod=False):
     from taiyaki_amd import synth
     T = chunk_len // stride
     out = []
     for i in range(n):
         s = seed * 1000 + i
-        seqlens = synth.realistic_seqlens(T, nbatch, s, chunk_len, 9.0)
-        seqs, _ = synth.sequences(seqlens, s)
+        seqlens = synth.realistic_seqlens(T, nbatch, s, chunk_len, spb)
+        seqs, bases = synth.sequences(seqlens, s)
         sig = synth.signal_chunks(chunk_len, nbatch, s)
-        out.append(dict(indata=torch.from_numpy(sig).to(dev),
-                        seqs=torch.from_numpy(seqs).to(device=dev, dtype=torch.int32),
-                        seqlens=torch.from_numpy(seqlens).to(device=dev, dtype=torch.int32)))
+        b = dict(indata=torch.from_numpy(sig).to(dev),
+                 seqs=torch.from_numpy(seqs).to(device=dev, dtype=torch.int32),
+                 seqlens=torch.from_numpy(seqlens).to(device=dev, dtype=torch.int32))
+        if cat_mod:
+            b["mod_cats"] = torch.from_numpy(synth.mod_cats(bases, s, CAN_NMODS)).to(device=dev, dtype=torch.int32)
+            b["can_mods_offsets"] = synth.can_mods_offsets(CAN_NMODS)
+            # train_flipflop.py:167-170, 312-313: mod_cat_weights = ones, times the mod_factor schedule
+            b["mod_cat_weights"] = np.full(len(CAN_NMODS) + int(sum(CAN_NMODS)), MOD_FACTOR, dtype=np.float32)
+        out.append(b)
     return out
 
 
-def pmc_traffic(T, N):
-    """HBM bytes per launch from the committed rocprofv3 PMC passes (FETCH_SIZE, WRITE_SIZE in
-    separate runs, gfx950 corrections applied -- profiles/r1_pmc_logz_*_traffic.json); None when
-    no counters were collected for this shape."""
-    here = os.path.dirname(os.path.abspath(__file__))
-    for name in sorted(os.listdir(os.path.join(here, "profiles"))) if os.path.isdir(os.path.join(here, "profiles")) else []:
-        if name.startswith("r1_pmc_logz_") and name.endswith("_traffic.json"):
-            with open(os.path.join(here, "profiles", name)) as fh:
-                d = json.load(fh)
-            if d["shape"]["T"] == T and d["shape"]["N"] == N:
-                return d["traffic_bytes"]
-    return None
+# ---------------------------------------------------------------------------------------------
+# launcher
+# ---------------------------------------------------------------------------------------------
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
 
 
-def time_logz_op(T, N, dev, reps, seed=1):
-    """Mean duration (s) of the logZ forward-backward op at (T, N) via HIP events."""
-    from taiyaki_amd import layers, synth
-    x = torch.from_numpy(synth.scores(T, N, 40, seed)).to(dev)
-    for _ in range(20):         # steady state: clocks and caches settle over the first ~15 launches
-        layers._logz_launch(x, True)
+def self_launch(args, argv):
+    """`--gpus N` outside torchrun: start the N ranks ourselves, one per GPU, over RCCL (the
+    reference launches its multi-GPU run the same way, workflow/test_multiGPU.sh:47-55,
+    bin/train_flipflop.py:255-268).  The JSON line of rank 0 is this process's output."""
+    if not args.dry_launch:
+        have = torch.cuda.device_count() if torch.cuda.is_available() else 0
+        if have < args.gpus:
+            raise SystemExit("bench.py --gpus %d: only %d GPU(s) visible -- refusing to measure fewer "
+                             "ranks than asked for" % (args.gpus, have))
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
+           "--master-addr", "127.0.0.1", "--master-port", str(_free_port()), os.path.abspath(__file__)] + argv
+    env = dict(os.environ)
+    env.setdefault("OMP_NUM_THREADS", "4")
+    pr = subprocess.run(cmd, env=env)
+    raise SystemExit(pr.returncode)
+
+
+# ---------------------------------------------------------------------------------------------
+# kernel timing
+# ---------------------------------------------------------------------------------------------
+def _events_mean_min(fn, reps, warm=20):
+    """Mean / min duration (s) of `fn` via HIP events on the launching (current) stream."""
+    for _ in range(warm):       # steady state: clocks and caches settle over the first ~15 launches
+        fn()
     torch.cuda.synchronize()
     # Keep the GPU busy while the host enqueues the timed launches: the ~40 us of Python between
     # an event record and the first kernel launch must not show up as GPU idle time inside the
-    # event window (the events then bracket exactly the three kernels, back to back).
+    # event window (the events then bracket exactly the op's kernels, back to back).
     torch.cuda._sleep(int(2.0e6 * max(1, reps // 10)))
     evs = []
     for _ in range(reps):
         a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         a.record()
-        layers._logz_launch(x, True)
+        fn()
         b.record()
         evs.append((a, b))
     torch.cuda.synchronize()
@@ -109,21 +166,135 @@ def time_logz_op(T, N, dev, reps, seed=1):
     return float(np.mean(ms)) * 1e-3, float(ms[0]) * 1e-3
 
 
-def time_crf_op(T, N, dev, reps, seed=1):
-    from taiyaki_amd import ctc, synth
-    inp = synth.crf_case(T, N, seed)
-    x = torch.from_numpy(inp["scores"]).to(dev)
-    seqs, seqlens = torch.from_numpy(inp["seqs"]), torch.from_numpy(inp["seqlens"])
-    for _ in range(2):
-        ctc._run(x, seqs, seqlens, 1.0, 1.0, 1.0, 40, True)
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for _ in range(reps):
-        ctc._run(x, seqs, seqlens, 1.0, 1.0, 1.0, 40, True)
-    torch.cuda.synchronize()
-    return (time.perf_counter() - t0) / reps
+class LossOps:
+    """The loss path's two operators on synthetic tensors resident in HBM, launched through the
+    C ABI with every device buffer allocated ONCE (what a captured train step replays): the timed
+    region contains the kernels only."""
+
+    def __init__(self, T, N, dev, realistic_chunk_len=None, spb=9.0, seed=1, cat_mod=False):
+        from taiyaki_amd import _lib, synth
+        self.T, self.N, self.dev = T, N, dev
+        seqlens = None
+        if realistic_chunk_len:
+            seqlens = synth.realistic_seqlens(T, N, 17000 + seed, realistic_chunk_len, spb)
+        inp = synth.crf_case(T, N, seed, seqlens=seqlens, nmods_per_base=CAN_NMODS if cat_mod else None)
+        self.S = inp["scores"].shape[2]
+        self.x = torch.from_numpy(inp["scores"]).to(dev)
+        self.x40 = self.x[:, :, :40].contiguous() if cat_mod else self.x
+        self.seqs = torch.from_numpy(inp["seqs"]).to(device=dev, dtype=torch.int32)
+        self.seqlens = torch.from_numpy(inp["seqlens"]).to(device=dev, dtype=torch.int32)
+        self.maxlen = int(inp["seqlens"].max())
+        self.mod = None
+        if cat_mod:
+            self.mod = (torch.from_numpy(inp["mod_cats"]).to(device=dev, dtype=torch.int32),
+                        inp["can_mods_offsets"], inp["mod_cat_weights"])
+        self.host = inp
+        L = _lib.lib()
+        total = self.seqs.numel()
+        self.seqoff = torch.empty(N + 1, dtype=torch.int64, device=dev)
+        self.stay = torch.empty(max(total, 1), dtype=torch.int32, device=dev)
+        self.move = torch.empty(max(total, 1), dtype=torch.int32, device=dev)
+        self.modidx = self.modfact = self.cmo = self.mcw = None
+        if cat_mod:
+            self.modidx = torch.empty(max(total, 1), dtype=torch.int32, device=dev)
+            self.modfact = torch.empty(max(total, 1), dtype=torch.float32, device=dev)
+            self.cmo = torch.as_tensor(inp["can_mods_offsets"], dtype=torch.int32).to(dev)
+            self.mcw = torch.as_tensor(inp["mod_cat_weights"], dtype=torch.float32).to(dev)
+        self.cost = torch.empty(N, dtype=torch.float32, device=dev)
+        self.grad = torch.empty_like(self.x)
+        self.crf_wsb = L.tk_crf_flipflop_workspace_bytes(self.S, T, N, self.maxlen, 1)
+        self.crf_ws = torch.empty(self.crf_wsb, dtype=torch.uint8, device=dev)
+        self.logz = torch.empty(N, dtype=torch.float32, device=dev)
+        self.lgrad = torch.empty_like(self.x40)
+        self.lz_wsb = L.tk_flipflop_logz_workspace_bytes(T, N, 4)
+        self.lz_ws = torch.empty(self.lz_wsb, dtype=torch.uint8, device=dev)
+        self.status = torch.zeros(1, dtype=torch.int32, device=dev)
+
+    def crf(self):
+        from taiyaki_amd import _lib
+        L, p = _lib.lib(), _lib.ptr
+        st = _lib.stream_ptr()
+        rc = L.tk_flipflop_build_indices_dev(p(self.seqs), p(self.seqlens), self.N, self.seqs.numel(), 4,
+                                             p(self.mod[0]) if self.mod else None, p(self.cmo), p(self.mcw),
+                                             p(self.seqoff), p(self.stay), p(self.move), p(self.modidx),
+                                             p(self.modfact), st)
+        _lib.check(rc, "tk_flipflop_build_indices_dev")
+        rc = L.tk_crf_flipflop_dev(p(self.x), self.S, self.T, self.N, p(self.stay), p(self.move), p(self.modidx),
+                                   p(self.modfact), p(self.seqlens), p(self.seqoff), self.maxlen, 40, 1.0, 1.0, 1.0,
+                                   p(self.cost), p(self.grad), p(self.crf_ws), self.crf_wsb, p(self.status), st)
+        _lib.check(rc, "tk_crf_flipflop_dev")
+
+    def logz_op(self):
+        from taiyaki_amd import _lib
+        L, p = _lib.lib(), _lib.ptr
+        rc = L.tk_flipflop_logz_dev(p(self.x40), self.T, self.N, 4, p(self.logz), p(self.lgrad), p(self.lz_ws),
+                                    self.lz_wsb, p(self.status), _lib.stream_ptr())
+        _lib.check(rc, "tk_flipflop_logz_dev")
+
+    def both(self):
+        self.crf()
+        self.logz_op()
+
+    def finite(self):
+        return int(self.status.item()) == 0
 
 
+def kernel_hash():
+    """Hash of the kernel sources: ties a committed PMC profile to the code it was taken from."""
+    h = hashlib.sha256()
+    d = os.path.join(ROOT, "taiyaki_amd", "csrc")
+    for name in sorted(os.listdir(d)):
+        if name.endswith((".hip", ".h")):
+            with open(os.path.join(d, name), "rb") as fh:
+                h.update(fh.read())
+    return h.hexdigest()[:16]
+
+
+def committed_traffic(op, T, N):
+    """HBM bytes per launch from the newest committed rocprofv3 PMC summary for (op, T, N)."""
+    pdir = os.path.join(ROOT, "profiles")
+    best = None
+    for name in sorted(os.listdir(pdir)) if os.path.isdir(pdir) else []:
+        if name.endswith("_traffic.json") and "_pmc_" in name:
+            with open(os.path.join(pdir, name)) as fh:
+                d = json.load(fh)
+            if d.get("op", "logz") == op and d["shape"]["T"] == T and d["shape"]["N"] == N:
+                best = (name, d)
+    if best is None:
+        return None, None
+    name, d = best
+    src = dict(measured="profiles/" + name, kernel_hash=d.get("kernel_hash"))
+    src["current"] = d.get("kernel_hash") == kernel_hash()
+    return d["traffic_bytes"], src
+
+
+def measure_traffic_now(specs, timeout=240):
+    """FETCH_SIZE / WRITE_SIZE of the listed (op, T, N, realistic) launches, measured in this
+    run: two rocprofv3 --pmc passes (the counters do not fit one pass) over tools/pmc_traffic.py.
+    Returns {key: bytes} or {} when rocprofv3 is missing / fails / times out."""
+    if shutil.which("rocprofv3") is None or os.environ.get("TK_BENCH_NO_PMC"):
+        return {}
+    tool = os.path.join(ROOT, "tools", "pmc_traffic.py")
+    arg = ",".join("%s:%d:%d:%d" % s for s in specs)
+    try:
+        pr = subprocess.run([sys.executable, tool, "--ops", arg, "--json"], capture_output=True, text=True,
+                            timeout=timeout, env={k: v for k, v in os.environ.items()
+                                                  if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK")})
+        line = [ln for ln in pr.stdout.splitlines() if ln.startswith("{")]
+        return json.loads(line[-1]) if pr.returncode == 0 and line else {}
+    except Exception:
+        return {}
+
+
+def roofline_record(kernel, alg, mean_s, min_s, reps, traffic, source):
+    return dict(bound="hbm", kernel=kernel, achieved=round(alg / mean_s / 1e9, 1), peak=HBM_PEAK_GBS, unit="GB/s",
+                frac=round(alg / mean_s / 1e9 / HBM_PEAK_GBS, 4), traffic=traffic, traffic_source=source,
+                algorithmic_bytes=alg, mean_us=round(mean_s * 1e6, 2), min_us=round(min_s * 1e6, 2), launches=reps)
+
+
+# ---------------------------------------------------------------------------------------------
+# CPU legs (the only part of this file that touches oracle/)
+# ---------------------------------------------------------------------------------------------
 def cpu_baseline(T, N, budget_s=12.0):
     """The loss path (A: crf grad, B: logZ fwd-bwd) on the host cores, same shape
     as one GPU's share of a train step.  A runs on the genuine reference C when
@@ -150,9 +321,10 @@ def cpu_baseline(T, N, budget_s=12.0):
     threads = min(cores, 8)     # the reference's own advice: OMP_NUM_THREADS=8 (README.md:362-372)
     reps, el = run(threads, budget_s)
     out = dict(value=round(N * reps / el, 2),
-               unit="chunks/s (loss path only: crf grad + logZ fwd-bwd)",
+               unit="chunks/s (loss path only: crf grad + logZ fwd-bwd; compare with loss_path.gpu_chunks_per_s, "
+                    "not with value)",
                cores=threads, kind="reference" if use_ref else "port",
-               sample="%d reps of T=%d N=%d (cfg 2 shape, SPEED_TEST inputs), %.1f s; host has %d "
+               sample="%d reps of T=%d N=%d (the step's shape, SPEED_TEST inputs), %.1f s; host has %d "
                       "cores; A = %s, B = oracle port" % (
                           reps, T, N, el, cores,
                           "genuine reference C (oracle/_ref)" if use_ref else "oracle port"))
@@ -164,14 +336,64 @@ def cpu_baseline(T, N, budget_s=12.0):
     return out
 
 
+def reference_copies_ms(T, N, S, dev, reps=10):
+    """The device<->host traffic the reference design adds to every loss call: logprob D->H
+    (ctc.pyx:119) and the gradient H->D (ctc.pyx:139-141, pinned like the reference's)."""
+    x = torch.empty(T, N, S, device=dev)
+    h = torch.empty(T, N, S).pin_memory()
+    for _ in range(2):
+        h.copy_(x)
+        x.copy_(h)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        h.copy_(x)
+        x.copy_(h)
+    torch.cuda.synchronize()
+    return (time.perf_counter() - t0) / reps * 1e3
+
+
+# ---------------------------------------------------------------------------------------------
+def dry_launch(args):
+    """Launcher check without GPUs (tests/test_data_parallel.py): the ranks rendezvous over gloo,
+    all-reduce a gradient arena and rank 0 prints the JSON line with n_gpus = world."""
+    from taiyaki_amd import models, parallel
+    rank, local, world = parallel.init_from_env(backend="gloo")
+    torch.manual_seed(3 + rank)
+    net = models.mLstm_flipflop(size=8, stride=5)
+    parallel.broadcast_parameters(net)
+    arena = parallel.FlatGradArena(net, overlap_buckets=3)
+    x = torch.randn(60, 2, 1)
+    arena.zero()
+    net(x).square().mean().backward()
+    arena.allreduce_async()
+    arena.finish()
+    seen = [torch.zeros(1, dtype=torch.int64) for _ in range(world)]
+    dist.all_gather(seen, torch.tensor([rank], dtype=torch.int64))
+    t0 = time.perf_counter()
+    for _ in range(5):
+        dist.all_reduce(arena.flat)
+    el = (time.perf_counter() - t0) / 5
+    dist.barrier()
+    if rank == 0:
+        print(json.dumps(dict(metric="launcher dry run (no GPU, gloo)", dry_launch=True, n_gpus=world,
+                              ranks_seen=sorted(int(t.item()) for t in seen),
+                              rccl=dict(ranks=world, backend="gloo", bytes=arena.flat.numel() * 4,
+                                        allreduce_us=round(el * 1e6, 1), overlap_buckets=len(arena._buckets)))),
+              flush=True)
+    dist.destroy_process_group()
+
+
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--gpus", type=int, default=None)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--chunk-len", type=int, default=4000)
-    ap.add_argument("--batch", type=int, default=128, help="chunks per GPU")
-    ap.add_argument("--size", type=int, default=256)
+    ap.add_argument("--config", type=int, default=2, choices=sorted(CONFIGS),
+                    help="BASELINE.json configuration, SURVEY.md section 8 numbering (default 2 = configs[1])")
+    ap.add_argument("--chunk-len", type=int, default=None)
+    ap.add_argument("--batch", type=int, default=None, help="chunks per GPU")
+    ap.add_argument("--size", type=int, default=None)
     ap.add_argument("--conv", choices=["gemm", "miopen"], default="gemm",
                     help="evaluate the Convolution layers as unfold+GEMM (default) or nn.Conv1d")
     ap.add_argument("--miopen-find", action="store_true", help="torch.backends.cudnn.benchmark")
@@ -193,28 +415,49 @@ def main():
                          "store: every step samples, filters and assembles its batch on the device "
                          "from a synthetic mapped-signal set resident in HBM "
                          "(taiyaki_amd.mapped_signal, the reference's prepare_random_batches)")
+    ap.add_argument("--overlap-buckets", type=int, default=4,
+                    help="gradient all-reduce slices issued from backward hooks (N > 1); 0 = one all-reduce "
+                         "after backward")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-rowk", action="store_true")
+    ap.add_argument("--no-pmc", action="store_true", help="do not run the rocprofv3 PMC passes")
     ap.add_argument("--probe-graph", action="store_true", help=argparse.SUPPRESS)
-    args = ap.parse_args()
+    ap.add_argument("--dry-launch", action="store_true", help=argparse.SUPPRESS)
+    argv = sys.argv[1:]
+    args = ap.parse_args(argv)
+    cfg = dict(CONFIGS[args.config])
+    if args.gpus is None:
+        args.gpus = 8 if args.config == 3 and "WORLD_SIZE" not in os.environ else int(os.environ.get("WORLD_SIZE", "1"))
+        if args.config == 3 and "--gpus" not in argv:
+            argv = argv + ["--gpus", str(args.gpus)]
+    for k, a in (("chunk_len", args.chunk_len), ("batch", args.batch), ("size", args.size)):
+        if a is not None:
+            cfg[k] = a
 
-    from taiyaki_amd import _lib, layers, models, parallel, train
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ and not args.probe_graph:
+        self_launch(args, argv)
+    if args.dry_launch:
+        return dry_launch(args)
+
+    from taiyaki_amd import _lib, models, parallel, train
     if args.probe_graph:
         rank, local, world = 0, int(os.environ.get("LOCAL_RANK", "0")), 1
     else:
         rank, local, world = parallel.init_from_env()
     if world != args.gpus and not args.probe_graph:
-        if rank == 0:
-            print("warning: --gpus %d but WORLD_SIZE=%d" % (args.gpus, world), file=sys.stderr)
+        raise SystemExit("bench.py: --gpus %d but the launcher started WORLD_SIZE=%d ranks" % (args.gpus, world))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an AMD GPU (the flip-flop operators have no CPU fallback)")
+    if torch.cuda.device_count() <= local:
+        raise SystemExit("bench.py: rank %d has no GPU (%d visible)" % (rank, torch.cuda.device_count()))
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     _lib.lib()
     _lib.set_strict(False)      # status words are checked once, after the timed region
 
-    stride = 5
-    T = args.chunk_len // stride
+    stride, chunk_len, nbatch, size = cfg["stride"], cfg["chunk_len"], cfg["batch"], cfg["size"]
+    cat_mod = cfg["model"] == "mLstm_cat_mod_flipflop"
+    T = chunk_len // stride
     torch.manual_seed(1234)     # same init on every rank, then broadcast anyway
     torch.backends.cudnn.benchmark = bool(args.miopen_find)
     if args.lstm == "native":
@@ -228,9 +471,9 @@ def main():
     if use_graph and not args.probe_graph:
         # a failed capture aborts the process inside the HIP runtime, so try it in a child first,
         # at the real shapes (what is probed is this very capture, workspace sizes included)
-        cmd = [sys.executable, os.path.abspath(__file__), "--probe-graph", "--chunk-len",
-               str(args.chunk_len), "--batch", str(args.batch), "--size", str(args.size),
-               "--conv", args.conv, "--lstm", args.lstm]
+        cmd = [sys.executable, os.path.abspath(__file__), "--probe-graph", "--config", str(args.config),
+               "--chunk-len", str(chunk_len), "--batch", str(nbatch), "--size", str(size),
+               "--conv", args.conv, "--lstm", args.lstm, "--gpus", "1"]
         cmd += ["--hybrid"] if hybrid else ["--graph"]
         env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE")}
         try:
@@ -241,23 +484,28 @@ def main():
                       file=sys.stderr)
         except subprocess.TimeoutExpired:
             use_graph = False
-    net = models.mLstm_flipflop(size=args.size, stride=stride).to(dev)
+    if cfg["model"] == "mGru_flipflop":
+        net = models.mGru_flipflop(size=size, stride=stride).to(dev)
+    elif cat_mod:
+        net = models.mLstm_cat_mod_flipflop(size=size, stride=stride, can_nmods=CAN_NMODS).to(dev)
+    else:
+        net = models.mLstm_flipflop(size=size, stride=stride).to(dev)
     for m in net.modules():
         if hasattr(m, "use_gemm"):
             m.use_gemm = args.conv == "gemm"
     parallel.broadcast_parameters(net)
-    arena = parallel.FlatGradArena(net)
+    arena = parallel.FlatGradArena(net, overlap_buckets=args.overlap_buckets)
     # the reference's default adaptive clipping (--gradient_clip_num_mads 0, window 1000):
     # gradient maxima every step, clamp once 1000 steps have been seen
     trainer = train.Trainer(net, arena, clip_num_mads=0)
-    batches = make_batches(args.batch, args.chunk_len, stride, 17 + rank, dev,
-                           n=2 if args.probe_graph else 4)
+    batches = make_batches(nbatch, chunk_len, stride, 17 + rank, dev, n=2 if args.probe_graph else 4,
+                           spb=cfg["spb"], cat_mod=cat_mod)
     mode = "eager"
     stepper = trainer
     if use_graph:
         try:
             cls = train.HybridGraphTrainer if hybrid else train.GraphedTrainer
-            g = cls(trainer, batches[0], seq_capacity=args.batch * (T + 1))
+            g = cls(trainer, batches[0], seq_capacity=nbatch * (T + 1))
             g.load(batches[0])
             g.capture()
             stepper, mode = g, ("hipGraph replay of forward+loss and of AdamW, eager backward"
@@ -278,13 +526,13 @@ def main():
         # flip-flop coding as three launches on this stream, nothing on the host
         from taiyaki_amd import mapped_signal, synth
         store = mapped_signal.MappedSignalStore(
-            synth.mapped_reads(1500, 31 + rank, mean_reflen=max(900, args.chunk_len // 4),
+            synth.mapped_reads(1500, 31 + rank, mean_reflen=max(900, chunk_len // 4),
                                long_dwell_prob=0.0003), dev)
         torch.manual_seed(99 + rank)
-        fparams = store.sample_filter_parameters(1000, args.chunk_len, 3.0, 10.0, 0.5, stride, 1.1)
+        fparams = store.sample_filter_parameters(1000, chunk_len, 3.0, 10.0, 0.5, stride, 1.1)
 
         def next_batch(i):
-            b = store.sample_chunks(args.batch, args.chunk_len, fparams, max_bases_per_chunk=T + 1)
+            b = store.sample_chunks(nbatch, chunk_len, fparams, max_bases_per_chunk=T + 1)
             return dict(indata=b.indata, seqs=b.seqs, seqlens=b.seqlens)
     for i in range(args.warmup):
         stepper.step(next_batch(i))
@@ -299,50 +547,114 @@ def main():
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
     _lib.raise_if_nonfinite()
+    rccl = None
     if dist.is_initialized():
         tmax = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         elapsed = float(tmax.item())
+        # the gradient all-reduce on its own, event-timed on the launching stream (a blocking
+        # all_reduce makes the current stream wait for RCCL's)
+        for _ in range(5):
+            dist.all_reduce(arena.flat)
+        torch.cuda.synchronize()
+        dist.barrier()
+        evs = []
+        for _ in range(20):
+            a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            a.record()
+            dist.all_reduce(arena.flat)
+            b.record()
+            evs.append((a, b))
+        torch.cuda.synchronize()
+        us = sorted(a.elapsed_time(b) * 1e3 for a, b in evs)
+        rccl = dict(ranks=world, backend=dist.get_backend(), bytes=arena.flat.numel() * 4,
+                    allreduce_us=round(float(np.mean(us)), 1), allreduce_min_us=round(us[0], 1),
+                    overlap_buckets=len(arena._buckets),
+                    note="one flat fp32 gradient arena; in the step it is reduced in %d slices issued from "
+                         "backward hooks on RCCL's high-priority stream" % max(1, len(arena._buckets)))
 
     if rank == 0:
-        nglobal = args.batch * world
-        # Roofline of the loss path's HBM-bound operator (logZ forward-backward), HIP events
-        # on the launching stream, right after the timed steps (the step itself may be a
-        # hipGraph replay, so per-launch events cannot be interleaved with it).
-        #   roofline          : the tensor BASELINE.json's north_star quotes the target on
-        #                       (T=4000 blocks x N=256 reads x 40 transitions)
-        #   roofline_in_step  : the very launch the train step makes (configs[1]: T=800, N=128)
-        def logz_roofline(t, n, reps, label):
-            mean_s, min_s = time_logz_op(t, n, dev, reps)
-            alg = 3.0 * t * n * 40 * 4
-            return dict(bound="hbm", kernel="logZ forward-backward op (logz_transfer + logz_middle + "
-                        "logz_posterior), T=%d N=%d (%s)" % (t, n, label),
-                        achieved=round(alg / mean_s / 1e9, 1), peak=HBM_PEAK_GBS, unit="GB/s",
-                        frac=round(alg / mean_s / 1e9 / HBM_PEAK_GBS, 4), traffic=pmc_traffic(t, n),
-                        algorithmic_bytes=alg, mean_us=round(mean_s * 1e6, 2),
-                        min_us=round(min_s * 1e6, 2), launches=reps)
+        nglobal = nbatch * world
+        S = 46 if cat_mod else 40
         out = dict(metric="signal-chunks/sec (T=4000) flip-flop train step", value=round(
                        nglobal * args.steps / elapsed, 2),
                    unit="chunks/s", n_gpus=world, steps=args.steps, warmup=args.warmup,
                    ms_per_step=round(elapsed / args.steps * 1e3, 3), higher_is_better=True,
                    scaling="weak", vs_baseline=None, dtype="f32", data="synthetic",
-                   config=dict(workload="configs[1]: mLstm_flipflop r9.4.1 DNA, chunk_len=%d (T=%d "
-                               "blocks), %d chunks/GPU, size %d, HIP flip-flop CRF loss + logZ, gradient maxima/clipping, AdamW"
-                               % (args.chunk_len, T, args.batch, args.size),
-                               global_batch=nglobal, chunk_len=args.chunk_len, launch=mode,
+                   config=dict(workload="%s, chunk_len=%d (T=%d blocks), %d chunks/GPU, size %d, HIP flip-flop %s "
+                               "loss + logZ, gradient maxima/clipping, AdamW"
+                               % (cfg["label"], chunk_len, T, nbatch, size, "cat-mod" if cat_mod else "CRF"),
+                               config_id=args.config, model=cfg["model"],
+                               global_batch=nglobal, chunk_len=chunk_len, launch=mode,
                                hw_queues=int(os.environ.get("GPU_MAX_HW_QUEUES", "0")),
                                conv=args.conv, lstm=args.lstm,
                                batches=("assembled on the device every step from a mapped-signal set in HBM"
                                         if args.data == "store" else "pre-assembled, cycled from HBM"),
-                               parallelism="dp%d (reads sharded, flat RCCL all-reduce)" % world))
+                               parallelism="dp%d (reads sharded, bucketed RCCL all-reduce overlapped with backward)"
+                               % world))
+        if rccl is not None:
+            out["rccl"] = rccl
+        # ---- loss-path kernels, HIP events on the launching stream, right after the timed steps
+        #      (the step itself may be a hipGraph replay, so per-launch events cannot be
+        #      interleaved with it) -----------------------------------------------------------
+        step_ops = LossOps(T, nbatch, dev, realistic_chunk_len=chunk_len, spb=cfg["spb"], cat_mod=cat_mod)
+        specs = [("logz", T, nbatch, 0), ("crf", T, nbatch, chunk_len)]
+        rowk = None
         if not args.no_rowk:
-            out["roofline"] = logz_roofline(4000, 256, 50, "north_star kernel shape")
-            out["roofline_in_step"] = logz_roofline(T, args.batch, 30, "the train step's own launch")
-            out["crf_op_ms"] = dict(cfg2=round(time_crf_op(T, args.batch, dev, 5) * 1e3, 3))
+            rowk = LossOps(4000, 256, dev)
+            specs = [("logz", 4000, 256, 0), ("crf", 4000, 256, 0)] + specs
+        measured = {} if args.no_pmc else measure_traffic_now(specs)
+        khash = kernel_hash()
+
+        def traffic_of(op, t, n, realistic):
+            key = "%s:%d:%d:%d" % (op, t, n, realistic)
+            if key in measured:
+                return measured[key], dict(measured="in this run (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, "
+                                                    "separate passes, tools/pmc_traffic.py)", kernel_hash=khash,
+                                           current=True)
+            return committed_traffic(op, t, n)
+
+        def logz_roofline(ops, reps, label):
+            mean_s, min_s = _events_mean_min(ops.logz_op, reps)
+            tr, src = traffic_of("logz", ops.T, ops.N, 0)
+            return roofline_record("logZ forward-backward op (logz_transfer + logz_middle + logz_posterior), "
+                                   "T=%d N=%d (%s)" % (ops.T, ops.N, label), 3.0 * ops.T * ops.N * 40 * 4,
+                                   mean_s, min_s, reps, tr, src)
+
+        def crf_roofline(ops, reps, label, realistic):
+            mean_s, min_s = _events_mean_min(ops.crf, reps, warm=5)
+            tr, src = traffic_of("crf", ops.T, ops.N, realistic)
+            return roofline_record("sequence CRF op (build_indices + crf_band_sweep + crf_band_posterior), "
+                                   "T=%d N=%d S=%d, max L %d (%s)" % (ops.T, ops.N, ops.S, ops.maxlen, label),
+                                   3.0 * ops.T * ops.N * ops.S * 4, mean_s, min_s, reps, tr, src)
+
+        if rowk is not None:
+            out["roofline"] = logz_roofline(rowk, 50, "north_star kernel shape")
+            out["roofline_in_step"] = logz_roofline(step_ops, 30, "the train step's own launch")
+            out["roofline_crf"] = dict(
+                in_step=crf_roofline(step_ops, 20, "the train step's own launch, realistic lengths", chunk_len),
+                rowK=crf_roofline(rowk, 5, "north_star shape, SPEED_TEST lengths 0.45-0.55 T", 0),
+                note="latency/issue-bound by the serial lattice recursion, not by HBM: achieved is the "
+                     "algorithmic 3*T*N*S*4 bytes over the op's duration; traffic is dominated by the two "
+                     "lattices of the band")
         else:
-            out["roofline"] = logz_roofline(T, args.batch, 30, "the train step's own launch")
+            out["roofline"] = logz_roofline(step_ops, 30, "the train step's own launch")
+        # ---- the whole loss path in one unit ------------------------------------------------
+        lp_mean, _ = _events_mean_min(step_ops.both, 20, warm=5)
+        assert step_ops.finite()
+        out["loss_path"] = dict(unit="chunks/s through crf grad + logZ fwd-bwd at the step's shape (T=%d, N=%d, "
+                                     "S=%d, realistic lengths)" % (T, nbatch, S),
+                                gpu_ms=round(lp_mean * 1e3, 4), gpu_chunks_per_s=round(nbatch / lp_mean, 1))
         if not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(T, args.batch)
+            cb = cpu_baseline(T, nbatch)
+            out["cpu_baseline"] = cb
+            copies = reference_copies_ms(T, nbatch, S, dev)
+            cpu_ms = nbatch / cb["value"] * 1e3
+            out["loss_path"].update(
+                cpu_chunks_per_s=cb["value"], cpu_ms=round(cpu_ms, 3), copies_ms=round(copies, 3),
+                cpu_with_copies_chunks_per_s=round(nbatch / ((cpu_ms + copies) * 1e-3), 2),
+                note="cpu = %s on %d host threads; copies = score tensor D->H + gradient H->D (pinned), what "
+                     "the reference's CPU extension adds per call (ctc.pyx:119, 139-141)" % (cb["kind"], cb["cores"]))
     else:
         out = None
     if dist.is_initialized():

@@ -72,7 +72,9 @@ class DeviceClipper:
         self.nseg, self.max_len = len(sizes), int(max(sizes))
         self.seg_off = torch.from_numpy(off).to(dev)
         self.maxs = torch.zeros(self.nseg, dtype=torch.float32, device=dev)
-        self.thresh = torch.zeros(self.nseg, dtype=torch.float32, device=dev)
+        # +inf = "no threshold yet": the clamp kernel skips such segments, so it can always be
+        # launched (and captured into a hipGraph) and starts clamping the moment thresholds arrive
+        self.thresh = torch.full((self.nseg,), float("inf"), dtype=torch.float32, device=dev)
         self.maxs_host = torch.zeros(self.nseg, dtype=torch.float32).pin_memory() if dev.type == "cuda" \
             else torch.zeros(self.nseg, dtype=torch.float32)
         self.thresh_host = torch.zeros(self.nseg, dtype=torch.float32).pin_memory() if dev.type == "cuda" \
@@ -103,22 +105,29 @@ class DeviceClipper:
         return self.last_maxs
 
     def launch_kernels(self):
-        """Only the device work (capturable into a hipGraph): maxima, clamp if thresholds exist."""
+        """Only the device work (capturable into a hipGraph): maxima, then the clamp (a no-op for
+        segments whose threshold is still +inf).  A whole-step graph replays this; the host side
+        of the step is `collect()` before the replay and `copy_maxima_async()` after it."""
         _lib.require_gpu(self.arena.flat, "DeviceClipper")
         L = _lib.lib()
         with torch.cuda.device(self.arena.flat.device):
             rc = L.tk_grad_maxabs_clip_dev(_lib.ptr(self.arena.flat), _lib.ptr(self.seg_off), self.nseg,
-                                           self.max_len, _lib.ptr(self.thresh) if self.active else None,
-                                           _lib.ptr(self.maxs), _lib.stream_ptr())
+                                           self.max_len, _lib.ptr(self.thresh), _lib.ptr(self.maxs),
+                                           _lib.stream_ptr())
             _lib.check(rc, "tk_grad_maxabs_clip_dev")
 
-    def launch(self):
-        """Enqueue maxima (+ clamp once thresholds exist) and the async copy of the maxima."""
-        self.launch_kernels()
+    def copy_maxima_async(self):
+        """The maxima of the step just enqueued (or replayed from a graph) start their way to the
+        host; `collect()` picks them up before the next step."""
         with torch.cuda.device(self.arena.flat.device):
             self.maxs_host.copy_(self.maxs, non_blocking=True)
             self.event = torch.cuda.Event()
             self.event.record()
+
+    def launch(self):
+        """Enqueue maxima (+ clamp once thresholds exist) and the async copy of the maxima."""
+        self.launch_kernels()
+        self.copy_maxima_async()
 
     def step(self):
         prev = self.collect()

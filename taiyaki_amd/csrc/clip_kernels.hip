@@ -69,12 +69,19 @@ __global__ __launch_bounds__(CLIP_THREADS) void grad_clamp_kernel(float *__restr
     }
 }
 
+__global__ void maxs_zero_kernel(float *__restrict__ maxs, int nseg) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < nseg) maxs[i] = 0.f;
+}
+
 int grad_clip_dispatch(float *grads, const int64_t *seg_off, size_t nseg, size_t max_seg_len,
                        const float *thresh, float *maxs, hipStream_t stream) {
     if (nseg == 0) return 0;
     const unsigned chunks = (unsigned)((max_seg_len + CLIP_THREADS * CLIP_PER_THREAD - 1) /
                                        (CLIP_THREADS * CLIP_PER_THREAD));
-    if (hipMemsetAsync(maxs, 0, nseg * sizeof(float), stream) != hipSuccess) return 4;
+    // (a kernel, not hipMemsetAsync: replayed from a hipGraph on ROCm 7.2 the memset node of this
+    // small buffer left garbage in some of its words, which atomicMax then kept for ever)
+    hipLaunchKernelGGL(maxs_zero_kernel, dim3((unsigned)((nseg + 255) / 256)), dim3(256), 0, stream, maxs, (int)nseg);
     hipLaunchKernelGGL(grad_maxabs_kernel, dim3((unsigned)nseg, chunks ? chunks : 1), dim3(CLIP_THREADS), 0,
                        stream, grads, seg_off, maxs);
     if (thresh != nullptr)

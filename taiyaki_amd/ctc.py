@@ -26,8 +26,8 @@ def _indices(seqs, seqlen, nbase, device, mod_cats=None, can_mods_offsets=None,
     mod = fact = mc = cmo = mcw = None
     if mod_cats is not None:
         mc = mod_cats.to(device=device, dtype=torch.int32, non_blocking=True).contiguous()
-        cmo = torch.as_tensor(np.asarray(can_mods_offsets), dtype=torch.int32).to(device)
-        mcw = torch.as_tensor(np.asarray(mod_cat_weights), dtype=torch.float32).to(device)
+        cmo = _device_constant(can_mods_offsets, torch.int32, device)
+        mcw = _device_constant(mod_cat_weights, torch.float32, device)
         mod = torch.empty(max(total, 1), dtype=torch.int32, device=device)
         fact = torch.empty(max(total, 1), dtype=torch.float32, device=device)
     rc = L.tk_flipflop_build_indices_dev(
@@ -37,6 +37,24 @@ def _indices(seqs, seqlen, nbase, device, mod_cats=None, can_mods_offsets=None,
     _lib.check(rc, "tk_flipflop_build_indices_dev")
     # keep the staging tensors alive until the caller has enqueued its kernel
     return seqlen_d, seqoff, stay, move, mod, fact, (seqs_d, mc, cmo, mcw)
+
+
+_CONSTANTS = {}
+
+
+def _device_constant(values, dtype, device):
+    """The few-element cat-mod tables (can_mods_offsets, mod_cat_weights * mod_factor) on the
+    device.  Tensors that already live there pass through; host values are uploaded once per
+    distinct content (so a captured step never contains a pageable host-to-device copy)."""
+    if torch.is_tensor(values) and values.device == device:
+        return values.to(dtype).contiguous()
+    arr = np.ascontiguousarray(values.cpu().numpy() if torch.is_tensor(values) else np.asarray(values))
+    key = (str(device), str(dtype), arr.dtype.str, arr.tobytes())
+    if key not in _CONSTANTS:
+        if len(_CONSTANTS) > 256:
+            _CONSTANTS.clear()
+        _CONSTANTS[key] = torch.as_tensor(arr).to(dtype).to(device)
+    return _CONSTANTS[key]
 
 
 _KEEP_WS = None      # debugging aid: set to a list to keep the kernels' workspaces alive

@@ -213,6 +213,10 @@ class GlobalNormFlipFlopCatMod(nn.Module):
             self.can_indices.append(np.concatenate([[0], np.arange(curr + 1, curr + 1 + n)]))
             curr += n
         self.size = self.ntrans_states + 1 + self.nmod_base
+        # index tensors live with the module (moved by .to(device)): nothing is uploaded in
+        # forward, so the layer can be captured into a hipGraph
+        for k, idx in enumerate(self.can_indices):
+            self.register_buffer("can_index_%d" % k, torch.as_tensor(idx, dtype=torch.int64), persistent=False)
         self.linear = nn.Linear(insize, self.size)
         _orthonormal_(self.linear.weight)
         _truncated_normal_(self.linear.bias, 0.5)
@@ -225,6 +229,6 @@ class GlobalNormFlipFlopCatMod(nn.Module):
         y = self.linear(x)
         trans = 5.0 * torch.tanh(y[:, :, :self.ntrans_states])
         cat = y[:, :, self.ntrans_states:]
-        mods = [torch.log_softmax(cat[:, :, torch.as_tensor(idx, device=y.device)], dim=2)
-                for idx in self.can_indices]
+        mods = [torch.log_softmax(cat.index_select(2, getattr(self, "can_index_%d" % k)), dim=2)
+                for k in range(self.ncan_base)]
         return torch.cat([trans] + mods, dim=2)

@@ -48,35 +48,97 @@ def init_from_env(backend=None):
 
 
 class FlatGradArena:
-    """All trainable gradients as views into one contiguous fp32 buffer."""
+    """All trainable gradients as views into one contiguous fp32 buffer.
 
-    def __init__(self, module):
+    `overlap_buckets=k` (k > 1, world > 1) cuts the arena into k contiguous slices and all-reduces
+    a slice as soon as autograd has accumulated the last gradient that lives in it (post-
+    accumulate hooks): backward produces the gradients of the last layers first, so their
+    reduction runs on RCCL's own stream while the RNN backward of the earlier layers is still
+    computing (the reference's DDP does the same with 25 MiB buckets; here the whole payload is
+    10.9 MB).  `finish()` waits for every slice, reduces whatever was not ready (unused
+    parameters) and applies the 1/world factor."""
+
+    def __init__(self, module, overlap_buckets=0):
         self.params = [p for p in module.parameters() if p.requires_grad]
         n = sum(p.numel() for p in self.params)
         dev = self.params[0].device
         self.flat = torch.zeros(n, dtype=torch.float32, device=dev)
+        self.spans = []
         off = 0
         for p in self.params:
             p.grad = self.flat[off:off + p.numel()].view_as(p)
+            self.spans.append((off, off + p.numel()))
             off += p.numel()
         self.world = dist.get_world_size() if dist.is_initialized() else 1
         self._always = dist.is_initialized() and bool(os.environ.get("TK_FORCE_PROCESS_GROUP"))
-        self._work = None
+        self._work = []
+        self._buckets = []          # [lo, hi, params still missing this step, issued]
+        self._hooks = []
+        self.hooks_enabled = True   # (switched off around a whole-step graph capture)
+        if overlap_buckets > 1 and (self.world > 1 or self._always):
+            self._install_hooks(overlap_buckets)
 
+    # -- overlap ---------------------------------------------------------------------------
+    def _install_hooks(self, nbuckets):
+        per = -(-self.flat.numel() // nbuckets)
+        bounds, lo, cnt = [], 0, []
+        owner = []
+        for (a, b) in self.spans:
+            if b - lo > per and a > lo:
+                bounds.append((lo, a))
+                lo = a
+            owner.append(len(bounds))
+        bounds.append((lo, self.flat.numel()))
+        cnt = [0] * len(bounds)
+        for k in owner:
+            cnt[k] += 1
+        self._bucket_size = cnt
+        self._buckets = [[a, b, c, False] for (a, b), c in zip(bounds, cnt)]
+        for p, k in zip(self.params, owner):
+            self._hooks.append(p.register_post_accumulate_grad_hook(self._make_hook(k)))
+
+    def _make_hook(self, k):
+        def hook(_param):
+            if not self.hooks_enabled:
+                return
+            b = self._buckets[k]
+            b[2] -= 1
+            if b[2] == 0 and not b[3]:
+                b[3] = True
+                self._work.append(dist.all_reduce(self.flat[b[0]:b[1]], op=dist.ReduceOp.SUM, async_op=True))
+        return hook
+
+    @property
+    def overlapped(self):
+        return bool(self._buckets)
+
+    # -- step interface ----------------------------------------------------------------------
     def zero(self):
         self.flat.zero_()
 
     def allreduce_async(self):
-        """SUM over ranks (the reference's DDP averages; the 1/world factor is
-        applied by `finish`)."""
-        if self.world > 1 or self._always:
-            self._work = dist.all_reduce(self.flat, op=dist.ReduceOp.SUM, async_op=True)
+        """SUM over ranks (the reference's DDP averages; the 1/world factor is applied by
+        `finish`).  With overlap hooks installed only the slices backward did not complete are
+        issued here."""
+        if not (self.world > 1 or self._always):
+            return
+        if self._buckets and self.hooks_enabled:
+            for b in self._buckets:
+                if not b[3]:
+                    b[3] = True
+                    self._work.append(dist.all_reduce(self.flat[b[0]:b[1]], op=dist.ReduceOp.SUM,
+                                                      async_op=True))
+        else:
+            self._work.append(dist.all_reduce(self.flat, op=dist.ReduceOp.SUM, async_op=True))
 
     def finish(self):
-        if self._work is not None:
-            self._work.wait()
-            self._work = None
+        if self._work:
+            for w in self._work:
+                w.wait()
+            self._work = []
             self.flat.mul_(1.0 / self.world)
+        for b, c in zip(self._buckets, getattr(self, "_bucket_size", [])):
+            b[2], b[3] = c, False
 
 
 def broadcast_parameters(module, src=0):

@@ -90,6 +90,12 @@ class GraphedTrainer:
             indata=torch.zeros_like(example_batch["indata"], device=dev),
             seqs=torch.zeros(seq_capacity, dtype=torch.int32, device=dev),
             seqlens=torch.zeros_like(example_batch["seqlens"], dtype=torch.int32, device=dev))
+        if example_batch.get("mod_cats") is not None:
+            # cat-mod batches (bin/train_flipflop.py:116-142): per-position modification
+            # categories next to the sequences; the two small tables stay constant
+            self.static["mod_cats"] = torch.zeros(seq_capacity, dtype=torch.int32, device=dev)
+            self.static["can_mods_offsets"] = example_batch["can_mods_offsets"]
+            self.static["mod_cat_weights"] = example_batch["mod_cat_weights"]
         self.loss = None
         self.graph = None
 
@@ -98,6 +104,8 @@ class GraphedTrainer:
         n = batch["seqs"].numel()
         self.static["seqs"][:n].copy_(batch["seqs"], non_blocking=True)
         self.static["seqlens"].copy_(batch["seqlens"], non_blocking=True)
+        if "mod_cats" in self.static:
+            self.static["mod_cats"][:n].copy_(batch["mod_cats"], non_blocking=True)
 
     def capture(self, warmup=3):
         side = torch.cuda.Stream()
@@ -108,13 +116,26 @@ class GraphedTrainer:
         torch.cuda.current_stream().wait_stream(side)
         torch.cuda.synchronize()
         self.graph = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(self.graph, **_CAPTURE):
-            self.loss = self.trainer.step(self.static)
+        arena = self.trainer.arena
+        arena.hooks_enabled = False         # one captured all-reduce, not hook-issued slices
+        try:
+            with torch.cuda.graph(self.graph, **_CAPTURE):
+                self.loss = self.trainer.step(self.static)
+        finally:
+            arena.hooks_enabled = True
         torch.cuda.synchronize()
 
     def step(self, batch):
+        """Replay.  The clipper's host half runs around the replay exactly as in the eager step:
+        last step's maxima -> rolling statistics -> thresholds (uploaded before the replay, so the
+        captured clamp kernel sees them), and this step's maxima start their way to the host."""
+        clipper = self.trainer.clipper
         self.load(batch)
+        if clipper is not None:
+            clipper.collect()
         self.graph.replay()
+        if clipper is not None:
+            clipper.copy_maxima_async()
         return self.loss
 
 

@@ -11,6 +11,10 @@ from taiyaki_amd import _lib, models, parallel, train  # noqa: E402
 
 
 def main():
+    whole = len(sys.argv) > 1 and sys.argv[1] == "whole"
+    if whole:
+        # the ATen per-timestep LSTM: the only RNN whose backward captures (bench.py --lstm native)
+        torch.backends.cudnn.enabled = False
     dev = torch.device("cuda", 0)
     torch.cuda.set_device(dev)
     _lib.set_strict(False)
@@ -25,12 +29,19 @@ def main():
     net_b = copy.deepcopy(net_a)
     batches = bench.make_batches(nbatch, chunk_len, stride, 5, dev, n=3)
     # adaptive clipping on, with a 3-step window so that the clamp is active inside the test
-    tr_a = train.Trainer(net_a, parallel.FlatGradArena(net_a), clip_num_mads=0, clip_window=3)
-    tr_b = train.Trainer(net_b, parallel.FlatGradArena(net_b), clip_num_mads=0, clip_window=3)
-    hy = train.HybridGraphTrainer(tr_b, batches[0], seq_capacity=nbatch * (T + 1))
+    mads = None if os.environ.get("TK_TEST_NOCLIP") else 0
+    tr_a = train.Trainer(net_a, parallel.FlatGradArena(net_a), clip_num_mads=mads, clip_window=3)
+    tr_b = train.Trainer(net_b, parallel.FlatGradArena(net_b), clip_num_mads=mads, clip_window=3)
+    cls = train.GraphedTrainer if whole else train.HybridGraphTrainer
+    hy = cls(tr_b, batches[0], seq_capacity=nbatch * (T + 1))
     hy.load(batches[0])
     hy.capture(warmup=1)        # one eager step + the capture's own tail step, both on batch 0
-    la = [float(tr_a.step(batches[0])), float(tr_a.step(batches[0]))]
+    if whole:
+        # (a whole-step capture only records: the reference trainer is one step ahead by the
+        # warm-up step alone; its clipper has seen one set of maxima, like the captured one)
+        la = [float(tr_a.step(batches[0]))]
+    else:
+        la = [float(tr_a.step(batches[0])), float(tr_a.step(batches[0]))]
     worst = 0.0
     for i in range(1, 6):
         b = batches[i % 3]
@@ -39,7 +50,13 @@ def main():
         worst = max(worst, abs(la[-1] - lb) / max(1e-6, abs(la[-1])))
     torch.cuda.synchronize()
     _lib.raise_if_nonfinite()
+    if os.environ.get("TK_TEST_DEBUG") and tr_a.clipper is not None:
+        print("thresh a", tr_a.clipper.thresh[:6].tolist(), "b", tr_b.clipper.thresh[:6].tolist())
+        print("maxs a", tr_a.clipper.last_maxs[:6], "b", tr_b.clipper.last_maxs[:6])
+        print("iters", tr_a.clipper.rolling._curr_iter, tr_b.clipper.rolling._curr_iter)
     pw = max(float((pa - pb).abs().max()) for pa, pb in zip(net_a.parameters(), net_b.parameters()))
+    if whole and mads is not None:
+        assert tr_b.clipper.active, "the captured step never received clipping thresholds"
     print("hybrid-ok loss_rel=%.3e param_abs=%.3e losses=%s" % (worst, pw, ["%.5f" % x for x in la]))
 
 

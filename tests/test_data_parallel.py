@@ -87,6 +87,100 @@ def test_flat_allreduce_world_size_2_gloo(tmp_path):
         assert "rank %d ok" % rank in out
 
 
+EQUIV_WORKER = textwrap.dedent('''
+    import os, sys
+    import torch
+    import torch.distributed as dist
+    sys.path.insert(0, %r)
+    from taiyaki_amd import models, parallel
+
+    rank, local, world = parallel.init_from_env(backend="gloo")
+    torch.manual_seed(5)                          # the SAME model on both ranks
+    net = models.mLstm_flipflop(size=16, stride=5)
+    arena = parallel.FlatGradArena(net, overlap_buckets=int(os.environ["TK_TEST_BUCKETS"]))
+    assert arena.overlapped == (int(os.environ["TK_TEST_BUCKETS"]) > 1)
+    torch.manual_seed(11)
+    x = torch.randn(200, 6, 1)                    # one fixed batch of 6 chunks ...
+    target = torch.randn(40, 6, 40)
+
+    def loss_of(net, xs, ts):
+        # per-chunk losses averaged over the chunks, like lossvector.mean() (train_flipflop.py:182)
+        return ((net(xs) - ts) ** 2).mean(dim=(0, 2)).mean()
+
+    half = slice(3 * rank, 3 * rank + 3)          # ... each rank takes its half
+    arena.zero()
+    loss_of(net, x[:, half], target[:, half]).backward()
+    arena.allreduce_async()
+    arena.finish()
+    got = arena.flat.clone()
+    # single-process reference: the whole batch on a fresh copy of the same model
+    torch.manual_seed(5)
+    ref = models.mLstm_flipflop(size=16, stride=5)
+    loss_of(ref, x, target).backward()
+    want = torch.cat([p.grad.reshape(-1) for p in ref.parameters() if p.requires_grad])
+    err = float((got - want).abs().max() / want.abs().max())
+    assert err < 2e-6, err
+    dist.barrier()
+    dist.destroy_process_group()
+    print("rank %%d ok err=%%.2e" %% (rank, err))
+''') % ROOT
+
+
+def _run_two_ranks(tmp_path, source, extra_env):
+    script = tmp_path / "worker.py"
+    script.write_text(source)
+    port = _free_port()
+    procs = []
+    for rank in range(2):
+        env = dict(os.environ, RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE="2",
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), OMP_NUM_THREADS="2", **extra_env)
+        procs.append(subprocess.Popen([sys.executable, str(script)], env=env,
+                                      stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True))
+    outs = []
+    for p in procs:
+        try:
+            out, _ = p.communicate(timeout=240)
+        except subprocess.TimeoutExpired:
+            p.kill()
+            out, _ = p.communicate()
+        outs.append(out)
+    for rank, (p, out) in enumerate(zip(procs, outs)):
+        assert p.returncode == 0, "rank %d failed:\n%s" % (rank, out[-3000:])
+        assert "rank %d ok" % rank in out
+
+
+@pytest.mark.parametrize("buckets", ["0", "3"])
+def test_two_rank_step_equals_one_rank_step_on_the_whole_batch(tmp_path, buckets):
+    """The data-parallel equivalence the reference never tested: two ranks, the same model, each
+    half of one fixed batch -> the averaged gradient arena equals the gradient of a single process
+    on the whole batch; with the single flat all-reduce and with the hook-issued slices that
+    overlap backward."""
+    _run_two_ranks(tmp_path, EQUIV_WORKER, dict(TK_TEST_BUCKETS=buckets))
+
+
+def test_bench_gpus_2_launches_two_ranks_itself(tmp_path):
+    """`python bench.py --gpus 2` outside torchrun starts the two ranks itself (one
+    torch.distributed.run child, 127.0.0.1 rendezvous) and rank 0 reports n_gpus = 2.  On this
+    GPU-less container the ranks run the launcher's dry mode over gloo."""
+    import json
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK")}
+    pr = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--dry-launch"],
+                        capture_output=True, text=True, timeout=300, env=env)
+    assert pr.returncode == 0, pr.stderr[-2000:]
+    line = [ln for ln in pr.stdout.splitlines() if ln.startswith("{")][-1]
+    out = json.loads(line)
+    assert out["n_gpus"] == 2 and out["ranks_seen"] == [0, 1]
+    assert out["rccl"]["ranks"] == 2 and out["rccl"]["bytes"] > 0 and out["rccl"]["overlap_buckets"] >= 2
+
+
+def test_bench_refuses_more_ranks_than_gpus():
+    """Asking for more GPUs than are visible must fail loudly, never measure fewer ranks."""
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK")}
+    pr = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "64"],
+                        capture_output=True, text=True, timeout=300, env=env)
+    assert pr.returncode != 0 and "refusing" in (pr.stderr + pr.stdout)
+
+
 def test_torchrun_env_rendezvous_single_process():
     """bench.py's rendezvous helper is a no-op at world size 1 (the default `python bench.py`)."""
     from taiyaki_amd import parallel

@@ -567,6 +567,22 @@ def test_hybrid_graph_trainer_matches_eager(gpu_device):
     assert float(m.group(1)) < 1e-4 and float(m.group(2)) < 1e-4, pr.stdout
 
 
+def test_whole_step_graph_trainer_clips_like_eager(gpu_device):
+    """GraphedTrainer (the whole step in one hipGraph, ATen LSTM) with adaptive clipping: the
+    clamp kernel is captured with +inf thresholds and must start clamping once the rolling
+    statistics (fed around every replay) produce thresholds -- same losses and parameters as the
+    eager Trainer with a 3-step window."""
+    import os
+    import re
+    import subprocess
+    import sys
+    script = os.path.join(os.path.dirname(os.path.abspath(__file__)), "helpers", "hybrid_vs_eager.py")
+    pr = subprocess.run([sys.executable, script, "whole"], capture_output=True, text=True, timeout=900)
+    assert pr.returncode == 0 and "hybrid-ok" in pr.stdout, (pr.stdout[-500:], pr.stderr[-800:])
+    m = re.search(r"loss_rel=(\S+) param_abs=(\S+)", pr.stdout)
+    assert m and float(m.group(1)) < 1e-4 and float(m.group(2)) < 1e-4, pr.stdout
+
+
 @pytest.mark.parametrize("scale,T,N", [(4.0, 600, 70), (8.0, 600, 70),
                                         (1.0, 2100, 320), (3.0, 2100, 320), (8.0, 2100, 320)])
 def test_logz_wide_dynamic_range(oracle_mod, gpu_device, scale, T, N):

@@ -217,7 +217,7 @@ class LossOps:
         rc = L.tk_flipflop_build_indices_dev(p(self.seqs), p(self.seqlens), self.N, self.seqs.numel(), 4,
                                              p(self.mod[0]) if self.mod else None, p(self.cmo), p(self.mcw),
                                              p(self.seqoff), p(self.stay), p(self.move), p(self.modidx),
-                                             p(self.modfact), st)
+                                             p(self.modfact), p(self.status), st)
         _lib.check(rc, "tk_flipflop_build_indices_dev")
         rc = L.tk_crf_flipflop_dev(p(self.x), self.S, self.T, self.N, p(self.stay), p(self.move), p(self.modidx),
                                    p(self.modfact), p(self.seqlens), p(self.seqoff), self.maxlen, 40, 1.0, 1.0, 1.0,
@@ -500,6 +500,9 @@ def main():
     trainer = train.Trainer(net, arena, clip_num_mads=0)
     batches = make_batches(nbatch, chunk_len, stride, 17 + rank, dev, n=2 if args.probe_graph else 4,
                            spb=cfg["spb"], cat_mod=cat_mod)
+    if args.data == "store":
+        for b in batches:               # (also captured: device-assembled batches may carry padding)
+            b["ignore_empty"] = True
     mode = "eager"
     stepper = trainer
     if use_graph:
@@ -533,7 +536,8 @@ def main():
 
         def next_batch(i):
             b = store.sample_chunks(nbatch, chunk_len, fparams, max_bases_per_chunk=T + 1)
-            return dict(indata=b.indata, seqs=b.seqs, seqlens=b.seqlens)
+            # (padding columns of a starved batch carry no sequence: keep them out of the loss)
+            return dict(indata=b.indata, seqs=b.seqs, seqlens=b.seqlens, ignore_empty=True)
     for i in range(args.warmup):
         stepper.step(next_batch(i))
     if dist.is_initialized():

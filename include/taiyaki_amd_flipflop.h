@@ -59,7 +59,12 @@ extern "C" {
 /* bits of the device-side status word */
 #define TK_STATUS_NONFINITE_SCORE 1u
 #define TK_STATUS_NONFINITE_GRAD 2u
-#define TK_STATUS_SEQS_OVERFLOW 4u      /* tk_chunks_gather_dev: seqs buffer too small */
+#define TK_STATUS_SEQS_OVERFLOW 4u      /* tk_chunks_gather_dev: seqs buffer too small; CRF: sequence
+                                           longer than the launch was sized for */
+#define TK_STATUS_BAD_LABEL 8u          /* tk_flipflop_build_indices_dev: a flip-flop code outside
+                                           [0, 2 nbase), a mod category outside its base's range, or
+                                           sum(seqlen) > total_len (the reference asserts that move /
+                                           stay indices lie in [0, ntrans), ctc.pyx:127-134) */
 
 /* library / build identification: returns e.g. "taiyaki_amd flipflop gfx950 r1" */
 const char *tk_version(void);
@@ -74,6 +79,8 @@ const char *tk_version(void);
  * sentinel):
  *   seqoff (nbatch+1) int64 prefix offsets ; stayidx, moveidx (sum L) int32 ;
  *   modidx (sum L) int32, modfact (sum L) f32 (only when mod_cats != NULL)
+ * Labels are range-checked: an offending code is clamped (so that no later kernel indexes out
+ * of range) and TK_STATUS_BAD_LABEL is OR-ed into *status (nullable).
  * ------------------------------------------------------------------------- */
 int tk_flipflop_build_indices_dev(const int32_t *seqs, const int32_t *seqlen,
                                   size_t nbatch, size_t total_len, size_t nbase,
@@ -82,7 +89,7 @@ int tk_flipflop_build_indices_dev(const int32_t *seqs, const int32_t *seqlen,
                                   const float *mod_cat_weights,
                                   int64_t *seqoff, int32_t *stayidx,
                                   int32_t *moveidx, int32_t *modidx,
-                                  float *modfact, void *stream);
+                                  float *modfact, uint32_t *status, void *stream);
 
 /* ------------------------------------------------------------------------- *
  * (A) sequence-constrained flip-flop CRF score and gradient
@@ -250,9 +257,15 @@ int tk_remap_path_to_ref_to_signal_dev(const int64_t *path, const int64_t *path_
 /* ------------------------------------------------------------------------- *
  * Exact reference prototypes (HOST pointers; taiyaki/ctc/c_crf_flipflop.h:3-11,
  * c_cat_mod_flipflop.h:3-13).  Index arrays use the reference layout
- * (moves: sum(seqlen) - nbatch entries).  These stage through device memory,
- * run the same kernels and synchronise; an internal failure yields NAN scores
- * (the reference's own out-of-memory behaviour, c_crf_flipflop.c:278-282).
+ * (moves: max(L - 1, 0) entries per read, concatenated, as ctc.pyx:127-134 builds
+ * them = sum(seqlen) - nbatch entries when no read is empty).  A batch with an
+ * EMPTY read that is not last is where this entry point departs from the
+ * reference C on purpose: the C indexes read b's moves at seqidx[b] - b
+ * (c_crf_flipflop.c:479-480), one slot early per empty read in front, i.e. into
+ * its neighbour's ids; here read b's moves start where the caller put them.
+ * These stage through device memory, run the same kernels and synchronise; an
+ * internal failure yields NAN scores (the reference's own out-of-memory
+ * behaviour, c_crf_flipflop.c:278-282).
  * ------------------------------------------------------------------------- */
 void crf_flipflop_grad(float const *logprob, size_t ntrans, size_t nblk,
                        size_t nbatch, size_t const *moveidxs,

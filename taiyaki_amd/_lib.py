@@ -24,7 +24,7 @@ _i = ctypes.c_int
 SIGNATURES = {
     "tk_version": (ctypes.c_char_p, []),
     "tk_flipflop_build_indices_dev": (_i, [_vp, _vp, _sz, _sz, _sz, _vp, _vp, _vp, _vp, _vp,
-                                          _vp, _vp, _vp, _vp]),
+                                          _vp, _vp, _vp, _vp, _vp]),
     "tk_crf_flipflop_workspace_bytes": (_sz, [_sz, _sz, _sz, _sz, _i]),
     "tk_crf_flipflop_dev": (_i, [_vp, _sz, _sz, _sz, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _sz,
                                  _f, _f, _f, _vp, _vp, _vp, _sz, _vp, _vp]),
@@ -123,8 +123,15 @@ def status_word(device):
 
 
 def _raise(bits):
+    if bits & 8:
+        # the reference: `assert np.all(stayidxs >= 0) and ...` style index checks in ctc.pyx
+        raise AssertionError("Error: sequence labels out of range for the flip-flop model (flip-flop code "
+                             "outside [0, 2 nbase), modification category outside its base's range, or "
+                             "sum(seqlen) larger than the label array)")
     if bits & 4:
-        raise RuntimeError("sequence longer than the max_seqlen the kernel was launched for")
+        raise RuntimeError("sequence buffer overflow: a sequence is longer than the max_seqlen the CRF kernel "
+                           "was launched for, or a chunk batch needed more than max_bases_per_chunk bases per "
+                           "chunk (its `seqs` would be truncated)")
     if bits & 1:
         raise AssertionError("Error: all costs must be finite.\n"
                              "Try restarting from a checkpoint with a lower learning rate.")

@@ -34,7 +34,7 @@ int build_indices_dispatch(const int32_t *seqs, const int32_t *seqlen, size_t nb
                            size_t nbase, const int32_t *mod_cats,
                            const int32_t *can_mods_offsets, const float *mod_cat_weights,
                            int64_t *seqoff, int32_t *stay, int32_t *move, int32_t *mod,
-                           float *fact, hipStream_t stream);
+                           float *fact, size_t total_len, uint32_t *status, hipStream_t stream);
 int chunks_locate_dispatch(const tk_mapped_store *st, const int32_t *cand_read, const int32_t *cand_start,
                            const double *cand_frac, size_t ncand, size_t chunk_len,
                            const tk_chunk_filter *fp, uint8_t *reason, int32_t *dacstart,
@@ -77,14 +77,13 @@ int tk_flipflop_build_indices_dev(const int32_t *seqs, const int32_t *seqlen, si
                                   const int32_t *can_mods_offsets,
                                   const float *mod_cat_weights, int64_t *seqoff,
                                   int32_t *stayidx, int32_t *moveidx, int32_t *modidx,
-                                  float *modfact, void *stream) {
-    (void)total_len;
+                                  float *modfact, uint32_t *status, void *stream) {
     if (!seqlen || !seqoff || !stayidx || !moveidx || nbatch == 0 || nbase == 0) return TK_ERR_BAD_ARG;
     if (total_len > 0 && !seqs) return TK_ERR_BAD_ARG;
     if (mod_cats && (!can_mods_offsets || !mod_cat_weights || !modidx || !modfact)) return TK_ERR_BAD_ARG;
     return tk::build_indices_dispatch(seqs, seqlen, nbatch, nbase, mod_cats, can_mods_offsets,
                                       mod_cat_weights, seqoff, stayidx, moveidx, modidx,
-                                      modfact, static_cast<hipStream_t>(stream));
+                                      modfact, total_len, status, static_cast<hipStream_t>(stream));
 }
 
 int tk_grad_maxabs_clip_dev(float *grads, const int64_t *seg_off, size_t nseg, size_t max_seg_len,
@@ -250,9 +249,14 @@ bool host_seq_call(float const *logprob, size_t ntrans, size_t nblk, size_t nbat
         mod.assign(total ? total : 1, 0);
         fact.assign(total ? total : 1, 0.f);
     }
-    // read b's moves start at off[b] - b (c_crf_flipflop.c:479-480: L - 1 slots per read).  With
-    // empty reads in front that can point before the array in the reference; clamp instead
-    auto mbase = [&](size_t b) { return (size_t)off[b] >= b ? (size_t)off[b] - b : (size_t)0; };
+    // Read b's moves start after the moves of the reads before it.  The caller (ctc.pyx:127-134)
+    // concatenates max(L - 1, 0) move ids per read, i.e. the start is off[b] minus the number of
+    // NON-EMPTY reads before b.  The reference C indexes off[b] - b (c_crf_flipflop.c:479-480),
+    // which is the same number when no read is empty and otherwise reads its neighbours' slots
+    // (before the array, even): this entry point follows the array the caller actually built.
+    std::vector<size_t> mstart(nbatch + 1, 0);
+    for (size_t b = 0; b < nbatch; ++b) mstart[b + 1] = mstart[b] + (seqlen[b] > 0 ? (size_t)seqlen[b] - 1 : 0);
+    auto mbase = [&](size_t b) { return mstart[b]; };
     for (size_t b = 0; b < nbatch; ++b) {
         const size_t L = (size_t)seqlen[b];
         for (size_t p = 0; p < L; ++p) {

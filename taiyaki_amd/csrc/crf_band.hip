@@ -767,18 +767,8 @@ static int band_launch(const BandArgs &a, hipStream_t stream) {
     if (!want_grad) return 0;
     const size_t lds = band_post_lds_bytes(R, a.W, MOD);
     if (lds > 160 * 1024) return 2;
-    if (lds > 64 * 1024) {
-        // raised once per device and instantiation (kept out of the steady-state launch path)
-        static bool raised[64] = {};
-        int dev = 0;
-        if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return 4;
-        if (!raised[dev]) {
-            if (hipFuncSetAttribute(reinterpret_cast<const void *>(&crf_band_posterior_kernel<R, MOD>),
-                                    hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)
-                return 4;
-            raised[dev] = true;
-        }
-    }
+    if (lds > 64 * 1024 && raise_dynamic_lds(reinterpret_cast<const void *>(&crf_band_posterior_kernel<R, MOD>)))
+        return 4;
     const int rows = POST_WAVES * POST_ROWS;
     hipLaunchKernelGGL((crf_band_posterior_kernel<R, MOD>), dim3(a.N, (a.T + rows - 1) / rows),
                        dim3(POST_WAVES * WAVE), lds, stream, a);

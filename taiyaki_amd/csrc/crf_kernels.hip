@@ -482,7 +482,7 @@ __global__ __launch_bounds__(W *WAVE) void crf_kernel(CrfArgs a) {
 // index construction (flipflopfings.py:6-31, ctc.pyx:127-134, 282-292)
 // ---------------------------------------------------------------------------
 __global__ void seqoff_kernel(const int32_t *__restrict__ seqlen, int nbatch,
-                              int64_t *__restrict__ seqoff) {
+                              int64_t *__restrict__ seqoff, long long total_len, uint32_t *status) {
     // single block; chunked serial prefix sum (nbatch is a few thousand at most)
     __shared__ long long part[256];
     const int tid = threadIdx.x, nt = blockDim.x;
@@ -506,7 +506,10 @@ __global__ void seqoff_kernel(const int32_t *__restrict__ seqlen, int nbatch,
         seqoff[i] = acc;
         acc += seqlen[i];
     }
-    if (hi == nbatch && lo <= nbatch) seqoff[nbatch] = acc;     // identical value from every writer
+    if (hi == nbatch && lo <= nbatch) {
+        seqoff[nbatch] = acc;       // identical value from every writer
+        if (acc > total_len && status) atomicOr(status, 8u);    // more labels announced than handed over
+    }
 }
 
 __global__ void build_indices_kernel(const int32_t *__restrict__ seqs,
@@ -516,20 +519,34 @@ __global__ void build_indices_kernel(const int32_t *__restrict__ seqs,
                                      const int32_t *__restrict__ can_mods_offsets,
                                      const float *__restrict__ mod_cat_weights,
                                      int32_t *__restrict__ stay, int32_t *__restrict__ move,
-                                     int32_t *__restrict__ mod, float *__restrict__ fact) {
+                                     int32_t *__restrict__ mod, float *__restrict__ fact,
+                                     long long total_len, uint32_t *__restrict__ status) {
     const int n = blockIdx.x;
-    const int L = seqlen[n];
     const int64_t off = seqoff[n];
+    // (a batch that announces more labels than were handed over is flagged by seqoff_kernel;
+    // here its reads are cut at the end of the label array)
+    const int L = (int)max(0ll, min((long long)seqlen[n], total_len - (long long)off));
     const int ns = 2 * nbase, ncan = ns * (nbase + 1);
+    bool bad = false;
+    // the reference asserts 0 <= move / stay index < ntrans (ctc.pyx:127-134); a bad label is
+    // clamped here, so that no kernel downstream gathers out of range, and reported
+    auto label = [&](int64_t i) {
+        const int c = seqs[i];
+        bad |= c < 0 || c >= ns;
+        return min(max(c, 0), ns - 1);
+    };
     for (int p = threadIdx.x; p < L; p += blockDim.x) {
-        const int cp = seqs[off + p];
+        const int cp = label(off + p);
         stay[off + p] = cp + min(cp, nbase) * ns;                 // flipflopfings.py:20-31
         if (p + 1 < L) {
-            const int cn = seqs[off + p + 1];
+            const int cn = label(off + p + 1);
             move[off + p] = cp + min(cn, nbase) * ns;             // flipflopfings.py:6-17
             if (mod_cats != nullptr) {
                 // ctc.pyx:288-292
-                const int mseq = can_mods_offsets[cn % nbase] + mod_cats[off + p + 1];
+                const int lo = can_mods_offsets[cn % nbase], hi = can_mods_offsets[cn % nbase + 1];
+                int mseq = lo + mod_cats[off + p + 1];
+                bad |= mseq < lo || mseq >= hi;
+                mseq = min(max(mseq, lo), hi - 1);
                 mod[off + p] = ncan + mseq;
                 fact[off + p] = mod_cat_weights[mseq];
             }
@@ -541,17 +558,19 @@ __global__ void build_indices_kernel(const int32_t *__restrict__ seqs,
             }
         }
     }
+    if (bad && status) atomicOr(status, 8u);
 }
 
 int build_indices_dispatch(const int32_t *seqs, const int32_t *seqlen, size_t nbatch,
                            size_t nbase, const int32_t *mod_cats,
                            const int32_t *can_mods_offsets, const float *mod_cat_weights,
                            int64_t *seqoff, int32_t *stay, int32_t *move, int32_t *mod,
-                           float *fact, hipStream_t stream) {
-    hipLaunchKernelGGL(seqoff_kernel, dim3(1), dim3(256), 0, stream, seqlen, (int)nbatch, seqoff);
+                           float *fact, size_t total_len, uint32_t *status, hipStream_t stream) {
+    hipLaunchKernelGGL(seqoff_kernel, dim3(1), dim3(256), 0, stream, seqlen, (int)nbatch, seqoff,
+                       (long long)total_len, status);
     hipLaunchKernelGGL(build_indices_kernel, dim3((unsigned)nbatch), dim3(128), 0, stream, seqs,
                        seqlen, seqoff, (int)nbase, mod_cats, can_mods_offsets, mod_cat_weights,
-                       stay, move, mod, fact);
+                       stay, move, mod, fact, (long long)total_len, status);
     return hipGetLastError() == hipSuccess ? 0 : 4;
 }
 
@@ -618,16 +637,7 @@ template <int R, int W, bool MOD>
 static int crf_launch_one(const CrfArgs &a, hipStream_t stream) {
     const size_t lds = crf_lds_bytes(R, W, a.S, MOD ? 3 : 2);
     if (lds > 160 * 1024) return 2;
-    // raise the dynamic-LDS cap once per instantiation (kept out of the launch path so
-    // that launches are capturable into a hipGraph)
-    static size_t cap = 64 * 1024;
-    if (lds > cap) {
-        if (hipFuncSetAttribute(reinterpret_cast<const void *>(&crf_kernel<R, W, MOD>),
-                                hipFuncAttributeMaxDynamicSharedMemorySize,
-                                160 * 1024) != hipSuccess)
-            return 4;
-        cap = 160 * 1024;
-    }
+    if (raise_dynamic_lds(reinterpret_cast<const void *>(&crf_kernel<R, W, MOD>))) return 4;
     hipLaunchKernelGGL((crf_kernel<R, W, MOD>), dim3(a.N), dim3(W * WAVE), lds, stream, a);
     return hipGetLastError() == hipSuccess ? 0 : 4;
 }

@@ -1154,23 +1154,12 @@ static int logz_launch_ch(const float *scores, size_t T, size_t N, float *logz, 
     {
         const size_t bufwords = 4 * (size_t)WAVE * F::PIECES, imgwords = 4 * (size_t)XMat<NB>::NF4 * WAVE;
         const size_t lds = K1_WAVES * (imgwords > bufwords ? imgwords : bufwords) * sizeof(float);
-        static bool raised1 = false;
-        if (lds > 64 * 1024 && !raised1) {
-            if (hipFuncSetAttribute(reinterpret_cast<const void *>(&logz_transfer_kernel<NB, CH, 0, false>),
-                                    hipFuncAttributeMaxDynamicSharedMemorySize,
-                                    160 * 1024) != hipSuccess ||
-                hipFuncSetAttribute(reinterpret_cast<const void *>(&logz_transfer_kernel<NB, CH, 0, true>),
-                                    hipFuncAttributeMaxDynamicSharedMemorySize,
-                                    160 * 1024) != hipSuccess ||
-                hipFuncSetAttribute(reinterpret_cast<const void *>(&logz_transfer_kernel<NB, CH, K1_RING, false>),
-                                    hipFuncAttributeMaxDynamicSharedMemorySize,
-                                    160 * 1024) != hipSuccess ||
-                hipFuncSetAttribute(reinterpret_cast<const void *>(&logz_transfer_coop_kernel<NB, CH>),
-                                    hipFuncAttributeMaxDynamicSharedMemorySize,
-                                    160 * 1024) != hipSuccess)
-                return 4;
-            raised1 = true;
-        }
+        // (the ring form's LDS image can exceed the plain one's: raise for every form, whatever `lds` is)
+        if (raise_dynamic_lds(reinterpret_cast<const void *>(&logz_transfer_kernel<NB, CH, 0, false>)) ||
+            raise_dynamic_lds(reinterpret_cast<const void *>(&logz_transfer_kernel<NB, CH, 0, true>)) ||
+            raise_dynamic_lds(reinterpret_cast<const void *>(&logz_transfer_kernel<NB, CH, K1_RING, false>)) ||
+            raise_dynamic_lds(reinterpret_cast<const void *>(&logz_transfer_coop_kernel<NB, CH>)))
+            return 4;
         // one wave per chunk needs about a wave per SIMD to stream at full rate; below that
         // the cooperative form (4 waves per chunk) is faster
         if ((size_t)ncols * C >= 640) {
@@ -1203,15 +1192,9 @@ static int logz_launch_ch(const float *scores, size_t T, size_t N, float *logz, 
     {
         const size_t lds = logz_middle_lds_bytes<NB>(C, NSUP);
         if (lds > 160 * 1024) return 2;         // too many chunks for one LDS image
-        static bool raised2 = false;
-        if (!raised2) {
-            if (hipFuncSetAttribute(reinterpret_cast<const void *>(&logz_middle_kernel<NB, 8>),
-                                    hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess ||
-                hipFuncSetAttribute(reinterpret_cast<const void *>(&logz_middle_kernel<NB, 16>),
-                                    hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)
-                return 4;
-            raised2 = true;
-        }
+        if (raise_dynamic_lds(reinterpret_cast<const void *>(&logz_middle_kernel<NB, 8>)) ||
+            raise_dynamic_lds(reinterpret_cast<const void *>(&logz_middle_kernel<NB, 16>)))
+            return 4;
         if (SUP == 8)
             hipLaunchKernelGGL((logz_middle_kernel<NB, 8>), dim3((unsigned)N), dim3(K2_WAVES * WAVE), lds, stream,
                                (int)N, C, NSUP, Npad, ws, logz, grad != nullptr ? 1 : 0, status);
@@ -1225,14 +1208,7 @@ static int logz_launch_ch(const float *scores, size_t T, size_t N, float *logz, 
             ((CH / K3_WAVES) + 2) * F::NS * WAVE <= k3_buf_f4<NB, CH>() * 4;
         const size_t lds = K3_WAVES * (size_t)k3_buf_f4<NB, CH>() * sizeof(f4) +
                            (chain_in_buf ? 0 : 2 * F::NS * WAVE * sizeof(float));
-        static bool raised3 = false;
-        if (lds > 64 * 1024 && !raised3) {
-            if (hipFuncSetAttribute(reinterpret_cast<const void *>(&logz_posterior_kernel<NB, CH>),
-                                    hipFuncAttributeMaxDynamicSharedMemorySize,
-                                    160 * 1024) != hipSuccess)
-                return 4;
-            raised3 = true;
-        }
+        if (raise_dynamic_lds(reinterpret_cast<const void *>(&logz_posterior_kernel<NB, CH>))) return 4;
         const int nt_load = (size_t)T * N * F::S * sizeof(float) > ((size_t)200 << 20);
         hipLaunchKernelGGL((logz_posterior_kernel<NB, CH>), grid, block, lds, stream, scores, grad,
                            (int)T, (int)N, Npad, ws, status, nt_load);

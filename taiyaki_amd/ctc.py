@@ -13,7 +13,7 @@ from taiyaki_amd import _lib, flipflopfings
 
 
 def _indices(seqs, seqlen, nbase, device, mod_cats=None, can_mods_offsets=None,
-             mod_cat_weights=None):
+             mod_cat_weights=None, status=None):
     """Device-side move/stay(/mod) ids in the padded per-position layout."""
     L = _lib.lib()
     seqs_d = seqs.to(device=device, dtype=torch.int32, non_blocking=True).contiguous()
@@ -33,7 +33,7 @@ def _indices(seqs, seqlen, nbase, device, mod_cats=None, can_mods_offsets=None,
     rc = L.tk_flipflop_build_indices_dev(
         _lib.ptr(seqs_d), _lib.ptr(seqlen_d), nbatch, total, nbase, _lib.ptr(mc),
         _lib.ptr(cmo), _lib.ptr(mcw), _lib.ptr(seqoff), _lib.ptr(stay), _lib.ptr(move),
-        _lib.ptr(mod), _lib.ptr(fact), _lib.stream_ptr())
+        _lib.ptr(mod), _lib.ptr(fact), _lib.ptr(status), _lib.stream_ptr())
     _lib.check(rc, "tk_flipflop_build_indices_dev")
     # keep the staging tensors alive until the caller has enqueued its kernel
     return seqlen_d, seqoff, stay, move, mod, fact, (seqs_d, mc, cmo, mcw)
@@ -77,8 +77,9 @@ def _run(logprob, seqs, seqlen, sharp_can, sharp_mod, out_scale, ncan, want_grad
     nbase = flipflopfings.nbase_flipflop(ncan)
     dev = lp.device
     with torch.cuda.device(dev):
+        status = _lib.status_word(dev)
         seqlen_d, seqoff, stay, move, mod, fact, keep = _indices(
-            seqs, seqlen, nbase, dev, mod_cats, can_mods_offsets, mod_cat_weights)
+            seqs, seqlen, nbase, dev, mod_cats, can_mods_offsets, mod_cat_weights, status)
         maxlen = _max_seqlen(seqlen)
         cost = torch.empty(nbatch, dtype=torch.float32, device=dev)
         grad = torch.empty_like(lp) if want_grad else None
@@ -86,7 +87,6 @@ def _run(logprob, seqs, seqlen, sharp_can, sharp_mod, out_scale, ncan, want_grad
         ws = torch.empty(wsb, dtype=torch.uint8, device=dev)
         if _KEEP_WS is not None:
             ws.zero_()
-        status = _lib.status_word(dev)
         rc = L.tk_crf_flipflop_dev(
             _lib.ptr(lp), ntrans, nblk, nbatch, _lib.ptr(stay), _lib.ptr(move), _lib.ptr(mod),
             _lib.ptr(fact), _lib.ptr(seqlen_d), _lib.ptr(seqoff), maxlen, ncan,

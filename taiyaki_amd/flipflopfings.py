@@ -55,9 +55,17 @@ def nstate_flipflop(nbase):
 
 
 def nbase_flipflop(nstate):
-    """flipflopfings.py:171-184 (asserts that nstate is a valid flip-flop size)"""
-    nbase_f = np.sqrt(0.25 + (0.5 * np.float32(nstate))) - 0.5
-    assert np.mod(nbase_f, 1) == 0, (
-        'Number of states not valid for flip-flop model. '
-        'nstates: {}\tconverted nbases: {}').format(nstate, nbase_f)
-    return int(np.round(nbase_f))
+    """Inverse of `nstate_flipflop` (reference: flipflopfings.py:171-184, which solves the
+    quadratic in floating point and asserts an integer root).  Integer arithmetic here:
+    nstate = 2 b (b + 1)  <=>  b = (isqrt(1 + 2 nstate) - 1) / 2 with an exact square."""
+    nstate = int(nstate)
+    root = int(np.floor(np.sqrt(1.0 + 2.0 * nstate)))
+    while root * root > 1 + 2 * nstate:        # (float sqrt may land one off for large values)
+        root -= 1
+    while (root + 1) * (root + 1) <= 1 + 2 * nstate:
+        root += 1
+    nbase = (root - 1) // 2
+    if nstate <= 0 or root * root != 1 + 2 * nstate or nstate_flipflop(nbase) != nstate:
+        raise AssertionError("%d transitions is not a flip-flop layout: no whole number of bases b has "
+                             "2 b (b + 1) = %d" % (nstate, nstate))
+    return nbase

@@ -303,7 +303,10 @@ class MappedSignalStore:
             indata = torch.empty((chunk_len, nwant, 1), dtype=torch.float32, device=dev)
             seqs = torch.zeros(max(cap, 1), dtype=torch.int32, device=dev)       # tail beyond seqoff[-1] stays 0
             seqlens = torch.empty(max(nwant, 1), dtype=torch.int32, device=dev)[:nwant]
-            status = torch.zeros(1, dtype=torch.int32, device=dev)
+            # strict mode: a word of its own, read by ChunkBatch._counts(); deferred mode (training
+            # loops): the process-wide word that `_lib.raise_if_nonfinite()` checks once per step, so a
+            # too small `max_bases_per_chunk` cannot silently truncate `seqs`
+            status = _lib.status_word(dev)
             cl = ml = mc = None
             if mod_labels is not None:
                 cl = torch.as_tensor(np.asarray(can_labels), dtype=torch.int32).to(dev)

@@ -7,9 +7,15 @@ from taiyaki_amd import ctc, layers
 
 
 def calculate_loss(net, indata, seqs, seqlens, sharpen=1.0, mod_cats=None,
-                   can_mods_offsets=None, mod_cat_weights=None):
+                   can_mods_offsets=None, mod_cat_weights=None, ignore_empty=False):
     """lossvector = (A) crf / cat-mod loss + (B) logZ(outputs[:, :, :ntrans]) / nblk;
-    loss = mean (bin/train_flipflop.py:161-182)."""
+    loss = mean (bin/train_flipflop.py:161-182).
+
+    `ignore_empty`: batches assembled on the device keep their shape when fewer chunks than
+    asked for pass the filters and pad with zero-signal columns of sequence length 0
+    (mapped_signal.sample_chunks); the reference trains on the shorter batch.  With the flag the
+    mean runs over the columns with a sequence only (on the device, no sync), which is the same
+    loss and the same gradients as the reference's shorter batch."""
     outputs = net(indata)
     nblk = float(outputs.shape[0])
     ntrans = outputs.shape[2]
@@ -20,6 +26,9 @@ def calculate_loss(net, indata, seqs, seqlens, sharpen=1.0, mod_cats=None,
     else:
         lossvector = ctc.crf_flipflop_loss(outputs, seqs, seqlens, sharpen)
     lossvector = lossvector + layers.flipflop_logpartition(outputs[:, :, :ntrans]) / nblk
+    if ignore_empty:
+        live = (seqlens.to(lossvector.device) > 0).to(lossvector.dtype)
+        return (lossvector * live).sum() / live.sum().clamp(min=1.0), lossvector
     return lossvector.mean(), lossvector
 
 
@@ -96,6 +105,8 @@ class GraphedTrainer:
             self.static["mod_cats"] = torch.zeros(seq_capacity, dtype=torch.int32, device=dev)
             self.static["can_mods_offsets"] = example_batch["can_mods_offsets"]
             self.static["mod_cat_weights"] = example_batch["mod_cat_weights"]
+        if example_batch.get("ignore_empty"):
+            self.static["ignore_empty"] = True
         self.loss = None
         self.graph = None
 

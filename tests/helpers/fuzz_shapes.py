@@ -20,6 +20,47 @@ from taiyaki_amd import synth  # noqa: E402
 from tests import parity  # noqa: E402
 
 
+EDGES = [(1, 1), (15, 64), (16, 65), (17, 63), (639 * 16 // 10, 640), (2048, 300), (2049, 300),
+         (1536, 384), (1535, 385), (2400, 320), (3601, 256), (100, 1000), (9, 2048)]
+
+
+def case(k, rng, dev, oracle_mod=None):
+    """Case k of the sweep (the first len(EDGES) are the regime-switch shapes, the rest random).
+    Returns (ok, one-line description)."""
+    oracle_mod = oracle_mod or oracle
+    if k < len(EDGES):
+        T, N = EDGES[k]
+    else:
+        T, N = int(rng.randint(1, 2600)), int(rng.randint(1, 420))
+    sc = synth.scores(T, N, 40, 7000 + k)
+    r = parity.compare_logz(oracle_mod, sc, dev)
+    v = parity.compare_viterbi(oracle_mod, sc, dev)
+    L = max(1, min(T - 1, int(T * rng.uniform(0.05, 0.85)))) if T > 1 else 1
+    # a zero-length read is only put LAST: the reference's move-index layout gives every read
+    # L - 1 slots (c_crf_flipflop.c:479-480), i.e. minus one for an empty read, so an empty read
+    # in the middle makes its neighbours' slots overlap -- in the reference and in its oracle
+    seqlens = np.clip(rng.randint(1, L + 1, size=N), 1, max(T, 1)).astype(np.int32)
+    if k % 3 == 0:
+        seqlens[-1] = 0
+    inp = synth.crf_case(T, N, 7100 + k, seqlens=seqlens)
+    inp["scores"] = sc
+    c = parity.compare_crf(oracle_mod, inp, 1.0, dev)
+    # the cat-mod variant of the same kernels on every third case (46 columns, own scores)
+    cm_ok, cm = True, None
+    if k % 3 == 1 and T > 1:
+        minp = synth.crf_case(T, N, 7200 + k, nmods_per_base=(1, 1, 0, 0), seqlens=seqlens)
+        cm = parity.compare_crf(oracle_mod, minp, 1.0, dev)
+        cm_ok = cm["finite"] and cm["loss_rel"] < 1e-4 and cm["grad_abs"] < 5e-5
+    ok = cm_ok and (r["finite"] and r["logz_rel"] < 1e-5 and r["grad_abs"] < 2e-5 and r["nograd_same"] == 0.0 and
+                    v["path_mismatch"] == 0 and v["fwd_bit_mismatch"] == 0 and
+                    c["finite"] and c["loss_rel"] < 1e-4 and c["grad_abs"] < 2e-5)     # 1e-4: north_star; the fp32
+    # reference itself carries ~1e-5 at T ~ 2000 for one-base sequences
+    msg = "T=%4d N=%4d  logz %.1e / %.1e  viterbi %d  crf %.1e / %.1e" % (
+        T, N, r["logz_rel"], r["grad_abs"], v["path_mismatch"], c["loss_rel"], c["grad_abs"]) + (
+        "  catmod %.1e / %.1e" % (cm["loss_rel"], cm["grad_abs"]) if cm else "")
+    return bool(ok), msg
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--cases", type=int, default=40)
@@ -28,40 +69,10 @@ def main():
     rng = np.random.RandomState(args.seed)
     dev = torch.device("cuda:0")
     bad = 0
-    edges = [(1, 1), (15, 64), (16, 65), (17, 63), (639 * 16 // 10, 640), (2048, 300), (2049, 300),
-             (1536, 384), (1535, 385), (2400, 320), (3601, 256), (100, 1000), (9, 2048)]
     for k in range(args.cases):
-        if k < len(edges):
-            T, N = edges[k]
-        else:
-            T, N = int(rng.randint(1, 2600)), int(rng.randint(1, 420))
-        sc = synth.scores(T, N, 40, 7000 + k)
-        r = parity.compare_logz(oracle, sc, dev)
-        v = parity.compare_viterbi(oracle, sc, dev)
-        L = max(1, min(T - 1, int(T * rng.uniform(0.05, 0.85)))) if T > 1 else 1
-        # a zero-length read is only put LAST: the reference's move-index layout gives every read
-        # L - 1 slots (c_crf_flipflop.c:479-480), i.e. minus one for an empty read, so an empty read
-        # in the middle makes its neighbours' slots overlap -- in the reference and in its oracle
-        seqlens = np.clip(rng.randint(1, L + 1, size=N), 1, max(T, 1)).astype(np.int32)
-        if k % 3 == 0:
-            seqlens[-1] = 0
-        inp = synth.crf_case(T, N, 7100 + k, seqlens=seqlens)
-        inp["scores"] = sc
-        c = parity.compare_crf(oracle, inp, 1.0, dev)
-        # the cat-mod variant of the same kernels on every third case (46 columns, own scores)
-        cm_ok, cm = True, None
-        if k % 3 == 1 and T > 1:
-            minp = synth.crf_case(T, N, 7200 + k, nmods_per_base=(1, 1, 0, 0), seqlens=seqlens)
-            cm = parity.compare_crf(oracle, minp, 1.0, dev)
-            cm_ok = cm["finite"] and cm["loss_rel"] < 1e-4 and cm["grad_abs"] < 5e-5
-        ok = cm_ok and (r["finite"] and r["logz_rel"] < 1e-5 and r["grad_abs"] < 2e-5 and r["nograd_same"] == 0.0 and
-              v["path_mismatch"] == 0 and v["fwd_bit_mismatch"] == 0 and
-              c["finite"] and c["loss_rel"] < 1e-4 and c["grad_abs"] < 2e-5)     # 1e-4: north_star; the fp32
-              # reference itself carries ~1e-5 at T ~ 2000 for one-base sequences
+        ok, msg = case(k, rng, dev)
         bad += not ok
-        print("%s T=%4d N=%4d  logz %.1e / %.1e  viterbi %d  crf %.1e / %.1e" % (
-            "ok  " if ok else "FAIL", T, N, r["logz_rel"], r["grad_abs"], v["path_mismatch"], c["loss_rel"],
-            c["grad_abs"]) + ("  catmod %.1e / %.1e" % (cm["loss_rel"], cm["grad_abs"]) if cm else ""), flush=True)
+        print("%s %s" % ("ok  " if ok else "FAIL", msg), flush=True)
     print("fuzz: %d cases, %d failures" % (args.cases, bad))
     sys.exit(1 if bad else 0)
 

@@ -143,6 +143,17 @@ def test_c_harness_known_answers_host_abi(oracle_mod, gpu_device):
     L.cat_mod_flipflop_grad(p(lp, f32p), 45, 7, 2, p(move, szp), p(stay, szp), p(mm, szp),
                             p(mf, f32p), p(seqlen, i32p), p(score, f32p), p(grad, f32p))
     np.testing.assert_allclose(score, ka["ccm/score"], rtol=2e-6)
+    if oracle_mod.ref_available():
+        # ... and the cat-mod GRADIENT through the exact prototype against the genuine reference C
+        rscore = np.zeros(2, dtype=np.float32)
+        rgrad = np.zeros_like(lp)
+        fn = oracle_mod.ref().cat_mod_flipflop_grad
+        fn.restype = None
+        fn(p(lp, f32p), ctypes.c_size_t(45), ctypes.c_size_t(7), ctypes.c_size_t(2), p(move, szp), p(stay, szp),
+           p(mm, szp), p(mf, f32p), p(seqlen, i32p), p(rscore, f32p), p(rgrad, f32p))
+        np.testing.assert_allclose(score, rscore, rtol=2e-6)
+        np.testing.assert_allclose(grad, rgrad, atol=1e-5)
+        assert float(np.abs(rgrad[:, :, 40:]).max()) > 0        # the mod columns do receive gradient
 
 
 # ---------------------------------------------------------- (B) logZ --------
@@ -678,3 +689,116 @@ def test_config1_mgru_abinitio_lossvector(oracle_mod, gpu_device):
     olz, olgrad = oracle_mod.flipflop_logz_grad(sc)
     np.testing.assert_allclose(lossvector.detach().cpu().numpy(), oloss + olz / 1000, rtol=LOSS_RTOL)
     np.testing.assert_allclose(outputs.grad.cpu().numpy(), (ograd + olgrad / 1000) / N, atol=1e-6)
+
+
+@pytest.mark.parametrize("name", ["t9n3", "t60n4", "t40n2_sharp"])
+def test_catmod_producer_to_loss_chain_against_reference_golden(gpu_device, name):
+    """cat-mod end to end: the restated `GlobalNormFlipFlopCatMod`
+    with the reference's weights -> HIP `cat_mod_flipflop_loss` + HIP logZ / nblk -> backward to
+    the layer's input and weights, against lossvector and gradients produced by the genuine
+    reference (tests/golden/make_golden_catmod_layer.py)."""
+    import torch
+    from taiyaki_amd import ctc, layers
+    gold = load_golden("catmod_layer.npz")
+    g = {k: gold[name + "/" + k] for k in ("W", "b", "x", "y", "seqs", "seqlens", "mod_cats", "mod_cat_weights",
+                                          "sharp", "lossvector", "dx", "dW", "db", "can_mods_offsets", "can_nmods")}
+    lay = layers.GlobalNormFlipFlopCatMod(g["W"].shape[1], tuple(int(v) for v in g["can_nmods"])).to(gpu_device)
+    lay.load_state_dict({"linear.weight": torch.tensor(g["W"]), "linear.bias": torch.tensor(g["b"])}, strict=False)
+    x = torch.tensor(g["x"], device=gpu_device, requires_grad=True)
+    y = lay(x)
+    np.testing.assert_allclose(y.detach().cpu().numpy(), g["y"], rtol=2e-6, atol=2e-6)
+    T = y.shape[0]
+    lossvector = ctc.cat_mod_flipflop_loss(y, torch.tensor(g["seqs"]), torch.tensor(g["seqlens"]),
+                                           torch.tensor(g["mod_cats"]), g["can_mods_offsets"], g["mod_cat_weights"],
+                                           float(g["sharp"]))
+    ntrans = y.shape[2] - int(g["can_mods_offsets"][-1])
+    lossvector = lossvector + layers.flipflop_logpartition(y[:, :, :ntrans]) / float(T)
+    np.testing.assert_allclose(lossvector.detach().cpu().numpy(), g["lossvector"], rtol=1e-5)
+    lossvector.mean().backward()
+    np.testing.assert_allclose(x.grad.cpu().numpy(), g["dx"], atol=2e-6, rtol=1e-4)
+    np.testing.assert_allclose(lay.linear.weight.grad.cpu().numpy(), g["dW"], atol=2e-6, rtol=1e-4)
+    np.testing.assert_allclose(lay.linear.bias.grad.cpu().numpy(), g["db"], atol=2e-6, rtol=1e-4)
+
+
+def test_catmod_model_train_step_on_gpu(oracle_mod, gpu_device):
+    """configs[3]: one `calculate_loss` + backward + optimiser step of `mLstm_cat_mod_flipflop`
+    through the HIP cat-mod loss; lossvector and d loss / d outputs checked against the oracle
+    on the network's own outputs (bin/train_flipflop.py:161-182)."""
+    import torch
+    from taiyaki_amd import models, parallel, synth, train
+    torch.manual_seed(3)
+    chunk_len, stride, nbatch = 600, 5, 6
+    T = chunk_len // stride
+    net = models.mLstm_cat_mod_flipflop(size=32, stride=stride).to(gpu_device)
+    seqlens = synth.realistic_seqlens(T, nbatch, 4, chunk_len, 9.0)
+    seqs, bases = synth.sequences(seqlens, 4)
+    mods = synth.mod_cats(bases, 4, (1, 1, 0, 0))
+    cmo = synth.can_mods_offsets((1, 1, 0, 0))
+    mcw = np.full(6, 8.0, dtype=np.float32)
+    indata = torch.from_numpy(synth.signal_chunks(chunk_len, nbatch, 4)).to(gpu_device)
+    batch = dict(indata=indata, seqs=torch.from_numpy(seqs), seqlens=torch.from_numpy(seqlens),
+                 mod_cats=torch.from_numpy(mods), can_mods_offsets=cmo, mod_cat_weights=mcw)
+    outputs = net(indata).detach().requires_grad_()
+    from taiyaki_amd import ctc, layers
+    lv = ctc.cat_mod_flipflop_loss(outputs, batch["seqs"], batch["seqlens"], batch["mod_cats"], cmo, mcw, 1.0)
+    lv = lv + layers.flipflop_logpartition(outputs[:, :, :40]) / float(T)
+    lv.mean().backward()
+    sc = outputs.detach().cpu().numpy()
+    oloss, ograd = oracle_mod.cat_mod_flipflop_loss(sc, seqs, seqlens, mods, cmo, mcw, 1.0)
+    olz, olgrad = oracle_mod.flipflop_logz_grad(np.ascontiguousarray(sc[:, :, :40]))
+    np.testing.assert_allclose(lv.detach().cpu().numpy(), oloss + olz / T, rtol=1e-5)
+    want = ograd / nbatch
+    want[:, :, :40] += olgrad / (T * nbatch)
+    np.testing.assert_allclose(outputs.grad.cpu().numpy(), want, atol=2e-6)
+    trainer = train.Trainer(net, parallel.FlatGradArena(net))
+    before = [p.detach().clone() for p in net.parameters() if p.requires_grad]
+    loss = float(trainer.step(batch).detach())
+    assert np.isfinite(loss) and abs(loss - float(lv.mean())) < 1e-4
+    assert any(not torch.equal(a, b) for a, b in zip(before, [p for p in net.parameters() if p.requires_grad]))
+
+
+# ------------------------------------------------ seeded fuzz sweeps (bounded) ---
+@pytest.mark.parametrize("k", list(range(13)) + [13, 14, 16, 19, 22])
+def test_fuzz_shapes_seeded_subset(oracle_mod, gpu_device, k):
+    """tests/helpers/fuzz_shapes.py under pytest: the thirteen regime-switch shapes of the logZ /
+    Viterbi / CRF launchers plus five seeded random ones, every operator against the oracle
+    (cat-mod on every third case).  The full 45 + 36 case sweeps remain a script."""
+    from tests.helpers import fuzz_shapes
+    ok, msg = fuzz_shapes.case(k, np.random.RandomState(100 + k), gpu_device, oracle_mod)
+    assert ok, msg
+
+
+@pytest.mark.parametrize("k", range(8))
+def test_fuzz_prep_seeded_subset(gpu_device, k):
+    """tests/helpers/fuzz_prep.py under pytest: chunk batches and remapping with random
+    parameters, bit for bit against their oracles (eight seeded cases of each)."""
+    from tests.helpers import fuzz_prep
+    rng = np.random.RandomState(50 + k)
+    ok, what = fuzz_prep.chunk_case(k, rng, gpu_device)
+    assert ok, what
+    ok, what = fuzz_prep.remap_case(k, rng)
+    assert ok, what
+
+
+def test_bad_labels_raise_like_the_reference(gpu_device):
+    """The reference asserts that stay / move indices lie in [0, ntrans) (ctc.pyx:127-134) and
+    fails loudly on a bad label; here the index builder range-checks flip-flop codes,
+    modification categories and sum(seqlen) on the device and the operator raises the same
+    `AssertionError` class -- it neither gathers out of range nor returns garbage."""
+    import torch
+    from taiyaki_amd import ctc, synth
+    x = torch.from_numpy(synth.scores(20, 2, 40, 3)).to(gpu_device)
+    good = torch.tensor([0, 1, 2, 3, 0, 5])
+    assert bool(torch.isfinite(ctc.crf_flipflop_loss(x, good, torch.tensor([3, 3]), 1.0)).all())
+    for seqs, seqlens in ((torch.tensor([0, 1, 8, 3, 0, 5]), torch.tensor([3, 3])),      # code 8 >= 2 nbase
+                          (torch.tensor([0, -1, 2, 3, 0, 5]), torch.tensor([3, 3])),     # negative code
+                          (good, torch.tensor([3, 9]))):                                 # more labels than given
+        with pytest.raises(AssertionError, match="labels out of range"):
+            ctc.crf_flipflop_loss(x, seqs, seqlens, 1.0)
+    xm = torch.from_numpy(synth.scores(20, 2, 46, 4)).to(gpu_device)
+    cmo, mcw = synth.can_mods_offsets((1, 1, 0, 0)), np.full(6, 8.0, dtype=np.float32)
+    ok_mods = torch.tensor([0, 1, 0, 0, 0, 0])          # A is label 0 ... ; a mod on C (1 mod) is fine
+    assert bool(torch.isfinite(ctc.cat_mod_flipflop_loss(xm, good, torch.tensor([3, 3]), ok_mods, cmo, mcw, 1.0)).all())
+    bad_mods = torch.tensor([0, 0, 1, 0, 0, 0])         # G has no modification: category 1 is out of range
+    with pytest.raises(AssertionError, match="labels out of range"):
+        ctc.cat_mod_flipflop_loss(xm, good, torch.tensor([3, 3]), bad_mods, cmo, mcw, 1.0)

@@ -10,6 +10,8 @@ import numpy as np
 import pytest
 import torch
 
+from tests.conftest import load_golden
+
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
@@ -148,4 +150,94 @@ def test_c_abi_rejects_bad_arguments_before_touching_the_gpu():
     assert L.tk_crf_flipflop_dev(None, 40, 10, 2, None, None, None, None, None, None, 0, 40,
                                  1.0, 1.0, 1.0, None, None, None, 0, None, None) == BAD
     assert L.tk_flipflop_build_indices_dev(None, None, 0, 0, 4, None, None, None, None, None, None,
-                                           None, None, None) == BAD
+                                           None, None, None, None) == BAD
+
+
+def test_catmod_producer_layer_matches_reference_golden():
+    """`GlobalNormFlipFlopCatMod.forward` (taiyaki/layers.py:1616-1640) value-pinned: the
+    reference layer's weights, input and output (generated by importing the reference,
+    tests/golden/make_golden_catmod_layer.py) against the restated layer -- output order AYCZGT:
+    [5 tanh(40 transition scores), log_softmax{A, 6mA}, log_softmax{C, 5mC}, 0 (G), 0 (T)]."""
+    from taiyaki_amd import layers
+    gold = load_golden("catmod_layer.npz")
+    for name in ("t9n3", "t60n4", "t40n2_sharp"):
+        W, b, x, y = (gold[name + "/" + k] for k in ("W", "b", "x", "y"))
+        lay = layers.GlobalNormFlipFlopCatMod(W.shape[1], tuple(int(v) for v in gold[name + "/can_nmods"]))
+        assert lay.linear.weight.shape == W.shape and lay.nout == y.shape[2] == 46
+        lay.load_state_dict({"linear.weight": torch.tensor(W), "linear.bias": torch.tensor(b)}, strict=False)
+        got = lay(torch.tensor(x)).detach().numpy()
+        np.testing.assert_allclose(got, y, rtol=2e-6, atol=2e-6)
+        np.testing.assert_array_equal(lay.can_mods_offsets, gold[name + "/can_mods_offsets"])
+        # canonical-only bases (G, T) carry a constant 0 = log(1) in their category slot
+        assert np.all(got[:, :, 44:] == 0.0)
+
+
+def _calculate_loss_like_the_reference(net_outputs, seqs, seqlens, sharpen=1.0):
+    """The four lines of bin/train_flipflop.py:161-182 written against the REFERENCE's names."""
+    from taiyaki import ctc, layers
+    nblk = float(net_outputs.shape[0])
+    lossvector = ctc.crf_flipflop_loss(net_outputs, seqs, seqlens, sharpen)
+    lossvector = lossvector + layers.flipflop_logpartition(net_outputs) / nblk
+    return lossvector.mean()
+
+
+def test_shim_standalone_resolves_reference_names_to_the_hip_operators():
+    """`taiyaki_amd.shim.install()` with no reference package around: a caller written against
+    `taiyaki.ctc` / `taiyaki.layers` / `taiyaki.decode` resolves to the HIP operators (which
+    refuse CPU tensors: no fallback)."""
+    import sys
+    from taiyaki_amd import ctc, decode, layers, shim
+    assert shim.install(force_standalone=True) == "standalone"
+    try:
+        import taiyaki
+        from taiyaki import ctc as tctc, decode as tdecode, layers as tlayers
+        from taiyaki.flipflopfings import flipflop_code, nstate_flipflop
+        from taiyaki.maths import RollingMAD
+        assert tctc.crf_flipflop_loss is ctc.crf_flipflop_loss
+        assert tctc.cat_mod_flipflop_loss is ctc.cat_mod_flipflop_loss
+        assert tlayers.flipflop_logpartition is layers.flipflop_logpartition
+        assert tdecode.flipflop_viterbi is decode.flipflop_viterbi
+        assert tdecode.flipflop_make_trans is decode.flipflop_make_trans
+        assert nstate_flipflop(4) == 40 and RollingMAD(3, 0, 5).nparams == 3
+        assert list(flipflop_code(np.array([0, 0, 1, 1, 1]), 4)) == [0, 4, 1, 5, 1]
+        with pytest.raises(RuntimeError, match="no CPU fallback"):
+            _calculate_loss_like_the_reference(torch.zeros(6, 2, 40), torch.tensor([0, 1, 2]), torch.tensor([2, 1]))
+        assert getattr(taiyaki, "__taiyaki_amd_shim__", False)
+    finally:
+        shim.uninstall()
+    assert "taiyaki" not in sys.modules or not getattr(sys.modules["taiyaki"], "__taiyaki_amd_shim__", False)
+
+
+def test_shim_patches_an_importable_reference_package(tmp_path, monkeypatch):
+    """With a `taiyaki` package on the path (here a stand-in with the reference's module layout:
+    `ctc` extension module, `layers.flipflop_logpartition`, `decode.flipflop_viterbi`), install()
+    re-points exactly the hot-path names and uninstall() restores them."""
+    import importlib
+    import sys
+    pkg = tmp_path / "taiyaki"
+    (pkg / "ctc").mkdir(parents=True)
+    (pkg / "__init__.py").write_text("")
+    (pkg / "ctc" / "__init__.py").write_text("def crf_flipflop_loss(*a):\n    return 'cpu-extension'\n")
+    (pkg / "layers.py").write_text("def flipflop_logpartition(x, _never_use_cupy=False):\n    return 'torch-loop'\n"
+                                   "def other():\n    return 'untouched'\n")
+    (pkg / "decode.py").write_text("def flipflop_viterbi(s, _never_use_cupy=False):\n    return 'torch-loop'\n"
+                                   "def flipflop_make_trans(s, _never_use_cupy=False):\n    return 'torch-loop'\n")
+    monkeypatch.syspath_prepend(str(tmp_path))
+    for k in [k for k in sys.modules if k == "taiyaki" or k.startswith("taiyaki.")]:
+        monkeypatch.delitem(sys.modules, k)
+    importlib.invalidate_caches()
+    from taiyaki_amd import ctc, layers, shim
+    assert shim.install() == "patched"
+    try:
+        import taiyaki.layers as tl
+        from taiyaki import ctc as tctc
+        assert tctc is ctc and tl.flipflop_logpartition is layers.flipflop_logpartition
+        assert tl.other() == "untouched"
+        with pytest.raises(RuntimeError, match="no CPU fallback"):
+            _calculate_loss_like_the_reference(torch.zeros(6, 2, 40), torch.tensor([0, 1, 2]), torch.tensor([2, 1]))
+    finally:
+        shim.uninstall()
+    import taiyaki.layers as tl2
+    assert tl2.flipflop_logpartition(None) == "torch-loop"
+    for k in [k for k in sys.modules if k == "taiyaki" or k.startswith("taiyaki.")]:
+        sys.modules.pop(k, None)

@@ -232,8 +232,23 @@ class LossOps:
         _lib.check(rc, "tk_flipflop_logz_dev")
 
     def both(self):
-        self.crf()
-        self.logz_op()
+        """The loss path as the train step launches it: the fused (A) + (B) / nblk entry point
+        for the plain CRF, the two operators for cat-mod."""
+        if self.mod is not None:
+            self.crf()
+            self.logz_op()
+            return
+        from taiyaki_amd import _lib
+        L, p = _lib.lib(), _lib.ptr
+        st = _lib.stream_ptr()
+        rc = L.tk_flipflop_build_indices_dev(p(self.seqs), p(self.seqlens), self.N, self.seqs.numel(), 4, None, None,
+                                             None, p(self.seqoff), p(self.stay), p(self.move), None, None,
+                                             p(self.status), st)
+        _lib.check(rc, "tk_flipflop_build_indices_dev")
+        rc = L.tk_flipflop_loss_fused_dev(p(self.x), self.T, self.N, 4, p(self.stay), p(self.move), p(self.seqlens),
+                                          p(self.seqoff), self.maxlen, 1.0, p(self.cost), p(self.grad), p(self.logz),
+                                          p(self.crf_ws), self.crf_wsb, p(self.lz_ws), self.lz_wsb, p(self.status), st)
+        _lib.check(rc, "tk_flipflop_loss_fused_dev")
 
     def finite(self):
         return int(self.status.item()) == 0
@@ -648,6 +663,8 @@ def main():
         assert step_ops.finite()
         out["loss_path"] = dict(unit="chunks/s through crf grad + logZ fwd-bwd at the step's shape (T=%d, N=%d, "
                                      "S=%d, realistic lengths)" % (T, nbatch, S),
+                                launch=("two operators (cat-mod loss, logZ)" if cat_mod else
+                                        "tk_flipflop_loss_fused_dev: one gradient tensor"),
                                 gpu_ms=round(lp_mean * 1e3, 4), gpu_chunks_per_s=round(nbatch / lp_mean, 1))
         if not args.no_cpu_baseline:
             cb = cpu_baseline(T, nbatch)

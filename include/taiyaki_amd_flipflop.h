@@ -115,6 +115,27 @@ int tk_crf_flipflop_dev(const float *logprob, size_t ntrans, size_t nblk,
                         size_t workspace_bytes, uint32_t *status, void *stream);
 
 /* ------------------------------------------------------------------------- *
+ * Fused train-step loss (replaces the assembly in `calculate_loss`,
+ * bin/train_flipflop.py:172-182: crf_flipflop_loss(outputs, ...) +
+ * flipflop_logpartition(outputs) / nblk, two operators whose gradients autograd
+ * then adds).  One call, plain CRF (ntrans = 2 nbase (nbase + 1)):
+ *   lossvector (nbatch) = -score_A / (nblk sharp) + logZ / nblk
+ *   grad (nblk, nbatch, ntrans) = d lossvector[n] / d scores[:, n, :]
+ * Kernel A runs first (costs -> lossvector, its gradient -> grad); kernel B then
+ * ADDS logZ / nblk and (d logZ / d scores) / nblk in place, the latter inside its
+ * posterior kernel's coalesced row-set stores (one gradient tensor, no autograd
+ * add).  `logz` (nbatch) receives the log-partition values.  Workspaces as for
+ * the two separate entry points.
+ * ------------------------------------------------------------------------- */
+int tk_flipflop_loss_fused_dev(const float *scores, size_t nblk, size_t nbatch, size_t nbase,
+                               const int32_t *stayidx, const int32_t *moveidx,
+                               const int32_t *seqlen, const int64_t *seqoff,
+                               size_t max_seqlen, float sharpfact, float *lossvector,
+                               float *grad, float *logz, void *crf_workspace,
+                               size_t crf_workspace_bytes, void *logz_workspace,
+                               size_t logz_workspace_bytes, uint32_t *status, void *stream);
+
+/* ------------------------------------------------------------------------- *
  * (B) log-partition over the 2*nbase state lattice and its gradient
  *     logz[n] = log sum_{all flip-flop paths starting in a flip state} exp(sum_t s)
  *     grad[t,n,:] = d logz[n] / d scores[t,n,:]  == posterior transition

@@ -28,6 +28,8 @@ SIGNATURES = {
     "tk_crf_flipflop_workspace_bytes": (_sz, [_sz, _sz, _sz, _sz, _i]),
     "tk_crf_flipflop_dev": (_i, [_vp, _sz, _sz, _sz, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _sz,
                                  _f, _f, _f, _vp, _vp, _vp, _sz, _vp, _vp]),
+    "tk_flipflop_loss_fused_dev": (_i, [_vp, _sz, _sz, _sz, _vp, _vp, _vp, _vp, _sz, _f, _vp, _vp, _vp, _vp, _sz,
+                                       _vp, _sz, _vp, _vp]),
     "tk_flipflop_logz_workspace_bytes": (_sz, [_sz, _sz, _sz]),
     "tk_flipflop_logz_dev": (_i, [_vp, _sz, _sz, _sz, _vp, _vp, _vp, _sz, _vp, _vp]),
     "tk_flipflop_viterbi_workspace_bytes": (_sz, [_sz, _sz, _sz]),

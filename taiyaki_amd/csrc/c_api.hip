@@ -13,7 +13,7 @@ namespace tk {
 size_t logz_workspace_bytes(size_t T, size_t N, size_t nbase);
 int logz_dispatch(const float *scores, size_t T, size_t N, size_t nbase, float *logz,
                   float *grad, void *workspace, size_t workspace_bytes, uint32_t *status,
-                  hipStream_t stream);
+                  hipStream_t stream, float *loss_acc = nullptr, float acc_scale = 0.f);
 size_t viterbi_workspace_bytes(size_t T, size_t N, size_t nbase);
 int viterbi_dispatch(const float *scores, size_t T, size_t N, size_t nbase, float *fwd,
                      int64_t *tb, int64_t *path, void *workspace, size_t workspace_bytes,
@@ -190,6 +190,29 @@ int tk_crf_flipflop_dev(const float *logprob, size_t ntrans, size_t nblk, size_t
                             seqlen, seqoff, max_seqlen, ncan, sharp_can, sharp_mod, out_scale,
                             cost, grad, workspace, workspace_bytes, status,
                             static_cast<hipStream_t>(stream));
+}
+
+int tk_flipflop_loss_fused_dev(const float *scores, size_t nblk, size_t nbatch, size_t nbase,
+                               const int32_t *stayidx, const int32_t *moveidx, const int32_t *seqlen,
+                               const int64_t *seqoff, size_t max_seqlen, float sharpfact, float *lossvector,
+                               float *grad, float *logz, void *crf_workspace, size_t crf_workspace_bytes,
+                               void *logz_workspace, size_t logz_workspace_bytes, uint32_t *status, void *stream) {
+    if (!scores || !stayidx || !moveidx || !seqlen || !seqoff || !lossvector || !grad || !logz || !crf_workspace ||
+        !logz_workspace || nblk == 0 || nbatch == 0 || nbase == 0 || !(sharpfact > 0.f))
+        return TK_ERR_BAD_ARG;
+    if (!aligned16(scores) || !aligned16(grad)) return TK_ERR_BAD_ARG;
+    const size_t ntrans = 2 * nbase * (nbase + 1);
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    // (A) first: per-read costs into `lossvector`, its gradient into `grad`; (B) then ADDS
+    // logZ / nblk and (d logZ / d scores) / nblk in place -- in its posterior kernel, whose stores
+    // are whole coalesced row sets (the read-modify-write costs that HBM-bound kernel one more
+    // stream; done in kernel A's row-at-a-time posterior pass it cost ~18 us at the step's shape)
+    int rc = tk::crf_dispatch(scores, ntrans, nblk, nbatch, stayidx, moveidx, nullptr, nullptr, seqlen, seqoff,
+                              max_seqlen, ntrans, sharpfact, sharpfact, 1.0f / sharpfact, lossvector, grad,
+                              crf_workspace, crf_workspace_bytes, status, st);
+    if (rc != 0) return rc;
+    return tk::logz_dispatch(scores, nblk, nbatch, nbase, logz, grad, logz_workspace, logz_workspace_bytes, status, st,
+                             lossvector, 1.0f / (float)nblk);
 }
 
 size_t tk_flipflop_logz_workspace_bytes(size_t nblk, size_t nbatch, size_t nbase) {

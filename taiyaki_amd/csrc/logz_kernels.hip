@@ -174,6 +174,11 @@ struct LogzWs {
     f4 *Pc;         // [Npad][C][NF4] chunk transfer matrices, read-major (XMat words)
     float *Vin;     // [Npad][C][NS]    forward vector entering chunk c   (read-major)
     float *Uout;    // [Npad][C][NS]    backward vector leaving chunk c
+    // fused train-step loss (tk_flipflop_loss_fused_dev): kernel A ran first; its per-read costs
+    // and its gradient are already in place, this operator ADDS acc_scale * logZ resp.
+    // acc_scale * posterior (acc_scale = 1 / nblk).  Null: the plain operator.
+    float *loss_acc;
+    float acc_scale;
 };
 
 // per-wave LDS buffer of K3 in f4 units: the row-set transpose buffer, which
@@ -871,6 +876,7 @@ __global__ __launch_bounds__(K2_WAVES *WAVE, 8) void logz_middle_kernel(int N, i
         if (lane == 0) {
             const float lzf = (float)(macc + (double)eacc * 0.6931471805599453 + (double)logf(tot));
             logz[n] = lzf;
+            if (ws.loss_acc != nullptr) ws.loss_acc[n] += ws.acc_scale * lzf;       // lossvector = (A) + logZ / nblk
             if (status != nullptr && !isfinite(lzf)) atomicOr(status, 1u);
         }
     } else if (wave == 1 && want_grad) {
@@ -938,10 +944,11 @@ __global__ __launch_bounds__(K2_WAVES *WAVE, 8) void logz_middle_kernel(int N, i
 // between the waves through LDS; posteriors overwrite the rows in place and
 // are streamed out through the same coalescing transpose.
 // ---------------------------------------------------------------------------
-template <int NB, int CH>
+template <int NB, int CH, bool ACC = false>
 __global__ __launch_bounds__(K3_WAVES *WAVE, (CH / K3_WAVES <= 2 ? 4 : 2)) void logz_posterior_kernel(
     const float *__restrict__ scores, float *__restrict__ grad, int T, int N, int Npad,
     LogzWs ws, uint32_t *__restrict__ status, int nt_load) {
+    // ACC: add acc_scale * posterior to the gradient kernel A left in `grad` (fused loss)
     using F = FF<NB>;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int wave = threadIdx.x >> 6, lane = lane_id();
@@ -1078,7 +1085,7 @@ __global__ __launch_bounds__(K3_WAVES *WAVE, (CH / K3_WAVES <= 2 ? 4 : 2)) void 
                 w[j].set(F::FLOP0 + from, g);
                 sum += g;
             }
-            const float inv = 1.0f / sum;
+            const float inv = (ACC ? ws.acc_scale : 1.0f) / sum;
             bad |= !isfinite(inv);
 #pragma unroll
             for (int i = 0; i < F::S; ++i) w[j].set(i, w[j].get(i) * inv);
@@ -1095,6 +1102,12 @@ __global__ __launch_bounds__(K3_WAVES *WAVE, (CH / K3_WAVES <= 2 ? 4 : 2)) void 
     for (int j = 0; j < K3_ROWS; ++j) {
         if (tw + j < T) {
             w[j].to_pieces(buf, lane);
+            if constexpr (ACC) {
+                // read-modify-write in the coalesced piece layout: + kernel A's gradient row set
+                const f4 *src = reinterpret_cast<const f4 *>(gbase + (size_t)(tw + j) * rowstride);
+#pragma unroll
+                for (int q = 0; q < F::PIECES; ++q) w[j].v[q] += src[min(q * WAVE + lane, nvalid - 1)];
+            }
             if (TK_K3_NT_STORE) w[j].store_nt(gbase + (size_t)(tw + j) * rowstride, nvalid, lane);
             else w[j].store(gbase + (size_t)(tw + j) * rowstride, nvalid, lane);
         }
@@ -1140,7 +1153,7 @@ static size_t logz_ws_layout(size_t T, size_t N, void *base, LogzWs *ws) {
     f4 *Pc = reinterpret_cast<f4 *>(take(C * mbytes));
     float *Vin = reinterpret_cast<float *>(take(C * F::NS * Npad * sizeof(float)));
     float *Uout = reinterpret_cast<float *>(take(C * F::NS * Npad * sizeof(float)));
-    if (ws) *ws = LogzWs{Pc, Vin, Uout};
+    if (ws) *ws = LogzWs{Pc, Vin, Uout, nullptr, 0.f};
     return off;
 }
 
@@ -1208,10 +1221,16 @@ static int logz_launch_ch(const float *scores, size_t T, size_t N, float *logz, 
             ((CH / K3_WAVES) + 2) * F::NS * WAVE <= k3_buf_f4<NB, CH>() * 4;
         const size_t lds = K3_WAVES * (size_t)k3_buf_f4<NB, CH>() * sizeof(f4) +
                            (chain_in_buf ? 0 : 2 * F::NS * WAVE * sizeof(float));
-        if (raise_dynamic_lds(reinterpret_cast<const void *>(&logz_posterior_kernel<NB, CH>))) return 4;
+        if (raise_dynamic_lds(reinterpret_cast<const void *>(&logz_posterior_kernel<NB, CH, false>)) ||
+            raise_dynamic_lds(reinterpret_cast<const void *>(&logz_posterior_kernel<NB, CH, true>)))
+            return 4;
         const int nt_load = (size_t)T * N * F::S * sizeof(float) > ((size_t)200 << 20);
-        hipLaunchKernelGGL((logz_posterior_kernel<NB, CH>), grid, block, lds, stream, scores, grad,
-                           (int)T, (int)N, Npad, ws, status, nt_load);
+        if (ws.loss_acc != nullptr)
+            hipLaunchKernelGGL((logz_posterior_kernel<NB, CH, true>), grid, block, lds, stream, scores, grad,
+                               (int)T, (int)N, Npad, ws, status, nt_load);
+        else
+            hipLaunchKernelGGL((logz_posterior_kernel<NB, CH, false>), grid, block, lds, stream, scores, grad,
+                               (int)T, (int)N, Npad, ws, status, nt_load);
     }
     return hipGetLastError() == hipSuccess ? 0 : 4;
 }
@@ -1219,10 +1238,12 @@ static int logz_launch_ch(const float *scores, size_t T, size_t N, float *logz, 
 template <int NB>
 static int logz_launch(const float *scores, size_t T, size_t N, float *logz, float *grad,
                        void *workspace, size_t workspace_bytes, uint32_t *status,
-                       hipStream_t stream) {
+                       hipStream_t stream, float *loss_acc, float acc_scale) {
     LogzWs ws;
     const size_t need = logz_ws_layout<NB>(T, N, workspace, &ws);
     if (need > workspace_bytes) return 3;
+    ws.loss_acc = loss_acc;
+    ws.acc_scale = acc_scale;
     int ch = logz_pick_ch(T, N);
     if (const char *e = getenv("TK_LOGZ_CH")) ch = atoi(e);         // tuning override
     // the middle kernel keeps one read's chunk matrices in LDS: fall back to bigger chunks
@@ -1250,12 +1271,13 @@ size_t logz_workspace_bytes(size_t T, size_t N, size_t nbase) {
 
 int logz_dispatch(const float *scores, size_t T, size_t N, size_t nbase, float *logz,
                   float *grad, void *workspace, size_t workspace_bytes, uint32_t *status,
-                  hipStream_t stream) {
+                  hipStream_t stream, float *loss_acc, float acc_scale) {
+    if (loss_acc != nullptr && grad == nullptr) return 1;
     switch (nbase) {
-        case 1: return logz_launch<1>(scores, T, N, logz, grad, workspace, workspace_bytes, status, stream);
-        case 2: return logz_launch<2>(scores, T, N, logz, grad, workspace, workspace_bytes, status, stream);
-        case 3: return logz_launch<3>(scores, T, N, logz, grad, workspace, workspace_bytes, status, stream);
-        case 4: return logz_launch<4>(scores, T, N, logz, grad, workspace, workspace_bytes, status, stream);
+        case 1: return logz_launch<1>(scores, T, N, logz, grad, workspace, workspace_bytes, status, stream, loss_acc, acc_scale);
+        case 2: return logz_launch<2>(scores, T, N, logz, grad, workspace, workspace_bytes, status, stream, loss_acc, acc_scale);
+        case 3: return logz_launch<3>(scores, T, N, logz, grad, workspace, workspace_bytes, status, stream, loss_acc, acc_scale);
+        case 4: return logz_launch<4>(scores, T, N, logz, grad, workspace, workspace_bytes, status, stream, loss_acc, acc_scale);
         default: return 2;
     }
 }

@@ -148,3 +148,58 @@ class CatModFlipFlop(torch.autograd.Function):
 
 
 cat_mod_flipflop_loss = CatModFlipFlop.apply
+
+
+# ---------------------------------------------------------------------------------------------
+# fused train-step loss: (A) + (B) / nblk in one operator, one gradient tensor
+# ---------------------------------------------------------------------------------------------
+def _run_fused(outputs, seqs, seqlen, sharpfact, want_grad):
+    _lib.require_gpu(outputs, "flip-flop loss")
+    L = _lib.lib()
+    lp = outputs.detach().float().contiguous()
+    if lp.data_ptr() % 16 != 0:
+        lp = lp.clone()
+    nblk, nbatch, ntrans = lp.shape
+    nbase = flipflopfings.nbase_flipflop(ntrans)
+    dev = lp.device
+    with torch.cuda.device(dev):
+        status = _lib.status_word(dev)
+        seqlen_d, seqoff, stay, move, _, _, keep = _indices(seqs, seqlen, nbase, dev, status=status)
+        maxlen = _max_seqlen(seqlen)
+        lossvector = torch.empty(nbatch, dtype=torch.float32, device=dev)
+        logz = torch.empty(nbatch, dtype=torch.float32, device=dev)
+        grad = torch.empty_like(lp)
+        wsa = L.tk_crf_flipflop_workspace_bytes(ntrans, nblk, nbatch, maxlen, 1)
+        wsb = L.tk_flipflop_logz_workspace_bytes(nblk, nbatch, nbase)
+        ws_a = torch.empty(wsa, dtype=torch.uint8, device=dev)
+        ws_b = torch.empty(wsb, dtype=torch.uint8, device=dev)
+        rc = L.tk_flipflop_loss_fused_dev(
+            _lib.ptr(lp), nblk, nbatch, nbase, _lib.ptr(stay), _lib.ptr(move), _lib.ptr(seqlen_d),
+            _lib.ptr(seqoff), maxlen, float(sharpfact), _lib.ptr(lossvector), _lib.ptr(grad), _lib.ptr(logz),
+            _lib.ptr(ws_a), wsa, _lib.ptr(ws_b), wsb, _lib.ptr(status), _lib.stream_ptr())
+        _lib.check(rc, "tk_flipflop_loss_fused_dev")
+        _lib.finish(status)
+    del keep
+    return lossvector, (grad if want_grad else None), logz
+
+
+class FlipFlopLoss(torch.autograd.Function):
+    """`crf_flipflop_loss(outputs, seqs, seqlens, sharpen) + flipflop_logpartition(outputs) / nblk`
+    (the lossvector of bin/train_flipflop.py:172-182) as ONE operator: kernel B leaves
+    d logZ / d outputs in the gradient tensor, kernel A's posterior pass adds its own term in
+    place -- one (T, N, S) gradient tensor instead of two plus autograd's add."""
+
+    @staticmethod
+    def forward(ctx, outputs, seqs, seqlen, sharpfact: float):
+        lossvector, grad, _ = _run_fused(outputs, seqs, seqlen, sharpfact, ctx.needs_input_grad[0])
+        if grad is not None:
+            ctx.save_for_backward(grad)
+        return lossvector
+
+    @staticmethod
+    def backward(ctx, output_grads):
+        grads, = ctx.saved_tensors
+        return grads * output_grads.unsqueeze(1), None, None, None
+
+
+flipflop_loss = FlipFlopLoss.apply

@@ -1,9 +1,15 @@
 """The train step around the flip-flop loss: counterpart of `calculate_loss`
 (bin/train_flipflop.py:145-198) and the optimiser step of `train_model`
 (532-627), without per-step host synchronisation."""
+import os
+
 import torch
 
 from taiyaki_amd import ctc, layers
+
+# the fused (A) + (B) / nblk operator for the plain CRF (TK_FUSED_LOSS=0: the two reference
+# operators and autograd's add, as bin/train_flipflop.py:172-176 calls them)
+FUSED_LOSS = os.environ.get("TK_FUSED_LOSS", "1") != "0"
 
 
 def calculate_loss(net, indata, seqs, seqlens, sharpen=1.0, mod_cats=None,
@@ -23,9 +29,12 @@ def calculate_loss(net, indata, seqs, seqlens, sharpen=1.0, mod_cats=None,
         lossvector = ctc.cat_mod_flipflop_loss(outputs, seqs, seqlens, mod_cats,
                                                can_mods_offsets, mod_cat_weights, sharpen)
         ntrans -= int(can_mods_offsets[-1])
+    elif FUSED_LOSS and outputs.is_cuda:
+        lossvector = ctc.flipflop_loss(outputs, seqs, seqlens, sharpen)
     else:
         lossvector = ctc.crf_flipflop_loss(outputs, seqs, seqlens, sharpen)
-    lossvector = lossvector + layers.flipflop_logpartition(outputs[:, :, :ntrans]) / nblk
+    if mod_cats is not None or not (FUSED_LOSS and outputs.is_cuda):
+        lossvector = lossvector + layers.flipflop_logpartition(outputs[:, :, :ntrans]) / nblk
     if ignore_empty:
         live = (seqlens.to(lossvector.device) > 0).to(lossvector.dtype)
         return (lossvector * live).sum() / live.sum().clamp(min=1.0), lossvector

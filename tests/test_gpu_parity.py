@@ -802,3 +802,46 @@ def test_bad_labels_raise_like_the_reference(gpu_device):
     bad_mods = torch.tensor([0, 0, 1, 0, 0, 0])         # G has no modification: category 1 is out of range
     with pytest.raises(AssertionError, match="labels out of range"):
         ctc.cat_mod_flipflop_loss(xm, good, torch.tensor([3, 3]), bad_mods, cmo, mcw, 1.0)
+
+
+@pytest.mark.parametrize("name", list(cases.FULLSIZE))
+def test_fused_loss_at_full_size_against_reference_goldens(gpu_device, name):
+    """`ctc.flipflop_loss` (tk_flipflop_loss_fused_dev) = crf loss + logZ / nblk in one operator:
+    lossvector against the reference's goldens at every BASELINE size, and its single gradient
+    tensor against the sum of the two separate operators' gradients."""
+    import torch
+    from taiyaki_amd import ctc, layers
+    spec = cases.FULLSIZE[name]
+    inp = parity.fullsize_inputs(name)
+    if "mod_cats" in inp:
+        pytest.skip("the fused operator is the plain-CRF assembly; cat-mod goes through the two operators")
+    gold = load_golden("fullsize.npz")
+    x = torch.from_numpy(inp["scores"]).to(gpu_device).requires_grad_()
+    seqs, seqlens = torch.from_numpy(inp["seqs"]), torch.from_numpy(inp["seqlens"])
+    lv = ctc.flipflop_loss(x, seqs, seqlens, 1.0)
+    np.testing.assert_allclose(lv.detach().cpu().numpy(), gold[name + "/lossvector"], rtol=1e-4)
+    lv.sum().backward()
+    g = x.grad.clone()
+    x.grad = None
+    two = ctc.crf_flipflop_loss(x, seqs, seqlens, 1.0) + layers.flipflop_logpartition(x) / float(spec["T"])
+    two.sum().backward()
+    assert float((lv.detach() - two.detach()).abs().max()) < 2e-6 * float(two.detach().abs().max())
+    assert float((g - x.grad).abs().max()) < 1e-7
+
+
+@pytest.mark.parametrize("sharp", [1.0, 2.5])
+def test_fused_loss_small_against_oracle(oracle_mod, gpu_device, sharp):
+    """Fused operator vs the oracle's (A) + (B) / nblk incl. sharpening (A only), an empty read and
+    L = T + 1; its gradient = d A + (d logZ) / nblk."""
+    import torch
+    from taiyaki_amd import ctc, synth
+    T = 57
+    seqlens = np.array([20, 1, T + 1, 33, 0], dtype=np.int32)
+    inp = synth.crf_case(T, len(seqlens), 12, seqlens=seqlens)
+    x = torch.from_numpy(inp["scores"]).to(gpu_device).requires_grad_()
+    lv = ctc.flipflop_loss(x, torch.from_numpy(inp["seqs"]), torch.from_numpy(inp["seqlens"]), sharp)
+    lv.sum().backward()
+    oloss, ograd = oracle_mod.crf_flipflop_loss(inp["scores"], inp["seqs"], inp["seqlens"], sharp)
+    olz, olgrad = oracle_mod.flipflop_logz_grad(inp["scores"])
+    np.testing.assert_allclose(lv.detach().cpu().numpy(), oloss + olz / T, rtol=1e-5, atol=2e-6)
+    np.testing.assert_allclose(x.grad.cpu().numpy(), ograd + olgrad / T, atol=2e-5)

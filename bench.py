@@ -430,6 +430,10 @@ def main():
                          "store: every step samples, filters and assembles its batch on the device "
                          "from a synthetic mapped-signal set resident in HBM "
                          "(taiyaki_amd.mapped_signal, the reference's prepare_random_batches)")
+    ap.add_argument("--mapped-signal", default=None, metavar="FILE",
+                    help="with --data store: take the reads from this mapped-signal HDF5 (classic layout, read by "
+                         "taiyaki_amd.hdf5_lite) or packed .npz file instead of synthetic reads, e.g. "
+                         "tests/golden/mapped_signal/mapped_reads_0.hdf5 (real r9.4.1 reads)")
     ap.add_argument("--overlap-buckets", type=int, default=4,
                     help="gradient all-reduce slices issued from backward hooks (N > 1); 0 = one all-reduce "
                          "after backward")
@@ -543,9 +547,14 @@ def main():
         # batches straight from the file-format arrays: sample_chunks + filters + stacking +
         # flip-flop coding as three launches on this stream, nothing on the host
         from taiyaki_amd import mapped_signal, synth
-        store = mapped_signal.MappedSignalStore(
-            synth.mapped_reads(1500, 31 + rank, mean_reflen=max(900, chunk_len // 4),
-                               long_dwell_prob=0.0003), dev)
+        if args.mapped_signal and args.mapped_signal.endswith(".npz"):
+            store = mapped_signal.MappedSignalStore.from_npz(args.mapped_signal, dev)
+        elif args.mapped_signal:
+            store = mapped_signal.MappedSignalStore.from_hdf5(args.mapped_signal, dev)
+        else:
+            store = mapped_signal.MappedSignalStore(
+                synth.mapped_reads(1500, 31 + rank, mean_reflen=max(900, chunk_len // 4),
+                                   long_dwell_prob=0.0003), dev)
         torch.manual_seed(99 + rank)
         fparams = store.sample_filter_parameters(1000, chunk_len, 3.0, 10.0, 0.5, stride, 1.1)
 
@@ -599,7 +608,9 @@ def main():
                        nglobal * args.steps / elapsed, 2),
                    unit="chunks/s", n_gpus=world, steps=args.steps, warmup=args.warmup,
                    ms_per_step=round(elapsed / args.steps * 1e3, 3), higher_is_better=True,
-                   scaling="weak", vs_baseline=None, dtype="f32", data="synthetic",
+                   scaling="weak", vs_baseline=None, dtype="f32",
+                   data=("reads of " + os.path.basename(args.mapped_signal)
+                         if args.data == "store" and args.mapped_signal else "synthetic"),
                    config=dict(workload="%s, chunk_len=%d (T=%d blocks), %d chunks/GPU, size %d, HIP flip-flop %s "
                                "loss + logZ, gradient maxima/clipping, AdamW"
                                % (cfg["label"], chunk_len, T, nbatch, size, "cat-mod" if cat_mod else "CRF"),

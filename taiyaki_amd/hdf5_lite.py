@@ -1,0 +1,385 @@
+"""A small read-only HDF5 parser for mapped-signal files (no h5py in this image).
+
+The reference reads its training data with h5py (`taiyaki/mapped_signal_files.py:262-350`,
+layout in `docs/FILE_FORMATS.md:43-75`): root attributes `alphabet`, `collapse_alphabet`,
+`mod_long_names`, `version`; one group per read under `Reads/` with datasets `Dacs` (int16),
+`Ref_to_signal` (int32), `Reference` (int16) -- gzip + shuffle, chunked -- and five float
+attributes.  This module reads exactly that much of the HDF5 file format, from the format
+specification, for the CLASSIC on-disk layout:
+
+    superblock version 0/1, version-1 object headers (+ continuation blocks), symbol-table
+    groups (version-1 B-tree of group nodes + local heap), data layout message version 3
+    (compact / contiguous / chunked with a version-1 chunk B-tree), filter pipeline
+    (deflate, shuffle, fletcher32), attribute messages version 1-3 with fixed-point,
+    floating-point, fixed-length string and variable-length string (global heap) values.
+
+That is the layout of the mapped-signal files the reference ships with its tests
+(`test/data/mapped_signal_file/*.hdf5`), against which this parser is validated.  Files written
+with `libver='v108'` or later (version-2 object headers, dense link storage in fractal heaps --
+what `MappedSignalWriter` produces today, mapped_signal_files.py:372) are recognised and refused
+with a clear error; convert those with `tools/mapped_signal_to_npz.py` where h5py exists.
+"""
+import struct
+import zlib
+
+import numpy as np
+
+SIGNATURE = b"\x89HDF\r\n\x1a\n"
+UNDEF = 0xFFFFFFFFFFFFFFFF
+
+
+class Hdf5Error(Exception):
+    pass
+
+
+class _Datatype:
+    def __init__(self, cls, size, dtype=None, vlen_string=False, base=None):
+        self.cls, self.size, self.dtype, self.vlen_string, self.base = cls, size, dtype, vlen_string, base
+
+
+class Dataset:
+    def __init__(self, f, msgs):
+        self.f, self.attrs = f, f._attributes(msgs)
+        self.shape = self.dtype = None
+        self._layout = self._filters = None
+        for mtype, data in msgs:
+            if mtype == 0x01:
+                self.shape = f._dataspace(data)
+            elif mtype == 0x03:
+                self._dt = f._datatype(data, 0)[0]
+                self.dtype = self._dt.dtype
+            elif mtype == 0x08:
+                self._layout = data
+            elif mtype == 0x0B:
+                self._filters = f._filter_pipeline(data)
+        if self.shape is None or self.dtype is None or self._layout is None:
+            raise Hdf5Error("dataset without dataspace / numeric datatype / layout message")
+
+    def __getitem__(self, key):
+        return self.read()[key]
+
+    def read(self):
+        f, lay = self.f, self._layout
+        n = int(np.prod(self.shape)) if self.shape else 1
+        if lay[0] != 3:
+            raise Hdf5Error("data layout message version %d not supported (3 expected)" % lay[0])
+        cls = lay[1]
+        if cls == 0:                                    # compact
+            size = struct.unpack_from("<H", lay, 2)[0]
+            raw = lay[4:4 + size]
+            return np.frombuffer(raw, dtype=self.dtype, count=n).reshape(self.shape).copy()
+        if cls == 1:                                    # contiguous
+            addr, size = f._off(lay, 2), f._len(lay, 2 + f.offsz)
+            if addr == UNDEF:
+                return np.zeros(self.shape, dtype=self.dtype)
+            return np.frombuffer(f.buf, dtype=self.dtype, count=n, offset=f.base + addr).reshape(self.shape).copy()
+        if cls != 2:
+            raise Hdf5Error("unknown layout class %d" % cls)
+        rank = lay[2]                                   # dataset rank + 1 (element size)
+        btree = f._off(lay, 3)
+        cdims = struct.unpack_from("<%dI" % rank, lay, 3 + f.offsz)
+        chunk_shape, elsize = cdims[:-1], cdims[-1]
+        out = np.zeros(self.shape, dtype=self.dtype)
+        if btree == UNDEF or n == 0:
+            return out
+        for csize, mask, offs, addr in f._chunk_btree(btree, rank):
+            raw = bytes(f.buf[f.base + addr:f.base + addr + csize])
+            for k, (fid, cd) in reversed(list(enumerate(self._filters or []))):
+                if mask & (1 << k):
+                    continue
+                if fid == 1:
+                    raw = zlib.decompress(raw)
+                elif fid == 2:
+                    es = cd[0] if cd else elsize
+                    a = np.frombuffer(raw, dtype=np.uint8)
+                    m = len(a) // es
+                    raw = a[:m * es].reshape(es, m).T.tobytes() + a[m * es:].tobytes()
+                elif fid == 3:
+                    raw = raw[:-4]                      # fletcher32 checksum trailer
+                else:
+                    raise Hdf5Error("filter %d is not supported" % fid)
+            chunk = np.frombuffer(raw, dtype=self.dtype, count=int(np.prod(chunk_shape))).reshape(chunk_shape)
+            sel_out = tuple(slice(o, min(o + c, s)) for o, c, s in zip(offs, chunk_shape, self.shape))
+            sel_in = tuple(slice(0, s.stop - s.start) for s in sel_out)
+            out[sel_out] = chunk[sel_in]
+        return out
+
+
+class Group:
+    def __init__(self, f, msgs, btree, heap):
+        self.f, self.attrs, self._btree, self._heap = f, f._attributes(msgs), btree, heap
+        self._links = None
+
+    def _load(self):
+        if self._links is None:
+            self._links = dict(self.f._symbol_table(self._btree, self._heap))
+        return self._links
+
+    def keys(self):
+        return list(self._load())
+
+    def __contains__(self, name):
+        return name in self._load()
+
+    def __len__(self):
+        return len(self._load())
+
+    def __iter__(self):
+        return iter(self._load())
+
+    def __getitem__(self, path):
+        node = self
+        for part in [p for p in path.split("/") if p]:
+            links = node._load()
+            if part not in links:
+                raise KeyError(part)
+            node = node.f._object(links[part])
+        return node
+
+
+class File(Group):
+    """`File(path)['Reads/<read_id>/Dacs'].read()`, `.attrs`, `.keys()` -- the h5py subset the
+    mapped-signal reader needs."""
+
+    def __init__(self, path):
+        with open(path, "rb") as fh:
+            self.buf = memoryview(fh.read())
+        pos = 0
+        while pos < len(self.buf) and bytes(self.buf[pos:pos + 8]) != SIGNATURE:
+            pos = 512 if pos == 0 else pos * 2          # the superblock may sit at 0, 512, 1024, ...
+        if pos >= len(self.buf):
+            raise Hdf5Error("%s is not an HDF5 file" % path)
+        ver = self.buf[pos + 8]
+        if ver >= 2:
+            raise Hdf5Error(
+                "%s has a version-%d superblock (HDF5 1.8+ 'latest' layout: version-2 object headers, links in "
+                "fractal heaps); this reader handles the classic layout only -- convert the file with "
+                "tools/mapped_signal_to_npz.py on a machine that has h5py" % (path, ver))
+        self.offsz, self.lensz = self.buf[pos + 13], self.buf[pos + 14]
+        if self.offsz != 8 or self.lensz != 8:
+            raise Hdf5Error("only 8-byte offsets and lengths are supported")
+        p = pos + 24 + (4 if ver == 1 else 0)
+        self.base = struct.unpack_from("<Q", self.buf, p)[0]
+        root_ste = p + 4 * 8
+        root_hdr = struct.unpack_from("<Q", self.buf, root_ste + 8)[0]
+        self._cache = {}
+        msgs = self._object_header(root_hdr)
+        bt, hp = self._symtab_msg(msgs)
+        Group.__init__(self, self, msgs, bt, hp)
+
+    # -- primitives ----------------------------------------------------------------------------
+    def _off(self, b, o):
+        return struct.unpack_from("<Q", b, o)[0]
+
+    _len = _off
+
+    def _object(self, addr):
+        if addr not in self._cache:
+            msgs = self._object_header(addr)
+            st = self._symtab_msg(msgs)
+            self._cache[addr] = Group(self, msgs, *st) if st else Dataset(self, msgs)
+        return self._cache[addr]
+
+    def _symtab_msg(self, msgs):
+        for mtype, data in msgs:
+            if mtype == 0x11:
+                return self._off(data, 0), self._off(data, 8)
+        return None
+
+    def _object_header(self, addr):
+        b, p = self.buf, self.base + addr
+        if bytes(b[p:p + 4]) == b"OHDR":
+            raise Hdf5Error("version-2 object header: not a classic-layout file")
+        ver, _, nmsgs, _refs, hsize = struct.unpack_from("<BBHII", b, p)
+        if ver != 1:
+            raise Hdf5Error("object header version %d" % ver)
+        blocks = [(p + 16, hsize)]
+        msgs = []
+        while blocks and len(msgs) < nmsgs:
+            q, size = blocks.pop(0)
+            end = q + size
+            while q + 8 <= end and len(msgs) < nmsgs:
+                mtype, msize, _flags = struct.unpack_from("<HHB", b, q)
+                data = bytes(b[q + 8:q + 8 + msize])
+                q += 8 + msize
+                if mtype == 0x10:                       # continuation
+                    blocks.append((self.base + self._off(data, 0), self._len(data, 8)))
+                msgs.append((mtype, data))
+        return msgs
+
+    def _symbol_table(self, btree, heap):
+        b = self.buf
+        hp = self.base + heap
+        if bytes(b[hp:hp + 4]) != b"HEAP":
+            raise Hdf5Error("local heap signature")
+        hdata = self.base + self._off(b, hp + 24)
+
+        def name_at(o):
+            e = hdata + o
+            z = e
+            while b[z] != 0:
+                z += 1
+            return bytes(b[e:z]).decode("utf-8")
+
+        def walk(addr):
+            p = self.base + addr
+            if bytes(b[p:p + 4]) != b"TREE":
+                raise Hdf5Error("group B-tree signature")
+            ntype, level, nent = struct.unpack_from("<BBH", b, p + 4)
+            if ntype != 0:
+                raise Hdf5Error("group B-tree node type %d" % ntype)
+            q = p + 8 + 16
+            for i in range(nent):
+                child = self._off(b, q + 8 + i * 16)
+                if level > 0:
+                    yield from walk(child)
+                else:
+                    s = self.base + child
+                    if bytes(b[s:s + 4]) != b"SNOD":
+                        raise Hdf5Error("symbol node signature")
+                    nsym = struct.unpack_from("<H", b, s + 6)[0]
+                    for k in range(nsym):
+                        e = s + 8 + 40 * k
+                        yield name_at(self._off(b, e)), self._off(b, e + 8)
+        yield from walk(btree)
+
+    def _chunk_btree(self, addr, rank):
+        b, p = self.buf, self.base + addr
+        if bytes(b[p:p + 4]) != b"TREE":
+            raise Hdf5Error("chunk B-tree signature")
+        ntype, level, nent = struct.unpack_from("<BBH", b, p + 4)
+        if ntype != 1:
+            raise Hdf5Error("chunk B-tree node type %d" % ntype)
+        keysz = 8 + 8 * rank
+        q = p + 8 + 16
+        for i in range(nent):
+            k = q + i * (keysz + 8)
+            csize, mask = struct.unpack_from("<II", b, k)
+            offs = struct.unpack_from("<%dQ" % rank, b, k + 8)[:-1]
+            child = self._off(b, k + keysz)
+            if level > 0:
+                yield from self._chunk_btree(child, rank)
+            else:
+                yield csize, mask, offs, child
+
+    # -- messages ------------------------------------------------------------------------------
+    def _dataspace(self, d):
+        ver, rank, flags = d[0], d[1], d[2]
+        if ver == 1:
+            o = 8
+        elif ver == 2:
+            if d[3] == 2:                               # null dataspace
+                return (0,)
+            o = 4
+        else:
+            raise Hdf5Error("dataspace version %d" % ver)
+        return tuple(struct.unpack_from("<%dQ" % rank, d, o)) if rank else ()
+
+    def _datatype(self, d, o):
+        cv, b0, b1, _b2, size = struct.unpack_from("<BBBBI", d, o)
+        cls = cv & 0x0F
+        end = "<" if not (b0 & 1) else ">"
+        if cls == 0:                                    # fixed point
+            dt = np.dtype("%s%s%d" % (end, "i" if b0 & 8 else "u", size))
+            return _Datatype(cls, size, dt), o + 8 + 4
+        if cls == 1:                                    # floating point
+            return _Datatype(cls, size, np.dtype("%sf%d" % (end, size))), o + 8 + 12
+        if cls == 3:                                    # fixed-length string
+            return _Datatype(cls, size, np.dtype("S%d" % size)), o + 8
+        if cls == 9:                                    # variable length
+            base, nxt = self._datatype(d, o + 8)
+            return _Datatype(cls, size, None, vlen_string=(b0 & 0x0F) == 1, base=base), nxt
+        raise Hdf5Error("datatype class %d is not supported" % cls)
+
+    def _filter_pipeline(self, d):
+        ver, nf = d[0], d[1]
+        o = 8 if ver == 1 else 2
+        out = []
+        for _ in range(nf):
+            fid, = struct.unpack_from("<H", d, o)
+            if ver == 1 or fid >= 256:
+                namelen, _flags, ncd = struct.unpack_from("<HHH", d, o + 2)
+                o += 8 + (namelen + 7) // 8 * 8 if ver == 1 else 8 + namelen
+            else:
+                _flags, ncd = struct.unpack_from("<HH", d, o + 2)
+                o += 6
+            cd = struct.unpack_from("<%dI" % ncd, d, o)
+            o += 4 * ncd + (4 if ver == 1 and ncd % 2 else 0)
+            out.append((fid, cd))
+        return out
+
+    def _global_heap_object(self, addr, index):
+        b, p = self.buf, self.base + addr
+        if bytes(b[p:p + 4]) != b"GCOL":
+            raise Hdf5Error("global heap signature")
+        size = self._len(b, p + 8)
+        q, end = p + 16, p + size
+        while q + 16 <= end:
+            idx, _rc, _r, osz = struct.unpack_from("<HHIQ", b, q)
+            if idx == index:
+                return bytes(b[q + 16:q + 16 + osz])
+            if idx == 0:
+                break
+            q += 16 + (osz + 7) // 8 * 8
+        raise Hdf5Error("global heap object %d not found" % index)
+
+    def _attributes(self, msgs):
+        out = {}
+        for mtype, d in msgs:
+            if mtype != 0x0C:
+                continue
+            ver = d[0]
+            nsz, tsz, ssz = struct.unpack_from("<HHH", d, 2)
+            o = 8 + (1 if ver == 3 else 0)
+            pad = (lambda n: (n + 7) // 8 * 8) if ver == 1 else (lambda n: n)
+            name = d[o:o + nsz].split(b"\0")[0].decode("utf-8")
+            o += pad(nsz)
+            dt = self._datatype(d, o)[0]
+            o += pad(tsz)
+            shape = self._dataspace(d[o:o + ssz])
+            o += pad(ssz)
+            n = int(np.prod(shape)) if shape else 1
+            if dt.cls == 9:
+                vals = []
+                for i in range(n):
+                    ln, gaddr, gidx = struct.unpack_from("<IQI", d, o + 16 * i)
+                    raw = self._global_heap_object(gaddr, gidx)[:ln * (dt.base.size if dt.base else 1)] if ln else b""
+                    vals.append(raw.decode("utf-8") if dt.vlen_string else np.frombuffer(raw, dtype=dt.base.dtype))
+                val = vals[0] if not shape else vals
+            elif dt.cls == 3:
+                raw = np.frombuffer(d, dtype=dt.dtype, count=n, offset=o)
+                vals = [x.split(b"\0")[0].decode("utf-8") for x in raw]
+                val = vals[0] if not shape else vals
+            else:
+                arr = np.frombuffer(d, dtype=dt.dtype, count=n, offset=o)
+                val = arr[0] if not shape else arr.reshape(shape).copy()
+            out[name] = val
+        return out
+
+
+def read_mapped_signal_file(path, limit=None):
+    """The reads of a mapped-signal file as the dictionaries of
+    `SignalMapping.get_read_dictionary` (signal_mapping.py:318-350), plus the file's alphabet
+    attributes: what `MappedSignalReader.reads()` yields (mapped_signal_files.py:262-350)."""
+    f = File(path)
+    version = int(f.attrs.get("version", -1))
+    if version not in (7, 8):
+        raise Hdf5Error("mapped-signal file version %r (7 or 8 expected, mapped_signal_files.py:18)" % version)
+    info = dict(version=version, alphabet=f.attrs.get("alphabet"), collapse_alphabet=f.attrs.get("collapse_alphabet"),
+                mod_long_names=str(f.attrs.get("mod_long_names", "")).splitlines())
+    reads = []
+    group = f["Reads"]
+    for rid in group.keys():
+        if limit is not None and len(reads) >= limit:
+            break
+        g = group[rid]
+        rd = dict(read_id=rid, Dacs=g["Dacs"].read().astype(np.int16),
+                  Ref_to_signal=g["Ref_to_signal"].read().astype(np.int32),
+                  Reference=g["Reference"].read().astype(np.int16))
+        for k in ("shift_frompA", "scale_frompA", "range", "offset", "digitisation"):
+            rd[k] = float(g.attrs[k])
+        for k in ("mapping_score", "mapping_method"):
+            if k in g.attrs:
+                rd[k] = g.attrs[k]
+        reads.append(rd)
+    return info, reads

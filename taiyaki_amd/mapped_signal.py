@@ -221,6 +221,19 @@ class MappedSignalStore:
         store.alphabet, store.collapse_alphabet = alphabet, collapse
         return store
 
+    @classmethod
+    def from_hdf5(cls, path, device, limit=None):
+        """A mapped-signal HDF5 file as the reference's MappedSignalReader reads it
+        (mapped_signal_files.py:262-350, docs/FILE_FORMATS.md:43-75), through the built-in
+        classic-layout parser `hdf5_lite` (no h5py needed).  Files in the HDF5 1.8+ "latest"
+        layout are refused with a message that names the converter."""
+        from taiyaki_amd import hdf5_lite
+        info, reads = hdf5_lite.read_mapped_signal_file(path, limit=limit)
+        store = cls(reads, device)
+        store.alphabet, store.collapse_alphabet = info["alphabet"], info["collapse_alphabet"]
+        store.mod_long_names = info["mod_long_names"]
+        return store
+
     @property
     def nreads(self):
         return len(self.read_ids)

@@ -1,0 +1,110 @@
+"""The built-in mapped-signal HDF5 reader (taiyaki_amd/hdf5_lite.py; h5py is not in this image)
+on data files the reference's own tests hold (test/data/mapped_signal_file/*.hdf5 and one raw
+fast5 of test/data/reads, copied as fixtures to tests/golden/mapped_signal/).
+
+The container is validated three ways: the documented structure and invariants of the format
+(docs/FILE_FORMATS.md:43-75); an INDEPENDENT file -- the raw fast5 MinKNOW wrote for the same read
+(other chunking, other filters, other writer) must hold the same samples and channel constants;
+and the reference's own description of the files (2 reads from the walkthrough set,
+note_on_creation_of_test_data.txt)."""
+import os
+
+import numpy as np
+import pytest
+
+from taiyaki_amd import hdf5_lite
+
+HERE = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "mapped_signal")
+
+
+def test_mapped_signal_file_structure_and_invariants():
+    info, reads = hdf5_lite.read_mapped_signal_file(os.path.join(HERE, "mapped_reads_0.hdf5"))
+    assert info["version"] == 8 and info["alphabet"] == "ACGT" and info["collapse_alphabet"] == "ACGT"
+    assert info["mod_long_names"] == []
+    assert [r["read_id"] for r in reads] == ["302c746b-1b9e-4262-af6a-859bae0c00f8",
+                                             "6dc84c3b-840b-4b04-a817-013a036695f8"]
+    for r in reads:
+        dacs, rts, ref = r["Dacs"], r["Ref_to_signal"], r["Reference"]
+        assert dacs.dtype == np.int16 and rts.dtype == np.int32 and ref.dtype == np.int16
+        assert len(rts) == len(ref) + 1                         # FILE_FORMATS.md: Ref_to_signal has reflen + 1 entries
+        assert np.all(np.diff(rts) >= 0) and rts[0] >= -1 and rts[-1] <= len(dacs) + 1
+        assert ref.min() >= 0 and ref.max() < 4
+        assert r["digitisation"] == 8192.0 and 1000 < r["range"] < 2000 and 0 < r["scale_frompA"] < 100
+        # r9.4.1 DNA: about 9 samples per base
+        assert 7 < (rts[-1] - rts[0]) / len(ref) < 12
+    assert (len(reads[0]["Dacs"]), len(reads[0]["Reference"])) == (38344, 4090)
+    assert (len(reads[1]["Dacs"]), len(reads[1]["Reference"])) == (73060, 7161)
+
+
+def test_dacs_equal_the_raw_fast5_signal_of_the_same_read():
+    """Independent cross-check of the chunked / deflate / shuffle decoding: the mapped-signal
+    file's Dacs of read de1508c4... against the Signal dataset of that read's raw fast5."""
+    info, reads = hdf5_lite.read_mapped_signal_file(os.path.join(HERE, "mapped_remap_samref.hdf5"))
+    rd = [r for r in reads if r["read_id"].startswith("de1508c4")][0]
+    f5 = hdf5_lite.File(os.path.join(HERE, "de1508c4-755b-489e-9ffb-51af35c9a7e6.fast5"))
+    reads_group = f5["Raw/Reads"]
+    (name,) = reads_group.keys()
+    sig = reads_group[name]["Signal"].read()
+    assert sig.dtype == np.int16 and np.array_equal(sig, rd["Dacs"])
+    assert int(reads_group[name].attrs["duration"]) == len(sig)
+    ch = f5["UniqueGlobalKey/channel_id"].attrs
+    assert float(ch["range"]) == rd["range"] and float(ch["offset"]) == rd["offset"]
+    assert float(ch["digitisation"]) == rd["digitisation"] and ch["channel_number"] == "248"
+
+
+def test_latest_layout_is_refused_with_the_converter_named(tmp_path):
+    """HDF5 1.8+ 'latest' layout (what MappedSignalWriter writes today, libver='v108'): a
+    version-2 superblock is recognised and refused, never mis-parsed."""
+    p = tmp_path / "new.hdf5"
+    p.write_bytes(hdf5_lite.SIGNATURE + bytes([2, 8, 8, 0]) + bytes(64))
+    with pytest.raises(hdf5_lite.Hdf5Error, match="mapped_signal_to_npz"):
+        hdf5_lite.File(str(p))
+    q = tmp_path / "junk.bin"
+    q.write_bytes(b"not hdf5" * 100)
+    with pytest.raises(hdf5_lite.Hdf5Error, match="not an HDF5 file"):
+        hdf5_lite.File(str(q))
+
+
+def test_chunks_from_the_real_file_match_the_oracle_sampler():
+    """The reads of the real file through the numpy restatement of the reference's chunk
+    sampler (oracle/chunks.py): chunks come out with the documented shapes (host side; the
+    device path is compared with the same oracle in the -m gpu test below)."""
+    from oracle import chunks as oc
+    _, reads = hdf5_lite.read_mapped_signal_file(os.path.join(HERE, "mapped_reads_0.hdf5"))
+    rs = np.random.RandomState(3)
+    cands = [(int(rs.randint(len(reads))), int(rs.randint(20000))) for _ in range(12)]
+    fp = dict(filter_mean_dwell=3.0, filter_max_dwell=10.0, filter_min_pass_fraction=0.5, median_meandwell=None,
+              mad_meandwell=None, model_stride=5, path_buffer=1.1)
+    want, counts, attempts = oc.sample_chunks(reads, 6, 2000, fp, cands)
+    assert len(want) == 6 and attempts >= 6
+    indata, seqs, seqlens, _ = oc.assemble_batch(want, 4)
+    assert indata.shape == (2000, 6, 1) and np.all(np.abs(indata) < 10) and np.all(seqlens > 100)
+
+
+@pytest.mark.gpu
+def test_store_from_hdf5_feeds_the_loss(gpu_device):
+    """Real r9.4.1 reads: HDF5 file -> MappedSignalStore in HBM -> chunk batch assembled on the
+    device, bit for bit what the oracle sampler assembles from the same reads and candidates ->
+    HIP flip-flop loss with a finite value and gradient."""
+    import torch
+    from oracle import chunks as oc
+    from taiyaki_amd import ctc, mapped_signal
+    path = os.path.join(HERE, "mapped_reads_0.hdf5")
+    store = mapped_signal.MappedSignalStore.from_hdf5(path, gpu_device)
+    assert store.nreads == 2 and store.alphabet == "ACGT"
+    _, reads = hdf5_lite.read_mapped_signal_file(path)
+    rs = np.random.RandomState(5)
+    fp = store.sample_filter_parameters(30, 2000, 3.0, 10.0, 0.5, 5, 1.1, rng=rs)
+    cand = store.reference_candidates(16, 2000, rs)
+    cb = store.sample_chunks(8, 2000, fp, candidates=cand)
+    want, _, _ = oc.sample_chunks(reads, 8, 2000, dict(fp._asdict()), list(zip(*cand)))
+    assert cb.naccepted == len(want) == 8
+    indata, seqs, seqlens, _ = oc.assemble_batch(want, 4)
+    got = cb.trimmed()
+    assert np.array_equal(got[0].cpu().numpy().view(np.uint32), indata.view(np.uint32))
+    assert np.array_equal(got[1].cpu().numpy(), seqs) and np.array_equal(got[2].cpu().numpy(), seqlens)
+    T = 2000 // 5
+    x = (torch.randn(T, 8, 40, device=gpu_device) * 2).requires_grad_()
+    lv = ctc.flipflop_loss(x, got[1].cpu().long(), got[2].cpu().long(), 1.0)
+    lv.mean().backward()
+    assert bool(torch.isfinite(lv).all()) and bool(torch.isfinite(x.grad).all())

@@ -136,6 +136,25 @@ int tk_flipflop_loss_fused_dev(const float *scores, size_t nblk, size_t nbatch, 
                                size_t logz_workspace_bytes, uint32_t *status, void *stream);
 
 /* ------------------------------------------------------------------------- *
+ * Hash beam search (replaces taiyaki/decodeutil/c_hashdecode.h:10
+ * `flipflop_beamsearch` + the guiding backward pass c_flipflopfwdbwd.h
+ * `flipflop_backward` + the wrapper decodeutil.pyx:9-51), a batch of reads per
+ * launch, one wavefront per read:
+ *   scores (nblk, nbatch, ntrans) device; beam_width <= 12 (reference default 5);
+ *   beam_cut in [0, 1] (0 = no cutting); guided != 0 uses the backward scores.
+ *   seq (nbatch, nblk) int8 flip-flop states of the best sequence, -1 padded;
+ *   seqlen (nbatch); score (nbatch) = the reference's return value.
+ * Records of exactly equal score are ordered as the reference's sort procedure
+ * (decodeutil/qsort.h) orders them.  Returns 0, 1 (beam_cut outside [0, 1]),
+ * 2 (nbase > 4, beam_width outside 1..12), 3 (workspace too small), 4 (launch).
+ * ------------------------------------------------------------------------- */
+size_t tk_flipflop_beamsearch_workspace_bytes(size_t nblk, size_t nbatch, size_t nbase);
+int tk_flipflop_beamsearch_dev(const float *scores, size_t nblk, size_t nbatch, size_t nbase,
+                               int beam_width, float beam_cut, int guided, int8_t *seq,
+                               int32_t *seqlen, float *score, void *workspace,
+                               size_t workspace_bytes, void *stream);
+
+/* ------------------------------------------------------------------------- *
  * (B) log-partition over the 2*nbase state lattice and its gradient
  *     logz[n] = log sum_{all flip-flop paths starting in a flip state} exp(sum_t s)
  *     grad[t,n,:] = d logz[n] / d scores[t,n,:]  == posterior transition

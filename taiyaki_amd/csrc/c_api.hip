@@ -26,6 +26,10 @@ int crf_dispatch(const float *logprob, size_t ntrans, size_t nblk, size_t nbatch
                  size_t max_seqlen, size_t ncan, float sharp_can, float sharp_mod,
                  float out_scale, float *cost, float *grad, void *workspace,
                  size_t workspace_bytes, uint32_t *status, hipStream_t stream);
+size_t beam_workspace_bytes(size_t T, size_t N, size_t nbase);
+int beam_dispatch(const float *scores, size_t T, size_t N, size_t nbase, int width, float beam_cut, int guided,
+                  signed char *seq, int *seqlen, float *score, void *workspace, size_t workspace_bytes,
+                  hipStream_t stream);
 int grad_clip_dispatch(float *grads, const int64_t *seg_off, size_t nseg, size_t max_seg_len,
                        const float *thresh, float *maxs, hipStream_t stream);
 int errprobs_dispatch(const float *trans, const int64_t *path, size_t T, size_t N, size_t nbase,
@@ -213,6 +217,19 @@ int tk_flipflop_loss_fused_dev(const float *scores, size_t nblk, size_t nbatch, 
     if (rc != 0) return rc;
     return tk::logz_dispatch(scores, nblk, nbatch, nbase, logz, grad, logz_workspace, logz_workspace_bytes, status, st,
                              lossvector, 1.0f / (float)nblk);
+}
+
+size_t tk_flipflop_beamsearch_workspace_bytes(size_t nblk, size_t nbatch, size_t nbase) {
+    return tk::beam_workspace_bytes(nblk, nbatch, nbase);
+}
+
+int tk_flipflop_beamsearch_dev(const float *scores, size_t nblk, size_t nbatch, size_t nbase, int beam_width,
+                               float beam_cut, int guided, int8_t *seq, int32_t *seqlen, float *score,
+                               void *workspace, size_t workspace_bytes, void *stream) {
+    if (!scores || !seq || !seqlen || !score || !workspace || nblk == 0 || nbatch == 0) return TK_ERR_BAD_ARG;
+    return tk::beam_dispatch(scores, nblk, nbatch, nbase, beam_width, beam_cut, guided,
+                             reinterpret_cast<signed char *>(seq), seqlen, score, workspace, workspace_bytes,
+                             static_cast<hipStream_t>(stream));
 }
 
 size_t tk_flipflop_logz_workspace_bytes(size_t nblk, size_t nbatch, size_t nbase) {

@@ -1,0 +1,44 @@
+"""Drop-in for ``taiyaki.decodeutil.beamsearch`` (taiyaki/decodeutil/decodeutil.pyx:9-51):
+hash beam search over the flip-flop lattice, on the gfx950 kernel of csrc/beam_kernels.hip.
+
+The reference decodes one read per call on the host; here a call takes one read ``(T, S)`` --
+same return value ``(sequence, score)`` -- or a batch ``(T, N, S)`` (one wavefront per read, one
+launch) and then returns ``(list of sequences, scores)``.
+"""
+import numpy as np
+import torch
+
+from taiyaki_amd import _lib, flipflopfings
+
+
+def beamsearch(score, beam_cut=0.0, beam_width=5, guided=True):
+    """decodeutil.pyx:9-51.  `score`: torch tensor on the GPU (or a numpy array, uploaded) of
+    shape (T, ntrans) or (T, N, ntrans).  Returns (int8 flip-flop state sequence, score) resp.
+    ([sequences], scores (N,) float32)."""
+    if not torch.is_tensor(score):
+        if not torch.cuda.is_available():
+            raise RuntimeError("beamsearch: no AMD GPU; the flip-flop operators only run as HIP kernels "
+                               "(no CPU fallback)")
+        score = torch.as_tensor(np.ascontiguousarray(score, dtype=np.float32)).cuda()
+    _lib.require_gpu(score, "beamsearch")
+    single = score.dim() == 2
+    sc = (score.unsqueeze(1) if single else score).detach().float().contiguous()
+    T, N, S = sc.shape
+    nbase = flipflopfings.nbase_flipflop(S)
+    L = _lib.lib()
+    dev = sc.device
+    with torch.cuda.device(dev):
+        seq = torch.empty((N, T), dtype=torch.int8, device=dev)
+        seqlen = torch.empty(N, dtype=torch.int32, device=dev)
+        out = torch.empty(N, dtype=torch.float32, device=dev)
+        wsb = L.tk_flipflop_beamsearch_workspace_bytes(T, N, nbase)
+        ws = torch.empty(wsb, dtype=torch.uint8, device=dev)
+        rc = L.tk_flipflop_beamsearch_dev(_lib.ptr(sc), T, N, nbase, int(beam_width), float(beam_cut),
+                                          int(bool(guided)), _lib.ptr(seq), _lib.ptr(seqlen), _lib.ptr(out),
+                                          _lib.ptr(ws), wsb, _lib.stream_ptr())
+        _lib.check(rc, "tk_flipflop_beamsearch_dev")
+    seq_h, len_h, sc_h = seq.cpu().numpy(), seqlen.cpu().numpy(), out.cpu().numpy()
+    seqs = [seq_h[n, :len_h[n]].copy() for n in range(N)]
+    if single:
+        return seqs[0], float(sc_h[0])
+    return seqs, sc_h

@@ -10,12 +10,13 @@
   `taiyaki.ctc` (the Cython extension module, taiyaki/ctc/__init__.py:1) is replaced by
   `taiyaki_amd.ctc`, `taiyaki.layers.flipflop_logpartition` (layers.py:1875-1890),
   `taiyaki.decode.flipflop_viterbi` / `flipflop_make_trans` (decode.py:15-72),
-  `taiyaki.qscores.errprobs_from_trans` (qscores.py:88-142) and
-  `taiyaki.flipflop_remap.flipflop_remap` (flipflop_remap.py:6-88) by their HIP counterparts;
+  `taiyaki.qscores.errprobs_from_trans` (qscores.py:88-142),
+  `taiyaki.flipflop_remap.flipflop_remap` (flipflop_remap.py:6-88) and
+  `taiyaki.decodeutil.beamsearch` (decodeutil/decodeutil.pyx:9-51) by their HIP counterparts;
 * it is not (this repository on its own): a package `taiyaki` is registered whose submodules
   ARE the taiyaki_amd ones, so `bin/train_flipflop.py`-shaped callers resolve every name of
   the hot path (`ctc`, `layers`, `decode`, `flipflopfings`, `flipflop_remap`, `qscores`,
-  `basecall_helpers`, `maths.RollingMAD`).
+  `decodeutil`, `basecall_helpers`, `maths.RollingMAD`).
 
 `uninstall()` restores what was there.  Nothing here computes: it is name plumbing, and the
 operators it installs still refuse CPU tensors (no fallback).
@@ -34,6 +35,7 @@ _SUBMODULES = {
     "flipflopfings": "taiyaki_amd.flipflopfings",
     "flipflop_remap": "taiyaki_amd.flipflop_remap",
     "qscores": "taiyaki_amd.qscores",
+    "decodeutil": "taiyaki_amd.decodeutil",
     "basecall_helpers": "taiyaki_amd.basecall_helpers",
 }
 _FUNCTIONS = [
@@ -43,6 +45,7 @@ _FUNCTIONS = [
     ("decode", "flipflop_make_trans", "taiyaki_amd.decode"),
     ("qscores", "errprobs_from_trans", "taiyaki_amd.qscores"),
     ("flipflop_remap", "flipflop_remap", "taiyaki_amd.flipflop_remap"),
+    ("decodeutil", "beamsearch", "taiyaki_amd.decodeutil"),
 ]
 
 

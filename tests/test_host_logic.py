@@ -198,6 +198,11 @@ def test_shim_standalone_resolves_reference_names_to_the_hip_operators():
         assert tlayers.flipflop_logpartition is layers.flipflop_logpartition
         assert tdecode.flipflop_viterbi is decode.flipflop_viterbi
         assert tdecode.flipflop_make_trans is decode.flipflop_make_trans
+        from taiyaki import decodeutil as tdu                   # bin/basecall.py:10,218
+        from taiyaki_amd import decodeutil
+        assert tdu.beamsearch is decodeutil.beamsearch
+        with pytest.raises(RuntimeError, match="no CPU fallback"):
+            tdu.beamsearch(np.zeros((5, 40), dtype=np.float32), 0.0, 5, True)
         assert nstate_flipflop(4) == 40 and RollingMAD(3, 0, 5).nparams == 3
         assert list(flipflop_code(np.array([0, 0, 1, 1, 1]), 4)) == [0, 4, 1, 5, 1]
         with pytest.raises(RuntimeError, match="no CPU fallback"):

@@ -109,6 +109,10 @@ _strict = os.environ.get("TAIYAKI_AMD_STRICT", "1") != "0"
 _deferred = {}
 
 
+def is_strict():
+    return _strict
+
+
 def set_strict(flag):
     """strict (default): every operator call checks its device status word at once
     (one host sync, exactly the reference's error timing).  Non-strict: status

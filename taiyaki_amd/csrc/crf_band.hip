@@ -38,7 +38,10 @@
 
 namespace tk {
 
-constexpr int BK = 8;               // time steps per block (= per workgroup barrier)
+#ifndef TK_BAND_BK
+#define TK_BAND_BK 8
+#endif
+constexpr int BK = TK_BAND_BK;               // time steps per block (= per workgroup barrier)
 constexpr int BNORM = 8;            // steps between renormalisations (a multiple of 4 that divides BK)
 constexpr int BSUB = BK / BNORM;
 constexpr int BAND_MAXW = 16;       // waves per workgroup

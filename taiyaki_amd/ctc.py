@@ -61,11 +61,15 @@ _KEEP_WS = None      # debugging aid: set to a list to keep the kernels' workspa
 
 
 def _max_seqlen(seqlen):
-    """Exact bound without a device sync when seqlen lives on the host
-    (bin/train_flipflop.py:133-138); 0 (= unknown) otherwise."""
-    if seqlen.is_cuda:
+    """Exact bound when seqlen lives on the host (bin/train_flipflop.py:133-138) -- no device
+    sync.  For a device tensor (train_abinitio.py:207-210): in strict mode the call ends in a host
+    sync anyway (the status word), so one more for the true maximum costs nothing and sizes the
+    launch and its workspace by it; in non-strict mode 0 (= unknown: sized for nblk + 1)."""
+    if not seqlen.numel():
         return 0
-    return int(seqlen.max()) if seqlen.numel() else 0
+    if seqlen.is_cuda and not _lib.is_strict():
+        return 0
+    return int(seqlen.max())
 
 
 def _run(logprob, seqs, seqlen, sharp_can, sharp_mod, out_scale, ncan, want_grad,

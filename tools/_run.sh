@@ -1,14 +1,4 @@
-set -x
 cd /root/repo
-timeout 900 python -m pytest tests/test_beamsearch.py -x -q -m gpu 2>&1 | tail -15
-timeout 300 python - <<'PY'
-import torch, time, numpy as np
-from taiyaki_amd import decodeutil, synth
-for T, N in ((2000, 512), (4000, 1024), (800, 128)):
-    sc = torch.from_numpy((synth.scores(T, N, 40, 5) * np.float32(0.8)).astype(np.float32)).cuda()
-    decodeutil.beamsearch(sc, 0.0, 5, True); torch.cuda.synchronize()
-    t0 = time.time()
-    for _ in range(3): decodeutil.beamsearch(sc, 0.0, 5, True)
-    torch.cuda.synchronize(); dt = (time.time() - t0) / 3
-    print("beam T=%d N=%d: %.2f ms/call, %.2f Mblocks/s" % (T, N, dt * 1e3, T * N / dt / 1e6))
-PY
+echo "== BK=8"; timeout 300 python tools/crfbench.py --reps 20 --shapes cfg2r,cfg5r,rowK,cfg4 --modes band 2>&1 | grep -v amdgpu.ids
+echo "== BK=16"; TAIYAKI_AMD_LIB=/root/repo/tools/lab_bk16.so timeout 300 python tools/crfbench.py --reps 20 --shapes cfg2r,cfg5r,rowK,cfg4 --modes band 2>&1 | grep -v amdgpu.ids
+TAIYAKI_AMD_LIB=/root/repo/tools/lab_bk16.so timeout 900 python -m pytest tests/test_gpu_parity.py -x -q -m gpu -k "crf or band or catmod or fused or fuzz_shapes or fullsize or ragged or poison" 2>&1 | tail -4

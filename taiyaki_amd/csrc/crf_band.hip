@@ -534,10 +534,25 @@ __global__ __launch_bounds__(BAND_MAXW *WAVE) void crf_band_sweep_kernel(BandArg
         band_sweep<R, MOD, false, true>(a, n, L, E, Eoff, Escratch);
 }
 
+// Inclusive wave prefix sum in six fused DPP adds (the row_bcast steps write only the rows they
+// apply to; hipcc's expansion spends a v_mov_dpp + v_add on each of those and re-zeroes a register).
+__device__ __forceinline__ float wave_scan_fused(float x) {
+    asm("s_nop 1\n\tv_add_f32_dpp %0, %0, %0 row_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:1" : "+v"(x));
+    asm("s_nop 1\n\tv_add_f32_dpp %0, %0, %0 row_shr:2 row_mask:0xf bank_mask:0xf bound_ctrl:1" : "+v"(x));
+    asm("s_nop 1\n\tv_add_f32_dpp %0, %0, %0 row_shr:4 row_mask:0xf bank_mask:0xf bound_ctrl:1" : "+v"(x));
+    asm("s_nop 1\n\tv_add_f32_dpp %0, %0, %0 row_shr:8 row_mask:0xf bank_mask:0xf bound_ctrl:1" : "+v"(x));
+    asm("s_nop 1\n\tv_add_f32_dpp %0, %0, %0 row_bcast:15 row_mask:0xa bank_mask:0xf" : "+v"(x));
+    asm("s_nop 1\n\tv_add_f32_dpp %0, %0, %0 row_bcast:31 row_mask:0xc bank_mask:0xf" : "+v"(x));
+    return x;
+}
+
 // ===========================================================================
-// posterior pass: grid (N, ceil(T / (POST_WAVES * POST_ROWS))), wave = POST_ROWS rows
+// posterior pass, rows outside (the round-2 first form): one row at a time, looping over its live
+// chunks.  Kept for R = 4 (T = 4000: the pass is HBM-bound there, 17 GB of lattice, and wants
+// the occupancy of its 52 registers and a row's chunks read as one contiguous run; the
+// chunks-outside form below needs 141 registers at R = 4 and measured 2.59 ms against 2.24).
 // ===========================================================================
-__host__ __device__ inline size_t band_post_lds_bytes(int R, int W, bool mod) {
+__host__ __device__ inline size_t band_post_rows_lds_bytes(int R, int W, bool mod) {
     const int EPL = (mod ? 3 : 2) * R, PW = R * WAVE;
     size_t words = (size_t)W * EPL * WAVE * (mod ? 2 : 1) + (size_t)W * WAVE +
                    (size_t)POST_WAVES * (2 * PW + 4);
@@ -545,7 +560,7 @@ __host__ __device__ inline size_t band_post_lds_bytes(int R, int W, bool mod) {
 }
 
 template <int R, bool MOD>
-__global__ __launch_bounds__(POST_WAVES *WAVE) void crf_band_posterior_kernel(BandArgs a) {
+__global__ __launch_bounds__(POST_WAVES *WAVE) void crf_band_posterior_rows_kernel(BandArgs a) {
     constexpr int PW = R * WAVE;
     constexpr int KINDS = MOD ? 3 : 2;
     constexpr int EPL = KINDS * R;
@@ -714,6 +729,221 @@ __global__ __launch_bounds__(POST_WAVES *WAVE) void crf_band_posterior_kernel(Ba
     if (a.status && bad) atomicOr(a.status, 2u);
 }
 
+// ===========================================================================
+// posterior pass: grid (N, ceil(T / (POST_WAVES * POST_ROWS))), wave = POST_ROWS rows.
+// Chunks outside, the wave's rows inside: what belongs to a chunk -- its sorted instance
+// records as LDS / bpermute addresses, the end-of-segment look-ups, its log2 offsets (one
+// sub-block of BNORM = POST_ROWS rows) -- is set up once per chunk and serves all the rows,
+// and the lattice cells of all the rows of a chunk are requested before the first is used.
+// The pass is bound by VALU throughput at the train step's shape (four SIMD cycles per
+// instruction; ~47 instructions per (row, chunk) at R = 1, 81 with the rows outside) and by
+// HBM at T = 4000 (17 GB of lattice).
+// ===========================================================================
+static_assert(POST_ROWS == BNORM, "a wave's rows share one sub-block of log2 offsets");
+__host__ __device__ inline size_t band_post_lds_bytes(int R, int W, bool mod) {
+    (void)W;
+    (void)mod;
+    return (size_t)POST_WAVES * (2 * R * WAVE + WAVE) * 4;
+}
+
+template <int R, bool MOD>
+__global__ __launch_bounds__(POST_WAVES *WAVE) void crf_band_posterior_kernel(BandArgs a) {
+    constexpr int PW = R * WAVE;
+    constexpr int KINDS = MOD ? 3 : 2;
+    constexpr int EPL = KINDS * R;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & (WAVE - 1);
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);      // wave-uniform: SGPR
+    const int n = blockIdx.x;
+    const int N = a.N, T = a.T, S = a.S, W = a.W;
+    const int L = a.seqlen[n];
+    const size_t rowstride = (size_t)N * S;
+    const int t0 = (blockIdx.y * POST_WAVES + wave) * POST_ROWS;
+
+    if (L == 0 || L > W * PW) {
+        if (blockIdx.y == 0 && tid == 0) {
+            a.cost[n] = (L == 0) ? 0.f : __builtin_nanf("");     // c_crf_flipflop.c:269-272, 458-464
+            if (L != 0 && a.status) atomicOr(a.status, 4u);
+        }
+        if (L == 0 && lane < S)
+            for (int t = t0; t < min(t0 + POST_ROWS, T); ++t)
+                a.grad[(size_t)t * rowstride + (size_t)n * S + lane] = 0.f;
+        return;
+    }
+    const int Wn = (L + PW - 1) / PW;                           // chunks this read has
+    float *sF = reinterpret_cast<float *>(smem) + (size_t)wave * (2 * PW + WAVE);
+    float *sB = sF + PW;                                        // PW cells + the next chunk's first (x 64)
+    if (t0 >= T) return;
+
+    const double scoreF = a.scoreF[n];
+    if (blockIdx.y == 0 && tid == 0) {
+        // score = mean of the two sweeps (c_crf_flipflop.c:482-491), cost = -score / T
+        const double score2 = 0.5 * (scoreF + a.scoreB[n]);
+        const float cst = (float)(-(score2 * 0.6931471805599453) / (double)T) * a.out_scale;
+        a.cost[n] = cst;
+        if (a.status && !isfinite(cst)) atomicOr(a.status, 1u);
+    }
+    const float *lpn = a.lp + (size_t)n * S;
+    const int col = min(lane, S - 1);
+    const bool is_col = lane < S;
+    const float sent = (lane == S) ? NEG_LARGE : 0.f;
+    const float neg = NEG_LARGE * LOG2E;
+    const float c = a.c_can;
+    const bool trim = L <= T + 1;
+    const int NSUB = (T + BNORM - 1) / BNORM;
+    const int nrows = min(POST_ROWS, T - t0);
+
+    // the wave's score rows, one register each (lane = transition id)
+    float row[POST_ROWS];
+#pragma unroll
+    for (int k = 0; k < POST_ROWS; ++k) row[k] = band_row(lpn, rowstride, min(t0 + k, T - 1), col, sent, is_col);
+    // log2 offsets of the chunks for these rows (one sub-block): lane c holds chunk c's
+    const int cl = min(lane, W - 1);
+    const int oF = a.offF[((size_t)n * NSUB + t0 / BNORM) * W + cl];
+    const int oB = a.offB[((size_t)n * NSUB + t0 / BNORM) * W + cl];
+    const float ctv = (float)(scoreF - (double)(oF + oB));
+
+    // live chunks of row t: chunk [a, b] holds a cell of some complete path through row t iff
+    // a <= t  and  b + 1 >= L - T + t
+    auto chunk_lo = [&](int t) {
+        const int need = L - T + t;
+        return (trim && need > 0) ? max(0, (need + PW - 1) / PW - 1) : 0;
+    };
+    auto chunk_hi = [&](int t) { return trim ? min(Wn - 1, t / PW) : Wn - 1; };
+    const int cmin = chunk_lo(t0), cmax = chunk_hi(t0 + nrows - 1);       // both bounds grow with t
+    // lane k < nrows: the live chunk range of row t0 + k (one ballot per chunk gives the rows' mask)
+    const int tl = t0 + min(lane, POST_ROWS - 1);
+    const int lo_l = chunk_lo(tl), hi_l = (lane < nrows) ? chunk_hi(tl) : -1;
+
+    float colacc[POST_ROWS], total[POST_ROWS];
+#pragma unroll
+    for (int k = 0; k < POST_ROWS; ++k) colacc[k] = total[k] = 0.f;
+    const float *Fn = a.latF + (size_t)n * T * a.LP + lane * R;
+    const float *Bn = a.latB + (size_t)n * T * a.LP + lane * R;
+    const float *Bfirst = a.latB + (size_t)n * T * a.LP;
+    const uint32_t *recn = a.rec + (size_t)n * W * EPL * WAVE + lane;
+    const float *recwn = MOD ? a.recw + (size_t)n * W * EPL * WAVE + lane : nullptr;
+
+    for (int ck = cmin; ck <= cmax; ++ck) {
+        const int apos = ck * PW;
+        // ---- per chunk: instance records -> LDS / bpermute addresses, end-of-segment look-up
+        const float *pF[EPL], *pB[EPL];
+        int aS[EPL], aM[MOD ? EPL : 1];
+        float mfw[MOD ? EPL : 1], scl[MOD ? EPL : 1];
+#pragma unroll
+        for (int r = 0; r < EPL; ++r) {
+            const uint32_t word = recn[((size_t)ck * EPL + r) * WAVE];
+            pF[r] = sF + (word & 0xffu);
+            pB[r] = sB + ((word >> 8) & 0x1ffu);
+            aS[r] = (int)((word >> 17) & 63u) * 4;
+            if (MOD) {
+                const float mf = recwn[((size_t)ck * EPL + r) * WAVE];
+                aM[MOD ? r : 0] = (int)((word >> 23) & 63u) * 4;
+                mfw[MOD ? r : 0] = mf * a.c_mod;
+                scl[MOD ? r : 0] = ((word >> 29) == 2u) ? mf : 1.f;      // d/d(mod score) = posterior * modfact
+            }
+        }
+        // where the inclusive prefix at the END of key `lane`'s segment lives: lane q, register r
+        const int sidx = a.segend[((size_t)n * W + ck) * WAVE + lane] - 1;
+        const int sq_addr = (sidx / EPL) * 4, sq_reg = sidx % EPL;
+        const float ct = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(ctv), ck));
+        const int oBc = __builtin_amdgcn_readlane(oB, ck);
+        const int oBr = __builtin_amdgcn_readlane(oB, min(ck + 1, W - 1));
+        const float dright = (float)(oBr - oBc);
+        const int right_col = min(apos + PW, (int)a.LP - 1);
+        const unsigned long long live = __ballot(ck >= lo_l && ck <= hi_l);
+        // the next chunk's first cell (the target of this chunk's last move) was stored iff that
+        // chunk had started by row t: rows t >= apos + PW - 1 when the band is trimmed
+        const bool has_right = ck + 1 < Wn;
+        const int right_from = trim ? apos + PW - 1 : 0;
+
+        // ---- the cells of every row of this chunk (rows that are not live here read cells nobody
+        //      wrote; they are loaded -- the workspace is there -- and never used)
+        float fv[POST_ROWS][R], bv[POST_ROWS][R], br[POST_ROWS];
+#pragma unroll
+        for (int k = 0; k < POST_ROWS; ++k) {
+            const size_t trow = (size_t)min(t0 + k, T - 1) * a.LP;
+            if constexpr (R == 4) {
+                const f4 f = *reinterpret_cast<const f4 *>(Fn + trow + apos);
+                const f4 b = *reinterpret_cast<const f4 *>(Bn + trow + apos);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    fv[k][j] = f[j];
+                    bv[k][j] = b[j];
+                }
+            } else if constexpr (R == 2) {
+                const f2 f = *reinterpret_cast<const f2 *>(Fn + trow + apos);
+                const f2 b = *reinterpret_cast<const f2 *>(Bn + trow + apos);
+                fv[k][0] = f[0];
+                fv[k][1] = f[1];
+                bv[k][0] = b[0];
+                bv[k][1] = b[1];
+            } else {
+                fv[k][0] = Fn[trow + apos];
+                bv[k][0] = Bn[trow + apos];
+            }
+            br[k] = Bfirst[trow + right_col];
+        }
+#pragma unroll
+        for (int k = 0; k < POST_ROWS; ++k) {
+            if (!((live >> k) & 1ull)) continue;                // wave-uniform
+            const float bright = (has_right && t0 + k >= right_from) ? br[k] + dright : neg;
+            if constexpr (R == 4) {
+                *reinterpret_cast<f4 *>(sF + lane * 4) =
+                    f4{fv[k][0] - ct, fv[k][1] - ct, fv[k][2] - ct, fv[k][3] - ct};
+                *reinterpret_cast<f4 *>(sB + lane * 4) = f4{bv[k][0], bv[k][1], bv[k][2], bv[k][3]};
+            } else if constexpr (R == 2) {
+                *reinterpret_cast<f2 *>(sF + lane * 2) = f2{fv[k][0] - ct, fv[k][1] - ct};
+                *reinterpret_cast<f2 *>(sB + lane * 2) = f2{bv[k][0], bv[k][1]};
+            } else {
+                sF[lane] = fv[k][0] - ct;
+                sB[lane] = bv[k][0];
+            }
+            sB[PW + lane] = bright;                             // every lane: no exec-mask detour; word PW is read
+            wave_lds_fence();
+            // ---- the chunk's instances in sorted order: lane l holds sorted positions
+            //      l*EPL .. l*EPL + EPL-1; running (inclusive) prefix in v[]
+            float v[EPL];
+#pragma unroll
+            for (int r = 0; r < EPL; ++r) {
+                float xx = fmaf(bperm(aS[r], row[k]), c, *pF[r] + *pB[r]);
+                if (MOD) xx = fmaf(bperm(aM[MOD ? r : 0], row[k]), mfw[MOD ? r : 0], xx);
+                float pr = fast_exp2(xx);
+                if (MOD) pr *= scl[MOD ? r : 0];
+                v[r] = (r == 0) ? pr : v[r > 0 ? r - 1 : 0] + pr;
+            }
+            const float incl = wave_scan_fused(v[EPL - 1]);
+            const float base = incl - v[EPL - 1];
+            float P = 0.f;
+#pragma unroll
+            for (int r = 0; r < EPL; ++r) {
+                const float cand = bperm(sq_addr, v[r] + base);
+                if (sq_reg == r) P = cand;
+            }
+            if (sidx < 0) P = 0.f;
+            const float prev = wave_shift_up1(P, 0.f);
+            colacc[k] += P - prev;
+            // row normaliser: all stay and move instances (the reference's softmax over the
+            // 2L-1 transitions, c_crf_flipflop.c:400-401); mod ids sort after them
+            total[k] += __int_as_float(__builtin_amdgcn_readlane(__float_as_int(P), a.ncan - 1));
+            wave_lds_fence();
+        }
+    }
+    bool bad = false;
+#pragma unroll
+    for (int k = 0; k < POST_ROWS; ++k) {
+        if (k < nrows) {
+            // gradient of -score / T  (ctc.pyx:113)
+            const float g = colacc[k] * (-1.0f / (total[k] * (float)T));
+            if (lane < S) {
+                bad |= !isfinite(g);
+                a.grad[(size_t)(t0 + k) * rowstride + (size_t)n * S + lane] = g;
+            }
+        }
+    }
+    if (a.status && bad) atomicOr(a.status, 2u);
+}
+
 // ---------------------------------------------------------------------------
 // host side
 // ---------------------------------------------------------------------------
@@ -768,13 +998,19 @@ static int band_launch(const BandArgs &a, hipStream_t stream) {
                        stream, a);
     if (hipGetLastError() != hipSuccess) return 4;
     if (!want_grad) return 0;
-    const size_t lds = band_post_lds_bytes(R, a.W, MOD);
-    if (lds > 160 * 1024) return 2;
-    if (lds > 64 * 1024 && raise_dynamic_lds(reinterpret_cast<const void *>(&crf_band_posterior_kernel<R, MOD>)))
-        return 4;
     const int rows = POST_WAVES * POST_ROWS;
-    hipLaunchKernelGGL((crf_band_posterior_kernel<R, MOD>), dim3(a.N, (a.T + rows - 1) / rows),
-                       dim3(POST_WAVES * WAVE), lds, stream, a);
+    if constexpr (R == 4) {
+        const size_t lds = band_post_rows_lds_bytes(R, a.W, MOD);
+        if (lds > 160 * 1024) return 2;
+        if (lds > 64 * 1024 &&
+            raise_dynamic_lds(reinterpret_cast<const void *>(&crf_band_posterior_rows_kernel<R, MOD>)))
+            return 4;
+        hipLaunchKernelGGL((crf_band_posterior_rows_kernel<R, MOD>), dim3(a.N, (a.T + rows - 1) / rows),
+                           dim3(POST_WAVES * WAVE), lds, stream, a);
+    } else {
+        hipLaunchKernelGGL((crf_band_posterior_kernel<R, MOD>), dim3(a.N, (a.T + rows - 1) / rows),
+                           dim3(POST_WAVES * WAVE), band_post_lds_bytes(R, a.W, MOD), stream, a);
+    }
     return hipGetLastError() == hipSuccess ? 0 : 4;
 }
 

@@ -1,4 +1,5 @@
 cd /root/repo
-echo "== BK=8"; timeout 300 python tools/crfbench.py --reps 20 --shapes cfg2r,cfg5r,rowK,cfg4 --modes band 2>&1 | grep -v amdgpu.ids
-echo "== BK=16"; TAIYAKI_AMD_LIB=/root/repo/tools/lab_bk16.so timeout 300 python tools/crfbench.py --reps 20 --shapes cfg2r,cfg5r,rowK,cfg4 --modes band 2>&1 | grep -v amdgpu.ids
-TAIYAKI_AMD_LIB=/root/repo/tools/lab_bk16.so timeout 900 python -m pytest tests/test_gpu_parity.py -x -q -m gpu -k "crf or band or catmod or fused or fuzz_shapes or fullsize or ragged or poison" 2>&1 | tail -4
+timeout 900 python -m pytest tests/test_gpu_parity.py -x -q -m gpu -k "crf or band or catmod or fused or fuzz_shapes or fullsize or ragged or poison or write" 2>&1 | tail -4
+cd /tmp && export TMPDIR=/tmp
+timeout 300 rocprofv3 --kernel-trace --stats -d /root/repo/gpurun_out/prof_post -o p -- python /root/repo/tools/crfbench.py --reps 20 --shapes cfg2r,cfg5r,rowK,cfg4 --modes band 2>&1 | grep "^band"
+python /root/repo/tools/prof_by_shape.py /root/repo/gpurun_out/prof_post/p_results.db 2>/dev/null | grep -i "band" | head -20

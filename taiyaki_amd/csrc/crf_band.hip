@@ -857,12 +857,14 @@ __global__ __launch_bounds__(POST_WAVES *WAVE) void crf_band_posterior_kernel(Ba
         const bool has_right = ck + 1 < Wn;
         const int right_from = trim ? apos + PW - 1 : 0;
 
-        // ---- the cells of every row of this chunk (rows that are not live here read cells nobody
-        //      wrote; they are loaded -- the workspace is there -- and never used)
+        // ---- the cells of every row of this chunk, requested before the first is used.  A row that
+        //      is not live in this chunk asks for the first live row's cells again (a scalar select
+        //      of the address: no branch in the load stream, no extra HBM traffic) and drops them
+        const int kfirst = __builtin_ctzll(live | (1ull << (POST_ROWS - 1)));
         float fv[POST_ROWS][R], bv[POST_ROWS][R], br[POST_ROWS];
 #pragma unroll
         for (int k = 0; k < POST_ROWS; ++k) {
-            const size_t trow = (size_t)min(t0 + k, T - 1) * a.LP;
+            const size_t trow = (size_t)min(t0 + (((live >> k) & 1ull) ? k : kfirst), T - 1) * a.LP;
             if constexpr (R == 4) {
                 const f4 f = *reinterpret_cast<const f4 *>(Fn + trow + apos);
                 const f4 b = *reinterpret_cast<const f4 *>(Bn + trow + apos);

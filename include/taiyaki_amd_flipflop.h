@@ -154,6 +154,16 @@ int tk_flipflop_beamsearch_dev(const float *scores, size_t nblk, size_t nbatch, 
                                int32_t *seqlen, float *score, void *workspace,
                                size_t workspace_bytes, void *stream);
 
+/* The decoder's lattice passes on their own (replace c_flipflopfwdbwd.h
+ * `flipflop_forward` / `flipflop_backward` + decodeutil.pyx:54-108): unnormalised
+ * forward (forward != 0) or backward scores of every block,
+ *   out (nbatch, nblk + 1, 2 nbase), first (forward) resp. last (backward) row =
+ *   init (nbatch, 2 nbase) or zeros when init is NULL; total (nbatch) = the
+ *   reference's return value (log-sum-exp over the final row). */
+int tk_flipflop_lattice_dev(const float *scores, size_t nblk, size_t nbatch, size_t nbase,
+                            int forward, const float *init, float *out, float *total,
+                            void *stream);
+
 /* ------------------------------------------------------------------------- *
  * (B) log-partition over the 2*nbase state lattice and its gradient
  *     logz[n] = log sum_{all flip-flop paths starting in a flip state} exp(sum_t s)

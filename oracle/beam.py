@@ -161,6 +161,29 @@ def qsort_inplace(A, less):
     return A
 
 
+def forward(score, init=None):
+    """c_flipflopfwdbwd.c:112-152 / decodeutil.pyx:82-108: (fwd (T+1, 2nb), total)."""
+    score = np.asarray(score, dtype=f32)
+    T, ntrans = score.shape
+    nb = int(round((np.sqrt(1 + 2 * ntrans) - 1) / 2))
+    ns = 2 * nb
+    fwd = np.zeros((T + 1, ns), dtype=f32)
+    if init is not None:
+        fwd[0] = init
+    for blk in range(T):
+        p, c, s = fwd[blk], fwd[blk + 1], score[blk]
+        for b in range(nb):
+            c[b + nb] = logsumexpf(f32(s[ns * nb + b] + p[b]), f32(s[ns * nb + b + nb] + p[b + nb]))
+        for to in range(nb):
+            c[to] = f32(s[to * ns] + p[0])
+            for fr in range(1, ns):
+                c[to] = logsumexpf(c[to], f32(s[to * ns + fr] + p[fr]))
+    total = fwd[T, 0]
+    for i in range(1, ns):
+        total = logsumexpf(total, fwd[T, i])
+    return fwd, float(total)
+
+
 def beamsearch(score, beam_cut=0.0, beam_width=5, guided=True):
     """decodeutil.pyx:9-51 + c_hashdecode.c:346-507.  Returns (sequence int8 (flip-flop states), score)."""
     score = np.ascontiguousarray(score, dtype=f32)
@@ -255,3 +278,19 @@ def ref_beamsearch(score, beam_cut=0.0, beam_width=5, guided=True):
     res = res[:T]
     neg = np.nonzero(res == -1)[0]
     return res[:neg[0]] if len(neg) else res, float(sc), bwd
+
+
+def ref_lattice(score, init=None, forward_pass=True):
+    """decodeutil.forward / backward through the reference C (wrapper logic of decodeutil.pyx:54-108)."""
+    ref_beamsearch(np.zeros((1, 40), dtype=f32))          # loads the library
+    score = np.ascontiguousarray(score, dtype=f32)
+    T, ntrans = score.shape
+    nb = int(round((np.sqrt(1 + 2 * ntrans) - 1) / 2))
+    res = np.zeros((T + 1, 2 * nb), dtype=f32)
+    if init is not None:
+        res[0 if forward_pass else T] = init
+    fp = ctypes.POINTER(ctypes.c_float)
+    _REF.flipflop_forward.restype = ctypes.c_float
+    fn = _REF.flipflop_forward if forward_pass else _REF.flipflop_backward
+    tot = fn(score.ctypes.data_as(fp), ctypes.c_size_t(nb), ctypes.c_size_t(T), res.ctypes.data_as(fp))
+    return res, float(tot)

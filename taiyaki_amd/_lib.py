@@ -30,6 +30,7 @@ SIGNATURES = {
                                  _f, _f, _f, _vp, _vp, _vp, _sz, _vp, _vp]),
     "tk_flipflop_loss_fused_dev": (_i, [_vp, _sz, _sz, _sz, _vp, _vp, _vp, _vp, _sz, _f, _vp, _vp, _vp, _vp, _sz,
                                        _vp, _sz, _vp, _vp]),
+    "tk_flipflop_lattice_dev": (_i, [_vp, _sz, _sz, _sz, _i, _vp, _vp, _vp, _vp]),
     "tk_flipflop_beamsearch_workspace_bytes": (_sz, [_sz, _sz, _sz]),
     "tk_flipflop_beamsearch_dev": (_i, [_vp, _sz, _sz, _sz, _i, _f, _i, _vp, _vp, _vp, _vp, _sz, _vp]),
     "tk_flipflop_logz_workspace_bytes": (_sz, [_sz, _sz, _sz]),

@@ -305,6 +305,63 @@ __global__ __launch_bounds__(WAVE) void beam_kernel(BeamArgs a) {
     }
 }
 
+// ---------------------------------------------------------------------------------------------
+// The single-read lattice passes of the decoder on their own: flipflop_forward / flipflop_backward
+// (c_flipflopfwdbwd.c:55-152) with the wrappers' optional initial vector (decodeutil.pyx:54-108).
+// One wavefront per read, lane = state; every log-sum-exp in the reference's order, so the
+// matrices agree with the reference's to the rounding of expf / log1pf.
+//   out (N, T + 1, 2 nbase); total (N) = logsumexp over the last (forward) / first (backward) row.
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(WAVE) void lattice_kernel(const float *__restrict__ scores, int T, int N, int nb,
+                                                       int forward, const float *__restrict__ init,
+                                                       float *__restrict__ out, float *__restrict__ total) {
+    const int n = blockIdx.x, lane = threadIdx.x;
+    const int ns = 2 * nb, S = ns * (nb + 1);
+    const size_t rowstride = (size_t)N * S;
+    const float *sc = scores + (size_t)n * S;
+    float *mat = out + (size_t)n * (T + 1) * ns;
+    const int col = min(lane, S - 1), st = min(lane, ns - 1);
+    float p = (init != nullptr) ? init[(size_t)n * ns + st] : 0.f;
+    if (forward) {
+        if (lane < ns) mat[lane] = p;
+        for (int blk = 0; blk < T; ++blk) {
+            const float row = sc[(size_t)blk * rowstride + col];
+            // every lane runs both recurrences (ds_bpermute returns 0 for a source lane that is
+            // masked off, so the gathers must not sit in divergent code) and keeps its own
+            const int b = st % nb;
+            // to the flop of base b: from its flip, then from itself (:129-134)
+            const float cflop = beam_lse(bpf(row, ns * nb + b) + bpf(p, b), bpf(row, ns * nb + b + nb) + bpf(p, b + nb));
+            // to the flip of base b: from every state, in order (:136-143)
+            float cflip = bpf(row, b * ns) + rdl(p, 0);
+            for (int fr = 1; fr < ns; ++fr) cflip = beam_lse(cflip, bpf(row, b * ns + fr) + rdl(p, fr));
+            const float c = (st >= nb) ? cflop : cflip;
+            p = c;
+            if (lane < ns) mat[(size_t)(blk + 1) * ns + lane] = c;
+        }
+    } else {
+        if (lane < ns) mat[(size_t)T * ns + lane] = p;
+        for (int blk = T; blk > 0; --blk) {
+            const float row = sc[(size_t)(blk - 1) * rowstride + col];
+            float c = bpf(row, ns * nb + st) + bpf(p, nb + st % nb);
+            for (int to = 0; to < nb; ++to) c = beam_lse(c, bpf(row, to * ns + st) + rdl(p, to));
+            p = c;
+            if (lane < ns) mat[(size_t)(blk - 1) * ns + lane] = c;
+        }
+    }
+    float tot = rdl(p, 0);
+    for (int i = 1; i < ns; ++i) tot = beam_lse(tot, rdl(p, i));
+    if (lane == 0) total[n] = tot;
+}
+
+int lattice_dispatch(const float *scores, size_t T, size_t N, size_t nbase, int forward, const float *init,
+                     float *out, float *total, hipStream_t stream) {
+    if (nbase < 1 || nbase > 4) return 2;
+    if (N == 0) return 0;
+    hipLaunchKernelGGL(lattice_kernel, dim3((unsigned)N), dim3(WAVE), 0, stream, scores, (int)T, (int)N, (int)nbase,
+                       forward, init, out, total);
+    return hipGetLastError() == hipSuccess ? 0 : 4;
+}
+
 size_t beam_workspace_bytes(size_t T, size_t N, size_t nbase) {
     return N * (T + 1) * 2 * nbase * sizeof(float) + N * T * 16 + 512;
 }

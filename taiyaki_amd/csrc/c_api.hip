@@ -27,6 +27,8 @@ int crf_dispatch(const float *logprob, size_t ntrans, size_t nblk, size_t nbatch
                  float out_scale, float *cost, float *grad, void *workspace,
                  size_t workspace_bytes, uint32_t *status, hipStream_t stream);
 size_t beam_workspace_bytes(size_t T, size_t N, size_t nbase);
+int lattice_dispatch(const float *scores, size_t T, size_t N, size_t nbase, int forward, const float *init,
+                     float *out, float *total, hipStream_t stream);
 int beam_dispatch(const float *scores, size_t T, size_t N, size_t nbase, int width, float beam_cut, int guided,
                   signed char *seq, int *seqlen, float *score, void *workspace, size_t workspace_bytes,
                   hipStream_t stream);
@@ -217,6 +219,13 @@ int tk_flipflop_loss_fused_dev(const float *scores, size_t nblk, size_t nbatch, 
     if (rc != 0) return rc;
     return tk::logz_dispatch(scores, nblk, nbatch, nbase, logz, grad, logz_workspace, logz_workspace_bytes, status, st,
                              lossvector, 1.0f / (float)nblk);
+}
+
+int tk_flipflop_lattice_dev(const float *scores, size_t nblk, size_t nbatch, size_t nbase, int forward,
+                            const float *init, float *out, float *total, void *stream) {
+    if (scores == nullptr || out == nullptr || total == nullptr) return 1;
+    return tk::lattice_dispatch(scores, nblk, nbatch, nbase, forward, init, out, total,
+                                static_cast<hipStream_t>(stream));
 }
 
 size_t tk_flipflop_beamsearch_workspace_bytes(size_t nblk, size_t nbatch, size_t nbase) {

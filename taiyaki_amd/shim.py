@@ -12,7 +12,8 @@
   `taiyaki.decode.flipflop_viterbi` / `flipflop_make_trans` (decode.py:15-72),
   `taiyaki.qscores.errprobs_from_trans` (qscores.py:88-142),
   `taiyaki.flipflop_remap.flipflop_remap` (flipflop_remap.py:6-88) and
-  `taiyaki.decodeutil.beamsearch` (decodeutil/decodeutil.pyx:9-51) by their HIP counterparts;
+  `taiyaki.decodeutil.beamsearch` / `forward` / `backward` (decodeutil/decodeutil.pyx:9-108) by their
+  HIP counterparts;
 * it is not (this repository on its own): a package `taiyaki` is registered whose submodules
   ARE the taiyaki_amd ones, so `bin/train_flipflop.py`-shaped callers resolve every name of
   the hot path (`ctc`, `layers`, `decode`, `flipflopfings`, `flipflop_remap`, `qscores`,
@@ -46,6 +47,8 @@ _FUNCTIONS = [
     ("qscores", "errprobs_from_trans", "taiyaki_amd.qscores"),
     ("flipflop_remap", "flipflop_remap", "taiyaki_amd.flipflop_remap"),
     ("decodeutil", "beamsearch", "taiyaki_amd.decodeutil"),
+    ("decodeutil", "forward", "taiyaki_amd.decodeutil"),
+    ("decodeutil", "backward", "taiyaki_amd.decodeutil"),
 ]
 
 

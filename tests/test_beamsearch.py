@@ -147,3 +147,104 @@ def test_hip_beamsearch_batch_against_restatement(gpu_device):
     # decoded states are a valid flip-flop path: consecutive states differ, a repeated base flips
     for s in seqs:
         assert np.all(s[1:] != s[:-1]) and s.min() >= 0 and s.max() < 8
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("block", range(3))
+def test_fuzz_beam_seeded_subset(gpu_device, correctly_rounded_oracle, block):
+    """A bounded, seeded part of tests/helpers/fuzz_beam.py (150 cases per run when called as a
+    script): random T / width / cut / guided over continuous, grid and saturated scores, batches of
+    reads per launch; sequences and float scores bit for bit."""
+    from tests.helpers import fuzz_beam
+    rng = np.random.RandomState(500 + block)
+    for k in range(8):
+        ok, msg = fuzz_beam.case(k, rng, gpu_device)
+        assert ok, msg
+
+
+@pytest.mark.gpu
+def test_hip_beamsearch_long_read_walks_back_through_global_memory(gpu_device):
+    """Reads longer than the 3584 back-pointer rows that fit the LDS keep the table in HBM only
+    (csrc/beam_kernels.hip: lds_rows); two reads in the launch, the short one padded with -1."""
+    import torch
+    from taiyaki_amd import decodeutil, synth
+    T = 3700
+    sc = (synth.scores(T, 2, 40, 91) * np.float32(0.8)).astype(np.float32)
+    seqs, scores = decodeutil.beamsearch(torch.from_numpy(sc).to(gpu_device), 0.0, 5, True)
+    for n in range(2):
+        one = np.ascontiguousarray(sc[:, n])
+        if beam.ref_available():
+            ws, wsc, _ = beam.ref_beamsearch(one, 0.0, 5, True)
+        else:
+            ws, wsc = beam.beamsearch(one, 0.0, 5, True)
+        assert np.array_equal(seqs[n], ws) and abs(scores[n] - wsc) <= 2e-6 * abs(wsc)
+
+
+# ---- the decoder's lattice passes (decodeutil.forward / backward) -------------------------------
+def reference_unit_test_weights():
+    """test/unit/test_decodeutil.py:16-18: the reference's own fixture and known answer."""
+    rs = np.random.RandomState(0xdeadbeef)
+    return rs.randn(12, 40).astype("f4"), 27.16876983642578
+
+
+def lse(x, axis=None):
+    m = np.max(x, axis=axis, keepdims=True)
+    return np.squeeze(m + np.log(np.sum(np.exp(x - m), axis=axis, keepdims=True)), axis=axis)
+
+
+def check_reference_unit_test_properties(fwd_fn, bwd_fn):
+    """test/unit/test_decodeutil.py:22-62 on the given implementation."""
+    w, expt = reference_unit_test_weights()
+    fwd, _ = fwd_fn(w)
+    bwd, _ = bwd_fn(w)
+    assert fwd.shape == bwd.shape == (13, 8)
+    assert abs(float(lse(bwd[0])) - expt) < 1e-5 and abs(float(lse(fwd[-1])) - expt) < 1e-5      # :40-50
+    score = lse(fwd + bwd, axis=1)                                                               # :52-62
+    assert abs(float(score.mean()) - expt) < 1e-5 and float(score.max() - score.min()) < 1e-5
+    init = np.zeros(8, dtype="f4")
+    init[4:] = -50000                                                                            # :24-32
+    fwd2, _ = fwd_fn(w, init=init)
+    import oracle
+    lz, _ = oracle.flipflop_logz_grad(w[:, None, :])
+    assert abs(float(lse(fwd2[-1])) - float(lz[0])) < 1e-5
+    assert abs(float(lse(bwd[0, :4])) - float(lz[0])) < 1e-5                                     # :34-38
+
+
+def test_lattice_restatement_against_reference_library_and_unit_test():
+    check_reference_unit_test_properties(beam.forward, beam.backward)
+    if not beam.ref_available():
+        pytest.skip("oracle/_ref/libref_decodeutil.so not built (no /root/reference here)")
+    rng = np.random.RandomState(8)
+    for k in range(6):
+        sc = (rng.randn(int(rng.randint(1, 90)), 40) * 2).astype(np.float32)
+        init = None if k % 2 else (rng.randn(8) * 3).astype(np.float32)
+        for fwdp, fn in ((True, beam.forward), (False, beam.backward)):
+            mine, ref = fn(sc, init), beam.ref_lattice(sc, init, fwdp)
+            assert np.array_equal(mine[0], ref[0]) and np.float32(mine[1]) == np.float32(ref[1])
+
+
+@pytest.mark.gpu
+def test_hip_lattice_passes(gpu_device, correctly_rounded_oracle):
+    """decodeutil.forward / backward on the device: the reference's unit test, the oracle with the
+    kernel's rounding bit for bit (one read and a batch, with and without an initial vector), the
+    reference library to float rounding."""
+    import torch
+    from taiyaki_amd import decodeutil
+    check_reference_unit_test_properties(decodeutil.forward, decodeutil.backward)
+    rng = np.random.RandomState(9)
+    T, N = 150, 5
+    sc = (rng.randn(T, N, 40) * 2).astype(np.float32)
+    init = (rng.randn(N, 8) * 3).astype(np.float32)
+    for fwdp, fn, ofn in ((True, decodeutil.forward, correctly_rounded_oracle.forward),
+                          (False, decodeutil.backward, correctly_rounded_oracle.backward)):
+        for use_init in (False, True):
+            mats, tots = fn(torch.from_numpy(sc).to(gpu_device), init if use_init else None)
+            assert mats.shape == (N, T + 1, 8) and tots.shape == (N,)
+            for n in range(N):
+                want = ofn(np.ascontiguousarray(sc[:, n]), init[n] if use_init else None)
+                assert np.array_equal(mats[n], want[0]) and np.float32(tots[n]) == np.float32(want[1])
+                if beam.ref_available():
+                    ref = beam.ref_lattice(np.ascontiguousarray(sc[:, n]), init[n] if use_init else None, fwdp)
+                    assert np.abs(mats[n] - ref[0]).max() <= 1e-5 * max(1.0, np.abs(ref[0]).max())
+    one, tot = decodeutil.backward(sc[:, 0])                    # numpy in, one read: the reference's call
+    assert one.shape == (T + 1, 8) and isinstance(tot, float)

@@ -200,7 +200,8 @@ def test_shim_standalone_resolves_reference_names_to_the_hip_operators():
         assert tdecode.flipflop_make_trans is decode.flipflop_make_trans
         from taiyaki import decodeutil as tdu                   # bin/basecall.py:10,218
         from taiyaki_amd import decodeutil
-        assert tdu.beamsearch is decodeutil.beamsearch
+        assert tdu.beamsearch is decodeutil.beamsearch and tdu.forward is decodeutil.forward
+        assert tdu.backward is decodeutil.backward
         with pytest.raises(RuntimeError, match="no CPU fallback"):
             tdu.beamsearch(np.zeros((5, 40), dtype=np.float32), 0.0, 5, True)
         assert nstate_flipflop(4) == 40 and RollingMAD(3, 0, 5).nparams == 3

@@ -1,5 +1,2 @@
 cd /root/repo
-timeout 900 python -m pytest tests/test_beamsearch.py -x -q -m gpu 2>&1 | tail -6
-cd /tmp && export TMPDIR=/tmp
-timeout 300 rocprofv3 --kernel-trace --stats -d /root/repo/gpurun_out/prof_beam -o b -- python /root/repo/tools/beambench.py 2>&1 | grep "^beam"
-python /root/repo/tools/rocpd_stats.py /root/repo/gpurun_out/prof_beam/b_results.db 2>/dev/null | head -8
+for ch in 8 16 32; do echo "== TK_LOGZ_CH=$ch"; TK_LOGZ_CH=$ch timeout 200 python tools/microbench.py --reps 40 --shapes cfg2,cfg5 --ops logz 2>&1 | grep "^logz"; done

@@ -633,7 +633,12 @@ def main():
         if not args.no_rowk:
             rowk = LossOps(4000, 256, dev)
             specs = [("logz", 4000, 256, 0), ("crf", 4000, 256, 0)] + specs
-        measured = {} if args.no_pmc else measure_traffic_now(specs)
+        # N > 1: the other ranks wait in a barrier while rank 0 fills in the kernel records -- no
+        # rocprofv3 passes and no CPU leg there (both belong to the N = 1 line; `traffic` then
+        # comes from the committed profile of the same kernel hash)
+        no_pmc = args.no_pmc or world > 1
+        no_cpu = args.no_cpu_baseline or world > 1
+        measured = {} if no_pmc else measure_traffic_now(specs)
         khash = kernel_hash()
 
         def traffic_of(op, t, n, realistic):
@@ -677,7 +682,7 @@ def main():
                                 launch=("two operators (cat-mod loss, logZ)" if cat_mod else
                                         "tk_flipflop_loss_fused_dev: one gradient tensor"),
                                 gpu_ms=round(lp_mean * 1e3, 4), gpu_chunks_per_s=round(nbatch / lp_mean, 1))
-        if not args.no_cpu_baseline:
+        if not no_cpu:
             cb = cpu_baseline(T, nbatch)
             out["cpu_baseline"] = cb
             copies = reference_copies_ms(T, nbatch, S, dev)

@@ -26,6 +26,11 @@ def beamsearch(score, beam_cut=0.0, beam_width=5, guided=True):
     sc = (score.unsqueeze(1) if single else score).detach().float().contiguous()
     T, N, S = sc.shape
     nbase = flipflopfings.nbase_flipflop(S)
+    if not 1 <= int(beam_width) <= 12 or int(beam_width) * (nbase + 1) > 64:
+        raise ValueError("beamsearch: beam_width %d not in 1..12 (one candidate record per lane of a wavefront: "
+                         "beam_width * (nbase + 1) <= 64)" % int(beam_width))
+    if not 0.0 <= float(beam_cut) <= 1.0:
+        raise ValueError("beamsearch: beam_cut %r outside [0, 1]" % (beam_cut,))
     L = _lib.lib()
     dev = sc.device
     with torch.cuda.device(dev):

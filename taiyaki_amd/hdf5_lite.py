@@ -14,10 +14,12 @@ specification, for the CLASSIC on-disk layout:
     floating-point, fixed-length string and variable-length string (global heap) values.
 
 That is the layout of the mapped-signal files the reference ships with its tests
-(`test/data/mapped_signal_file/*.hdf5`), against which this parser is validated.  Files written
-with `libver='v108'` or later (version-2 object headers, dense link storage in fractal heaps --
-what `MappedSignalWriter` produces today, mapped_signal_files.py:372) are recognised and refused
-with a clear error; convert those with `tools/mapped_signal_to_npz.py` where h5py exists.
+(`test/data/mapped_signal_file/*.hdf5`, per-read groups), against which this parser is validated,
+and of what the writers' default, the batch format, produces (`BatchHDF5Writer` opens its file
+with h5py's default `libver`, mapped_signal_files.py:582; read by `reads_of_batches`).  Files
+written with `libver='v108'` or later (version-2 object headers, dense link storage in fractal
+heaps -- the per-read writer of today, mapped_signal_files.py:372) are recognised and refused with a
+clear error; convert those with `tools/mapped_signal_to_npz.py` where h5py exists.
 """
 import struct
 import zlib
@@ -48,6 +50,8 @@ class Dataset:
             elif mtype == 0x03:
                 self._dt = f._datatype(data, 0)[0]
                 self.dtype = self._dt.dtype
+                if self._dt.cls == 9:                   # variable length: 16-byte (length, heap address, index) elements
+                    self.dtype = np.dtype("V16")
             elif mtype == 0x08:
                 self._layout = data
             elif mtype == 0x0B:
@@ -59,6 +63,12 @@ class Dataset:
         return self.read()[key]
 
     def read(self):
+        raw = self._read_raw()
+        if getattr(self, "_dt", None) is not None and self._dt.cls == 9:
+            return decode_vlen(self.f, self._dt, raw)
+        return raw
+
+    def _read_raw(self):
         f, lay = self.f, self._layout
         n = int(np.prod(self.shape)) if self.shape else 1
         if lay[0] != 3:
@@ -103,6 +113,18 @@ class Dataset:
             sel_in = tuple(slice(0, s.stop - s.start) for s in sel_out)
             out[sel_out] = chunk[sel_in]
         return out
+
+
+def decode_vlen(f, dt, raw):
+    """Variable-length elements (strings: h5py's `special_dtype(vlen=str)`, what the mapped-signal
+    writers use for read ids, mapped_signal_files.py:21) -> list of str / arrays, through the
+    global heap."""
+    out = []
+    for el in np.asarray(raw).reshape(-1):
+        ln, gaddr, gidx = struct.unpack("<IQI", el.tobytes())
+        data = f._global_heap_object(gaddr, gidx)[:ln * (dt.base.size if dt.base else 1)] if ln else b""
+        out.append(data.decode("utf-8") if dt.vlen_string else np.frombuffer(data, dtype=dt.base.dtype))
+    return out
 
 
 class Group:
@@ -368,6 +390,11 @@ def read_mapped_signal_file(path, limit=None):
     info = dict(version=version, alphabet=f.attrs.get("alphabet"), collapse_alphabet=f.attrs.get("collapse_alphabet"),
                 mod_long_names=str(f.attrs.get("mod_long_names", "")).splitlines())
     reads = []
+    if "Reads" not in f.keys():
+        if "Batches" in f.keys():
+            return info, reads_of_batches(f["Batches"], limit)
+        raise Hdf5Error("neither a 'Reads' nor a 'Batches' group: not a mapped-signal file "
+                        "(mapped_signal_files.py:19-20)")
     group = f["Reads"]
     for rid in group.keys():
         if limit is not None and len(reads) >= limit:
@@ -383,3 +410,55 @@ def read_mapped_signal_file(path, limit=None):
                 rd[k] = g.attrs[k]
         reads.append(rd)
     return info, reads
+
+
+BATCH_ARRAYS = (("Dacs", np.int16), ("Ref_to_signal", np.int32), ("Reference", np.int16))
+BATCH_SCALARS = ("shift_frompA", "scale_frompA", "range", "offset", "digitisation")
+
+
+def reads_of_batches(batches, limit=None):
+    """The batch layout (`BatchHDF5Writer`, mapped_signal_files.py:562-668, the writers' default):
+    group `Batches/Batch_<k>` holds, for its reads, the concatenated `Dacs` / `Ref_to_signal` /
+    `Reference` arrays with their `<name>_lengths`, one 1-d dataset per scalar field and the
+    variable-length strings `read_id` (and `mapping_method`); `BatchHDF5Reader._load_reads_batch`
+    (:503-540) splits the arrays at the cumulative lengths.  `batches` is anything with `keys()` and
+    `[name].read()`.
+    The reference's test data holds no file of this layout (and h5py is not here to write one): the
+    dataset primitives under this function are validated on the per-read files, the splitting on
+    synthetic groups (tests/test_hdf5_reader.py) -- unpinned against a genuine batch file."""
+    reads = []
+    for bname in batches.keys():
+        g = batches[bname]
+        names = set(g.keys())
+        cols, nreads = {}, None
+        for key, dt in BATCH_ARRAYS:
+            if key not in names or key + "_lengths" not in names:
+                raise Hdf5Error("batch %s lacks %s or %s_lengths" % (bname, key, key))
+            lens = np.asarray(g[key + "_lengths"].read(), dtype=np.int64)
+            flat = np.asarray(g[key].read())
+            if int(lens.sum()) != flat.shape[0]:
+                raise Hdf5Error("batch %s: %s has %d values, its lengths add up to %d"
+                                % (bname, key, flat.shape[0], int(lens.sum())))
+            cols[key] = [a.astype(dt) for a in np.split(flat, np.cumsum(lens[:-1]))] if len(lens) else []
+            if nreads is not None and nreads != len(lens):
+                raise Hdf5Error("batch %s: %s holds %d reads, not %d" % (bname, key, len(lens), nreads))
+            nreads = len(lens)
+        for key in BATCH_SCALARS:
+            cols[key] = np.asarray(g[key].read(), dtype=np.float64)
+            if cols[key].shape[0] != nreads:
+                raise Hdf5Error("batch %s: %s holds %d values, not %d" % (bname, key, cols[key].shape[0], nreads))
+        try:
+            ids = [x.decode() if isinstance(x, bytes) else str(x) for x in g["read_id"].read()]
+        except (Hdf5Error, KeyError, struct.error):
+            ids = []
+        if len(ids) != nreads:
+            ids = ["%s/%d" % (bname, k) for k in range(nreads)]
+        for k in range(nreads):
+            if limit is not None and len(reads) >= limit:
+                return reads
+            rd = dict(read_id=ids[k], Dacs=cols["Dacs"][k], Ref_to_signal=cols["Ref_to_signal"][k],
+                      Reference=cols["Reference"][k])
+            for key in BATCH_SCALARS:
+                rd[key] = float(cols[key][k])
+            reads.append(rd)
+    return reads

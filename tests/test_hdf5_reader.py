@@ -53,7 +53,7 @@ def test_dacs_equal_the_raw_fast5_signal_of_the_same_read():
 
 
 def test_latest_layout_is_refused_with_the_converter_named(tmp_path):
-    """HDF5 1.8+ 'latest' layout (what MappedSignalWriter writes today, libver='v108'): a
+    """HDF5 1.8+ 'latest' layout (what the per-read writer uses today, libver='v108'): a
     version-2 superblock is recognised and refused, never mis-parsed."""
     p = tmp_path / "new.hdf5"
     p.write_bytes(hdf5_lite.SIGNATURE + bytes([2, 8, 8, 0]) + bytes(64))
@@ -108,3 +108,64 @@ def test_store_from_hdf5_feeds_the_loss(gpu_device):
     lv = ctc.flipflop_loss(x, got[1].cpu().long(), got[2].cpu().long(), 1.0)
     lv.mean().backward()
     assert bool(torch.isfinite(lv).all()) and bool(torch.isfinite(x.grad).all())
+
+
+class _FakeDataset:
+    def __init__(self, value):
+        self.value = value
+
+    def read(self):
+        return self.value
+
+
+class _FakeGroup(dict):
+    def keys(self):
+        return list(dict.keys(self))
+
+
+def test_batch_layout_is_split_like_the_reference_reader():
+    """`BatchHDF5Reader._load_reads_batch` (mapped_signal_files.py:503-540): the reads of the real
+    per-read fixture, packed the way `BatchHDF5Writer.write_curr_batch` (:593-645) packs them
+    (concatenated arrays + `_lengths`, scalars as 1-d arrays, two batches), come back identical.
+    (No genuine batch-layout file exists in the reference's test data; the dataset decoding under
+    this is what the tests above validate.)"""
+    info, reads = hdf5_lite.read_mapped_signal_file(os.path.join(HERE, "mapped_remap_samref.hdf5"))
+    assert len(reads) >= 3
+    batches = _FakeGroup()
+    for b, part in enumerate((reads[:2], reads[2:])):
+        g = _FakeGroup()
+        for key in ("Dacs", "Ref_to_signal", "Reference"):
+            g[key] = _FakeDataset(np.concatenate([r[key] for r in part]))
+            g[key + "_lengths"] = _FakeDataset(np.array([len(r[key]) for r in part], dtype=np.int32))
+        for key in hdf5_lite.BATCH_SCALARS:
+            g[key] = _FakeDataset(np.array([r[key] for r in part], dtype=np.float64))
+        g["read_id"] = _FakeDataset([r["read_id"] for r in part])
+        batches["Batch_%d" % b] = g
+    back = hdf5_lite.reads_of_batches(batches)
+    assert [r["read_id"] for r in back] == [r["read_id"] for r in reads]
+    for a, b in zip(back, reads):
+        for key, dt in hdf5_lite.BATCH_ARRAYS:
+            assert a[key].dtype == dt and np.array_equal(a[key], b[key])
+        assert all(a[k] == b[k] for k in hdf5_lite.BATCH_SCALARS)
+    assert len(hdf5_lite.reads_of_batches(batches, limit=1)) == 1
+    # inconsistent lengths are an error, not a silent truncation
+    batches["Batch_0"]["Dacs_lengths"] = _FakeDataset(np.array([1, 2], dtype=np.int32))
+    with pytest.raises(hdf5_lite.Hdf5Error, match="add up"):
+        hdf5_lite.reads_of_batches(batches)
+
+
+def test_variable_length_string_elements_decode_through_the_global_heap():
+    """The 16-byte (length, collection address, object index) elements of an h5py
+    `special_dtype(vlen=str)` dataset (mapped_signal_files.py:21, the read ids of a batch)."""
+    import struct
+
+    class FakeFile:
+        heap = {(4096, 1): b"read-one", (4096, 2): b"r2\0\0\0\0", (8192, 7): b""}
+
+        def _global_heap_object(self, addr, index):
+            return self.heap[(addr, index)]
+
+    dt = hdf5_lite._Datatype(9, 16, None, vlen_string=True, base=None)
+    raw = np.frombuffer(struct.pack("<IQI", 8, 4096, 1) + struct.pack("<IQI", 2, 4096, 2) +
+                        struct.pack("<IQI", 0, 0, 0), dtype="V16")
+    assert hdf5_lite.decode_vlen(FakeFile(), dt, raw) == ["read-one", "r2", ""]

@@ -4,9 +4,10 @@
 run it wherever the training data lives).
 
     python tools/mapped_signal_to_npz.py mapped_reads.hdf5 mapped_reads.npz [--limit N]
-File layout read here: attributes `alphabet`, `collapse_alphabet` on the root; group `Reads/<read_id>`
-with datasets `Dacs` (int16), `Ref_to_signal` (int32), `Reference` (int16) and attributes
-`shift_frompA`, `scale_frompA`, `range`, `offset`, `digitisation`.
+File layouts read here: attributes `alphabet`, `collapse_alphabet` on the root; per-read: group
+`Reads/<read_id>` with datasets `Dacs` (int16), `Ref_to_signal` (int32), `Reference` (int16) and
+attributes `shift_frompA`, `scale_frompA`, `range`, `offset`, `digitisation`; batched (the writers'
+default): groups `Batches/Batch_<k>` with the concatenated arrays and their `_lengths`.
 """
 import argparse
 import os
@@ -24,6 +25,30 @@ def read_hdf5(path, limit=None):
             return v.decode() if isinstance(v, bytes) else v
         alphabet = attr(h5, "alphabet", "ACGT")
         collapse = attr(h5, "collapse_alphabet", alphabet)
+        if "Reads" not in h5 and "Batches" in h5:
+            # the writers' default layout (BatchHDF5Writer, mapped_signal_files.py:562-668): the same
+            # splitting as the built-in reader, over h5py datasets
+            from taiyaki_amd import hdf5_lite
+
+            class _Ds:
+                def __init__(self, d):
+                    self.d = d
+
+                def read(self):
+                    return self.d[()]
+
+            class _Grp:
+                def __init__(self, g):
+                    self.g = g
+
+                def keys(self):
+                    return list(self.g.keys())
+
+                def __getitem__(self, k):
+                    v = self.g[k]
+                    return _Grp(v) if isinstance(v, h5py.Group) else _Ds(v)
+
+            return hdf5_lite.reads_of_batches(_Grp(h5["Batches"]), limit), str(alphabet), str(collapse)
         for k, rid in enumerate(h5["Reads"]):
             if limit is not None and k >= limit:
                 break

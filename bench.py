@@ -669,9 +669,10 @@ def main():
             out["roofline_crf"] = dict(
                 in_step=crf_roofline(step_ops, 20, "the train step's own launch, realistic lengths", chunk_len),
                 rowK=crf_roofline(rowk, 5, "north_star shape, SPEED_TEST lengths 0.45-0.55 T", 0),
-                note="latency/issue-bound by the serial lattice recursion, not by HBM: achieved is the "
-                     "algorithmic 3*T*N*S*4 bytes over the op's duration; traffic is dominated by the two "
-                     "lattices of the band")
+                note="the sweep is issue-bound by the serial lattice recursion (one wave per 64 R cells, all of "
+                     "a read's waves on one CU), the posterior pass HBM-bound by the two lattices of the band "
+                     "(written once, read once: `traffic`); achieved is the algorithmic 3*T*N*S*4 bytes over "
+                     "the op's duration")
         else:
             out["roofline"] = logz_roofline(step_ops, 30, "the train step's own launch")
         # ---- the whole loss path in one unit ------------------------------------------------

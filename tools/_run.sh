@@ -1,7 +1,7 @@
 cd /root/repo
-mkdir -p gpurun_out/ev2
-timeout 2400 python -m pytest tests -x -q -m gpu 2>&1 | tail -3 > gpurun_out/ev2/pytest_gpu.txt
-timeout 300 python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | tail -2 >> gpurun_out/ev2/pytest_gpu.txt
-timeout 900 python bench.py > gpurun_out/ev2/bench_default.json 2> gpurun_out/ev2/bench_default.err
-timeout 900 python tools/pmc_traffic.py --ops logz:4000:256:0,logz:800:128:0,crf:800:128:4000,crf:4000:256:0,catmod:800:128:4000 --save gpurun_out/ev2/r2b > gpurun_out/ev2/pmc.log 2>&1
-cat gpurun_out/ev2/pytest_gpu.txt; cut -c1-300 gpurun_out/ev2/bench_default.json; grep "x algorithmic" gpurun_out/ev2/pmc.log
+for seed in 101 202 303; do
+  timeout 1500 python -m tests.helpers.fuzz_shapes --cases 150 --seed $seed 2>&1 | grep -v amdgpu.ids > gpurun_out/fuzz_shapes_$seed.log
+  grep -n "FAIL\|fuzz:" gpurun_out/fuzz_shapes_$seed.log
+done
+timeout 1200 python -m tests.helpers.fuzz_prep --cases 200 --seed 404 2>&1 | grep -n "FAIL\|fuzz:"
+timeout 1200 python -m tests.helpers.fuzz_beam --cases 200 --seed 505 2>&1 | grep -n "FAIL\|fuzz_beam:"

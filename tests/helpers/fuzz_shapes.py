@@ -24,6 +24,17 @@ EDGES = [(1, 1), (15, 64), (16, 65), (17, 63), (639 * 16 // 10, 640), (2048, 300
          (1536, 384), (1535, 385), (2400, 320), (3601, 256), (100, 1000), (9, 2048)]
 
 
+def loss_ok(c):
+    """Every read: 1e-4 relative (north_star; the fp32 reference itself carries ~1e-5 at T ~ 2000 for
+    one-base sequences) OR 2e-6 absolute -- a read whose path scores cancel to a loss of ~1e-5 (T = 2237,
+    L = 1: kernel 2.3772e-05, fp32 oracle 2.3796e-05, float64 2.3768e-05, tests/helpers/fuzz_debug.py)
+    has no relative accuracy to speak of in fp32.  Per read: the largest relative and the largest
+    absolute error of a batch usually sit in different reads."""
+    loss, oloss = np.asarray(c["loss"], dtype=np.float64), np.asarray(c["oloss"], dtype=np.float64)
+    err = np.abs(loss - oloss)
+    return bool(np.all((err <= 1e-4 * np.abs(oloss)) | (err < 2e-6)))
+
+
 def case(k, rng, dev, oracle_mod=None):
     """Case k of the sweep (the first len(EDGES) are the regime-switch shapes, the rest random).
     Returns (ok, one-line description)."""
@@ -50,12 +61,10 @@ def case(k, rng, dev, oracle_mod=None):
     if k % 3 == 1 and T > 1:
         minp = synth.crf_case(T, N, 7200 + k, nmods_per_base=(1, 1, 0, 0), seqlens=seqlens)
         cm = parity.compare_crf(oracle_mod, minp, 1.0, dev)
-        cm_ok = cm["finite"] and (cm["loss_rel"] < 1e-4 or cm["loss_abs"] < 2e-6) and cm["grad_abs"] < 5e-5
+        cm_ok = cm["finite"] and loss_ok(cm) and cm["grad_abs"] < 5e-5
     ok = cm_ok and (r["finite"] and r["logz_rel"] < 1e-5 and r["grad_abs"] < 2e-5 and r["nograd_same"] == 0.0 and
                     v["path_mismatch"] == 0 and v["fwd_bit_mismatch"] == 0 and
-                    c["finite"] and (c["loss_rel"] < 1e-4 or c["loss_abs"] < 2e-6) and c["grad_abs"] < 2e-5)
-    # 1e-4: north_star (the fp32 reference itself carries ~1e-5 at T ~ 2000 for one-base sequences); a read whose
-    # loss is ~0 (T = 9, one of 2048 reads: relative 2.3e-4 of a loss of 1e-3) is held to 2e-6 absolute instead
+                    c["finite"] and loss_ok(c) and c["grad_abs"] < 2e-5)
     msg = "T=%4d N=%4d  logz %.1e / %.1e  viterbi %d  crf %.1e (abs %.1e) / %.1e" % (
         T, N, r["logz_rel"], r["grad_abs"], v["path_mismatch"], c["loss_rel"], c["loss_abs"], c["grad_abs"]) + (
         "  catmod %.1e / %.1e" % (cm["loss_rel"], cm["grad_abs"]) if cm else "")

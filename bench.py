@@ -129,7 +129,7 @@ def self_launch(args, argv):
     """`--gpus N` outside torchrun: start the N ranks ourselves, one per GPU, over RCCL (the
     reference launches its multi-GPU run the same way, workflow/test_multiGPU.sh:47-55,
     bin/train_flipflop.py:255-268).  The JSON line of rank 0 is this process's output."""
-    if not args.dry_launch:
+    if not args.dry_launch and not os.environ.get("TK_BENCH_SHARE_GPU"):
         have = torch.cuda.device_count() if torch.cuda.is_available() else 0
         if have < args.gpus:
             raise SystemExit("bench.py --gpus %d: only %d GPU(s) visible -- refusing to measure fewer "
@@ -453,6 +453,10 @@ def main():
         if a is not None:
             cfg[k] = a
 
+    if os.environ.get("TK_BENCH_STACKS_AFTER"):
+        # debugging aid: dump every thread's Python stack to stderr after that many seconds
+        import faulthandler
+        faulthandler.dump_traceback_later(float(os.environ["TK_BENCH_STACKS_AFTER"]), repeat=False)
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ and not args.probe_graph:
         self_launch(args, argv)
     if args.dry_launch:
@@ -461,8 +465,17 @@ def main():
     from taiyaki_amd import _lib, models, parallel, train
     if args.probe_graph:
         rank, local, world = 0, int(os.environ.get("LOCAL_RANK", "0")), 1
+        if os.environ.get("TK_BENCH_SHARE_GPU"):
+            local = 0
     else:
-        rank, local, world = parallel.init_from_env()
+        # TK_BENCH_SHARE_GPU=1 (tests, 1-GPU boxes): every rank drives cuda:0 and the gradients are
+        # reduced over gloo -- RCCL refuses two ranks on one device.  Exercises the whole N > 1
+        # choreography (sharding, hooks, barrier bracket, max over ranks, rank-0 report) on the real
+        # kernels; the number it prints is not a scaling measurement
+        share = bool(os.environ.get("TK_BENCH_SHARE_GPU"))
+        rank, local, world = parallel.init_from_env(backend="gloo" if share else None)
+        if share:
+            local = 0
     if world != args.gpus and not args.probe_graph:
         raise SystemExit("bench.py: --gpus %d but the launcher started WORLD_SIZE=%d ranks" % (args.gpus, world))
     if not torch.cuda.is_available():
@@ -498,11 +511,22 @@ def main():
         try:
             pr = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900)
             use_graph = pr.returncode == 0 and "graph-probe-ok" in pr.stdout
-            if not use_graph and rank == 0:
-                print("hipGraph probe failed (rc %d): %s" % (pr.returncode, pr.stderr[-400:]),
+            if not use_graph:
+                print("[rank %d] hipGraph probe failed (rc %d): %s" % (rank, pr.returncode, pr.stderr[-400:]),
                       file=sys.stderr)
         except subprocess.TimeoutExpired:
             use_graph = False
+            print("[rank %d] hipGraph probe timed out" % rank, file=sys.stderr)
+    if dist.is_initialized() and world > 1:
+        # every rank must take the same road: the graphed and the eager trainer issue different
+        # numbers of collectives while they set up (a rank whose probe failed would sit in the
+        # timing barrier while the others wait for it inside the capture's warm-up all-reduce)
+        flag = torch.tensor([1 if use_graph else 0], dtype=torch.int32,
+                            device=dev if dist.get_backend() == "nccl" else "cpu")
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+        if use_graph and int(flag.item()) == 0 and rank == 0:
+            print("hipGraph probe failed on another rank: every rank launches eagerly", file=sys.stderr)
+        use_graph = bool(int(flag.item()))
     if cfg["model"] == "mGru_flipflop":
         net = models.mGru_flipflop(size=size, stride=stride).to(dev)
     elif cat_mod:
@@ -535,6 +559,14 @@ def main():
         except Exception as exc:      # report, never hide
             print("hipGraph capture failed (%s: %s); running eagerly" % (type(exc).__name__, exc),
                   file=sys.stderr)
+    if dist.is_initialized() and world > 1 and not args.probe_graph:
+        # (same agreement after the capture itself: a rank that fell back launches eagerly everywhere)
+        flag = torch.tensor([1 if mode != "eager" else 0], dtype=torch.int32,
+                            device=dev if dist.get_backend() == "nccl" else "cpu")
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+        if int(flag.item()) == 0 and mode != "eager":
+            print("[rank %d] another rank could not capture: launching eagerly" % rank, file=sys.stderr)
+            stepper, mode = trainer, "eager"
     if args.probe_graph:
         stepper.step(batches[1])
         torch.cuda.synchronize()

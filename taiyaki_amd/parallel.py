@@ -47,6 +47,13 @@ def init_from_env(backend=None):
     return rank, local, world
 
 
+def _trace(msg):
+    """TK_ARENA_TRACE=1: every collective this rank issues, to stderr (debugging rank mismatches)."""
+    if os.environ.get("TK_ARENA_TRACE"):
+        import sys
+        print("[arena rank %s] %s" % (os.environ.get("RANK", "?"), msg), file=sys.stderr, flush=True)
+
+
 class FlatGradArena:
     """All trainable gradients as views into one contiguous fp32 buffer.
 
@@ -105,6 +112,7 @@ class FlatGradArena:
             b[2] -= 1
             if b[2] == 0 and not b[3]:
                 b[3] = True
+                _trace("hook bucket %d [%d:%d]" % (k, b[0], b[1]))
                 self._work.append(dist.all_reduce(self.flat[b[0]:b[1]], op=dist.ReduceOp.SUM, async_op=True))
         return hook
 
@@ -123,15 +131,18 @@ class FlatGradArena:
         if not (self.world > 1 or self._always):
             return
         if self._buckets and self.hooks_enabled:
-            for b in self._buckets:
+            for k, b in enumerate(self._buckets):
                 if not b[3]:
                     b[3] = True
+                    _trace("late bucket %d [%d:%d] missing %d" % (k, b[0], b[1], b[2]))
                     self._work.append(dist.all_reduce(self.flat[b[0]:b[1]], op=dist.ReduceOp.SUM,
                                                       async_op=True))
         else:
+            _trace("whole arena")
             self._work.append(dist.all_reduce(self.flat, op=dist.ReduceOp.SUM, async_op=True))
 
     def finish(self):
+        _trace("finish: %d pending" % len(self._work))
         if self._work:
             for w in self._work:
                 w.wait()

@@ -639,6 +639,32 @@ def test_bench_contract_with_live_rccl_group(gpu_device):
     assert {"bound", "achieved", "peak", "unit", "frac", "traffic"} <= set(out["roofline"])
 
 
+def test_bench_two_ranks_self_launched_on_one_gpu(gpu_device):
+    """`python bench.py --gpus 2` from a plain shell: the bench starts both ranks itself
+    (torch.distributed.run), they shard the batch, reduce the gradient arena from backward hooks,
+    bracket the timed steps with barriers and rank 0 alone prints the contract line with
+    n_gpus = 2 and a global batch of two shards.  On this 1-GPU box both ranks drive cuda:0 and the
+    reduction goes over gloo (TK_BENCH_SHARE_GPU: RCCL refuses two ranks on one device) -- the
+    choreography and every kernel are the real ones, the number is not a scaling measurement."""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK")}
+    env["TK_BENCH_SHARE_GPU"] = "1"
+    pr = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--chunk-len", "400",
+                         "--batch", "8", "--size", "32", "--steps", "3", "--warmup", "1", "--no-rowk"],
+                        env=env, capture_output=True, text=True, timeout=1200)
+    assert pr.returncode == 0, (pr.stdout[-400:], pr.stderr[-1200:])
+    lines = [ln for ln in pr.stdout.strip().splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, lines                        # one JSON line: rank 0's
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 2 and out["config"]["global_batch"] == 16 and out["value"] > 0
+    assert out["rccl"]["ranks"] == 2 and out["rccl"]["bytes"] > 0
+    assert "cpu_baseline" not in out                     # N > 1 lines carry no CPU leg
+
+
 def test_logz_very_long_chunks(oracle_mod, gpu_device):
     """T = 9000: more 16-row chunks than one LDS image of the middle kernel holds -> the
     launcher falls back to 32-row chunks; T = 21000 exceeds the build and must say so."""

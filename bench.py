@@ -509,7 +509,9 @@ def main():
         cmd += ["--hybrid"] if hybrid else ["--graph"]
         env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE")}
         try:
-            pr = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900)
+            # (well inside the process group's 10-minute collective timeout: the other ranks wait for
+            # this rank's verdict in an all-reduce)
+            pr = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=420)
             use_graph = pr.returncode == 0 and "graph-probe-ok" in pr.stdout
             if not use_graph:
                 print("[rank %d] hipGraph probe failed (rc %d): %s" % (rank, pr.returncode, pr.stderr[-400:]),

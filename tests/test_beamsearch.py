@@ -248,3 +248,27 @@ def test_hip_lattice_passes(gpu_device, correctly_rounded_oracle):
                     assert np.abs(mats[n] - ref[0]).max() <= 1e-5 * max(1.0, np.abs(ref[0]).max())
     one, tot = decodeutil.backward(sc[:, 0])                    # numpy in, one read: the reference's call
     assert one.shape == (T + 1, 8) and isinstance(tot, float)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("nbase", [1, 2, 3])
+def test_hip_beamsearch_and_lattice_other_alphabets(gpu_device, correctly_rounded_oracle, nbase):
+    """Alphabets of 1-3 bases (ntrans = 2 nbase (nbase + 1)): the kernels index by nbase, nothing is
+    fixed to 40 columns."""
+    import torch
+    from taiyaki_amd import decodeutil
+    rng = np.random.RandomState(40 + nbase)
+    ntrans = 2 * nbase * (nbase + 1)
+    for T, w, cut, guided in ((60, 5, 0.0, True), (45, 3, 0.05, True), (30, 12 if nbase < 4 else 8, 0.0, False)):
+        sc = (rng.randn(T, ntrans) * 2).astype(np.float32)
+        ws, wsc = correctly_rounded_oracle.beamsearch(sc, cut, w, guided)
+        seq, score = decodeutil.beamsearch(torch.from_numpy(sc).to(gpu_device), cut, w, guided)
+        assert np.array_equal(seq, ws) and np.float32(score) == np.float32(wsc), (nbase, T, w, cut, guided)
+        if beam.ref_available():
+            rs, rsc, _ = beam.ref_beamsearch(sc, cut, w, guided)
+            assert np.array_equal(seq, rs) and abs(score - rsc) <= 2e-6 * max(1.0, abs(rsc))
+        for fn, ofn in ((decodeutil.forward, correctly_rounded_oracle.forward),
+                        (decodeutil.backward, correctly_rounded_oracle.backward)):
+            mat, tot = fn(sc)
+            want = ofn(sc)
+            assert np.array_equal(mat, want[0]) and np.float32(tot) == np.float32(want[1])

@@ -26,6 +26,7 @@ int crf_dispatch(const float *logprob, size_t ntrans, size_t nblk, size_t nbatch
                  size_t max_seqlen, size_t ncan, float sharp_can, float sharp_mod,
                  float out_scale, float *cost, float *grad, void *workspace,
                  size_t workspace_bytes, uint32_t *status, hipStream_t stream);
+void crf_band_lab_phase(int phase);
 size_t beam_workspace_bytes(size_t T, size_t N, size_t nbase);
 int lattice_dispatch(const float *scores, size_t T, size_t N, size_t nbase, int forward, const float *init,
                      float *out, float *total, hipStream_t stream);
@@ -220,6 +221,9 @@ int tk_flipflop_loss_fused_dev(const float *scores, size_t nblk, size_t nbatch, 
     return tk::logz_dispatch(scores, nblk, nbatch, nbase, logz, grad, logz_workspace, logz_workspace_bytes, status, st,
                              lossvector, 1.0f / (float)nblk);
 }
+
+// lab only (not declared in the public header): see crf_band.hip
+void tk_lab_crf_band_phase(int phase) { tk::crf_band_lab_phase(phase); }
 
 int tk_flipflop_lattice_dev(const float *scores, size_t nblk, size_t nbatch, size_t nbase, int forward,
                             const float *init, float *out, float *total, void *stream) {

@@ -993,13 +993,18 @@ BandLayout crf_band_layout(size_t ntrans, size_t nblk, size_t nbatch, size_t max
     return l;
 }
 
+// lab knob (tools/overlap_probe.py): 0 both passes, 1 the sweep launch only, 2 the posterior pass only
+static int g_band_lab_phase = 0;
+void crf_band_lab_phase(int phase) { g_band_lab_phase = phase; }
+
 template <int R, bool MOD>
 static int band_launch(const BandArgs &a, hipStream_t stream) {
     const bool want_grad = a.grad != nullptr;
-    hipLaunchKernelGGL((crf_band_sweep_kernel<R, MOD>), dim3((want_grad ? 3 : 1) * a.N), dim3(a.W * WAVE), 0,
-                       stream, a);
+    if (g_band_lab_phase != 2)
+        hipLaunchKernelGGL((crf_band_sweep_kernel<R, MOD>), dim3((want_grad ? 3 : 1) * a.N), dim3(a.W * WAVE), 0,
+                           stream, a);
     if (hipGetLastError() != hipSuccess) return 4;
-    if (!want_grad) return 0;
+    if (!want_grad || g_band_lab_phase == 1) return 0;
     const int rows = POST_WAVES * POST_ROWS;
     if constexpr (R == 4) {
         const size_t lds = band_post_rows_lds_bytes(R, a.W, MOD);

@@ -1,2 +1,2 @@
 cd /root/repo
-timeout 900 python -m pytest tests/test_beamsearch.py -x -q -m gpu 2>&1 | tail -8
+GPU_MAX_HW_QUEUES=4 timeout 300 python tools/overlap_probe.py 2>&1 | grep -v amdgpu

@@ -141,13 +141,16 @@ class FlatGradArena:
             _trace("whole arena")
             self._work.append(dist.all_reduce(self.flat, op=dist.ReduceOp.SUM, async_op=True))
 
-    def finish(self):
+    def finish(self, scale=1.0):
+        """Wait for the slices, apply 1 / world (x `scale`: 1 / number of accumulated sub-batches)."""
         _trace("finish: %d pending" % len(self._work))
         if self._work:
             for w in self._work:
                 w.wait()
             self._work = []
-            self.flat.mul_(1.0 / self.world)
+            scale = scale / self.world
+        if scale != 1.0:
+            self.flat.mul_(scale)
         for b, c in zip(self._buckets, getattr(self, "_bucket_size", [])):
             b[2], b[3] = c, False
 

@@ -64,14 +64,26 @@ class Trainer:
         self.grad_clip = grad_clip
 
     def step(self, batch):
+        """`batch`: one batch (dict) or a list of sub-batches.  Sub-batches are the reference's way
+        to fit a big batch (bin/train_flipflop.py:153-198): one forward / backward each, gradients
+        accumulated and divided by their number (:190-193), ONE optimiser step; returns the mean of
+        the sub-batch losses (:195).  The reference's DDP reduces after every sub-batch's backward;
+        here only the last backward issues the (hook-overlapped) all-reduce -- the same average."""
+        subs = batch if isinstance(batch, (list, tuple)) else [batch]
         self.arena.zero()
-        loss, _ = calculate_loss(self.net, **batch)
-        loss.backward()
+        hooks = self.arena.hooks_enabled
+        total = None
+        for k, sub in enumerate(subs):
+            self.arena.hooks_enabled = hooks and k == len(subs) - 1
+            loss, _ = calculate_loss(self.net, **sub)
+            loss.backward()
+            total = loss.detach() if total is None else total + loss.detach()
+        self.arena.hooks_enabled = hooks
         self.arena.allreduce_async()
-        self.arena.finish()
+        self.arena.finish(scale=1.0 / len(subs))
         self.clip()
         self.opt.step()
-        return loss
+        return loss if len(subs) == 1 else total / len(subs)
 
     def clip(self):
         """Gradient maxima / clipping between the all-reduce and the optimiser step."""

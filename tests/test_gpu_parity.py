@@ -783,6 +783,45 @@ def test_catmod_model_train_step_on_gpu(oracle_mod, gpu_device):
     assert any(not torch.equal(a, b) for a, b in zip(before, [p for p in net.parameters() if p.requires_grad]))
 
 
+def test_trainer_accumulates_sub_batches_like_the_reference(gpu_device):
+    """bin/train_flipflop.py:153-198: a step over k sub-batches = one backward each, gradients
+    divided by k, ONE optimiser step, reported loss = mean of the sub-batch losses."""
+    import torch
+    from taiyaki_amd import models, parallel, synth, train
+    chunk_len, stride, nbatch = 600, 5, 5
+    T = chunk_len // stride
+
+    def make(seed):
+        seqlens = synth.realistic_seqlens(T, nbatch, seed, chunk_len, 9.0)
+        seqs, _ = synth.sequences(seqlens, seed)
+        return dict(indata=torch.from_numpy(synth.signal_chunks(chunk_len, nbatch, seed)).to(gpu_device),
+                    seqs=torch.from_numpy(seqs), seqlens=torch.from_numpy(seqlens))
+
+    subs = [make(11), make(12), make(13)]
+    torch.manual_seed(5)
+    net = models.mLstm_flipflop(size=32, stride=stride).to(gpu_device)
+    # by hand: mean gradient and mean loss of the three sub-batches
+    grads, losses = None, []
+    for b in subs:
+        net.zero_grad(set_to_none=True)
+        loss, _ = train.calculate_loss(net, **b)
+        loss.backward()
+        g = [p.grad.detach().clone() for p in net.parameters() if p.requires_grad]
+        grads = g if grads is None else [a + c for a, c in zip(grads, g)]
+        losses.append(float(loss.detach()))
+    want = torch.cat([(g / 3.0).reshape(-1) for g in grads])
+    arena = parallel.FlatGradArena(net)
+    trainer = train.Trainer(net, arena)
+    trainer.opt.step = lambda: None                     # keep the accumulated gradient to look at
+    loss = trainer.step(subs)
+    torch.cuda.synchronize()
+    assert abs(float(loss) - float(np.mean(losses))) < 1e-5
+    assert torch.allclose(arena.flat, want, rtol=1e-4, atol=1e-6)
+    # and a single batch is still a plain step
+    one = trainer.step(subs[0])
+    assert abs(float(one.detach()) - losses[0]) < 1e-4
+
+
 # ------------------------------------------------ seeded fuzz sweeps (bounded) ---
 @pytest.mark.parametrize("k", list(range(13)) + [13, 14, 16, 19, 22])
 def test_fuzz_shapes_seeded_subset(oracle_mod, gpu_device, k):

@@ -109,9 +109,22 @@ EQUIV_WORKER = textwrap.dedent('''
 
     half = slice(3 * rank, 3 * rank + 3)          # ... each rank takes its half
     arena.zero()
-    loss_of(net, x[:, half], target[:, half]).backward()
-    arena.allreduce_async()
-    arena.finish()
+    nsub = int(os.environ.get("TK_TEST_SUBBATCHES", "1"))
+    if nsub == 1:
+        loss_of(net, x[:, half], target[:, half]).backward()
+        arena.allreduce_async()
+        arena.finish()
+    else:
+        # the half in three sub-batches of one chunk, accumulated the way Trainer.step does it:
+        # hooks (= the overlapped all-reduce) only on the last backward, 1 / nsub in finish()
+        hooks = arena.hooks_enabled
+        for k in range(nsub):
+            arena.hooks_enabled = hooks and k == nsub - 1
+            one = slice(3 * rank + k, 3 * rank + k + 1)
+            loss_of(net, x[:, one], target[:, one]).backward()
+        arena.hooks_enabled = hooks
+        arena.allreduce_async()
+        arena.finish(scale=1.0 / nsub)
     got = arena.flat.clone()
     # single-process reference: the whole batch on a fresh copy of the same model
     torch.manual_seed(5)
@@ -156,6 +169,14 @@ def test_two_rank_step_equals_one_rank_step_on_the_whole_batch(tmp_path, buckets
     on the whole batch; with the single flat all-reduce and with the hook-issued slices that
     overlap backward."""
     _run_two_ranks(tmp_path, EQUIV_WORKER, dict(TK_TEST_BUCKETS=buckets))
+
+
+@pytest.mark.parametrize("buckets", ["0", "3"])
+def test_two_rank_sub_batch_accumulation_equals_the_whole_batch(tmp_path, buckets):
+    """bin/train_flipflop.py:153-198 under data parallelism: every rank accumulates three
+    sub-batches (all-reduce issued by the last backward only), the arena then holds the gradient
+    of a single process on all six chunks."""
+    _run_two_ranks(tmp_path, EQUIV_WORKER, dict(TK_TEST_BUCKETS=buckets, TK_TEST_SUBBATCHES="3"))
 
 
 def test_bench_gpus_2_launches_two_ranks_itself(tmp_path):

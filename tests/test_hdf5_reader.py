@@ -169,3 +169,38 @@ def test_variable_length_string_elements_decode_through_the_global_heap():
     raw = np.frombuffer(struct.pack("<IQI", 8, 4096, 1) + struct.pack("<IQI", 2, 4096, 2) +
                         struct.pack("<IQI", 0, 0, 0), dtype="V16")
     assert hdf5_lite.decode_vlen(FakeFile(), dt, raw) == ["read-one", "r2", ""]
+
+
+REFDATA = "/root/reference/test/data"
+
+
+@pytest.mark.skipif(not os.path.isdir(REFDATA), reason="the reference's test data is only in the build container")
+def test_every_hdf5_file_of_the_reference_test_data_parses():
+    """All nine HDF5 containers under the reference's test/data (three mapped-signal files, five
+    single-read fast5, one multi-read fast5): structure invariants, and the multi-read fast5 holds
+    exactly the signals of the single-read files (two writers, two layouts of the same reads)."""
+    import glob
+    for path in sorted(glob.glob(os.path.join(REFDATA, "mapped_signal_file", "*.hdf5"))):
+        info, reads = hdf5_lite.read_mapped_signal_file(path)
+        assert info["version"] == 8 and len(reads) >= 2
+        for r in reads:
+            assert len(r["Ref_to_signal"]) == len(r["Reference"]) + 1 and np.all(np.diff(r["Ref_to_signal"]) >= 0)
+            assert r["Ref_to_signal"][-1] <= len(r["Dacs"]) + 1
+    multi = hdf5_lite.File(glob.glob(os.path.join(REFDATA, "multireads", "*.fast5"))[0])
+    singles = {}
+    for path in glob.glob(os.path.join(REFDATA, "reads", "*.fast5")):
+        rg = hdf5_lite.File(path)["Raw/Reads"]
+        (name,) = rg.keys()
+        sig = rg[name]["Signal"].read()
+        assert int(rg[name].attrs["duration"]) == len(sig)
+        singles[str(rg[name].attrs["read_id"])] = sig
+    assert len(singles) == 5
+    seen = 0
+    for key in multi.keys():
+        raw = multi[key]["Raw"]
+        rid = str(raw.attrs["read_id"])
+        assert key == "read_" + rid
+        if rid in singles:
+            assert np.array_equal(raw["Signal"].read(), singles[rid])
+            seen += 1
+    assert seen == 5

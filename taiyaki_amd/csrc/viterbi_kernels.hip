@@ -5,218 +5,222 @@
 // ties go to the flip source) and arithmetic (one fp32 add per candidate) are
 // reproduced exactly, so fwd, traceback and path are bit-identical.
 //
-// EIGHT LANES PER READ: lane (r, j) owns destination state j of read r (8 reads per
-// wave).  The max-plus recursion stays serial in T by construction (a time-parallel form
-// would re-associate the fp32 adds and break bit-exactness), so the work is in making one
-// step short:
-//   * every lane evaluates the same eight candidates f[from] + s[from]; a flop lane's
-//     invalid sources are masked to -inf (when the row is used, not when it is fetched: the
-//     loads stay in flight for VIT_PF steps), so there is no flip / flop divergence;
-//   * the all-gather of the eight state values is folded into the adds: the value of lane
-//     4q+k of the lane's own quad is a quad_perm DPP operand (v_add_f32_dpp), the other
-//     quad comes from one lane^4 exchange (two bank-masked row shifts) -- no ds_bpermute;
-//   * "first index wins" is kept by scanning each quad's four candidates in order and
-//     letting the lower quad win ties;
-//   * every lane drops its source index as ONE BYTE (a single 64-byte store per wave and
-//     step); the eight bytes of a read are one 64-bit word, so the path pass reads them
-//     with prefetched, address-independent loads instead of chasing the int64 tensor.
-// Score rows are prefetched VIT_PF steps ahead.
+// The max-plus recursion is serial in T by construction (a time-parallel form would
+// re-associate the fp32 adds and break bit-exactness) and has 2 nbase <= 8 states: it is a
+// pure latency problem, so the design minimises the DEPENDENT instructions of a step.
+//
+// ONE WAVEFRONT PER READ, lane = (to, from) = (lane / 8, lane % 8): every candidate
+// f[from] + s[to, from] of a step is one lane's single v_add_f32.  Then
+//   * the maximum over `from` is three DPP steps inside the 8-lane group (quad_perm x 2,
+//     row_half_mirror), result in all eight lanes;
+//   * the new state vector is transposed back (lane (to, from) needs f[from], which group
+//     `from` now holds) by ONE ds_bpermute with a constant address;
+//   * off the chain: "first index wins" = the lowest set bit of the group's byte of the ballot
+//     (candidate == maximum); that index is the traceback byte.
+// A step is add -> 3 x v_max_f32_dpp -> ds_bpermute: ~60 ns, against ~270 ns for the
+// round-1 layout (8 lanes per read, every lane scanning eight candidates: ~80 instructions
+// per step on the chain's wave).  Invalid sources of a flop state are masked in the SCORE
+// (-inf), one step ahead of its use; rows are requested VIT_PF steps ahead.
+// The path pass decodes 64 steps per batch: every lane fetches the 8-byte traceback word of
+// one step (next batch in flight while this one is decoded).  A word IS the table state ->
+// previous state, and v_perm_b32 composes two such tables (four entries per instruction), so
+// the batch is an inclusive SCAN over the lanes (6 levels) instead of a 64-step walk; the 64
+// states go out in one store.
 #include <type_traits>
 
 #include "ff_common.h"
 
 namespace tk {
 
-constexpr int VIT_GRP = 8;      // lanes per read
-constexpr int VIT_PF = 8;       // score rows in flight per lane
-constexpr int VIT_TB = 16;      // traceback steps prefetched per batch
+constexpr int VIT_GRP = 8;      // lanes per destination state = source states
+constexpr int VIT_PF = 12;      // score rows in flight
 constexpr float VIT_NEG_INF = -__builtin_huge_valf();
 
-// lane l <- lane l ^ 4 (inside every 8-lane group): two bank-masked row shifts
-__device__ __forceinline__ float xor4_f32(float x) {
-    int r = __builtin_amdgcn_update_dpp(0, __float_as_int(x), 0x104, 0xF, 0x5, false);   // row_shl:4 -> lanes 0-3, 8-11
-    r = __builtin_amdgcn_update_dpp(r, __float_as_int(x), 0x114, 0xF, 0xA, false);       // row_shr:4 -> lanes 4-7, 12-15
-    return __int_as_float(r);
-}
-
-// c[k] = s[k] + x[lane 4q + k] (k < 4), c[4 + k] = s[4 + k] + xo[lane 4q + k]
-__device__ __forceinline__ void vit_candidates(const float (&s)[8], float x, float xo, float (&c)[8]) {
+// maximum over the 8-lane group, in every lane of the group
+__device__ __forceinline__ float vit_grp_max(float x) {
+    float r;
     asm("s_nop 1\n\t"
-        "v_add_f32_dpp %0, %8, %10 quad_perm:[0,0,0,0] row_mask:0xf bank_mask:0xf\n\t"
-        "v_add_f32_dpp %1, %8, %11 quad_perm:[1,1,1,1] row_mask:0xf bank_mask:0xf\n\t"
-        "v_add_f32_dpp %2, %8, %12 quad_perm:[2,2,2,2] row_mask:0xf bank_mask:0xf\n\t"
-        "v_add_f32_dpp %3, %8, %13 quad_perm:[3,3,3,3] row_mask:0xf bank_mask:0xf\n\t"
-        "v_add_f32_dpp %4, %9, %14 quad_perm:[0,0,0,0] row_mask:0xf bank_mask:0xf\n\t"
-        "v_add_f32_dpp %5, %9, %15 quad_perm:[1,1,1,1] row_mask:0xf bank_mask:0xf\n\t"
-        "v_add_f32_dpp %6, %9, %16 quad_perm:[2,2,2,2] row_mask:0xf bank_mask:0xf\n\t"
-        "v_add_f32_dpp %7, %9, %17 quad_perm:[3,3,3,3] row_mask:0xf bank_mask:0xf"
-        : "=&v"(c[0]), "=&v"(c[1]), "=&v"(c[2]), "=&v"(c[3]), "=&v"(c[4]), "=&v"(c[5]), "=&v"(c[6]),
-          "=&v"(c[7])
-        : "v"(x), "v"(xo), "v"(s[0]), "v"(s[1]), "v"(s[2]), "v"(s[3]), "v"(s[4]), "v"(s[5]), "v"(s[6]),
-          "v"(s[7]));
+        "v_max_f32_dpp %0, %1, %1 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
+        "s_nop 1\n\t"
+        "v_max_f32_dpp %0, %0, %0 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n\t"
+        "s_nop 1\n\t"
+        "v_max_f32_dpp %0, %0, %0 row_half_mirror row_mask:0xf bank_mask:0xf"
+        : "=&v"(r) : "v"(x));
+    return r;
 }
 
-template <int NB>
+template <int NB, bool FULLOUT>
 __global__ __launch_bounds__(WAVE) void viterbi_kernel(const float *__restrict__ scores, int T,
                                                       int N, float *__restrict__ fwd_out,
                                                       int64_t *__restrict__ tb_out,
                                                       int64_t *__restrict__ path_out,
-                                                      unsigned char *__restrict__ packed) {
+                                                      unsigned char *__restrict__ packed, int npad) {
     using F = FF<NB>;
-    static_assert(F::NS <= VIT_GRP, "one lane per state");
+    static_assert(F::NS <= VIT_GRP, "one lane group per state");
     const int lane = lane_id();
-    const int j = lane & (VIT_GRP - 1), rloc = lane >> 3, q = j >> 2;
-    const size_t nreal = (size_t)blockIdx.x * VIT_GRP + rloc;
-    const bool live = nreal < (size_t)N && j < F::NS;
-    const size_t n = min(nreal, (size_t)N - 1);
-    const int jc = min(j, F::NS - 1);
-    const bool flip = jc < NB;
+    const int to = lane >> 3, from = lane & 7;
+    const int n = blockIdx.x;
+    // decode.py:99-105: a flip state is reached from every state, flop b only from flip b and
+    // from itself
+    const bool flip = to < NB;
+    const bool valid = to < F::NS && from < F::NS && (flip || from == to - NB || from == to);
+    const int sidx = flip ? to * F::NS + min(from, F::NS - 1) : F::FLOP0 + min(from, F::NS - 1);
+    const bool leader = from == 0 && to < F::NS;
     const size_t rowstride = (size_t)N * F::S;
-    // every lane reads the NS contiguous floats of its destination's block (no divergent
-    // branch around the loads): flip lane j the block s[j*NS ..], flop lanes the flop block
-    // s[FLOP0 ..] = [from-flip scores | flop-stay scores].  All global accesses are a
-    // wave-uniform row pointer (scalar registers) plus a 32-bit lane offset.
-    const int mine = (int)n * F::S + (flip ? jc * F::NS : F::FLOP0);
-    const int slot = (int)min(nreal, (size_t)N - 1) * F::NS + jc;       // lane's element of an (N, NS) row
-    // register word w pairs with source state src[w]: the lane's own quad first (4q + w),
-    // then the other quad (4 (1 - q) + w - 4)
-    int src[8];
-    bool ok[8];
-#pragma unroll
-    for (int w = 0; w < 8; ++w) {
-        src[w] = (w < 4) ? 4 * q + w : 4 * (1 - q) + (w - 4);
-        // decode.py:99-105: a flip state is reached from every state, flop b only from flip b
-        // and from itself
-        ok[w] = src[w] < F::NS && (flip || src[w] == jc - NB || src[w] == jc);
-    }
+    const int tr4 = 4 * ((from << 3) | to);                     // transpose: the lane of group `from`
 
-    const int base_own = 4 * q, base_other = 4 * (1 - q);
-    float best = (j < NB) ? 0.f : ((j < F::NS) ? NEG_LARGE : VIT_NEG_INF);      // decode.py:93-95
-    if (fwd_out != nullptr && live) fwd_out[slot] = best;
+    float f = (from < NB) ? 0.f : ((from < F::NS) ? NEG_LARGE : VIT_NEG_INF);      // decode.py:93-95
+    if (FULLOUT && leader) fwd_out[(size_t)n * F::NS + to] = (to < NB) ? 0.f : NEG_LARGE;
 
-    float sc[VIT_PF][8];
-    // running wave-uniform pointers (scalar adds per step, no index multiplications)
-    const float *frow = scores;                 // row being fetched (stops at row T - 1)
-    int tfetch = 0;
-    // the fetch only issues loads: anything computed on the loaded words here would make the
-    // wave wait for the row it has just requested (one L2 round trip per step)
-    auto fetch = [&](float (&dst)[8]) {
-        if constexpr (F::NS == 8) {
-            // the two float4 halves of the block, own quad's sources first
-            const f4 a = *reinterpret_cast<const f4 *>(frow + (mine + 4 * q));
-            const f4 b = *reinterpret_cast<const f4 *>(frow + (mine + 4 * (1 - q)));
+    // Memory goes through buffer instructions: a descriptor per group of VIT_PF steps (scalar
+    // ALU), a constant per-lane offset, a scalar per-step offset -- no vector address arithmetic
+    // among the ~15 instructions of a step.
+    constexpr int RSRC3 = 0x00027000;
+    const unsigned rs4 = 4u * (unsigned)rowstride;
+    const unsigned lane_ld4 = 4u * (unsigned)((size_t)n * F::S + min(sidx, F::S - 1));
+    float sc[VIT_PF];
+    auto fetch_group = [&](int t0, int k0, int k1) {            // rows t0 + k0 .. t0 + k1 - 1 -> sc[k]
+        const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(
+            const_cast<float *>(scores + (size_t)min(t0, max(T - 1, 0)) * rowstride), 0, 0x7fffffff, RSRC3);
+        const int last = max(T - 1 - min(t0, max(T - 1, 0)), 0);        // rows past the end re-read the last one
 #pragma unroll
-            for (int k = 0; k < 4; ++k) {
-                dst[k] = a[k];
-                dst[4 + k] = b[k];
-            }
-        } else {
-#pragma unroll
-            for (int w = 0; w < 8; ++w) dst[w] = frow[mine + min(src[w], F::NS - 1)];
-        }
-        // clamped, never branched on: past the end the last row is fetched again
-        frow += (tfetch < T - 1) ? rowstride : 0;
-        ++tfetch;
+        for (int k = 0; k < VIT_PF; ++k)
+            if (k >= k0 && k < k1)
+                sc[k] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rs, lane_ld4, rs4 * (unsigned)min(k, last), 0));
     };
-#pragma unroll
-    for (int k = 0; k < VIT_PF; ++k) fetch(sc[k]);
+    fetch_group(0, 0, VIT_PF);
 
-    const int wave_row = blockIdx.x;            // 8 reads per wave
-    const size_t nwaves = gridDim.x;
-    // traceback bytes: one per lane (= destination state) and step, [t][wave][64]
-    unsigned char *prow = packed + (size_t)wave_row * WAVE;
-    float *fout = fwd_out != nullptr ? fwd_out + (size_t)N * F::NS : nullptr;        // row t + 1
-    int64_t *tout = tb_out;
-    // The loop body is instantiated per (outputs wanted, every lane live): the per-step
-    // "is this pointer null / is this lane live" tests are loop invariants, but left inside
-    // they cost a scalar compare + branch + exec-mask round trip each, every step.
-    auto steps = [&](auto want_full, auto all_live) {
-        constexpr bool FULLOUT = decltype(want_full)::value, ALLLIVE = decltype(all_live)::value;
-        for (int t0 = 0; t0 < T; t0 += VIT_PF) {
+    const size_t pstride = (size_t)npad * VIT_GRP;               // traceback bytes [t][npad][8]
+    const unsigned lane_tb = (unsigned)((size_t)n * VIT_GRP + to);
+    const unsigned lane_o4 = 4u * (unsigned)((size_t)n * F::NS + min(to, F::NS - 1));
+    const size_t ostride = (size_t)N * F::NS;
+
+    float m = VIT_NEG_INF;
+    float snext = valid ? sc[0] : VIT_NEG_INF;
+    // every lane of a group holds the group's result: all eight store it (same byte, same address)
+    // instead of one leader lane behind an exec-mask branch; only alphabets with dead groups
+    // (2 nbase < 8) need the mask
+    constexpr bool ALL_GROUPS_LIVE = F::NS == VIT_GRP;
+    // One group of up to VIT_PF steps, straight-line: with a branch between the steps the
+    // compiler can no longer count the loads in flight and waits for the newest but one -- a
+    // memory round trip per step.  The rows of the NEXT group are requested as their registers
+    // fall free.
+    auto group = [&](int t0, auto full) {
+        constexpr bool FULL = decltype(full)::value;
+        const __amdgpu_buffer_rsrc_t rnext = __builtin_amdgcn_make_buffer_rsrc(
+            const_cast<float *>(scores + (size_t)min(t0 + VIT_PF, max(T - 1, 0)) * rowstride), 0, 0x7fffffff, RSRC3);
+        const int lastn = max(T - 1 - min(t0 + VIT_PF, max(T - 1, 0)), 0);
+        const __amdgpu_buffer_rsrc_t rtb = __builtin_amdgcn_make_buffer_rsrc(
+            packed + (size_t)t0 * pstride, 0, 0x7fffffff, RSRC3);
+        const __amdgpu_buffer_rsrc_t rfo = __builtin_amdgcn_make_buffer_rsrc(
+            FULLOUT ? fwd_out + (size_t)(t0 + 1) * ostride : nullptr, 0, 0x7fffffff, RSRC3);
+        int64_t *tout = FULLOUT ? tb_out + (size_t)t0 * ostride + (size_t)n * F::NS + min(to, F::NS - 1) : nullptr;
 #pragma unroll
-            for (int k = 0; k < VIT_PF; ++k) {
-                const int t = t0 + k;
-                if (t < T) {
-                    // a flop lane's invalid sources are masked when the row is USED, VIT_PF
-                    // steps after it was requested
-                    float sm[8], c[8];
-#pragma unroll
-                    for (int w = 0; w < 8; ++w) sm[w] = ok[w] ? sc[k][w] : VIT_NEG_INF;
-                    vit_candidates(sm, best, xor4_f32(best), c);
-                    fetch(sc[k]);
-                    // first maximum of each quad's four candidates, in source order
-                    float bo = c[0], bt = c[4];
-                    int ao = 0, at = 0;
-#pragma unroll
-                    for (int i = 1; i < 4; ++i) {
-                        if (c[i] > bo) {
-                            bo = c[i];
-                            ao = i;
-                        }
-                        if (c[4 + i] > bt) {
-                            bt = c[4 + i];
-                            at = i;
-                        }
-                    }
-                    // the quad holding the lower source indices wins ties (own quad for q = 0)
-                    const bool take_other = (q == 0) ? (bt > bo) : !(bo > bt);
-                    best = take_other ? bt : bo;
-                    const int arg = (take_other ? at : ao) + (take_other ? base_other : base_own);
-                    prow[lane] = (unsigned char)arg;        // one 64-byte store per wave and step
-                    prow += nwaves * WAVE;
-                    if constexpr (FULLOUT) {
-                        if (ALLLIVE || live) {
-                            fout[slot] = best;
-                            tout[slot] = (int64_t)arg;
-                        }
-                        fout += (size_t)N * F::NS;
-                        tout += (size_t)N * F::NS;
+        for (int k = 0; k < VIT_PF; ++k) {
+            if (FULL || t0 + k < T) {
+                const float cand = f + snext;
+                m = vit_grp_max(cand);
+                f = __int_as_float(__builtin_amdgcn_ds_bpermute(tr4, __float_as_int(m)));
+                // ---- off the chain
+                sc[k] = __uint_as_float(
+                    __builtin_amdgcn_raw_buffer_load_b32(rnext, lane_ld4, rs4 * (unsigned)min(k, lastn), 0));
+                // the next step's scores, masked one step ahead of their use (requested VIT_PF - 1
+                // steps ago; at the last step of a group: row 0 of the next, requested at step 0)
+                snext = valid ? sc[(k + 1) % VIT_PF] : VIT_NEG_INF;
+                // "first index wins": the lowest set bit of the group's byte of the ballot
+                // (candidate == maximum) is the traceback byte
+                const unsigned long long eq = __ballot(cand == m);
+                const unsigned bits = (unsigned)(eq >> (8 * to));
+                const unsigned arg = (unsigned)__builtin_ctz((bits & 0xffu) | 0x100u) & 7u;
+                if (ALL_GROUPS_LIVE || to < F::NS) {
+                    __builtin_amdgcn_raw_buffer_store_b8((unsigned char)arg, rtb, lane_tb,
+                                                         (unsigned)(k * pstride), 0);
+                    if (FULLOUT) {
+                        __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(m), rfo, lane_o4,
+                                                              4u * (unsigned)(k * ostride), 0);
+                        tout[(size_t)k * ostride] = (int64_t)arg;
                     }
                 }
             }
         }
     };
-    const bool every_lane_live = __all(live);
-    if (fwd_out != nullptr && tb_out != nullptr) {
-        if (every_lane_live) steps(std::true_type{}, std::true_type{});
-        else steps(std::true_type{}, std::false_type{});
-    } else {
-        steps(std::false_type{}, std::true_type{});
-    }
+    const int tfull = T / VIT_PF * VIT_PF;
+    for (int t0 = 0; t0 < tfull; t0 += VIT_PF) group(t0, std::true_type{});
+    if (tfull < T) group(tfull, std::false_type{});
 
-    // traceback (decode.py:108-113); argmax = first maximal index.  One lane per read; the
-    // group's eight final values are gathered once.
-    float f[F::NS];
+#ifdef TK_VIT_NOPATH
+    return;                                     // lab: forward pass alone
+#endif
+    // ---- traceback (decode.py:108-113); argmax = first maximal state
+    unsigned st = 0;
+    {
+        float top = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(m), 0));
+        if (T == 0) top = 0.f;
 #pragma unroll
-    for (int s = 0; s < F::NS; ++s) f[s] = __shfl(best, (lane & ~(VIT_GRP - 1)) | s, WAVE);
-    uint32_t st = 0;
-    float top = f[0];
-#pragma unroll
-    for (int s = 1; s < F::NS; ++s) {
-        if (f[s] > top) {
-            top = f[s];
-            st = s;
+        for (int s = 1; s < F::NS; ++s) {
+            float v = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(m), s * VIT_GRP));
+            if (T == 0) v = (s < NB) ? 0.f : NEG_LARGE;
+            if (v > top) {
+                top = v;
+                st = s;
+            }
         }
     }
-    const bool tracer = j == 0 && nreal < (size_t)N;
-    if (tracer) path_out[(size_t)T * N + nreal] = (int64_t)st;
-    // the eight bytes of this read's group at a step are one 64-bit word: no dependent address
-    const unsigned long long *words = reinterpret_cast<const unsigned long long *>(packed) +
-                                      (size_t)wave_row * VIT_GRP + rloc;
-    const size_t wstride = nwaves * VIT_GRP;
-    for (int thi = T; thi > 0; thi -= VIT_TB) {
-        unsigned long long wd[VIT_TB];
+    if (lane == 0) path_out[(size_t)T * N + n] = (int64_t)st;
+    // the eight bytes of a read at a step are one 64-bit word: no dependent address
+    const unsigned long long *words = reinterpret_cast<const unsigned long long *>(packed) + n;
+    auto load_batch = [&](int thi) {                            // lane k: the word of step thi - 1 - k
+        const int t = max(thi - 1 - lane, 0);                   // clamped, never branched
+        return words[(size_t)t * npad];
+    };
+    // four batches in flight (a batch's scan is ~0.3 us, a load round trip a multiple of that);
+    // the ring rotates by NAME -- the loop is unrolled four times -- because a register copy of a
+    // word in flight would wait for its load
+    constexpr int VIT_TBQ = 4;
+    unsigned long long q[VIT_TBQ];
 #pragma unroll
-        for (int k = 0; k < VIT_TB; ++k) {
-            const int t = max(thi - 1 - k, 0);      // clamped, never branched: one straight load run
-            wd[k] = words[(size_t)t * wstride];
+    for (int b = 0; b < VIT_TBQ; ++b) q[b] = load_batch(T - b * WAVE);
+    // The eight bytes of a step's word are the table  state -> previous state,  and v_perm_b32
+    // with a table as byte selector COMPOSES two tables, four entries at a time (selectors 0-3
+    // pick bytes of the low dword, 4-7 of the high one).  So the 64 steps of a batch are not walked
+    // one after the other: an inclusive scan over the lanes (six levels, two v_perm_b32 + two
+    // ds_bpermute each) leaves in lane k the composition of steps 0..k, and one more look-up with
+    // the incoming state gives every lane its own state.  The scans of the four batches in flight
+    // do not depend on each other (only that last look-up chains them): they are issued together
+    // so that one's ds_bpermute round trips hide behind the others'.
+    auto scan = [&](unsigned long long cur, unsigned &lo, unsigned &hi) {
+        lo = (unsigned)cur;
+        hi = (unsigned)(cur >> 32);
+#pragma unroll
+        for (int d = 1; d < WAVE; d <<= 1) {
+            const int src4 = 4 * (lane - d);                    // (wraps for lane < d: not used there)
+            const unsigned blo = (unsigned)__builtin_amdgcn_ds_bpermute(src4, (int)lo);
+            const unsigned bhi = (unsigned)__builtin_amdgcn_ds_bpermute(src4, (int)hi);
+            // (this step's table) o (the steps before): entry s = mine[theirs[s]]
+            const unsigned nlo = __builtin_amdgcn_perm(hi, lo, blo), nhi = __builtin_amdgcn_perm(hi, lo, bhi);
+            if (lane >= d) {
+                lo = nlo;
+                hi = nhi;
+            }
+        }
+    };
+    for (int thi = T; thi > 0; thi -= VIT_TBQ * WAVE) {
+        unsigned lo[VIT_TBQ], hi[VIT_TBQ];
+#pragma unroll
+        for (int b = 0; b < VIT_TBQ; ++b) {
+            const unsigned long long cur = q[b];
+            q[b] = load_batch(thi - (b + VIT_TBQ) * WAVE);
+            scan(cur, lo[b], hi[b]);
         }
 #pragma unroll
-        for (int k = 0; k < VIT_TB; ++k) {
-            const int t = thi - 1 - k;
-            if (t >= 0) {
-                st = (uint32_t)(wd[k] >> (8 * st)) & 7u;
-                if (tracer) path_out[(size_t)t * N + nreal] = (int64_t)st;
+        for (int b = 0; b < VIT_TBQ; ++b) {
+            const int th = thi - b * WAVE;
+            if (th > 0) {                                        // wave-uniform
+                const unsigned mine = __builtin_amdgcn_perm(hi[b], lo[b], st) & 0xffu;     // st: the batch's start state
+                const int t = th - 1 - lane;
+                if (t >= 0) path_out[(size_t)t * N + n] = (int64_t)mine;
+                // (lanes before the start of the read re-read step 0; the walk ends with this batch then)
+                st = (unsigned)__builtin_amdgcn_readlane((int)mine, WAVE - 1);
             }
         }
     }
@@ -224,16 +228,21 @@ __global__ __launch_bounds__(WAVE) void viterbi_kernel(const float *__restrict__
 
 size_t viterbi_workspace_bytes(size_t T, size_t N, size_t nbase) {
     (void)nbase;
-    const size_t nwaves = (N + VIT_GRP - 1) / VIT_GRP;
-    return (T > 0 ? T : 1) * nwaves * WAVE;         // one byte per lane and step
+    const size_t npad = (N + VIT_GRP - 1) / VIT_GRP * VIT_GRP;
+    return (T > 0 ? T : 1) * npad * VIT_GRP;        // one byte per state and step
 }
 
 template <int NB>
 static int viterbi_launch(const float *scores, size_t T, size_t N, float *fwd, int64_t *tb,
                           int64_t *path, void *workspace, hipStream_t stream) {
-    const int ngrp = (int)((N + VIT_GRP - 1) / VIT_GRP);
-    hipLaunchKernelGGL(viterbi_kernel<NB>, dim3(ngrp), dim3(WAVE), 0, stream, scores, (int)T,
-                       (int)N, fwd, tb, path, static_cast<unsigned char *>(workspace));
+    const int npad = (int)((N + VIT_GRP - 1) / VIT_GRP * VIT_GRP);
+    if (N == 0) return 0;
+    if (fwd != nullptr && tb != nullptr)
+        hipLaunchKernelGGL((viterbi_kernel<NB, true>), dim3((unsigned)N), dim3(WAVE), 0, stream, scores, (int)T,
+                           (int)N, fwd, tb, path, static_cast<unsigned char *>(workspace), npad);
+    else
+        hipLaunchKernelGGL((viterbi_kernel<NB, false>), dim3((unsigned)N), dim3(WAVE), 0, stream, scores, (int)T,
+                           (int)N, fwd, tb, path, static_cast<unsigned char *>(workspace), npad);
     return hipGetLastError() == hipSuccess ? 0 : 4;
 }
 

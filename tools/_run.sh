@@ -1,2 +1,4 @@
 cd /root/repo
-for i in 1 2 3; do timeout 1200 python -m pytest tests -x -q -m gpu -p no:cacheprovider 2>&1 | tail -1; done
+timeout 2400 python -m pytest tests -x -q -m gpu 2>&1 | tail -2
+timeout 300 python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | tail -1
+timeout 300 python tools/microbench.py --reps 20 --shapes rowK,cfg2,cfg5 --ops viterbi 2>&1 | grep "^viterbi"

@@ -1,4 +1,5 @@
 cd /root/repo
-timeout 2400 python -m pytest tests -x -q -m gpu 2>&1 | tail -2
-timeout 300 python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | tail -1
-timeout 300 python tools/microbench.py --reps 20 --shapes rowK,cfg2,cfg5 --ops viterbi 2>&1 | grep "^viterbi"
+mkdir -p gpurun_out/ev4
+timeout 900 python bench.py > gpurun_out/ev4/bench_default.json 2> gpurun_out/ev4/bench_default.err
+timeout 900 python tools/pmc_traffic.py --ops logz:4000:256:0,logz:800:128:0,crf:800:128:4000,crf:4000:256:0,catmod:800:128:4000 --save gpurun_out/ev4/r2b > gpurun_out/ev4/pmc.log 2>&1
+cut -c1-200 gpurun_out/ev4/bench_default.json; grep "x algorithmic" gpurun_out/ev4/pmc.log | head -3

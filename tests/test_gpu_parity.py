@@ -220,6 +220,25 @@ def test_viterbi_reference_unit_test_and_ties(oracle_mod, gpu_device):
     np.testing.assert_array_equal(fwd, ka["ties/fwd"])
 
 
+@pytest.mark.parametrize("T", [1, 2, 11, 12, 13, 63, 64, 65, 255, 256, 257, 300, 1037])
+def test_viterbi_batch_edges_and_tie_heavy_scores(oracle_mod, gpu_device, T):
+    """The kernel runs groups of 12 steps straight-line and decodes the path 64 steps per scan, four
+    scans in flight: lengths around those boundaries, on scores quantised to a grid of 0.5 (exact
+    ties in nearly every step -> the first-index rule decides, decode.py:99-105) and on continuous
+    ones; forward scores, traceback and paths bit for bit, full outputs and path-only."""
+    import torch
+    from taiyaki_amd import decode
+    rng = np.random.RandomState(T)
+    for quantised in (True, False):
+        sc = rng.randn(T, 11, 40).astype(np.float32) * 2
+        if quantised:
+            sc = (np.round(sc * 2) / 2).astype(np.float32)
+        r = parity.compare_viterbi(oracle_mod, sc, gpu_device)
+        assert r["path_mismatch"] == 0 and r["tb_mismatch"] == 0 and r["fwd_bit_mismatch"] == 0, (T, quantised)
+        path_only = decode.flipflop_viterbi_path(torch.from_numpy(sc).to(gpu_device)).cpu().numpy()
+        np.testing.assert_array_equal(path_only, r["path"])
+
+
 # ------------------------------------------------ BASELINE.json full sizes ---
 @pytest.mark.parametrize("name", list(cases.FULLSIZE))
 def test_fullsize_against_reference_goldens(gpu_device, name):

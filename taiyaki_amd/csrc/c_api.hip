@@ -24,7 +24,7 @@ int crf_dispatch(const float *logprob, size_t ntrans, size_t nblk, size_t nbatch
                  const int32_t *stayidx, const int32_t *moveidx, const int32_t *modidx,
                  const float *modfact, const int32_t *seqlen, const int64_t *seqoff,
                  size_t max_seqlen, size_t ncan, float sharp_can, float sharp_mod,
-                 float out_scale, float *cost, float *grad, void *workspace,
+                 float out_scale, float grad_scale, float *cost, float *grad, void *workspace,
                  size_t workspace_bytes, uint32_t *status, hipStream_t stream);
 void crf_band_lab_phase(int phase);
 size_t beam_workspace_bytes(size_t T, size_t N, size_t nbase);
@@ -194,7 +194,7 @@ int tk_crf_flipflop_dev(const float *logprob, size_t ntrans, size_t nblk, size_t
     if (ntrans == 0 || nblk == 0 || nbatch == 0) return TK_ERR_BAD_ARG;
     if ((modidx == nullptr) != (modfact == nullptr)) return TK_ERR_BAD_ARG;
     return tk::crf_dispatch(logprob, ntrans, nblk, nbatch, stayidx, moveidx, modidx, modfact,
-                            seqlen, seqoff, max_seqlen, ncan, sharp_can, sharp_mod, out_scale,
+                            seqlen, seqoff, max_seqlen, ncan, sharp_can, sharp_mod, out_scale, 1.0f,
                             cost, grad, workspace, workspace_bytes, status,
                             static_cast<hipStream_t>(stream));
 }
@@ -215,7 +215,7 @@ int tk_flipflop_loss_fused_dev(const float *scores, size_t nblk, size_t nbatch, 
     // are whole coalesced row sets (the read-modify-write costs that HBM-bound kernel one more
     // stream; done in kernel A's row-at-a-time posterior pass it cost ~18 us at the step's shape)
     int rc = tk::crf_dispatch(scores, ntrans, nblk, nbatch, stayidx, moveidx, nullptr, nullptr, seqlen, seqoff,
-                              max_seqlen, ntrans, sharpfact, sharpfact, 1.0f / sharpfact, lossvector, grad,
+                              max_seqlen, ntrans, sharpfact, sharpfact, 1.0f / sharpfact, 1.0f, lossvector, grad,
                               crf_workspace, crf_workspace_bytes, status, st);
     if (rc != 0) return rc;
     return tk::logz_dispatch(scores, nblk, nbatch, nbase, logz, grad, logz_workspace, logz_workspace_bytes, status, st,
@@ -361,7 +361,7 @@ bool host_seq_call(float const *logprob, size_t ntrans, size_t nblk, size_t nbat
         modmoveidxs ? static_cast<const int32_t *>(d_mod.p) : nullptr,
         modmoveidxs ? static_cast<const float *>(d_fact.p) : nullptr,
         static_cast<const int32_t *>(d_len.p), static_cast<const int64_t *>(d_off.p),
-        (size_t)maxlen, ncan, 1.0f, 1.0f, 1.0f, static_cast<float *>(d_cost.p),
+        (size_t)maxlen, ncan, 1.0f, 1.0f, 1.0f, 1.0f, static_cast<float *>(d_cost.p),
         grad ? static_cast<float *>(d_grad.p) : nullptr, d_ws.p, wsb, nullptr, nullptr);
     if (rc != 0 || hipDeviceSynchronize() != hipSuccess) return false;
     std::vector<float> cost(nbatch);

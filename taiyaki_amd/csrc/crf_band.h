@@ -20,28 +20,34 @@ struct BandArgs {
     float c_can;                // sharp_can * log2(e)
     float c_mod;                // sharp_mod * log2(e)
     float out_scale;            // cost multiplier (1 / sharpfact)
+    float grad_scale;           // gradient multiplier (1 for the reference's operators)
     float *cost;                // (N)
     float *grad;                // (T, N, S) or null (cost only)
     uint32_t *status;
     int W;                      // chunks (= waves) per read
-    int LP;                     // lattice row pitch = W * 64 * R
-    float *latF, *latB;         // [N][T][LP]  forward column t / backward column t + 1 (band only)
-    int *offF, *offB;           // [N][ceil(T/4)][W]  integer log2 offsets of (row group, chunk)
+    int LP;                     // checkpoint row pitch = W * 64 * R
+    int Wp;                     // 64-cell chunks per checkpoint row = LP / 64 (the gradient pass's chunks)
+    // one checkpoint column per time block and sweep: cell = m * 2^f
+    float *ckFm, *ckBm;         // [N][NB][LP]  mantissas (forward: column 8 j; backward: column 8 j + nvalid)
+    int *ckFf, *ckBf;           // [N][NB][LP]  frames (exponents), fixed for the block
+    float *bndF, *bndB;         // [N][NB][Wp][8]  forward: the LAST cell of a 64-cell chunk before every step of the
+                                // block; backward: its FIRST cell
     double *scoreF, *scoreB;    // [N]  log2 scores of the two sweeps
-    uint32_t *rec;              // [N][W][EPL][64]  sorted transition instances of every chunk
-    float *recw;                // (cat-mod) their mod weights
-    int *segend;                // [N][W][64]  end of every transition id's segment
-    unsigned long long *dbg;    // lab builds only (TK_LAB_STAMPS): s_memtime stamps of workgroup 0, wave 0
+    uint32_t *rec;              // [N][Wp][KINDS][64]  sorted transition instances of every 64-cell chunk
+    int *segend;                // [N][Wp][64]  end of every transition id's segment
+    int *gate;                  // [N]  1: the linear path disowns this read (redone by crf_kernel)
+    unsigned long long *dbg;    // lab builds only (TK_LAB_STAMPS)
 };
 
 struct BandLayout {
     int R, W;
     size_t LP;
-    size_t latF, latB, offF, offB, scoreF, scoreB, rec, recw, segend, total;
+    size_t ckFm, ckBm, ckFf, ckBf, bndF, bndB, scoreF, scoreB, rec, segend, gate, total;
 };
 
 bool crf_band_fits(size_t max_seqlen);
-BandLayout crf_band_layout(size_t ntrans, size_t nblk, size_t nbatch, size_t max_seqlen, bool mod);
+BandLayout crf_band_layout(size_t ntrans, size_t nblk, size_t nbatch, size_t max_seqlen, bool mod,
+                           bool want_grad);
 int crf_band_dispatch(const BandArgs &a, int R, bool mod, hipStream_t stream);
 
 }  // namespace tk

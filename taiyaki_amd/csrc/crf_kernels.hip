@@ -42,6 +42,8 @@ struct CrfArgs {
     float *ckpt;                // workspace: checkpoint columns
     double *ckoff;              // workspace: checkpoint offsets
     uint32_t *status;
+    const int *gate;            // nullable; (N): only reads with gate[n] != 0 are computed (the band path's rejects)
+    float grad_scale;           // gradient multiplier (1 for the reference's operators)
 };
 
 __host__ __device__ inline int crf_ck(int R, int W, int kinds) {
@@ -87,6 +89,7 @@ __global__ __launch_bounds__(W *WAVE) void crf_kernel(CrfArgs a) {
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & (WAVE - 1);
     const int n = blockIdx.x;
     const int T = a.T, N = a.N, S = a.S, SP = S + 2;
+    if (a.gate != nullptr && a.gate[n] == 0) return;             // the linear band path owns this read
     const int L = a.seqlen[n];
     const bool want_grad = a.grad != nullptr;
 
@@ -454,7 +457,7 @@ __global__ __launch_bounds__(W *WAVE) void crf_kernel(CrfArgs a) {
                     }
                     wave_lds_fence();
                 }
-                const float g = colval * (-1.0f / (total * (float)T));
+                const float g = colval * (-a.grad_scale / (total * (float)T));
                 if (lane < S) {
                     bad |= !isfinite(g);
                     a.grad[(size_t)(t0 + row) * rowstride + (size_t)n * S + lane] = g;
@@ -600,37 +603,37 @@ static size_t crf_ckpt_bytes(size_t nblk, size_t nbatch, CrfShape sh) {
 }
 
 // Which form of kernel A runs (TK_CRF_MODE overrides: band | ckpt):
-//   band     crf_band.hip -- banded skewed sweep + row-parallel posterior pass (default whenever
-//            the sequences fit 16 waves x 256 cells and the two lattices fit the workspace cap)
-//   ckpt     the single-launch checkpoint/recompute kernel of this file: no lattice in HBM, three
-//            serial passes per read (workspace-bound batches)
+//   band     crf_band.hip -- linear-domain banded skewed sweep + recomputing gradient pass, followed
+//            by a GATED launch of crf_kernel that redoes the reads the band path disowned
+//            (default whenever the sequences fit 16 waves x 256 cells and the checkpoint columns
+//            fit the workspace cap)
+//   ckpt     the single-launch log-domain checkpoint/recompute kernel of this file on every read:
+//            three serial passes per read (workspace-bound batches, and the band path's safety net)
 enum CrfMode { CRF_BAND, CRF_CKPT };
 static size_t crf_lattice_cap_bytes() {
     size_t cap_mb = 40960;          // 40 GiB of the 288 GB
     if (const char *e = getenv("TK_CRF_LATTICE_MB")) cap_mb = (size_t)atoll(e);
     return cap_mb * 1024 * 1024;
 }
-static CrfMode crf_pick_mode(size_t ntrans, size_t nblk, size_t nbatch, size_t max_seqlen, bool want_grad,
-                             bool mod, CrfShape sh) {
+static CrfMode crf_pick_mode(size_t ntrans, size_t nblk, size_t nbatch, size_t max_seqlen, bool want_grad) {
     const char *e = getenv("TK_CRF_MODE");
-    (void)sh;
     const bool force_ckpt = e && e[0] == 'c';
     if (!force_ckpt && crf_band_fits(max_seqlen) &&
-        (!want_grad || crf_band_layout(ntrans, nblk, nbatch, max_seqlen, mod).total <= crf_lattice_cap_bytes()))
+        crf_band_layout(ntrans, nblk, nbatch, max_seqlen, true, want_grad).total <= crf_lattice_cap_bytes())
         return CRF_BAND;
     return CRF_CKPT;
 }
 
+// workspace = [band layout (band mode only)] [checkpoint columns + offsets of crf_kernel]
 size_t crf_workspace_bytes(size_t ntrans, size_t nblk, size_t nbatch, size_t max_seqlen,
                            int want_grad) {
-    if (!want_grad) return 256;
     if (max_seqlen == 0) max_seqlen = nblk + 1;
     const CrfShape sh = crf_pick_shape(max_seqlen);
+    size_t total = crf_ckpt_bytes(nblk, nbatch, sh);
     // (the cat-mod layout is the larger one: an upper bound for both)
-    switch (crf_pick_mode(ntrans, nblk, nbatch, max_seqlen, true, true, sh)) {
-        case CRF_BAND: return crf_band_layout(ntrans, nblk, nbatch, max_seqlen, true).total;
-        default: return crf_ckpt_bytes(nblk, nbatch, sh);
-    }
+    if (crf_pick_mode(ntrans, nblk, nbatch, max_seqlen, want_grad != 0) == CRF_BAND)
+        total += crf_band_layout(ntrans, nblk, nbatch, max_seqlen, true, want_grad != 0).total;
+    return total;
 }
 
 template <int R, int W, bool MOD>
@@ -665,7 +668,7 @@ int crf_dispatch(const float *logprob, size_t ntrans, size_t nblk, size_t nbatch
                  const int32_t *stayidx, const int32_t *moveidx, const int32_t *modidx,
                  const float *modfact, const int32_t *seqlen, const int64_t *seqoff,
                  size_t max_seqlen, size_t ncan, float sharp_can, float sharp_mod,
-                 float out_scale, float *cost, float *grad, void *workspace,
+                 float out_scale, float grad_scale, float *cost, float *grad, void *workspace,
                  size_t workspace_bytes, uint32_t *status, hipStream_t stream) {
     if (ntrans > 62 || ncan > ntrans || ncan == 0) return 2;
     if (max_seqlen == 0) max_seqlen = nblk + 1;
@@ -688,13 +691,16 @@ int crf_dispatch(const float *logprob, size_t ntrans, size_t nblk, size_t nbatch
     a.c_can = sharp_can * LOG2E;
     a.c_mod = sharp_mod * LOG2E;
     a.out_scale = out_scale;
+    a.grad_scale = grad_scale;
     a.cost = cost;
     a.grad = grad;
+    a.gate = nullptr;
+    a.status = status;
     const bool mod = modidx != nullptr;
-    const CrfMode mode = crf_pick_mode(ntrans, nblk, nbatch, max_seqlen, grad != nullptr, true, sh);
-    if (mode == CRF_BAND) {
-        const BandLayout l = crf_band_layout(ntrans, nblk, nbatch, max_seqlen, mod);
-        char *wb = static_cast<char *>(workspace);
+    char *wb = static_cast<char *>(workspace);
+    if (crf_pick_mode(ntrans, nblk, nbatch, max_seqlen, grad != nullptr) == CRF_BAND) {
+        const bool g = grad != nullptr;
+        const BandLayout l = crf_band_layout(ntrans, nblk, nbatch, max_seqlen, mod, g);
         BandArgs b;
         b.lp = logprob;
         b.T = (int)nblk;
@@ -710,34 +716,41 @@ int crf_dispatch(const float *logprob, size_t ntrans, size_t nblk, size_t nbatch
         b.c_can = sharp_can * LOG2E;
         b.c_mod = sharp_mod * LOG2E;
         b.out_scale = out_scale;
+        b.grad_scale = grad_scale;
         b.cost = cost;
         b.grad = grad;
         b.status = status;
         b.W = l.W;
         b.LP = (int)l.LP;
-        const bool g = grad != nullptr;
-        b.latF = g ? reinterpret_cast<float *>(wb + l.latF) : nullptr;
-        b.latB = g ? reinterpret_cast<float *>(wb + l.latB) : nullptr;
-        b.offF = g ? reinterpret_cast<int *>(wb + l.offF) : nullptr;
-        b.offB = g ? reinterpret_cast<int *>(wb + l.offB) : nullptr;
+        b.Wp = (int)(l.LP / WAVE);
+        b.ckFm = g ? reinterpret_cast<float *>(wb + l.ckFm) : nullptr;
+        b.ckBm = g ? reinterpret_cast<float *>(wb + l.ckBm) : nullptr;
+        b.ckFf = g ? reinterpret_cast<int *>(wb + l.ckFf) : nullptr;
+        b.ckBf = g ? reinterpret_cast<int *>(wb + l.ckBf) : nullptr;
+        b.bndF = g ? reinterpret_cast<float *>(wb + l.bndF) : nullptr;
+        b.bndB = g ? reinterpret_cast<float *>(wb + l.bndB) : nullptr;
         b.scoreF = g ? reinterpret_cast<double *>(wb + l.scoreF) : nullptr;
         b.scoreB = g ? reinterpret_cast<double *>(wb + l.scoreB) : nullptr;
         b.rec = g ? reinterpret_cast<uint32_t *>(wb + l.rec) : nullptr;
-        b.recw = g ? reinterpret_cast<float *>(wb + l.recw) : nullptr;
         b.segend = g ? reinterpret_cast<int *>(wb + l.segend) : nullptr;
+        b.gate = reinterpret_cast<int *>(wb + l.gate);
         b.dbg = nullptr;
-        return crf_band_dispatch(b, l.R, mod, stream);
+        const int rc = crf_band_dispatch(b, l.R, mod, stream);
+        if (rc != 0) return rc;
+        // the reads the linear path disowned, redone in the log domain
+        a.gate = b.gate;
+        wb += crf_band_layout(ntrans, nblk, nbatch, max_seqlen, true, g).total;
+        if (const char *e = getenv("TK_CRF_NO_FALLBACK"))       // lab: time / test the band path alone
+            if (e[0] == '1') return 0;
     }
     {
-        const int CK = crf_ck(sh.R, sh.W, modidx != nullptr ? 3 : 2);
+        const int CK = crf_ck(sh.R, sh.W, mod ? 3 : 2);
         const size_t NK = (nblk + CK - 1) / CK;
         const size_t ckb = (nbatch * NK * (size_t)sh.R * sh.W * WAVE * sizeof(float) + 255) / 256 * 256;
-        char *wsb = static_cast<char *>(workspace);
-        a.ckpt = reinterpret_cast<float *>(wsb);
-        a.ckoff = reinterpret_cast<double *>(wsb + (grad ? ckb : 0));
+        a.ckpt = reinterpret_cast<float *>(wb);
+        a.ckoff = reinterpret_cast<double *>(wb + (grad ? ckb : 0));
     }
-    a.status = status;
-    return modidx != nullptr ? crf_launch_mod<true>(sh, a, stream) : crf_launch_mod<false>(sh, a, stream);
+    return mod ? crf_launch_mod<true>(sh, a, stream) : crf_launch_mod<false>(sh, a, stream);
 }
 
 }  // namespace tk

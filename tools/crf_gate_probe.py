@@ -1,0 +1,91 @@
+#!/usr/bin/env python
+"""Which reads does kernel A's linear band path disown (gate -> log-domain crf_kernel), and how far is
+it from the checkpoint kernel on the reads it keeps?
+
+    python tools/crf_gate_probe.py [--shapes cfg2,cfg2r,cfg5,rowK,narrow,sharp]
+Runs every shape three times: TK_CRF_MODE=ckpt (the log-domain kernel on every read = the reference
+arithmetic), band with TK_CRF_NO_FALLBACK=1 (the linear path alone) and band as shipped."""
+import argparse
+import os
+import sys
+
+import numpy as np
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from taiyaki_amd import _lib, ctc, synth  # noqa: E402
+
+SHAPES = {
+    "tiny": (20, [9, 1, 21, 20, 2, 0], 1.0, None),
+    "t37": (37, [12, 30, 38, 5], 1.0, None),
+    "t200": (200, [90, 150, 201, 30, 195, 180], 1.0, None),
+    "cfg2": (800, "speed128", 1.0, None),
+    "cfg2r": (800, "real128", 1.0, None),
+    "narrow": (800, [400, 533, 380, 700, 780, 800, 801, 790, 760, 100, 5, 1], 1.0, None),
+    "sharp": (800, "speed32", 2.5, None),
+    "cfg4": (800, "speed128", 1.0, (1, 1, 0, 0)),
+    "cfg4w1": (800, "speed128", 1.0, (1, 1, 0, 0)),
+    "cfg5": (1600, "speed64", 1.0, None),
+    "rowK": (4000, "speed256", 1.0, None),
+    "t19": (19, [20, 3], 1.0, None),
+}
+
+
+def run(x, seqs, seqlens, sharp, extra, env):
+    for k in ("TK_CRF_MODE", "TK_CRF_NO_FALLBACK"):
+        os.environ.pop(k, None)
+    os.environ.update(env)
+    # poison what the caching allocator will hand out for the outputs: a read nobody computes shows as NaN
+    junk = [torch.full_like(x, float("nan")), torch.full((x.shape[1],), float("nan"), device=x.device)]
+    del junk
+    if extra:
+        cost, grad = ctc._run(x, seqs, seqlens, sharp, 1.0, 1.0 / sharp, 40, True, *extra)
+    else:
+        cost, grad = ctc._run(x, seqs, seqlens, sharp, sharp, 1.0 / sharp, x.shape[2], True)
+    torch.cuda.synchronize()
+    return cost.cpu().numpy(), grad.cpu().numpy()
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--shapes", default="tiny,t19,t37,t200,cfg2,cfg2r,narrow,sharp,cfg4,cfg5,rowK")
+    args = ap.parse_args()
+    dev = torch.device("cuda:0")
+    _lib.set_strict(False)
+    for sh in args.shapes.split(","):
+        T, lens, sharp, mods = SHAPES[sh]
+        if isinstance(lens, str):
+            N = int(lens[5:] if lens.startswith("speed") else lens[4:])
+            seqlens = None if lens.startswith("speed") else synth.realistic_seqlens(T, N, 17000, T * 5, 9.0)
+        else:
+            N, seqlens = len(lens), np.array(lens, dtype=np.int32)
+        inp = synth.crf_case(T, N, 1, seqlens=seqlens, nmods_per_base=mods)
+        x = torch.from_numpy(inp["scores"]).to(dev)
+        seqs, sl = torch.from_numpy(inp["seqs"]), torch.from_numpy(inp["seqlens"])
+        extra = ()
+        if mods is not None:
+            wts = inp["mod_cat_weights"] * (0.125 if sh.endswith("w1") else 1.0)
+            extra = (torch.from_numpy(inp["mod_cats"]), inp["can_mods_offsets"], wts)
+        c0, g0 = run(x, seqs, sl, sharp, extra, dict(TK_CRF_MODE="ckpt"))
+        c1, g1 = run(x, seqs, sl, sharp, extra, dict(TK_CRF_MODE="band", TK_CRF_NO_FALLBACK="1"))
+        c2, g2 = run(x, seqs, sl, sharp, extra, dict(TK_CRF_MODE="band"))
+        with np.errstate(all="ignore"):
+            kept = np.isfinite(c1) & np.array([np.isfinite(g1[:, n]).all() for n in range(N)])
+            rel = np.abs(c2 - c0) / np.maximum(np.abs(c0), 1e-30)
+            gd = np.array([np.abs(g2[:, n] - g0[:, n]).max() for n in range(N)])
+            relk = np.abs(c1 - c0) / np.maximum(np.abs(c0), 1e-30)
+            gdk = np.array([np.abs(g1[:, n] - g0[:, n]).max() for n in range(N)])
+        print("%-7s T=%d N=%d sharp=%.1f: gated %d / %d reads; shipped vs ckpt: cost rel %.2e grad %.2e; "
+              "kept reads, linear path alone: cost rel %.2e grad %.2e"
+              % (sh, T, N, sharp, int((~kept).sum()), N, np.nanmax(rel), np.nanmax(gd),
+                 np.nanmax(np.where(kept, relk, 0)), np.nanmax(np.where(kept, gdk, 0))), flush=True)
+        if (~kept).any() and N <= 16:
+            print("        gated reads: lengths", inp["seqlens"][~kept].tolist())
+    try:
+        _lib.raise_if_nonfinite()
+    except Exception as e:                      # noqa: BLE001
+        print("status:", type(e).__name__, str(e)[:80])
+
+
+if __name__ == "__main__":
+    main()

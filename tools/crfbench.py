@@ -21,7 +21,7 @@ SHAPES = {"cfg2": (800, 128, None), "cfg2r": (800, 128, 4000), "cfg5": (1600, 64
           "one": (800, 1, 4000), "short": (800, 128, 450), "short1": (800, 1, 450), "mid": (800, 128, 1100)}
 MODES = {"band1": dict(TK_CRF_MODE="band", TK_CRF_BAND_R="1"), "band2": dict(TK_CRF_MODE="band", TK_CRF_BAND_R="2"),
          "band4": dict(TK_CRF_MODE="band", TK_CRF_BAND_R="4"), "band": dict(TK_CRF_MODE="band"),
-         "ckpt": dict(TK_CRF_MODE="ckpt")}
+         "bandnf": dict(TK_CRF_MODE="band", TK_CRF_NO_FALLBACK="1"), "ckpt": dict(TK_CRF_MODE="ckpt")}
 
 
 def timed(fn, reps):
@@ -63,10 +63,10 @@ def main():
             extra = (torch.from_numpy(inp["mod_cats"]), inp["can_mods_offsets"], inp["mod_cat_weights"])
         ref = None
         for mode in args.modes.split(","):
-            for k in ("TK_CRF_MODE", "TK_CRF_BAND_R"):
+            for k in ("TK_CRF_MODE", "TK_CRF_BAND_R", "TK_CRF_NO_FALLBACK"):
                 os.environ.pop(k, None)
             os.environ.update(MODES[mode])
-            if mode.startswith("band") and mode != "band":
+            if mode.startswith("band") and mode[4:].isdigit():
                 R = int(mode[4:])
                 if int(inp["seqlens"].max()) > 1024 * R:
                     continue

@@ -178,6 +178,8 @@ class LossOps:
         if realistic_chunk_len:
             seqlens = synth.realistic_seqlens(T, N, 17000 + seed, realistic_chunk_len, spb)
         inp = synth.crf_case(T, N, seed, seqlens=seqlens, nmods_per_base=CAN_NMODS if cat_mod else None)
+        if cat_mod:
+            synth.normalise_mod_columns(inp)    # log-softmax mod columns, like the producer layer's
         self.S = inp["scores"].shape[2]
         self.x = torch.from_numpy(inp["scores"]).to(dev)
         self.x40 = self.x[:, :, :40].contiguous() if cat_mod else self.x

@@ -35,6 +35,7 @@ struct BandArgs {
     double *scoreF, *scoreB;    // [N]  log2 scores of the two sweeps
     uint32_t *rec;              // [N][Wp][KINDS][64]  sorted transition instances of every 64-cell chunk
     int *segend;                // [N][Wp][64]  end of every transition id's segment
+    const float *zeros;         // 64 B of zeros (the boundary row of lanes that take none)
     int *gate;                  // [N]  1: the linear path disowns this read (redone by crf_kernel)
     unsigned long long *dbg;    // lab builds only (TK_LAB_STAMPS)
 };
@@ -42,7 +43,7 @@ struct BandArgs {
 struct BandLayout {
     int R, W;
     size_t LP;
-    size_t ckFm, ckBm, ckFf, ckBf, bndF, bndB, scoreF, scoreB, rec, segend, gate, total;
+    size_t ckFm, ckBm, ckFf, ckBf, bndF, bndB, scoreF, scoreB, rec, segend, gate, zeros, total;
 };
 
 bool crf_band_fits(size_t max_seqlen);

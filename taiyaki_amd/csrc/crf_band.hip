@@ -452,6 +452,7 @@ __global__ __launch_bounds__(WCAP *WAVE) void crf_band_sweep_kernel(BandArgs a) 
     const int n = blockIdx.x - slot3 * N;
     const int L = a.seqlen[n];
     if (role == 2 && tid == 0) a.gate[n] = 0;
+    if (role == 2 && tid < 16) const_cast<float *>(a.zeros)[tid] = 0.f;   // (every rank workgroup: the same zeros)
     if (L == 0 || L > W * PW) {
         // c_crf_flipflop.c:269-272: cost 0 for an empty read (the gradient pass does it when
         // there is one); too long for the launch: flagged
@@ -614,9 +615,9 @@ __global__ __launch_bounds__(POST_WAVES *WAVE) void crf_band_posterior_kernel(Ba
     // (a row of the block that a chunk is not live for only adds exact zeros: its forward or its
     // backward cells are all dead there)
 
-    float colacc[BK], total[BK];
+    float pacc[BK];
 #pragma unroll
-    for (int k = 0; k < BK; ++k) colacc[k] = total[k] = 0.f;
+    for (int k = 0; k < BK; ++k) pacc[k] = 0.f;
     const size_t ckrow = ((size_t)n * NB + jb) * a.LP;
     const float *bndFn = a.bndF + ((size_t)n * NB + jb) * W * BK;
     const float *bndBn = a.bndB + ((size_t)n * NB + jb) * W * BK;
@@ -662,16 +663,16 @@ __global__ __launch_bounds__(POST_WAVES *WAVE) void crf_band_posterior_kernel(Ba
         // boundary cells: forward from chunk ck-1 into lane 0, backward from chunk ck+1 into lane 63
         float einF[BK], einB[BK];
         {
-            const f4 *pF = reinterpret_cast<const f4 *>(bndFn + (size_t)max(ck - 1, 0) * BK);
-            const f4 *pB = reinterpret_cast<const f4 *>(bndBn + (size_t)min(ck + 1, W - 1) * BK);
-            const bool useF = plF && lane == 0, useB = plB && lane == WAVE - 1;
+            // (the lanes that take no boundary cell read a row of zeros instead: no selects)
+            const f4 *pF = reinterpret_cast<const f4 *>((plF && lane == 0) ? bndFn + (size_t)(ck - 1) * BK : a.zeros);
+            const f4 *pB = reinterpret_cast<const f4 *>((plB && lane == WAVE - 1) ? bndBn + (size_t)(ck + 1) * BK : a.zeros);
 #pragma unroll
             for (int q4 = 0; q4 < BK / 4; ++q4) {
                 const f4 e = pF[q4], g = pB[q4];
 #pragma unroll
                 for (int q = 0; q < 4; ++q) {
-                    einF[q4 * 4 + q] = useF ? e[q] : 0.f;
-                    einB[q4 * 4 + q] = useB ? g[q] : 0.f;
+                    einF[q4 * 4 + q] = e[q];
+                    einB[q4 * 4 + q] = g[q];
                 }
             }
         }
@@ -696,7 +697,6 @@ __global__ __launch_bounds__(POST_WAVES *WAVE) void crf_band_posterior_kernel(Ba
 #pragma unroll
         for (int r = 0; r < EPL; ++r) addr[r] = (int)a.rec[(((size_t)n * W + ck) * EPL + r) * WAVE + lane];
         const int sidx = a.segend[((size_t)n * W + ck) * WAVE + lane] - 1;
-        const int sq_addr = (sidx / EPL) * 4, sq_reg = sidx % EPL;
 
         // ---- backward columns t0+1 .. t0+nrows: bv[i] = column t0+i+1 (bv[nrows-1] = the checkpoint)
         if (!FULL) {
@@ -730,10 +730,10 @@ __global__ __launch_bounds__(POST_WAVES *WAVE) void crf_band_posterior_kernel(Ba
                 if (!FULL && i + 1 >= nrows) continue;          // wave-uniform
                 // consume row t0+i+1: column t0+i+2 -> t0+i+1
                 float nxt[R];
-                const float upl = wave_shift_down1(bv[i + 1][0], 0.f);     // the next lane's first cell (lane 63: the ring's)
+                const float upl = wave_shift_down1(bv[i + 1][0], einB[i + 1]);     // the next lane's first cell (lane 63: the ring's)
 #pragma unroll
                 for (int j = 0; j < R; ++j) {
-                    const float up = (j == R - 1) ? upl + einB[i + 1] : bv[i + 1][j < R - 1 ? j + 1 : 0];
+                    const float up = (j == R - 1) ? upl : bv[i + 1][j < R - 1 ? j + 1 : 0];
                     nxt[j] = fmaf(bv[i + 1][j], esr[i + 1][j], up * emo[i + 1][j]);
                 }
 #pragma unroll
@@ -750,7 +750,7 @@ __global__ __launch_bounds__(POST_WAVES *WAVE) void crf_band_posterior_kernel(Ba
             for (int kk = 0; kk < RG; ++kk) {
                 const int k = g0 + kk;
                 float Fs[R], Fm[R];
-                const float upl = wave_shift_up1(fv[R - 1], 0.f);       // the previous lane's last cell (lane 0: the ring's)
+                const float upl = wave_shift_up1(fv[R - 1], einF[k]);   // the previous lane's last cell (lane 0: the ring's)
 #pragma unroll
                 for (int j = 0; j < R; ++j) {
                     float em;
@@ -758,7 +758,7 @@ __global__ __launch_bounds__(POST_WAVES *WAVE) void crf_band_posterior_kernel(Ba
                         em = fast_exp2(fmaf(bperm(di4[MOD ? j : 0], raw[k]), fwi[MOD ? j : 0], bperm(mi4[j], raw[k]) * c));
                     else
                         em = bperm(mi4[j], er[k]);
-                    const float up = (j == 0) ? upl + einF[k] : fv[j > 0 ? j - 1 : 0];
+                    const float up = (j == 0) ? upl : fv[j > 0 ? j - 1 : 0];
                     Fs[j] = fv[j] * esr[k][j];
                     Fm[j] = up * (em * scF[j]);
                 }
@@ -807,7 +807,7 @@ __global__ __launch_bounds__(POST_WAVES *WAVE) void crf_band_posterior_kernel(Ba
             float base[RG];
 #pragma unroll
             for (int kk = 0; kk < RG; ++kk) base[kk] = wave_scan_fused(v[kk][EPL - 1]) - v[kk][EPL - 1];
-            if constexpr (EPL > 2) {
+            if constexpr (true) {
                 // the inclusive prefixes go back to LDS in sorted order (the rows' regions are free
                 // again: every lane has read its values), the segment ends are one read each
                 wave_lds_fence();
@@ -821,22 +821,10 @@ __global__ __launch_bounds__(POST_WAVES *WAVE) void crf_band_posterior_kernel(Ba
             }
 #pragma unroll
             for (int kk = 0; kk < RG; ++kk) {
-                float P = 0.f;
-                if constexpr (EPL > 2) {
-                    P = sP[kk * (EPL * WAVE) + max(sidx, 0)];
-                } else {
-#pragma unroll
-                    for (int r = 0; r < EPL; ++r) {
-                        const float cand = bperm(sq_addr, v[kk][r] + base[kk]);
-                        if (sq_reg == r) P = cand;
-                    }
-                }
-                if (sidx < 0) P = 0.f;
-                const float prev = wave_shift_up1(P, 0.f);
-                colacc[g0 + kk] += P - prev;
-                // row normaliser: all stay and move instances (the reference's softmax over the
-                // 2L-1 transitions, c_crf_flipflop.c:400-401); mod ids sort after them
-                total[g0 + kk] += __int_as_float(__builtin_amdgcn_readlane(__float_as_int(P), a.ncan - 1));
+                // lane b: the prefix at the end of id b's segment, summed over the chunks (the per-id
+                // sums and the row total are differences / one lane of it: taken once, after the loop)
+                const float P = sP[kk * (EPL * WAVE) + max(sidx, 0)];
+                pacc[g0 + kk] += (sidx < 0) ? 0.f : P;
             }
             wave_lds_fence();
         }
@@ -856,10 +844,15 @@ __global__ __launch_bounds__(POST_WAVES *WAVE) void crf_band_posterior_kernel(Ba
 #pragma unroll
     for (int k = 0; k < BK; ++k) {
         if (k < nrows) {
-            const float dev = fast_log2(total[k]) - zfrac;
+            // per-id sums = differences of the prefixes at the segment ends.  Row normaliser: all stay
+            // and move instances (the reference's softmax over the 2L-1 transitions,
+            // c_crf_flipflop.c:400-401); mod ids sort after them
+            const float colacc = pacc[k] - wave_shift_up1(pacc[k], 0.f);
+            const float total = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(pacc[k]), a.ncan - 1));
+            const float dev = fast_log2(total) - zfrac;
             lost |= !(dev > -ROWZ_TOL && dev < ROWZ_TOL);
             // gradient of -score / T  (ctc.pyx:113)
-            const float g = colacc[k] * (-a.grad_scale / (total[k] * (float)T));
+            const float g = colacc * (-a.grad_scale / (total * (float)T));
             if (lane < S) a.grad[(size_t)(t0 + k) * rowstride + (size_t)n * S + lane] = g;
         }
     }
@@ -910,6 +903,8 @@ BandLayout crf_band_layout(size_t ntrans, size_t nblk, size_t nbatch, size_t max
     l.segend = take(nbatch * Wp * WAVE * sizeof(int));
     l.gate = off;
     off += (nbatch * sizeof(int) + 255) / 256 * 256;
+    l.zeros = off;
+    off += 256;
     l.total = off + 256;
     return l;
 }

@@ -734,6 +734,7 @@ int crf_dispatch(const float *logprob, size_t ntrans, size_t nblk, size_t nbatch
         b.rec = g ? reinterpret_cast<uint32_t *>(wb + l.rec) : nullptr;
         b.segend = g ? reinterpret_cast<int *>(wb + l.segend) : nullptr;
         b.gate = reinterpret_cast<int *>(wb + l.gate);
+        b.zeros = reinterpret_cast<const float *>(wb + l.zeros);
         b.dbg = nullptr;
         const int rc = crf_band_dispatch(b, l.R, mod, stream);
         if (rc != 0) return rc;

@@ -147,6 +147,19 @@ def crf_case(T, N, seed, nbase=4, nmods_per_base=None, seqlens=None):
     return out
 
 
+def normalise_mod_columns(inp, ncan=40):
+    """Turn the free scores of a cat-mod case's mod columns into what GlobalNormFlipFlopCatMod emits
+    there (layers.py:1627-1640): per canonical base a log-softmax over {unmodified, its
+    modifications}.  In place; returns inp."""
+    offs = np.asarray(inp["can_mods_offsets"])
+    sc = inp["scores"]
+    for b in range(len(offs) - 1):
+        blk = sc[:, :, ncan + offs[b]:ncan + offs[b + 1]].astype(np.float64)
+        blk -= np.log(np.exp(blk).sum(axis=2, keepdims=True))
+        sc[:, :, ncan + offs[b]:ncan + offs[b + 1]] = blk.astype(np.float32)
+    return inp
+
+
 def mapped_reads(nreads, seed, nlabel=4, mean_reflen=400, mean_dwell=9, clip_prob=0.5,
                  slip_prob=0.03, long_dwell_prob=0.01):
     """Synthetic per-read dictionaries with the fields of the reference's mapped-signal

@@ -43,3 +43,79 @@ def test_band_windows_cover_exactly_the_cells_on_complete_paths():
                 if p <= t and L - 1 - p <= T - t:      # column t, on a complete path
                     j0, j1 = win[p // PW]
                     assert j0 <= t // KB <= j1 or t == T, (T, L, t, p)
+
+
+# ---------------------------------------------------------------------------------------------
+# round 3: the LINEAR-domain arithmetic of the band kernel (tests/helpers/crf_linear_model.py)
+# ---------------------------------------------------------------------------------------------
+def _reads(oracle_mod, T, Ls, seed=None):
+    from taiyaki_amd import synth
+    inp = synth.crf_case(T, len(Ls), (3 + T) if seed is None else seed, seqlens=np.array(Ls, dtype=np.int32))
+    mv, stv = oracle_mod.flipflop_indices(inp["seqs"], inp["seqlens"], 4)
+    off = np.concatenate([[0], np.cumsum(Ls)])
+    for n, L in enumerate(Ls):
+        yield n, L, inp, stv[off[n]:off[n] + L].astype(int), mv[off[n] - n:off[n] - n + L - 1].astype(int)
+
+
+@pytest.mark.parametrize("T,Ls,PW", [
+    (20, [9, 1, 21, 20, 2], 4),         # L = 1, L = T, L = T + 1 (every block moves)
+    (37, [12, 30, 38, 5], 4),
+    (64, [33, 50, 7], 8),
+    (50, [25, 26], 64),                 # one chunk
+    (19, [20, 3], 2),                   # T not a multiple of the time block
+    (200, [90, 150, 30, 180], 64),      # cliffs of 2^60+ between neighbouring cells near the diagonal front
+    (400, [200, 266, 350], 64),
+])
+def test_linear_band_model_matches_oracle(oracle_mod, T, Ls, PW):
+    from tests.helpers import crf_linear_model as lin
+    oloss = ograd = None
+    for n, L, inp, st, mo in _reads(oracle_mod, T, Ls):
+        if oloss is None:
+            oloss, ograd = oracle_mod.crf_flipflop_loss(inp["scores"], inp["seqs"], inp["seqlens"], 1.0)
+        cost, grad, info = lin.crf_model(inp["scores"][:, n], st, mo, L, PW)
+        assert not info["bad"], (T, L, info)
+        assert abs(cost - oloss[n]) <= 2e-6 * abs(oloss[n]), (L, cost, oloss[n])
+        assert np.abs(grad - ograd[:, n]).max() < 2e-6
+        # every row's posterior total is the partition function (the kernel's mass-loss detector)
+        assert info["rowz_dev"] < 1e-4
+        assert abs(info["scoreF"] - info["scoreB"]) < 1e-4
+
+
+def test_linear_band_model_disowns_what_it_cannot_represent(oracle_mod):
+    """Bands a few cells wide lose their (tiny) front cells to the frames' flush, sharpened scores
+    overflow inside a block: the model -- like the kernel -- must SAY so (non-finite score, or a
+    row whose posterior total is not the partition function), never return a wrong number."""
+    from tests.helpers import crf_linear_model as lin
+    flagged = 0
+    for T, Ls, sharp in ((200, [201, 199, 195], 1.0), (400, [390, 401], 1.0), (200, [100, 150], 2.5)):
+        oloss = None
+        for n, L, inp, st, mo in _reads(oracle_mod, T, Ls):
+            if oloss is None:
+                oloss, ograd = oracle_mod.crf_flipflop_loss(inp["scores"], inp["seqs"], inp["seqlens"], sharp)
+            cost, grad, info = lin.crf_model(inp["scores"][:, n], st, mo, L, 64, sharp=sharp)
+            disowned = info["bad"] or not (info["rowz_dev"] < 1e-3)
+            flagged += disowned
+            if not disowned:
+                assert abs(cost - oloss[n]) <= 2e-6 * abs(oloss[n])
+                assert np.abs(grad - ograd[:, n]).max() < 2e-6
+    assert flagged >= 3
+
+
+def test_linear_band_model_catmod(oracle_mod):
+    from taiyaki_amd import synth
+    from tests.helpers import crf_linear_model as lin
+    T, Ls = 60, [25, 40, 7]
+    inp = synth.crf_case(T, len(Ls), 11, seqlens=np.array(Ls, dtype=np.int32), nmods_per_base=(1, 1, 0, 0))
+    wts = (inp["mod_cat_weights"] * 0.125).astype(np.float32)
+    oloss, ograd = oracle_mod.cat_mod_flipflop_loss(inp["scores"], inp["seqs"], inp["seqlens"], inp["mod_cats"],
+                                                    inp["can_mods_offsets"], wts, 1.0)
+    mv, stv = oracle_mod.flipflop_indices(inp["seqs"], inp["seqlens"], 4)
+    mdv, mfv = oracle_mod.cat_mod_indices(inp["seqs"], inp["seqlens"], inp["mod_cats"], inp["can_mods_offsets"], wts, 4)
+    off = np.concatenate([[0], np.cumsum(Ls)])
+    for n, L in enumerate(Ls):
+        sl = slice(off[n] - n, off[n] - n + L - 1)
+        cost, grad, info = lin.crf_model(inp["scores"][:, n], stv[off[n]:off[n] + L].astype(int), mv[sl].astype(int),
+                                         L, 16, mod=mdv[sl].astype(int), modfact=mfv[sl].astype(np.float32))
+        assert not info["bad"]
+        assert abs(cost - oloss[n]) <= 2e-6 * abs(oloss[n])
+        assert np.abs(grad - ograd[:, n]).max() < 2e-6

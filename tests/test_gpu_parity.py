@@ -489,10 +489,10 @@ def test_logz_streaming_transfer_kernel_is_the_same_arithmetic(oracle_mod, gpu_d
 @pytest.mark.parametrize("mode_mb", ["0", "6144"])
 @pytest.mark.parametrize("name", ["t7n2_len1", "t50n3_zero_last", "t200n8", "t130n5_long", "t300n3_wide"])
 def test_crf_both_gradient_modes(oracle_mod, gpu_device, name, mode_mb, monkeypatch):
-    """The gradient path has two implementations: the band of both lattices in HBM (banded
-    skewed sweep + row-parallel posterior pass, csrc/crf_band.hip) and checkpoint + recompute
-    (one kernel) for batches whose lattices exceed the workspace cap.  TK_CRF_LATTICE_MB=0
-    forces the second; both must match the oracle."""
+    """The gradient path has two implementations: the linear-domain banded sweep + recomputing
+    gradient pass (csrc/crf_band.hip) and the log-domain checkpoint + recompute kernel (one launch)
+    for batches whose checkpoint columns exceed the workspace cap -- and for the reads the first
+    one disowns.  TK_CRF_LATTICE_MB=0 forces the second; both must match the oracle."""
     monkeypatch.setenv("TK_CRF_LATTICE_MB", mode_mb)
     inp = cases.crf_inputs(cases.CRF_SMALL[name])
     r = parity.compare_crf(oracle_mod, inp, 1.0, gpu_device)
@@ -532,12 +532,96 @@ def test_crf_band_shapes_against_oracle(oracle_mod, gpu_device, R, monkeypatch):
             assert parity.abs_err(grad[:, n:n + 1], ograd) < GRAD_ATOL, (T, L)
 
 
+def _crf_alone(inp, n, L, off):
+    return dict(scores=np.ascontiguousarray(inp["scores"][:, n:n + 1]), seqs=inp["seqs"][off[n]:off[n + 1]],
+                seqlens=np.array([L], dtype=np.int32))
+
+
+@pytest.mark.parametrize("R", ["1", "4"])
+def test_crf_linear_band_path_disowns_reads_and_the_log_domain_kernel_redoes_them(oracle_mod, gpu_device, R,
+                                                                                  monkeypatch):
+    """Round 3: the band path works in the LINEAR domain (per-cell power-of-two frames) and is
+    exact or says so.  One batch holds reads it keeps (wide bands), reads it must disown (bands
+    a few cells wide lose their front to the frames' flush; L = T + 1 is one forced path) and an
+    empty read.  (a) as shipped every read matches the oracle; (b) with the fallback launch
+    suppressed (TK_CRF_NO_FALLBACK=1) and the outputs poisoned, the kept reads are already right
+    and the disowned ones are NOT computed -- nobody returns a wrong number."""
+    import torch
+    from taiyaki_amd import ctc, synth
+    monkeypatch.setenv("TK_CRF_MODE", "band")
+    monkeypatch.setenv("TK_CRF_BAND_R", R)
+    T, Ls = 400, [200, 390, 401, 150, 399, 266, 1, 0]
+    inp = synth.crf_case(T, len(Ls), 5, seqlens=np.array(Ls, dtype=np.int32))
+    off = np.concatenate([[0], np.cumsum(Ls)])
+    x = torch.from_numpy(inp["scores"]).to(gpu_device)
+    seqs, sl = torch.from_numpy(inp["seqs"]), torch.from_numpy(inp["seqlens"])
+
+    def run():
+        junk = [torch.full_like(x, float("nan")), torch.full((len(Ls),), float("nan"), device=gpu_device)]
+        del junk                        # the caching allocator hands these blocks out for the outputs
+        c, g = ctc._run(x, seqs, sl, 1.0, 1.0, 1.0, 40, True)
+        torch.cuda.synchronize()
+        return c.cpu().numpy(), g.cpu().numpy()
+
+    cost, grad = run()
+    monkeypatch.setenv("TK_CRF_NO_FALLBACK", "1")
+    cost_nf, grad_nf = run()
+    kept = []
+    for n, L in enumerate(Ls):
+        if L == 0:
+            assert cost[n] == 0.0 and np.all(grad[:, n] == 0.0)
+            continue
+        oloss, ograd = parity.oracle_crf(oracle_mod, _crf_alone(inp, n, L, off), 1.0)
+        # (a loss that is itself ~0 is a cancelled sum: bound its absolute error instead)
+        assert (parity.rel_err(cost[n:n + 1], oloss) < LOSS_RTOL
+                or parity.abs_err(cost[n:n + 1], oloss) < 2e-6), (L, cost[n], oloss)
+        assert parity.abs_err(grad[:, n:n + 1], ograd) < GRAD_ATOL, L
+        own = np.isfinite(cost_nf[n]) and np.isfinite(grad_nf[:, n]).all()
+        if own:
+            kept.append(L)
+            assert cost_nf[n] == cost[n] and np.array_equal(grad_nf[:, n], grad[:, n])
+    # wide bands stay on the linear path, the forced path (L = T + 1) and the 2-cell band do not
+    assert 200 in kept and 150 in kept and 266 in kept, kept
+    assert 401 not in kept and 399 not in kept, kept
+
+
+def test_crf_sharpened_scores_take_the_log_domain_kernel(oracle_mod, gpu_device, monkeypatch):
+    """sharp = 2.5 puts weights of 2^(+-18) on a step: eight of them overflow a block of the linear
+    path, which must notice (non-finite sweep score) and hand the read over."""
+    from taiyaki_amd import synth
+    monkeypatch.setenv("TK_CRF_MODE", "band")
+    T, N = 300, 6
+    inp = synth.crf_case(T, N, 9)
+    r = parity.compare_crf(oracle_mod, inp, 2.5, gpu_device)
+    assert r["finite"]
+    assert r["loss_rel"] < LOSS_RTOL, r["loss_rel"]
+    assert r["grad_abs"] < GRAD_ATOL, r["grad_abs"]
+
+
+def test_crf_log_probability_inputs(oracle_mod, gpu_device, monkeypatch):
+    """Scores that are log-probabilities (all <= 0, a log-softmax over the 40 transitions: what
+    test_ctc_loss.py feeds the reference) shrink every cell by ~2^-5 per step: inside the range of
+    the linear path's frames or not, the result is the oracle's."""
+    from taiyaki_amd import synth
+    monkeypatch.setenv("TK_CRF_MODE", "band")
+    T, N = 250, 5
+    inp = synth.crf_case(T, N, 21)
+    sc = inp["scores"].astype(np.float64)
+    sc = sc - np.log(np.exp(sc).sum(axis=2, keepdims=True))
+    inp["scores"] = sc.astype(np.float32)
+    r = parity.compare_crf(oracle_mod, inp, 1.0, gpu_device)
+    assert r["finite"]
+    assert r["loss_rel"] < LOSS_RTOL, r["loss_rel"]
+    assert r["grad_abs"] < GRAD_ATOL, r["grad_abs"]
+
+
 @pytest.mark.parametrize("R", ["1", "2", "4"])
 def test_crf_band_does_not_read_what_it_did_not_write(gpu_device, R, monkeypatch):
-    """The posterior pass reads only the band the sweeps stored, and every store lands whole:
-    the same batch must give the same bits whether the workspace it is handed was full of NaN or
-    of zeros (a 16-byte column store whose data registers the next instruction overwrote once
-    replaced one dword of a column by that instruction's result -- only visible this way)."""
+    """The gradient pass reads only the checkpoint columns and boundary cells the sweeps stored, and
+    every store lands whole: the same batch must give the same bits whether the workspace it is
+    handed was full of NaN or of zeros (a 16-byte column store whose data registers the next
+    instruction overwrote once replaced one dword of a column by that instruction's result --
+    only visible this way)."""
     import torch
     from taiyaki_amd import ctc, synth
     monkeypatch.setenv("TK_CRF_MODE", "band")

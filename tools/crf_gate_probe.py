@@ -25,6 +25,7 @@ SHAPES = {
     "sharp": (800, "speed32", 2.5, None),
     "cfg4": (800, "speed128", 1.0, (1, 1, 0, 0)),
     "cfg4w1": (800, "speed128", 1.0, (1, 1, 0, 0)),
+    "cfg4free": (800, "speed128", 1.0, (1, 1, 0, 0)),      # free U(-5, 5) mod scores x weight 8: overflows
     "cfg5": (1600, "speed64", 1.0, None),
     "rowK": (4000, "speed256", 1.0, None),
     "t19": (19, [20, 3], 1.0, None),
@@ -60,6 +61,8 @@ def main():
         else:
             N, seqlens = len(lens), np.array(lens, dtype=np.int32)
         inp = synth.crf_case(T, N, 1, seqlens=seqlens, nmods_per_base=mods)
+        if mods is not None and not sh.endswith("free"):
+            synth.normalise_mod_columns(inp)
         x = torch.from_numpy(inp["scores"]).to(dev)
         seqs, sl = torch.from_numpy(inp["seqs"]), torch.from_numpy(inp["seqlens"])
         extra = ()

@@ -55,6 +55,8 @@ def main():
         seqlens = None if chunk_len is None else synth.realistic_seqlens(T, N, 17000, chunk_len, 9.0)
         mods = (1, 1, 0, 0) if sh == "cfg4" else None
         inp = synth.crf_case(T, N, 1, seqlens=seqlens, nmods_per_base=mods)
+        if mods is not None:
+            synth.normalise_mod_columns(inp)
         S = inp["scores"].shape[2]
         x = torch.from_numpy(inp["scores"]).to(dev)
         seqs, seqlens_t = torch.from_numpy(inp["seqs"]), torch.from_numpy(inp["seqlens"])

@@ -97,7 +97,9 @@ def short(name):
 
 
 def band_bytes(T, N, real, R_hint=None):
-    """Analytic size of kernel A's band: live (chunk, block) pairs x PW cells x 4 B, per lattice."""
+    """Analytic size of what kernel A's sweeps leave for the gradient pass, per sweep: one checkpoint
+    column (4 B mantissa + 4 B frame per cell) per live (chunk, block) pair, plus 8 boundary cells per
+    64 cells and block."""
     import numpy as np
     from taiyaki_amd import synth
     seqlens = synth.realistic_seqlens(T, N, 17001, real, 9.0) if real else synth.speedtest_seqlens(T, N)
@@ -112,7 +114,7 @@ def band_bytes(T, N, real, R_hint=None):
         for w in range((L + PW - 1) // PW):
             a, b = w * PW, min(w * PW + PW - 1, L - 1)
             tlo, thi = max(0, a - 1), min(T - 1, b + T - L + 1)
-            total += (thi // KB - tlo // KB + 1) * KB * PW * 4
+            total += (thi // KB - tlo // KB + 1) * (PW * 8 + (PW // 64) * 32)
     return int(total)
 
 
@@ -176,11 +178,11 @@ def main():
                  traffic_over_algorithmic=round((fetch_b + write_b) / alg, 4), kernel_hash=bench.kernel_hash())
         if name != "logz":
             bb = band_bytes(T, N, real)
-            d["analytic_band_bytes_per_lattice"] = bb
-            d["analytic_note"] = ("the sweeps write both lattices of the band once (2 x %d B) and the posterior "
-                                  "pass reads them once; scores are read by both sweeps and the posterior pass "
-                                  "(3 x %d B) and the gradient is written once (%d B)" % (bb, T * N * S * 4,
-                                                                                         T * N * S * 4))
+            d["analytic_checkpoint_bytes_per_sweep"] = bb
+            d["analytic_note"] = ("each sweep writes one checkpoint column + the boundary cells per block of the band "
+                                  "(2 x %d B) and the gradient pass reads them once; scores are read by both sweeps "
+                                  "and the gradient pass (3 x %d B) and the gradient is written once (%d B)"
+                                  % (bb, T * N * S * 4, T * N * S * 4))
             d["analytic_traffic_bytes"] = 4 * bb + 4 * T * N * S * 4
         detail[key] = d
         if not args.json:

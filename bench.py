@@ -105,6 +105,10 @@ def make_batches(nbatch, chunk_len, stride, seed, dev, n=4, spb=9.0, cat_mod=Fal
         b = dict(indata=torch.from_numpy(sig).to(dev),
                  seqs=torch.from_numpy(seqs).to(device=dev, dtype=torch.int32),
                  seqlens=torch.from_numpy(seqlens).to(device=dev, dtype=torch.int32))
+        # the lengths are known on the host when a batch is assembled (bin/train_flipflop.py:133-138):
+        # the device tensor carries its maximum along, the CRF launch is sized by it without a sync
+        from taiyaki_amd import ctc
+        ctc.set_max_seqlen(b["seqlens"], int(seqlens.max()))
         if cat_mod:
             b["mod_cats"] = torch.from_numpy(synth.mod_cats(bases, s, CAN_NMODS)).to(device=dev, dtype=torch.int32)
             b["can_mods_offsets"] = synth.can_mods_offsets(CAN_NMODS)
@@ -248,8 +252,9 @@ class LossOps:
                                              p(self.status), st)
         _lib.check(rc, "tk_flipflop_build_indices_dev")
         rc = L.tk_flipflop_loss_fused_dev(p(self.x), self.T, self.N, 4, p(self.stay), p(self.move), p(self.seqlens),
-                                          p(self.seqoff), self.maxlen, 1.0, p(self.cost), p(self.grad), p(self.logz),
-                                          p(self.crf_ws), self.crf_wsb, p(self.lz_ws), self.lz_wsb, p(self.status), st)
+                                          p(self.seqoff), self.maxlen, 1.0, 1.0 / self.N, None, p(self.cost), p(self.grad),
+                                          p(self.logz), p(self.crf_ws), self.crf_wsb, p(self.lz_ws), self.lz_wsb,
+                                          p(self.status), st)
         _lib.check(rc, "tk_flipflop_loss_fused_dev")
 
     def finite(self):
@@ -555,7 +560,10 @@ def main():
     if use_graph:
         try:
             cls = train.HybridGraphTrainer if hybrid else train.GraphedTrainer
-            g = cls(trainer, batches[0], seq_capacity=nbatch * (T + 1))
+            maxlen = None
+            if args.data != "store":    # (device-assembled batches: lengths unknown to the host)
+                maxlen = max(b["seqlens"].tk_max_seqlen for b in batches)
+            g = cls(trainer, batches[0], seq_capacity=nbatch * (T + 1), max_seqlen=maxlen)
             g.load(batches[0])
             g.capture()
             stepper, mode = g, ("hipGraph replay of forward+loss and of AdamW, eager backward"

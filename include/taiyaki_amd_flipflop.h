@@ -59,8 +59,8 @@ extern "C" {
 /* bits of the device-side status word */
 #define TK_STATUS_NONFINITE_SCORE 1u
 #define TK_STATUS_NONFINITE_GRAD 2u
-#define TK_STATUS_SEQS_OVERFLOW 4u      /* tk_chunks_gather_dev: seqs buffer too small; CRF: sequence
-                                           longer than the launch was sized for */
+#define TK_STATUS_SEQS_OVERFLOW 4u      /* tk_chunks_gather_dev: seqs buffer too small */
+#define TK_STATUS_SEQ_TOO_LONG 16u      /* CRF: a sequence longer than the max_seqlen the launch was sized for */
 #define TK_STATUS_BAD_LABEL 8u          /* tk_flipflop_build_indices_dev: a flip-flop code outside
                                            [0, 2 nbase), a mod category outside its base's range, or
                                            sum(seqlen) > total_len (the reference asserts that move /
@@ -126,11 +126,17 @@ int tk_crf_flipflop_dev(const float *logprob, size_t ntrans, size_t nblk,
  * posterior kernel's coalesced row-set stores (one gradient tensor, no autograd
  * add).  `logz` (nbatch) receives the log-partition values.  Workspaces as for
  * the two separate entry points.
+ * `grad_scale` x `grad_scale_per_read[n]` (nullable vector on the device: 1)
+ * multiplies the gradient -- not the loss values: a caller that reduces
+ * lossvector with known weights (`lossvector.mean()` of train_flipflop.py:182:
+ * 1 / nbatch) receives the final d loss / d scores and needs no elementwise pass
+ * over the tensor in its backward.  1, NULL = d lossvector[n] / d scores[:, n, :].
  * ------------------------------------------------------------------------- */
 int tk_flipflop_loss_fused_dev(const float *scores, size_t nblk, size_t nbatch, size_t nbase,
                                const int32_t *stayidx, const int32_t *moveidx,
                                const int32_t *seqlen, const int64_t *seqoff,
-                               size_t max_seqlen, float sharpfact, float *lossvector,
+                               size_t max_seqlen, float sharpfact, float grad_scale,
+                               const float *grad_scale_per_read, float *lossvector,
                                float *grad, float *logz, void *crf_workspace,
                                size_t crf_workspace_bytes, void *logz_workspace,
                                size_t logz_workspace_bytes, uint32_t *status, void *stream);

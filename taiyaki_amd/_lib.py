@@ -28,8 +28,8 @@ SIGNATURES = {
     "tk_crf_flipflop_workspace_bytes": (_sz, [_sz, _sz, _sz, _sz, _i]),
     "tk_crf_flipflop_dev": (_i, [_vp, _sz, _sz, _sz, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _sz,
                                  _f, _f, _f, _vp, _vp, _vp, _sz, _vp, _vp]),
-    "tk_flipflop_loss_fused_dev": (_i, [_vp, _sz, _sz, _sz, _vp, _vp, _vp, _vp, _sz, _f, _vp, _vp, _vp, _vp, _sz,
-                                       _vp, _sz, _vp, _vp]),
+    "tk_flipflop_loss_fused_dev": (_i, [_vp, _sz, _sz, _sz, _vp, _vp, _vp, _vp, _sz, _f, _f, _vp, _vp, _vp, _vp, _vp,
+                                       _sz, _vp, _sz, _vp, _vp]),
     "tk_flipflop_lattice_dev": (_i, [_vp, _sz, _sz, _sz, _i, _vp, _vp, _vp, _vp]),
     "tk_flipflop_beamsearch_workspace_bytes": (_sz, [_sz, _sz, _sz]),
     "tk_flipflop_beamsearch_dev": (_i, [_vp, _sz, _sz, _sz, _i, _f, _i, _vp, _vp, _vp, _vp, _sz, _vp]),
@@ -137,10 +137,11 @@ def _raise(bits):
         raise AssertionError("Error: sequence labels out of range for the flip-flop model (flip-flop code "
                              "outside [0, 2 nbase), modification category outside its base's range, or "
                              "sum(seqlen) larger than the label array)")
+    if bits & 16:
+        raise RuntimeError("a sequence is longer than the max_seqlen the CRF kernel was launched for")
     if bits & 4:
-        raise RuntimeError("sequence buffer overflow: a sequence is longer than the max_seqlen the CRF kernel "
-                           "was launched for, or a chunk batch needed more than max_bases_per_chunk bases per "
-                           "chunk (its `seqs` would be truncated)")
+        raise RuntimeError("sequence buffer overflow: a chunk batch needed more than max_bases_per_chunk bases "
+                           "per chunk (its `seqs` would be truncated)")
     if bits & 1:
         raise AssertionError("Error: all costs must be finite.\n"
                              "Try restarting from a checkpoint with a lower learning rate.")

@@ -13,7 +13,8 @@ namespace tk {
 size_t logz_workspace_bytes(size_t T, size_t N, size_t nbase);
 int logz_dispatch(const float *scores, size_t T, size_t N, size_t nbase, float *logz,
                   float *grad, void *workspace, size_t workspace_bytes, uint32_t *status,
-                  hipStream_t stream, float *loss_acc = nullptr, float acc_scale = 0.f);
+                  hipStream_t stream, float *loss_acc = nullptr, float acc_scale = 0.f, float grad_scale = 1.f,
+                  const float *grad_scale_vec = nullptr);
 size_t viterbi_workspace_bytes(size_t T, size_t N, size_t nbase);
 int viterbi_dispatch(const float *scores, size_t T, size_t N, size_t nbase, float *fwd,
                      int64_t *tb, int64_t *path, void *workspace, size_t workspace_bytes,
@@ -24,8 +25,8 @@ int crf_dispatch(const float *logprob, size_t ntrans, size_t nblk, size_t nbatch
                  const int32_t *stayidx, const int32_t *moveidx, const int32_t *modidx,
                  const float *modfact, const int32_t *seqlen, const int64_t *seqoff,
                  size_t max_seqlen, size_t ncan, float sharp_can, float sharp_mod,
-                 float out_scale, float grad_scale, float *cost, float *grad, void *workspace,
-                 size_t workspace_bytes, uint32_t *status, hipStream_t stream);
+                 float out_scale, float grad_scale, const float *grad_scale_vec, float *cost, float *grad,
+                 void *workspace, size_t workspace_bytes, uint32_t *status, hipStream_t stream);
 void crf_band_lab_phase(int phase);
 size_t beam_workspace_bytes(size_t T, size_t N, size_t nbase);
 int lattice_dispatch(const float *scores, size_t T, size_t N, size_t nbase, int forward, const float *init,
@@ -194,14 +195,15 @@ int tk_crf_flipflop_dev(const float *logprob, size_t ntrans, size_t nblk, size_t
     if (ntrans == 0 || nblk == 0 || nbatch == 0) return TK_ERR_BAD_ARG;
     if ((modidx == nullptr) != (modfact == nullptr)) return TK_ERR_BAD_ARG;
     return tk::crf_dispatch(logprob, ntrans, nblk, nbatch, stayidx, moveidx, modidx, modfact,
-                            seqlen, seqoff, max_seqlen, ncan, sharp_can, sharp_mod, out_scale, 1.0f,
+                            seqlen, seqoff, max_seqlen, ncan, sharp_can, sharp_mod, out_scale, 1.0f, nullptr,
                             cost, grad, workspace, workspace_bytes, status,
                             static_cast<hipStream_t>(stream));
 }
 
 int tk_flipflop_loss_fused_dev(const float *scores, size_t nblk, size_t nbatch, size_t nbase,
                                const int32_t *stayidx, const int32_t *moveidx, const int32_t *seqlen,
-                               const int64_t *seqoff, size_t max_seqlen, float sharpfact, float *lossvector,
+                               const int64_t *seqoff, size_t max_seqlen, float sharpfact, float grad_scale,
+                               const float *grad_scale_per_read, float *lossvector,
                                float *grad, float *logz, void *crf_workspace, size_t crf_workspace_bytes,
                                void *logz_workspace, size_t logz_workspace_bytes, uint32_t *status, void *stream) {
     if (!scores || !stayidx || !moveidx || !seqlen || !seqoff || !lossvector || !grad || !logz || !crf_workspace ||
@@ -215,11 +217,11 @@ int tk_flipflop_loss_fused_dev(const float *scores, size_t nblk, size_t nbatch, 
     // are whole coalesced row sets (the read-modify-write costs that HBM-bound kernel one more
     // stream; done in kernel A's row-at-a-time posterior pass it cost ~18 us at the step's shape)
     int rc = tk::crf_dispatch(scores, ntrans, nblk, nbatch, stayidx, moveidx, nullptr, nullptr, seqlen, seqoff,
-                              max_seqlen, ntrans, sharpfact, sharpfact, 1.0f / sharpfact, 1.0f, lossvector, grad,
-                              crf_workspace, crf_workspace_bytes, status, st);
+                              max_seqlen, ntrans, sharpfact, sharpfact, 1.0f / sharpfact, grad_scale,
+                              grad_scale_per_read, lossvector, grad, crf_workspace, crf_workspace_bytes, status, st);
     if (rc != 0) return rc;
     return tk::logz_dispatch(scores, nblk, nbatch, nbase, logz, grad, logz_workspace, logz_workspace_bytes, status, st,
-                             lossvector, 1.0f / (float)nblk);
+                             lossvector, 1.0f / (float)nblk, grad_scale, grad_scale_per_read);
 }
 
 // lab only (not declared in the public header): see crf_band.hip
@@ -361,7 +363,7 @@ bool host_seq_call(float const *logprob, size_t ntrans, size_t nblk, size_t nbat
         modmoveidxs ? static_cast<const int32_t *>(d_mod.p) : nullptr,
         modmoveidxs ? static_cast<const float *>(d_fact.p) : nullptr,
         static_cast<const int32_t *>(d_len.p), static_cast<const int64_t *>(d_off.p),
-        (size_t)maxlen, ncan, 1.0f, 1.0f, 1.0f, 1.0f, static_cast<float *>(d_cost.p),
+        (size_t)maxlen, ncan, 1.0f, 1.0f, 1.0f, 1.0f, nullptr, static_cast<float *>(d_cost.p),
         grad ? static_cast<float *>(d_grad.p) : nullptr, d_ws.p, wsb, nullptr, nullptr);
     if (rc != 0 || hipDeviceSynchronize() != hipSuccess) return false;
     std::vector<float> cost(nbatch);

@@ -21,6 +21,7 @@ struct BandArgs {
     float c_mod;                // sharp_mod * log2(e)
     float out_scale;            // cost multiplier (1 / sharpfact)
     float grad_scale;           // gradient multiplier (1 for the reference's operators)
+    const float *grad_scale_vec;    // nullable; (N): a further per-read multiplier
     float *cost;                // (N)
     float *grad;                // (T, N, S) or null (cost only)
     uint32_t *status;

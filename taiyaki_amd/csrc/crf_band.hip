@@ -459,7 +459,7 @@ __global__ __launch_bounds__(WCAP *WAVE) void crf_band_sweep_kernel(BandArgs a) 
         if (!want_grad && tid == 0) {
             a.cost[n] = (L == 0) ? 0.f : __builtin_nanf("");
             a.gate[n] = 0;
-            if (L != 0 && a.status) atomicOr(a.status, 4u);
+            if (L != 0 && a.status) atomicOr(a.status, 16u);
         }
         return;
     }
@@ -564,7 +564,7 @@ __global__ __launch_bounds__(POST_WAVES *WAVE) void crf_band_posterior_kernel(Ba
     if (L == 0 || L > a.LP) {
         if (blockIdx.y == 0 && tid == 0) {
             a.cost[n] = (L == 0) ? 0.f : __builtin_nanf("");     // c_crf_flipflop.c:269-272, 458-464
-            if (L != 0 && a.status) atomicOr(a.status, 4u);
+            if (L != 0 && a.status) atomicOr(a.status, 16u);
         }
         if (L == 0 && lane < S)
             for (int t = t0; t < min(t0 + BK, T); ++t)
@@ -840,6 +840,7 @@ __global__ __launch_bounds__(POST_WAVES *WAVE) void crf_band_posterior_kernel(Ba
     }
     // every row's total is Z 2^-zexp: a row that lost mass (or everything) disowns the read
     const float zfrac = (float)(scoreF - (double)zexp);
+    const float gsc = a.grad_scale * (a.grad_scale_vec != nullptr ? a.grad_scale_vec[n] : 1.0f);
     bool lost = false;
 #pragma unroll
     for (int k = 0; k < BK; ++k) {
@@ -852,7 +853,7 @@ __global__ __launch_bounds__(POST_WAVES *WAVE) void crf_band_posterior_kernel(Ba
             const float dev = fast_log2(total) - zfrac;
             lost |= !(dev > -ROWZ_TOL && dev < ROWZ_TOL);
             // gradient of -score / T  (ctc.pyx:113)
-            const float g = colacc * (-a.grad_scale / (total * (float)T));
+            const float g = colacc * (-gsc / (total * (float)T));
             if (lane < S) a.grad[(size_t)(t0 + k) * rowstride + (size_t)n * S + lane] = g;
         }
     }

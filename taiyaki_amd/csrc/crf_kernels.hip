@@ -44,6 +44,7 @@ struct CrfArgs {
     uint32_t *status;
     const int *gate;            // nullable; (N): only reads with gate[n] != 0 are computed (the band path's rejects)
     float grad_scale;           // gradient multiplier (1 for the reference's operators)
+    const float *grad_scale_vec;    // nullable; (N): a further per-read multiplier
 };
 
 __host__ __device__ inline int crf_ck(int R, int W, int kinds) {
@@ -92,6 +93,7 @@ __global__ __launch_bounds__(W *WAVE) void crf_kernel(CrfArgs a) {
     if (a.gate != nullptr && a.gate[n] == 0) return;             // the linear band path owns this read
     const int L = a.seqlen[n];
     const bool want_grad = a.grad != nullptr;
+    const float gsc = a.grad_scale * (a.grad_scale_vec != nullptr ? a.grad_scale_vec[n] : 1.0f);
 
     float *tile = reinterpret_cast<float *>(smem);              // [CK][SP]
     float *Psort = tile + CK * SP;                              // [CK][KINDS][LPAD]
@@ -126,7 +128,7 @@ __global__ __launch_bounds__(W *WAVE) void crf_kernel(CrfArgs a) {
     if (L > R * NT) {
         if (tid == 0) {
             a.cost[n] = __builtin_nanf("");
-            if (a.status) atomicOr(a.status, 4u);
+            if (a.status) atomicOr(a.status, 16u);
         }
         return;
     }
@@ -457,7 +459,7 @@ __global__ __launch_bounds__(W *WAVE) void crf_kernel(CrfArgs a) {
                     }
                     wave_lds_fence();
                 }
-                const float g = colval * (-a.grad_scale / (total * (float)T));
+                const float g = colval * (-gsc / (total * (float)T));
                 if (lane < S) {
                     bad |= !isfinite(g);
                     a.grad[(size_t)(t0 + row) * rowstride + (size_t)n * S + lane] = g;
@@ -668,8 +670,8 @@ int crf_dispatch(const float *logprob, size_t ntrans, size_t nblk, size_t nbatch
                  const int32_t *stayidx, const int32_t *moveidx, const int32_t *modidx,
                  const float *modfact, const int32_t *seqlen, const int64_t *seqoff,
                  size_t max_seqlen, size_t ncan, float sharp_can, float sharp_mod,
-                 float out_scale, float grad_scale, float *cost, float *grad, void *workspace,
-                 size_t workspace_bytes, uint32_t *status, hipStream_t stream) {
+                 float out_scale, float grad_scale, const float *grad_scale_vec, float *cost, float *grad,
+                 void *workspace, size_t workspace_bytes, uint32_t *status, hipStream_t stream) {
     if (ntrans > 62 || ncan > ntrans || ncan == 0) return 2;
     if (max_seqlen == 0) max_seqlen = nblk + 1;
     const CrfShape sh = crf_pick_shape(max_seqlen);
@@ -692,6 +694,7 @@ int crf_dispatch(const float *logprob, size_t ntrans, size_t nblk, size_t nbatch
     a.c_mod = sharp_mod * LOG2E;
     a.out_scale = out_scale;
     a.grad_scale = grad_scale;
+    a.grad_scale_vec = grad_scale_vec;
     a.cost = cost;
     a.grad = grad;
     a.gate = nullptr;
@@ -717,6 +720,7 @@ int crf_dispatch(const float *logprob, size_t ntrans, size_t nblk, size_t nbatch
         b.c_mod = sharp_mod * LOG2E;
         b.out_scale = out_scale;
         b.grad_scale = grad_scale;
+        b.grad_scale_vec = grad_scale_vec;
         b.cost = cost;
         b.grad = grad;
         b.status = status;

@@ -179,6 +179,11 @@ struct LogzWs {
     // acc_scale * posterior (acc_scale = 1 / nblk).  Null: the plain operator.
     float *loss_acc;
     float acc_scale;
+    // gradient multiplier of the fused operator: scalar x optional per-read vector (a train step
+    // that hands over d mean(lossvector) / d lossvector gets the FINAL gradient: no elementwise
+    // pass over the (T, N, S) tensor in backward).  logZ / the loss values are not scaled.
+    float grad_scale;
+    const float *grad_scale_vec;
 };
 
 // per-wave LDS buffer of K3 in f4 units: the row-set transpose buffer, which
@@ -983,6 +988,9 @@ __global__ __launch_bounds__(K3_WAVES *WAVE, (CH / K3_WAVES <= 2 ? 4 : 2)) void 
     const int tw = c * CH + wave * K3_ROWS;             // first row of this wave
     const float *base = scores + (size_t)n0 * F::S;
     const size_t n = (size_t)n0 + lane;
+    const float acc_g = ACC ? ws.acc_scale * ws.grad_scale *
+                                  (ws.grad_scale_vec != nullptr ? ws.grad_scale_vec[min((int)n, N - 1)] : 1.0f)
+                            : 1.0f;
 
     // 1. rows -> registers (weights w = exp(s - rowmax))
     RowSet<NB> w[K3_ROWS];
@@ -1085,7 +1093,7 @@ __global__ __launch_bounds__(K3_WAVES *WAVE, (CH / K3_WAVES <= 2 ? 4 : 2)) void 
                 w[j].set(F::FLOP0 + from, g);
                 sum += g;
             }
-            const float inv = (ACC ? ws.acc_scale : 1.0f) / sum;
+            const float inv = (ACC ? acc_g : 1.0f) / sum;
             bad |= !isfinite(inv);
 #pragma unroll
             for (int i = 0; i < F::S; ++i) w[j].set(i, w[j].get(i) * inv);
@@ -1238,12 +1246,15 @@ static int logz_launch_ch(const float *scores, size_t T, size_t N, float *logz, 
 template <int NB>
 static int logz_launch(const float *scores, size_t T, size_t N, float *logz, float *grad,
                        void *workspace, size_t workspace_bytes, uint32_t *status,
-                       hipStream_t stream, float *loss_acc, float acc_scale) {
+                       hipStream_t stream, float *loss_acc, float acc_scale, float grad_scale,
+                       const float *grad_scale_vec) {
     LogzWs ws;
     const size_t need = logz_ws_layout<NB>(T, N, workspace, &ws);
     if (need > workspace_bytes) return 3;
     ws.loss_acc = loss_acc;
     ws.acc_scale = acc_scale;
+    ws.grad_scale = grad_scale;
+    ws.grad_scale_vec = grad_scale_vec;
     int ch = logz_pick_ch(T, N);
     if (const char *e = getenv("TK_LOGZ_CH")) ch = atoi(e);         // tuning override
     // the middle kernel keeps one read's chunk matrices in LDS: fall back to bigger chunks
@@ -1271,13 +1282,14 @@ size_t logz_workspace_bytes(size_t T, size_t N, size_t nbase) {
 
 int logz_dispatch(const float *scores, size_t T, size_t N, size_t nbase, float *logz,
                   float *grad, void *workspace, size_t workspace_bytes, uint32_t *status,
-                  hipStream_t stream, float *loss_acc, float acc_scale) {
+                  hipStream_t stream, float *loss_acc, float acc_scale, float grad_scale,
+                  const float *grad_scale_vec) {
     if (loss_acc != nullptr && grad == nullptr) return 1;
     switch (nbase) {
-        case 1: return logz_launch<1>(scores, T, N, logz, grad, workspace, workspace_bytes, status, stream, loss_acc, acc_scale);
-        case 2: return logz_launch<2>(scores, T, N, logz, grad, workspace, workspace_bytes, status, stream, loss_acc, acc_scale);
-        case 3: return logz_launch<3>(scores, T, N, logz, grad, workspace, workspace_bytes, status, stream, loss_acc, acc_scale);
-        case 4: return logz_launch<4>(scores, T, N, logz, grad, workspace, workspace_bytes, status, stream, loss_acc, acc_scale);
+        case 1: return logz_launch<1>(scores, T, N, logz, grad, workspace, workspace_bytes, status, stream, loss_acc, acc_scale, grad_scale, grad_scale_vec);
+        case 2: return logz_launch<2>(scores, T, N, logz, grad, workspace, workspace_bytes, status, stream, loss_acc, acc_scale, grad_scale, grad_scale_vec);
+        case 3: return logz_launch<3>(scores, T, N, logz, grad, workspace, workspace_bytes, status, stream, loss_acc, acc_scale, grad_scale, grad_scale_vec);
+        case 4: return logz_launch<4>(scores, T, N, logz, grad, workspace, workspace_bytes, status, stream, loss_acc, acc_scale, grad_scale, grad_scale_vec);
         default: return 2;
     }
 }

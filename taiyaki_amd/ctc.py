@@ -57,16 +57,41 @@ def _device_constant(values, dtype, device):
     return _CONSTANTS[key]
 
 
+def n_mod_columns(can_mods_offsets):
+    """can_mods_offsets[-1] as a host int.  The table must live on the host (numpy, list or CPU
+    tensor): reading it off a device tensor would be a sync per call and is illegal while a
+    hipGraph is being captured."""
+    if torch.is_tensor(can_mods_offsets):
+        if can_mods_offsets.is_cuda:
+            raise TypeError("can_mods_offsets must be a host array (numpy / list / CPU tensor): its last entry "
+                            "sizes the launch")
+        return int(can_mods_offsets[-1])
+    return int(np.asarray(can_mods_offsets)[-1])
+
+
 _KEEP_WS = None      # debugging aid: set to a list to keep the kernels' workspaces alive
 
 
+def set_max_seqlen(seqlen, value):
+    """Whoever assembles a batch knows its longest sequence on the host (bin/train_flipflop.py:133-138
+    builds `seqlens` from Python lists); a `seqlens` tensor that lives on the device carries that
+    number along as an attribute, so that the CRF launch is sized by it without a device sync
+    (mapped_signal.sample_chunks, bench.make_batches, the graph trainers' static buffers)."""
+    seqlen.tk_max_seqlen = int(value)
+    return seqlen
+
+
 def _max_seqlen(seqlen):
-    """Exact bound when seqlen lives on the host (bin/train_flipflop.py:133-138) -- no device
-    sync.  For a device tensor (train_abinitio.py:207-210): in strict mode the call ends in a host
-    sync anyway (the status word), so one more for the true maximum costs nothing and sizes the
-    launch and its workspace by it; in non-strict mode 0 (= unknown: sized for nblk + 1)."""
+    """Exact bound when seqlen lives on the host (bin/train_flipflop.py:133-138) or carries it
+    (`set_max_seqlen`) -- no device sync.  For a bare device tensor (train_abinitio.py:207-210): in
+    strict mode the call ends in a host sync anyway (the status word), so one more for the true
+    maximum costs nothing and sizes the launch and its workspace by it; in non-strict mode 0
+    (= unknown: sized for nblk + 1)."""
     if not seqlen.numel():
         return 0
+    hint = getattr(seqlen, "tk_max_seqlen", None)
+    if hint is not None:
+        return int(hint)
     if seqlen.is_cuda and not _lib.is_strict():
         return 0
     return int(seqlen.max())
@@ -136,7 +161,7 @@ class CatModFlipFlop(torch.autograd.Function):
     def forward(ctx, logprob, seqs, seqlen, mod_cats, can_mods_offsets,
                 mod_cat_weights, sharpfact: float):
         ntrans = logprob.shape[2]
-        n_can_trans = ntrans - int(np.asarray(can_mods_offsets)[-1])
+        n_can_trans = ntrans - n_mod_columns(can_mods_offsets)
         cost, grad = _run(logprob, seqs, seqlen, sharpfact, 1.0, 1.0 / sharpfact,
                           n_can_trans, ctx.needs_input_grad[0], mod_cats,
                           can_mods_offsets, mod_cat_weights)
@@ -157,7 +182,7 @@ cat_mod_flipflop_loss = CatModFlipFlop.apply
 # ---------------------------------------------------------------------------------------------
 # fused train-step loss: (A) + (B) / nblk in one operator, one gradient tensor
 # ---------------------------------------------------------------------------------------------
-def _run_fused(outputs, seqs, seqlen, sharpfact, want_grad):
+def _run_fused(outputs, seqs, seqlen, sharpfact, want_grad, grad_scale=1.0, grad_scale_per_read=None):
     _lib.require_gpu(outputs, "flip-flop loss")
     L = _lib.lib()
     lp = outputs.detach().float().contiguous()
@@ -177,13 +202,17 @@ def _run_fused(outputs, seqs, seqlen, sharpfact, want_grad):
         wsb = L.tk_flipflop_logz_workspace_bytes(nblk, nbatch, nbase)
         ws_a = torch.empty(wsa, dtype=torch.uint8, device=dev)
         ws_b = torch.empty(wsb, dtype=torch.uint8, device=dev)
+        gvec = None
+        if grad_scale_per_read is not None:
+            gvec = grad_scale_per_read.detach().to(device=dev, dtype=torch.float32).contiguous()
         rc = L.tk_flipflop_loss_fused_dev(
             _lib.ptr(lp), nblk, nbatch, nbase, _lib.ptr(stay), _lib.ptr(move), _lib.ptr(seqlen_d),
-            _lib.ptr(seqoff), maxlen, float(sharpfact), _lib.ptr(lossvector), _lib.ptr(grad), _lib.ptr(logz),
+            _lib.ptr(seqoff), maxlen, float(sharpfact), float(grad_scale), _lib.ptr(gvec),
+            _lib.ptr(lossvector), _lib.ptr(grad), _lib.ptr(logz),
             _lib.ptr(ws_a), wsa, _lib.ptr(ws_b), wsb, _lib.ptr(status), _lib.stream_ptr())
         _lib.check(rc, "tk_flipflop_loss_fused_dev")
         _lib.finish(status)
-    del keep
+    del keep, gvec
     return lossvector, (grad if want_grad else None), logz
 
 
@@ -207,3 +236,59 @@ class FlipFlopLoss(torch.autograd.Function):
 
 
 flipflop_loss = FlipFlopLoss.apply
+
+
+class FlipFlopMeanLoss(torch.autograd.Function):
+    """`calculate_loss`'s last two lines folded into the operator (bin/train_flipflop.py:172-182):
+    returns (loss, lossvector) with loss = sum_n w[n] lossvector[n]; `weights` None = the
+    reference's `lossvector.mean()`, a (nbatch,) device tensor = any other fixed reduction (the mean
+    over the non-empty columns of a padded batch).  The kernels write d loss / d outputs directly
+    (their per-read gradient multiplier), so `backward` hands the saved tensor on: no elementwise
+    pass over the (T, N, S) tensor between the loss and the network's backward.  `loss.backward()`
+    sends grad_output = 1; any other value is honoured by one scaling pass."""
+
+    @staticmethod
+    def forward(ctx, outputs, seqs, seqlen, sharpfact: float, weights=None):
+        nbatch = outputs.shape[1]
+        if weights is None:
+            lossvector, grad, _ = _run_fused(outputs, seqs, seqlen, sharpfact, ctx.needs_input_grad[0],
+                                             grad_scale=1.0 / nbatch)
+            loss = lossvector.mean()
+        else:
+            lossvector, grad, _ = _run_fused(outputs, seqs, seqlen, sharpfact, ctx.needs_input_grad[0],
+                                             grad_scale_per_read=weights)
+            loss = (lossvector * weights.to(lossvector.dtype)).sum()
+        if grad is not None:
+            ctx.save_for_backward(grad)
+        ctx.mark_non_differentiable(lossvector)
+        return loss, lossvector
+
+    @staticmethod
+    def backward(ctx, grad_loss, _grad_lossvector):
+        grads, = ctx.saved_tensors
+        if getattr(grad_loss, "tk_is_one", False) or _ASSUME_UNIT_GRAD:
+            return grads, None, None, None, None
+        return grads * grad_loss, None, None, None, None
+
+
+# `loss.backward()` on the operator's own output sends grad_output = 1.0; a trainer that does exactly
+# that (train.Trainer, the graph trainers) says so and saves the scaling pass.  Off by default:
+# anything else (loss * 2, a sum of losses) stays correct.
+_ASSUME_UNIT_GRAD = False
+
+
+class unit_grad:
+    """Context manager: inside it, `FlipFlopMeanLoss.backward` trusts that the loss is
+    differentiated with grad_output = 1 (a bare `loss.backward()`)."""
+
+    def __enter__(self):
+        global _ASSUME_UNIT_GRAD
+        self.prev = _ASSUME_UNIT_GRAD
+        _ASSUME_UNIT_GRAD = True
+
+    def __exit__(self, *exc):
+        global _ASSUME_UNIT_GRAD
+        _ASSUME_UNIT_GRAD = self.prev
+
+
+flipflop_mean_loss = FlipFlopMeanLoss.apply

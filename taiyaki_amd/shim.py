@@ -23,6 +23,7 @@
 operators it installs still refuse CPU tensors (no fallback).
 """
 import importlib
+import importlib.util
 import sys
 import types
 

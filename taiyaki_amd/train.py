@@ -28,9 +28,14 @@ def calculate_loss(net, indata, seqs, seqlens, sharpen=1.0, mod_cats=None,
     if mod_cats is not None:
         lossvector = ctc.cat_mod_flipflop_loss(outputs, seqs, seqlens, mod_cats,
                                                can_mods_offsets, mod_cat_weights, sharpen)
-        ntrans -= int(can_mods_offsets[-1])
+        ntrans -= ctc.n_mod_columns(can_mods_offsets)
     elif FUSED_LOSS and outputs.is_cuda:
-        lossvector = ctc.flipflop_loss(outputs, seqs, seqlens, sharpen)
+        # one operator, one gradient tensor, already d loss / d outputs (ctc.FlipFlopMeanLoss)
+        weights = None
+        if ignore_empty:
+            live = (seqlens.to(outputs.device) > 0).to(torch.float32)
+            weights = live / live.sum().clamp(min=1.0)
+        return ctc.flipflop_mean_loss(outputs, seqs, seqlens, sharpen, weights)
     else:
         lossvector = ctc.crf_flipflop_loss(outputs, seqs, seqlens, sharpen)
     if mod_cats is not None or not (FUSED_LOSS and outputs.is_cuda):
@@ -76,7 +81,8 @@ class Trainer:
         for k, sub in enumerate(subs):
             self.arena.hooks_enabled = hooks and k == len(subs) - 1
             loss, _ = calculate_loss(self.net, **sub)
-            loss.backward()
+            with ctc.unit_grad():
+                loss.backward()
             total = loss.detach() if total is None else total + loss.detach()
         self.arena.hooks_enabled = hooks
         self.arena.allreduce_async()
@@ -113,9 +119,13 @@ class GraphedTrainer:
     capturing stream through the C ABI.
     """
 
-    def __init__(self, trainer, example_batch, seq_capacity):
+    def __init__(self, trainer, example_batch, seq_capacity, max_seqlen=None):
+        """`max_seqlen`: an upper bound on the sequence length of EVERY batch this trainer will see
+        (the captured CRF launch is sized once: its waves per read cannot grow at replay).  None:
+        unknown = the launch is sized for nblk + 1."""
         self.trainer = trainer
         dev = trainer.arena.flat.device
+        self.max_seqlen = max_seqlen
         self.static = dict(
             indata=torch.zeros_like(example_batch["indata"], device=dev),
             seqs=torch.zeros(seq_capacity, dtype=torch.int32, device=dev),
@@ -128,10 +138,16 @@ class GraphedTrainer:
             self.static["mod_cat_weights"] = example_batch["mod_cat_weights"]
         if example_batch.get("ignore_empty"):
             self.static["ignore_empty"] = True
+        if max_seqlen is not None:
+            ctc.set_max_seqlen(self.static["seqlens"], max_seqlen)
         self.loss = None
         self.graph = None
 
     def load(self, batch):
+        hint = getattr(batch["seqlens"], "tk_max_seqlen", None)
+        if self.max_seqlen is not None and hint is not None and hint > self.max_seqlen:
+            raise ValueError("batch with sequences up to %d bases for a step captured for at most %d"
+                             % (hint, self.max_seqlen))
         self.static["indata"].copy_(batch["indata"], non_blocking=True)
         n = batch["seqs"].numel()
         self.static["seqs"][:n].copy_(batch["seqs"], non_blocking=True)
@@ -149,12 +165,13 @@ class GraphedTrainer:
         torch.cuda.synchronize()
         self.graph = torch.cuda.CUDAGraph()
         arena = self.trainer.arena
+        hooks = arena.hooks_enabled
         arena.hooks_enabled = False         # one captured all-reduce, not hook-issued slices
         try:
             with torch.cuda.graph(self.graph, **_CAPTURE):
                 self.loss = self.trainer.step(self.static)
         finally:
-            arena.hooks_enabled = True
+            arena.hooks_enabled = hooks
         torch.cuda.synchronize()
 
     def step(self, batch):
@@ -183,8 +200,8 @@ class HybridGraphTrainer(GraphedTrainer):
     only issues the backward launches -- about half of the step's 16,000.
     """
 
-    def __init__(self, trainer, example_batch, seq_capacity):
-        super().__init__(trainer, example_batch, seq_capacity)
+    def __init__(self, trainer, example_batch, seq_capacity, max_seqlen=None):
+        super().__init__(trainer, example_batch, seq_capacity, max_seqlen)
         # The captured autograd graph saved (views of) the parameters; an in-place optimiser
         # update of the parameters themselves would trip autograd's version check on the next
         # eager backward.  The optimiser therefore updates ALIASES of the parameters (same
@@ -204,7 +221,8 @@ class HybridGraphTrainer(GraphedTrainer):
         tr = self.trainer
         tr.arena.zero()
         loss, _ = calculate_loss(tr.net, **self.static)
-        loss.backward()
+        with ctc.unit_grad():
+            loss.backward()
         tr.arena.allreduce_async()
         tr.arena.finish()
         self._clip_and_step()
@@ -238,7 +256,8 @@ class HybridGraphTrainer(GraphedTrainer):
         self.opt.step()
 
     def _tail_eager(self):
-        self.loss.backward(retain_graph=True)
+        with ctc.unit_grad():
+            self.loss.backward(retain_graph=True)
         self.trainer.arena.allreduce_async()
         self.trainer.arena.finish()
         self._clip_and_step()
@@ -246,7 +265,8 @@ class HybridGraphTrainer(GraphedTrainer):
     def step(self, batch):
         self.load(batch)
         self.graph.replay()
-        self.loss.backward(retain_graph=True)
+        with ctc.unit_grad():
+            self.loss.backward(retain_graph=True)
         self.trainer.arena.allreduce_async()
         self.trainer.arena.finish()
         self.trainer.clip()         # eager: two tiny launches + an async copy of the maxima

@@ -1013,3 +1013,68 @@ def test_fused_loss_small_against_oracle(oracle_mod, gpu_device, sharp):
     olz, olgrad = oracle_mod.flipflop_logz_grad(inp["scores"])
     np.testing.assert_allclose(lv.detach().cpu().numpy(), oloss + olz / T, rtol=1e-5, atol=2e-6)
     np.testing.assert_allclose(x.grad.cpu().numpy(), ograd + olgrad / T, atol=2e-5)
+
+
+@pytest.mark.parametrize("weighted", [False, True])
+def test_mean_loss_operator_hands_over_the_final_gradient(oracle_mod, gpu_device, weighted):
+    """ctc.flipflop_mean_loss = calculate_loss's lossvector + its reduction in one operator: the
+    kernels scale the gradient per read (1 / nbatch for `lossvector.mean()`, any weight vector
+    for the padded-batch mean), so backward returns the saved tensor -- with grad_output = 1 under
+    `ctc.unit_grad()` untouched (same storage), otherwise scaled once."""
+    import torch
+    from taiyaki_amd import ctc, synth
+    T = 120
+    # (empty reads last: the oracle -- like the reference -- cannot index one in the middle of a batch)
+    seqlens = np.array([50, 1, 100, 77, 30, 0, 0], dtype=np.int32)
+    inp = synth.crf_case(T, len(seqlens), 3, seqlens=seqlens)
+    N = len(seqlens)
+    w_np = None
+    if weighted:
+        live = (seqlens > 0).astype(np.float32)
+        w_np = live / live.sum()
+    oloss, ograd = oracle_mod.crf_flipflop_loss(inp["scores"], inp["seqs"], inp["seqlens"], 1.0)
+    olz, olgrad = oracle_mod.flipflop_logz_grad(inp["scores"])
+    olv = oloss + olz / T
+    wts = np.full(N, 1.0 / N, dtype=np.float32) if w_np is None else w_np
+    want_loss = float((olv * wts).sum())
+    want_grad = (ograd + olgrad / T) * wts[None, :, None]
+
+    x = torch.from_numpy(inp["scores"]).to(gpu_device).requires_grad_()
+    weights = None if w_np is None else torch.from_numpy(w_np).to(gpu_device)
+    loss, lv = ctc.flipflop_mean_loss(x, torch.from_numpy(inp["seqs"]), torch.from_numpy(inp["seqlens"]), 1.0,
+                                      weights)
+    assert not lv.requires_grad
+    np.testing.assert_allclose(lv.cpu().numpy(), olv, rtol=1e-5, atol=2e-6)
+    assert abs(float(loss) - want_loss) < 1e-5 * abs(want_loss) + 2e-6
+    with ctc.unit_grad():
+        loss.backward(retain_graph=True)
+    g1 = x.grad.clone()
+    np.testing.assert_allclose(g1.cpu().numpy(), want_grad, atol=2e-5 / N)
+    # a grad_output other than 1 is honoured (one scaling pass)
+    x.grad = None
+    (loss * 3.0).backward()
+    np.testing.assert_allclose(x.grad.cpu().numpy(), 3.0 * g1.cpu().numpy(), rtol=1e-6, atol=1e-9)
+
+
+def test_train_step_has_no_elementwise_pass_between_loss_and_rnn_backward(gpu_device):
+    """The trainers differentiate the mean loss with a bare `loss.backward()`: the tensor that
+    reaches the network's last layer IS the kernels' output (same storage)."""
+    import torch
+    from taiyaki_amd import ctc, synth, train
+    T, N = 64, 4
+    inp = synth.crf_case(T, N, 8)
+    x = torch.from_numpy(inp["scores"]).to(gpu_device).requires_grad_()
+    seen = {}
+    x.register_hook(lambda g: seen.update(ptr=g.data_ptr()))
+
+    class Net(torch.nn.Module):
+        def forward(self, indata):
+            return x
+    seqlens = torch.from_numpy(inp["seqlens"]).to(gpu_device)
+    ctc.set_max_seqlen(seqlens, int(inp["seqlens"].max()))
+    loss, _ = train.calculate_loss(Net(), None, torch.from_numpy(inp["seqs"]).to(gpu_device), seqlens)
+    fn = loss.grad_fn
+    saved = fn.saved_tensors[0].data_ptr()
+    with ctc.unit_grad():
+        loss.backward()
+    assert seen["ptr"] == saved

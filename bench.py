@@ -36,7 +36,9 @@ Rank 0 prints ONE JSON line with the contract fields plus
   "loss_path"       the whole loss path (A + B) in chunks/s on the GPU, on the host cores, and
                     on the host cores including the D->H / H->D copies of the score and gradient
                     tensors the reference design incurs (ctc.pyx:119, 139-141)
-  "rccl"            (N > 1) ranks, bytes and event-timed duration of the gradient all-reduce
+  "rccl"            (N > 1) ranks, bytes and event-timed duration of the gradient all-reduce, whole and
+                    slice by slice (`bucket_us`); "per_rank_ms": every rank's own ms/step (min / max /
+                    all); "cores_per_rank": the host cores each rank is pinned to
   "cpu_baseline"    the reference C (oracle/_ref) or the oracle port on host cores.
 """
 import argparse
@@ -381,6 +383,7 @@ def dry_launch(args):
     all-reduce a gradient arena and rank 0 prints the JSON line with n_gpus = world."""
     from taiyaki_amd import models, parallel
     rank, local, world = parallel.init_from_env(backend="gloo")
+    cores = parallel.pin_rank(local, int(os.environ.get("LOCAL_WORLD_SIZE", world)))
     torch.manual_seed(3 + rank)
     net = models.mLstm_flipflop(size=8, stride=5)
     parallel.broadcast_parameters(net)
@@ -396,14 +399,34 @@ def dry_launch(args):
     for _ in range(5):
         dist.all_reduce(arena.flat)
     el = (time.perf_counter() - t0) / 5
+    bucket_us = []
+    for lo, hi in arena.slices():
+        t1 = time.perf_counter()
+        dist.all_reduce(arena.flat[lo:hi])
+        bucket_us.append(round((time.perf_counter() - t1) * 1e6, 1))
+    per_rank = _gather_per_rank(el * 1e3, torch.device("cpu"), world)
     dist.barrier()
     if rank == 0:
         print(json.dumps(dict(metric="launcher dry run (no GPU, gloo)", dry_launch=True, n_gpus=world,
+                              config=dict(workload="config %d" % args.config),
                               ranks_seen=sorted(int(t.item()) for t in seen),
+                              per_rank_ms=per_rank, cores_per_rank=len(cores),
                               rccl=dict(ranks=world, backend="gloo", bytes=arena.flat.numel() * 4,
-                                        allreduce_us=round(el * 1e6, 1), overlap_buckets=len(arena._buckets)))),
+                                        allreduce_us=round(el * 1e6, 1), overlap_buckets=len(arena._buckets),
+                                        bucket_bytes=[(hi - lo) * 4 for lo, hi in arena.slices()],
+                                        bucket_us=bucket_us))),
               flush=True)
     dist.destroy_process_group()
+
+
+def _gather_per_rank(ms, dev, world):
+    """Every rank's own ms/step: min / max / all -- a straggler (a rank whose launch thread was
+    starved, a GPU that clocks lower) shows here before it shows in the scaling curve."""
+    mine = torch.tensor([ms], dtype=torch.float64, device=dev)
+    out = [torch.zeros_like(mine) for _ in range(world)]
+    dist.all_gather(out, mine)
+    vals = [round(float(t.item()), 3) for t in out]
+    return dict(min=min(vals), max=max(vals), all=vals)
 
 
 def main():
@@ -491,6 +514,7 @@ def main():
         raise SystemExit("bench.py: rank %d has no GPU (%d visible)" % (rank, torch.cuda.device_count()))
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
+    cores = parallel.pin_rank(local, int(os.environ.get("LOCAL_WORLD_SIZE", world))) if world > 1 else []
     _lib.lib()
     _lib.set_strict(False)      # status words are checked once, after the timed region
 
@@ -620,7 +644,10 @@ def main():
     elapsed = time.perf_counter() - t0
     _lib.raise_if_nonfinite()
     rccl = None
+    per_rank = None
     if dist.is_initialized():
+        per_rank = _gather_per_rank(elapsed / args.steps * 1e3, dev if dist.get_backend() == "nccl" else
+                                    torch.device("cpu"), world)
         tmax = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         elapsed = float(tmax.item())
@@ -639,9 +666,22 @@ def main():
             evs.append((a, b))
         torch.cuda.synchronize()
         us = sorted(a.elapsed_time(b) * 1e3 for a, b in evs)
+        # ... and slice by slice, as the step issues them from the backward hooks
+        bucket_us = []
+        for lo, hi in arena.slices():
+            evb = []
+            for _ in range(10):
+                a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                a.record()
+                dist.all_reduce(arena.flat[lo:hi])
+                b.record()
+                evb.append((a, b))
+            torch.cuda.synchronize()
+            bucket_us.append(round(float(np.mean([a.elapsed_time(b) * 1e3 for a, b in evb])), 1))
         rccl = dict(ranks=world, backend=dist.get_backend(), bytes=arena.flat.numel() * 4,
                     allreduce_us=round(float(np.mean(us)), 1), allreduce_min_us=round(us[0], 1),
                     overlap_buckets=len(arena._buckets),
+                    bucket_bytes=[(hi - lo) * 4 for lo, hi in arena.slices()], bucket_us=bucket_us,
                     note="one flat fp32 gradient arena; in the step it is reduced in %d slices issued from "
                          "backward hooks on RCCL's high-priority stream" % max(1, len(arena._buckets)))
 
@@ -668,6 +708,8 @@ def main():
                                % world))
         if rccl is not None:
             out["rccl"] = rccl
+            out["per_rank_ms"] = per_rank
+            out["cores_per_rank"] = len(cores)
         # ---- loss-path kernels, HIP events on the launching stream, right after the timed steps
         #      (the step itself may be a hipGraph replay, so per-launch events cannot be
         #      interleaved with it) -----------------------------------------------------------

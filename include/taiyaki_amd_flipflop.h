@@ -345,6 +345,25 @@ void cat_mod_flipflop_cost(float const *logprob, size_t ntrans, size_t nblk,
                            float const *modmovefacts, int32_t const *seqlen,
                            float *score);
 
+/* ------------------------------------------------------------------------- *
+ * Multi-GPU: the data-parallel gradient all-reduce on RCCL over xGMI
+ * (libtaiyaki_amd_rccl.so -- a library of its own, see csrc/rccl_api.cpp).
+ * Replaces the collective inside the reference's DistributedDataParallel wrap
+ * (bin/train_flipflop.py:255-268 process group, 384-397 all-reduce in backward)
+ * and its checkpoint-file + barrier parameter hand-shake (380-392).
+ * One process per GPU; rank 0 makes the unique id and hands its
+ * tk_rccl_unique_id_bytes() bytes to the other ranks; every rank then calls
+ * tk_rccl_comm_init (collective).  tk_allreduce_f32_dev: SUM in place over the
+ * ranks, enqueued on `stream` (the 1 / nranks factor is the caller's);
+ * tk_broadcast_f32_dev: rank `root`'s buffer to every rank.
+ * ------------------------------------------------------------------------- */
+size_t tk_rccl_unique_id_bytes(void);
+int tk_rccl_unique_id(void *id_out, size_t bytes);
+int tk_rccl_comm_init(void **comm_out, int nranks, const void *id_bytes, int rank);
+int tk_allreduce_f32_dev(void *comm, float *buf, size_t n, void *stream);
+int tk_broadcast_f32_dev(void *comm, float *buf, size_t n, int root, void *stream);
+int tk_rccl_comm_destroy(void *comm);
+
 #ifdef __cplusplus
 }
 #endif

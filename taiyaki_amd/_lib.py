@@ -52,6 +52,19 @@ SIGNATURES = {
     "cat_mod_flipflop_cost": (None, [_vp, _sz, _sz, _sz, _vp, _vp, _vp, _vp, _vp, _vp]),
 }
 
+# libtaiyaki_amd_rccl.so (csrc/rccl_api.cpp): the gradient all-reduce straight on RCCL, for hosts
+# that do not go through torch.distributed.  A library of its own; the Python trainers use
+# ProcessGroupNCCL (the same RCCL calls) and never load it.
+RCCL_LIBNAME = "libtaiyaki_amd_rccl.so"
+RCCL_SIGNATURES = {
+    "tk_rccl_unique_id_bytes": (_sz, []),
+    "tk_rccl_unique_id": (_i, [_vp, _sz]),
+    "tk_rccl_comm_init": (_i, [ctypes.POINTER(_vp), _i, _vp, _i]),
+    "tk_allreduce_f32_dev": (_i, [_vp, _vp, _sz, _vp]),
+    "tk_broadcast_f32_dev": (_i, [_vp, _vp, _sz, _i, _vp]),
+    "tk_rccl_comm_destroy": (_i, [_vp]),
+}
+
 ERRORS = {1: "bad argument (NULL / shape / 16-byte alignment)",
           2: "unsupported nbase / ntrans / sequence length for this build",
           3: "workspace too small", 4: "HIP launch failure"}
@@ -81,6 +94,23 @@ def lib():
             fn.argtypes = args
         _lib = handle
     return _lib
+
+
+_rccl = None
+
+
+def rccl_lib():
+    """The RCCL C-ABI library (loads librccl: only for hosts that want the collective without
+    torch.distributed)."""
+    global _rccl
+    if _rccl is None:
+        handle = ctypes.CDLL(os.path.join(CSRC, RCCL_LIBNAME))
+        for name, (res, args) in RCCL_SIGNATURES.items():
+            fn = getattr(handle, name)
+            fn.restype = res
+            fn.argtypes = args
+        _rccl = handle
+    return _rccl
 
 
 def check(rc, what):

@@ -29,6 +29,12 @@ def init_from_env(backend=None):
         os.environ.setdefault("MASTER_PORT", "29500")
         if backend is None:
             backend = "nccl" if torch.cuda.is_available() else "gloo"
+        if os.environ.get("TK_ARENA_TRACE"):
+            # RCCL then prints its topology and, per collective, the algorithm / protocol / channel
+            # count it picked (ring vs tree, LL vs Simple) to stderr: the first thing to look at
+            # when the 8-GPU curve disappoints
+            os.environ.setdefault("NCCL_DEBUG", "INFO")
+            os.environ.setdefault("NCCL_DEBUG_SUBSYS", "INIT,COLL")
         if backend == "nccl":
             torch.cuda.set_device(local)
             # RCCL's kernels go to a HIGH-PRIORITY stream: HIP keeps a hardware queue per
@@ -45,6 +51,26 @@ def init_from_env(backend=None):
         else:
             dist.init_process_group(backend=backend)
     return rank, local, world
+
+
+def pin_rank(local, nlocal):
+    """One core set per rank: the host side of a step is ~8,000 eager launches of the RNN
+    backward from ONE thread per rank, and eight such threads (plus their OpenMP / autograd
+    helper threads) wandering over the same cores cost each other cache and time.  Rank `local`
+    of `nlocal` gets the `local`-th slice of the cores this process may use; intra-op threads are
+    capped to that slice.  Returns the cores (sorted) -- reported in the bench line."""
+    try:
+        cores = sorted(os.sched_getaffinity(0))
+    except AttributeError:          # not Linux
+        return []
+    per = max(1, len(cores) // max(1, nlocal))
+    mine = cores[(local * per) % len(cores):][:per] or cores
+    try:
+        os.sched_setaffinity(0, mine)
+    except OSError:
+        return cores
+    torch.set_num_threads(max(1, min(len(mine), int(os.environ.get("OMP_NUM_THREADS", "8")))))
+    return mine
 
 
 def _trace(msg):
@@ -119,6 +145,10 @@ class FlatGradArena:
     @property
     def overlapped(self):
         return bool(self._buckets)
+
+    def slices(self):
+        """(lo, hi) of every all-reduce a step issues (one: the whole arena without overlap hooks)."""
+        return [(b[0], b[1]) for b in self._buckets] or [(0, self.flat.numel())]
 
     # -- step interface ----------------------------------------------------------------------
     def zero(self):

@@ -194,6 +194,25 @@ def test_bench_gpus_2_launches_two_ranks_itself(tmp_path):
     assert out["rccl"]["ranks"] == 2 and out["rccl"]["bytes"] > 0 and out["rccl"]["overlap_buckets"] >= 2
 
 
+def test_bench_config_3_dry_launch_starts_eight_ranks(tmp_path):
+    """BASELINE configs[2] (batch 1024 over 8 GPUs) is the driver's to measure; what can be checked
+    here is its launch path: `python bench.py --config 3 --dry-launch` defaults to 8 ranks, each
+    pinned to its own cores, and rank 0 reports the per-rank and per-slice timings the real run
+    will carry."""
+    import json
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK")}
+    pr = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--config", "3", "--dry-launch"],
+                        capture_output=True, text=True, timeout=600, env=env)
+    assert pr.returncode == 0, pr.stderr[-2000:]
+    out = json.loads([ln for ln in pr.stdout.splitlines() if ln.startswith("{")][-1])
+    assert out["n_gpus"] == 8 and out["ranks_seen"] == list(range(8))
+    assert len(out["per_rank_ms"]["all"]) == 8 and out["per_rank_ms"]["min"] <= out["per_rank_ms"]["max"]
+    assert out["cores_per_rank"] >= 1
+    r = out["rccl"]
+    assert r["ranks"] == 8 and len(r["bucket_us"]) == len(r["bucket_bytes"]) == max(1, r["overlap_buckets"])
+    assert sum(r["bucket_bytes"]) == r["bytes"]
+
+
 def test_bench_refuses_more_ranks_than_gpus():
     """Asking for more GPUs than are visible must fail loudly, never measure fewer ranks."""
     env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK")}

@@ -429,6 +429,52 @@ def _gather_per_rank(ms, dev, world):
     return dict(min=min(vals), max=max(vals), all=vals)
 
 
+def variable_length_bench(args, cfg, trainer, dev, rank, use_graph):
+    """`--chunk-len-range MIN MAX`: the reference's per-iteration chunk length draw on graph replay."""
+    from taiyaki_amd import _lib, train
+    lo, hi = args.chunk_len_range
+    stride, cat_mod = cfg["stride"], cfg["model"] == "mLstm_cat_mod_flipflop"
+    lens = sorted({train.bucket_chunk_len(x, stride, args.len_bucket) for x in range(lo, hi + 1, stride)})
+    # the reference keeps samples per sub-batch constant: min_sub_batch_size * chunk_len_max / chunk_len
+    nb_of = lambda cl: max(1, int(cfg["batch"] * cfg["chunk_len"] / cl + 0.5))      # noqa: E731
+    by_len = {cl: make_batches(nb_of(cl), cl, stride, 17 + rank + cl, dev, n=2, spb=cfg["spb"], cat_mod=cat_mod)
+              for cl in lens}
+    maxlen = {cl: max(b["seqlens"].tk_max_seqlen for b in bs) for cl, bs in by_len.items()}
+    stepper = trainer
+    mode = "eager"
+    if use_graph:
+        stepper = train.GraphCacheTrainer(trainer, seq_capacity_per_chunk=lambda cl: cl // stride + 1,
+                                          max_seqlen_of=lambda cl: maxlen[cl])
+        mode = "one captured forward+loss graph per shape (train.GraphCacheTrainer), eager backward, AdamW replayed"
+    rng = np.random.RandomState(11)
+    draw = lambda: train.bucket_chunk_len(int(rng.randint(lo, hi + 1)), stride, args.len_bucket)    # noqa: E731
+    for cl in lens:                         # every shape once: captures
+        stepper.step(by_len[cl][0])
+    for i in range(args.warmup):
+        stepper.step(by_len[draw()][i % 2])
+    torch.cuda.synchronize()
+    chunks = samples = 0
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        cl = draw()
+        b = by_len[cl][i % 2]
+        stepper.step(b)
+        chunks += b["indata"].shape[1]
+        samples += b["indata"].shape[0] * b["indata"].shape[1]
+    torch.cuda.synchronize()
+    el = time.perf_counter() - t0
+    _lib.raise_if_nonfinite()
+    print(json.dumps(dict(
+        metric="signal-chunks/sec, flip-flop train step with the reference's per-iteration chunk length draw",
+        value=round(chunks / el, 2), unit="chunks/s", samples_per_s=round(samples / el, 1), n_gpus=1,
+        steps=args.steps, warmup=args.warmup, ms_per_step=round(el / args.steps * 1e3, 3), higher_is_better=True,
+        dtype="f32", data="synthetic",
+        config=dict(workload=cfg["label"] + ", chunk_len drawn in [%d, %d] per step, batch = %d * %d / chunk_len "
+                    "(bin/train_flipflop.py:554-563)" % (lo, hi, cfg["batch"], cfg["chunk_len"]),
+                    chunk_len_grid=lens, batch_of_len={str(cl): nb_of(cl) for cl in lens}, launch=mode,
+                    distinct_graphs=len(getattr(stepper, "entries", {}))))), flush=True)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=None)
@@ -467,6 +513,12 @@ def main():
     ap.add_argument("--overlap-buckets", type=int, default=4,
                     help="gradient all-reduce slices issued from backward hooks (N > 1); 0 = one all-reduce "
                          "after backward")
+    ap.add_argument("--chunk-len-range", type=int, nargs=2, default=None, metavar=("MIN", "MAX"),
+                    help="the reference's own schedule (bin/train_flipflop.py:554-563, defaults 3000 8000): every "
+                         "step draws a chunk length in [MIN, MAX] and rescales the batch to batch * chunk_len / "
+                         "length; lengths are rounded down to a grid (--len-bucket) and every shape replays its "
+                         "own captured graph (train.GraphCacheTrainer).  Prints its own JSON line")
+    ap.add_argument("--len-bucket", type=int, default=100, help="grid of --chunk-len-range in blocks (strides)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-rowk", action="store_true")
     ap.add_argument("--no-pmc", action="store_true", help="do not run the rocprofv3 PMC passes")
@@ -574,6 +626,8 @@ def main():
     # the reference's default adaptive clipping (--gradient_clip_num_mads 0, window 1000):
     # gradient maxima every step, clamp once 1000 steps have been seen
     trainer = train.Trainer(net, arena, clip_num_mads=0)
+    if args.chunk_len_range and not args.probe_graph:
+        return variable_length_bench(args, cfg, trainer, dev, rank, use_graph)
     batches = make_batches(nbatch, chunk_len, stride, 17 + rank, dev, n=2 if args.probe_graph else 4,
                            spb=cfg["spb"], cat_mod=cat_mod)
     if args.data == "store":

@@ -272,3 +272,107 @@ class HybridGraphTrainer(GraphedTrainer):
         self.trainer.clip()         # eager: two tiny launches + an async copy of the maxima
         self.opt_graph.replay()
         return self.loss
+
+
+class GraphCacheTrainer(HybridGraphTrainer):
+    """`HybridGraphTrainer` for the reference's own schedule, which draws a new chunk length for
+    every iteration and rescales the batch with it (bin/train_flipflop.py:554-563:
+    batch_chunk_len in [chunk_len_min, chunk_len_max], sub_batch_size = min_sub_batch_size *
+    chunk_len_max / batch_chunk_len): one captured forward + loss graph PER SHAPE
+    (indata.shape = (chunk_len, nbatch, 1)), captured the first time the shape is seen and
+    replayed from then on; the optimiser state and its graph are shared.  The caller keeps the
+    number of shapes small by drawing chunk lengths from a grid (`bucket_chunk_len`).
+
+    Capturing a new shape costs one eager forward / backward for the allocator and does NOT
+    touch the weights: the step that follows is this batch's ordinary step."""
+
+    def __init__(self, trainer, seq_capacity_per_chunk, max_seqlen_of=None, max_graphs=32):
+        """`seq_capacity_per_chunk(chunk_len) -> int`: bases reserved per chunk of that length;
+        `max_seqlen_of(chunk_len) -> int or None`: bound on a sequence's length (sizes the CRF
+        launch of that shape; None = unknown)."""
+        self.trainer = trainer
+        self.seq_capacity_per_chunk = seq_capacity_per_chunk
+        self.max_seqlen_of = max_seqlen_of or (lambda chunk_len: None)
+        self.max_graphs = max_graphs
+        self.entries = {}
+        self.opt_graph = None
+        self.nsteps = 0
+        arena = trainer.arena
+        self.alias = []
+        for p in arena.params:
+            a = p.data.requires_grad_(True)
+            a.grad = p.grad
+            self.alias.append(a)
+        g = trainer.opt.param_groups[0]
+        self.opt = torch.optim.AdamW(self.alias, lr=g["lr"], weight_decay=g["weight_decay"],
+                                     eps=g["eps"], betas=g["betas"], capturable=True)
+
+    @staticmethod
+    def key_of(batch):
+        return tuple(batch["indata"].shape) + (batch.get("mod_cats") is not None,)
+
+    def _capture_shape(self, batch):
+        if len(self.entries) >= self.max_graphs:
+            raise RuntimeError("GraphCacheTrainer: more than %d distinct batch shapes -- draw chunk lengths "
+                               "from a grid (bucket_chunk_len)" % self.max_graphs)
+        chunk_len, nbatch = batch["indata"].shape[0], batch["indata"].shape[1]
+        one = GraphedTrainer(self.trainer, batch, seq_capacity=nbatch * self.seq_capacity_per_chunk(chunk_len),
+                             max_seqlen=self.max_seqlen_of(chunk_len))
+        one.load(batch)
+        tr = self.trainer
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            # allocator / autotuner warm-up at this shape: forward + loss + backward, no optimiser
+            # step (the gradient arena is zeroed again by the captured graph)
+            for _ in range(2):
+                tr.arena.zero()
+                hooks = tr.arena.hooks_enabled
+                tr.arena.hooks_enabled = False
+                try:
+                    loss, _ = calculate_loss(tr.net, **one.static)
+                    with ctc.unit_grad():
+                        loss.backward()
+                finally:
+                    tr.arena.hooks_enabled = hooks
+        torch.cuda.current_stream().wait_stream(side)
+        torch.cuda.synchronize()
+        one.graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(one.graph, **_CAPTURE):
+            tr.arena.zero()
+            one.loss, _ = calculate_loss(tr.net, **one.static)
+        torch.cuda.synchronize()
+        return one
+
+    def step(self, batch):
+        key = self.key_of(batch)
+        one = self.entries.get(key)
+        if one is None:
+            one = self.entries[key] = self._capture_shape(batch)
+        one.load(batch)
+        one.graph.replay()
+        with ctc.unit_grad():
+            one.loss.backward(retain_graph=True)
+        self.trainer.arena.allreduce_async()
+        self.trainer.arena.finish()
+        self.trainer.clip()
+        if self.opt_graph is not None:
+            self.opt_graph.replay()
+        else:
+            self.opt.step()             # the first step creates the optimiser state eagerly ...
+            torch.cuda.synchronize()
+            self.opt_graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(self.opt_graph, **_CAPTURE):
+                self.opt.step()         # ... (capture records, it does not run) replayed from the second on
+            torch.cuda.synchronize()
+        self.nsteps += 1
+        return one.loss
+
+
+def bucket_chunk_len(chunk_len, stride, bucket_blocks=100):
+    """The reference forces a drawn chunk length to a multiple of the stride
+    (bin/train_flipflop.py:554-557); a trainer that replays captured graphs wants few distinct
+    lengths: round DOWN to a multiple of bucket_blocks strides (500 samples at stride 5: eleven
+    lengths over the default 3000-8000 range)."""
+    q = stride * bucket_blocks
+    return max(q, (int(chunk_len) // q) * q)

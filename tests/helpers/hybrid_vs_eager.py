@@ -10,7 +10,44 @@ import torch  # noqa: E402
 from taiyaki_amd import _lib, models, parallel, train  # noqa: E402
 
 
+def cache_main():
+    """GraphCacheTrainer over the reference's variable chunk length: six steps over three lengths
+    (batch size rescaled like bin/train_flipflop.py:558-563) against the eager Trainer."""
+    dev = torch.device("cuda", 0)
+    torch.cuda.set_device(dev)
+    _lib.set_strict(False)
+    try:
+        torch.backends.cuda.preferred_blas_library("cublas")
+    except Exception:
+        pass
+    stride, size = 5, 32
+    torch.manual_seed(7)
+    net_a = models.mLstm_flipflop(size=size, stride=stride).to(dev)
+    net_b = copy.deepcopy(net_a)
+    lens = [train.bucket_chunk_len(x, stride, 20) for x in (430, 655, 810)]        # -> 400, 600, 800
+    assert lens == [400, 600, 800]
+    by_len = {cl: bench.make_batches(int(6 * 800 / cl + 0.5), cl, stride, 5 + cl, dev, n=2) for cl in lens}
+    tr_a = train.Trainer(net_a, parallel.FlatGradArena(net_a), clip_num_mads=None)
+    tr_b = train.Trainer(net_b, parallel.FlatGradArena(net_b), clip_num_mads=None)
+    maxlen = {cl: max(b["seqlens"].tk_max_seqlen for b in bs) for cl, bs in by_len.items()}
+    gc = train.GraphCacheTrainer(tr_b, seq_capacity_per_chunk=lambda cl: cl // stride + 1,
+                                 max_seqlen_of=lambda cl: maxlen[cl])
+    worst = 0.0
+    order = [400, 600, 400, 800, 600, 800, 400]
+    for i, cl in enumerate(order):
+        b = by_len[cl][i % 2]
+        la = float(tr_a.step(b))
+        lb = float(gc.step(b))
+        worst = max(worst, abs(la - lb) / max(1e-6, abs(la)))
+    torch.cuda.synchronize()
+    _lib.raise_if_nonfinite()
+    pw = max(float((pa - pb).abs().max()) for pa, pb in zip(net_a.parameters(), net_b.parameters()))
+    print("hybrid-ok loss_rel=%.3e param_abs=%.3e graphs=%d" % (worst, pw, len(gc.entries)))
+
+
 def main():
+    if len(sys.argv) > 1 and sys.argv[1] == "cache":
+        return cache_main()
     whole = len(sys.argv) > 1 and sys.argv[1] == "whole"
     if whole:
         # the ATen per-timestep LSTM: the only RNN whose backward captures (bench.py --lstm native)

@@ -681,6 +681,24 @@ def test_hybrid_graph_trainer_matches_eager(gpu_device):
     assert float(m.group(1)) < 1e-4 and float(m.group(2)) < 1e-4, pr.stdout
 
 
+def test_graph_cache_trainer_follows_the_reference_chunk_length_schedule(gpu_device):
+    """bin/train_flipflop.py:554-563 draws a new chunk length (and batch size) every iteration:
+    GraphCacheTrainer keeps one captured forward + loss graph per shape (lengths drawn from a
+    grid), shares the optimiser state, and must train exactly like the eager Trainer over a
+    sequence that revisits three lengths."""
+    import os
+    import re
+    import subprocess
+    import sys
+    script = os.path.join(os.path.dirname(os.path.abspath(__file__)), "helpers", "hybrid_vs_eager.py")
+    pr = subprocess.run([sys.executable, script, "cache"], capture_output=True, text=True, timeout=900)
+    if pr.returncode != 0 and "hybrid-ok" not in pr.stdout:
+        pytest.skip("hipGraph capture of the MIOpen LSTM forward is not available here: " + pr.stderr[-300:])
+    m = re.search(r"loss_rel=(\S+) param_abs=(\S+) graphs=(\d+)", pr.stdout)
+    assert m, pr.stdout
+    assert float(m.group(1)) < 1e-4 and float(m.group(2)) < 1e-4 and int(m.group(3)) == 3, pr.stdout
+
+
 def test_whole_step_graph_trainer_clips_like_eager(gpu_device):
     """GraphedTrainer (the whole step in one hipGraph, ATen LSTM) with adaptive clipping: the
     clamp kernel is captured with +inf thresholds and must start clamping once the rolling

@@ -17,6 +17,7 @@
 //     recursion and writes every posterior to a slot PRE-SORTED by transition id; at tile flush
 //     a wave turns a row into per-id sums with a DPP prefix scan and boundary differences (no
 //     atomics), normalises the row (c_crf_flipflop.c:400-401) and streams it out once.
+#include <stdio.h>
 #include <stdlib.h>
 
 #include "crf_band.h"
@@ -742,6 +743,15 @@ int crf_dispatch(const float *logprob, size_t ntrans, size_t nblk, size_t nbatch
         b.dbg = nullptr;
         const int rc = crf_band_dispatch(b, l.R, mod, stream);
         if (rc != 0) return rc;
+        if (getenv("TK_CRF_GATE_DUMP")) {                       // lab: how many reads did the band path disown?
+            (void)hipStreamSynchronize(stream);
+            static int hostg[1 << 16];
+            const size_t ng = nbatch < (1u << 16) ? nbatch : (1u << 16);
+            (void)hipMemcpy(hostg, b.gate, ng * sizeof(int), hipMemcpyDeviceToHost);
+            size_t cnt = 0;
+            for (size_t i = 0; i < ng; ++i) cnt += hostg[i] != 0;
+            fprintf(stderr, "crf band: %zu of %zu reads gated\n", cnt, ng);
+        }
         // the reads the linear path disowned, redone in the log domain
         a.gate = b.gate;
         wb += crf_band_layout(ntrans, nblk, nbatch, max_seqlen, true, g).total;

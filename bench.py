@@ -799,7 +799,7 @@ def main():
         def crf_roofline(ops, reps, label, realistic):
             mean_s, min_s = _events_mean_min(ops.crf, reps, warm=5)
             tr, src = traffic_of("crf", ops.T, ops.N, realistic)
-            return roofline_record("sequence CRF op (build_indices + crf_band_sweep + crf_band_posterior), "
+            return roofline_record("sequence CRF op (build_indices + crf_band_sweep + crf_band_posterior + gated crf_kernel), "
                                    "T=%d N=%d S=%d, max L %d (%s)" % (ops.T, ops.N, ops.S, ops.maxlen, label),
                                    3.0 * ops.T * ops.N * ops.S * 4, mean_s, min_s, reps, tr, src)
 
@@ -809,10 +809,12 @@ def main():
             out["roofline_crf"] = dict(
                 in_step=crf_roofline(step_ops, 20, "the train step's own launch, realistic lengths", chunk_len),
                 rowK=crf_roofline(rowk, 5, "north_star shape, SPEED_TEST lengths 0.45-0.55 T", 0),
-                note="the sweep is issue-bound by the serial lattice recursion (one wave per 64 R cells, all of "
-                     "a read's waves on one CU), the posterior pass HBM-bound by the two lattices of the band "
-                     "(written once, read once: `traffic`); achieved is the algorithmic 3*T*N*S*4 bytes over "
-                     "the op's duration")
+                note="linear-domain band sweeps (per-cell power-of-two frames) + recomputing gradient pass: both are "
+                     "bound by instruction issue -- T serial steps per read, all of a read's waves on one CU -- "
+                     "not by HBM; `traffic` = scores read three times, one checkpoint column + boundary cells per "
+                     "8-step block written and read, the gradient written once; achieved is the algorithmic "
+                     "3*T*N*S*4 bytes over the op's duration (build_indices + sweeps + gradient pass + the gated "
+                     "log-domain launch, which finds nothing to redo on these inputs)")
         else:
             out["roofline"] = logz_roofline(step_ops, 30, "the train step's own launch")
         # ---- the whole loss path in one unit ------------------------------------------------

@@ -828,9 +828,10 @@ def test_config1_mgru_abinitio_lossvector(oracle_mod, gpu_device):
     indata = torch.from_numpy(synth.signal_chunks(chunk_len, N, 9)).to(gpu_device)
     outputs = net(indata).detach().requires_grad_(True)
     assert outputs.shape == (1000, N, 40)
-    _, lossvector = train.calculate_loss(lambda _x: outputs, indata, torch.from_numpy(seqs),
-                                         torch.from_numpy(seqlens))
-    lossvector.mean().backward()
+    loss, lossvector = train.calculate_loss(lambda _x: outputs, indata, torch.from_numpy(seqs),
+                                            torch.from_numpy(seqlens))
+    loss.backward()         # (the mean of the loss vector: the kernels write d mean / d outputs directly)
+    assert abs(float(loss) - float(lossvector.mean())) < 1e-6
     sc = outputs.detach().cpu().numpy()
     oloss, ograd = oracle_mod.crf_flipflop_loss(sc, seqs, seqlens, 1.0)
     olz, olgrad = oracle_mod.flipflop_logz_grad(sc)

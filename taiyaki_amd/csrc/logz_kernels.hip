@@ -184,6 +184,9 @@ struct LogzWs {
     // pass over the (T, N, S) tensor in backward).  logZ / the loss values are not scaled.
     float grad_scale;
     const float *grad_scale_vec;
+    // reads in the whole tensor: the row stride.  (A launch may cover a sub-range of the reads --
+    // every pointer then starts at its first read -- see logz_launch.)
+    int nstride;
 };
 
 // per-wave LDS buffer of K3 in f4 units: the row-set transpose buffer, which
@@ -230,7 +233,7 @@ __global__ __launch_bounds__(K1_WAVES *WAVE, 2) void logz_transfer_kernel(
     const int n0 = blockIdx.x * WAVE;
     const int nvalid = min(WAVE, N - n0) * F::PIECES;
     const int t0 = c * CH, t1 = min(T, t0 + CH);
-    const size_t rowstride = (size_t)N * F::S;
+    const size_t rowstride = (size_t)ws.nstride * F::S;
     const float *base = scores + (size_t)n0 * F::S;
 
     // The running product is kept as PAIRS OF ROWS (Pp[ip][j] = rows 2ip, 2ip+1 at column
@@ -465,7 +468,7 @@ __global__ __launch_bounds__(K1_WAVES *WAVE, 2) void logz_transfer_coop_kernel(
     const int nvalid = min(WAVE, N - n0) * F::PIECES;
     constexpr int K1_ROWS = CH / K1_WAVES;
     const int t0 = c * CH + wave * K1_ROWS, t1 = min(T, t0 + K1_ROWS);
-    const size_t rowstride = (size_t)N * F::S;
+    const size_t rowstride = (size_t)ws.nstride * F::S;
     const float *base = scores + (size_t)n0 * F::S;
 
     X P;
@@ -984,7 +987,7 @@ __global__ __launch_bounds__(K3_WAVES *WAVE, (CH / K3_WAVES <= 2 ? 4 : 2)) void 
     const int c = blockIdx.y;
     const int n0 = blockIdx.x * WAVE;
     const int nvalid = min(WAVE, N - n0) * F::PIECES;
-    const size_t rowstride = (size_t)N * F::S;
+    const size_t rowstride = (size_t)ws.nstride * F::S;
     const int tw = c * CH + wave * K3_ROWS;             // first row of this wave
     const float *base = scores + (size_t)n0 * F::S;
     const size_t n = (size_t)n0 + lane;
@@ -1165,14 +1168,21 @@ static size_t logz_ws_layout(size_t T, size_t N, void *base, LogzWs *ws) {
     return off;
 }
 
+constexpr int PH_TRANSFER = 1, PH_MIDDLE = 2, PH_POSTERIOR = 4, PH_ALL = 7;
+
+// `phases`: which of the three launches to enqueue (the two-queue pipeline of logz_launch issues
+// them separately); `nchunks_all`: chunk count of the WHOLE operator call, which picks the form of
+// the transfer kernel (a sub-range of the reads runs the form the whole call would).
 template <int NB, int CH>
 static int logz_launch_ch(const float *scores, size_t T, size_t N, float *logz, float *grad,
-                          LogzWs ws, uint32_t *status, hipStream_t stream) {
+                          LogzWs ws, uint32_t *status, hipStream_t stream, int phases = PH_ALL,
+                          size_t nchunks_all = 0) {
     using F = FF<NB>;
     const int C = (int)((T + CH - 1) / CH);
     const int SUP = logz_super(C), NSUP = (C + SUP - 1) / SUP;
     const int ncols = (int)((N + WAVE - 1) / WAVE), Npad = ncols * WAVE;
-    {
+    if (nchunks_all == 0) nchunks_all = (size_t)ncols * C;
+    if (phases & PH_TRANSFER) {
         const size_t bufwords = 4 * (size_t)WAVE * F::PIECES, imgwords = 4 * (size_t)XMat<NB>::NF4 * WAVE;
         const size_t lds = K1_WAVES * (imgwords > bufwords ? imgwords : bufwords) * sizeof(float);
         // (the ring form's LDS image can exceed the plain one's: raise for every form, whatever `lds` is)
@@ -1183,7 +1193,7 @@ static int logz_launch_ch(const float *scores, size_t T, size_t N, float *logz, 
             return 4;
         // one wave per chunk needs about a wave per SIMD to stream at full rate; below that
         // the cooperative form (4 waves per chunk) is faster
-        if ((size_t)ncols * C >= 640) {
+        if (nchunks_all >= 640) {
             if (logz_use_ring((size_t)ncols * C)) {
                 const size_t ringlds = K1_WAVES * (size_t)K1_RING * WAVE * F::PIECES * sizeof(f4);
                 hipLaunchKernelGGL((logz_transfer_kernel<NB, CH, K1_RING, false>), dim3(ncols, (C + K1_WAVES - 1) / K1_WAVES),
@@ -1196,7 +1206,7 @@ static int logz_launch_ch(const float *scores, size_t T, size_t N, float *logz, 
                 // transfer 130 us instead of 157, the op 385 instead of 412; break-even ~300 MB).
                 // Two instantiations, not a runtime flag: a branch in the load stream costs the
                 // whole gain
-                bool nt_load = (size_t)T * N * F::S * sizeof(float) > ((size_t)300 << 20);
+                bool nt_load = (size_t)T * ws.nstride * F::S * sizeof(float) > ((size_t)300 << 20);
                 if (const char *e = getenv("TK_K1_NT")) nt_load = atoi(e) != 0;     // tuning / test override
                 const dim3 grid(ncols, (C + K1_WAVES - 1) / K1_WAVES);
                 if (nt_load)
@@ -1210,7 +1220,7 @@ static int logz_launch_ch(const float *scores, size_t T, size_t N, float *logz, 
             hipLaunchKernelGGL((logz_transfer_coop_kernel<NB, CH>), dim3(ncols, C), dim3(K1_WAVES * WAVE),
                                lds, stream, scores, (int)T, (int)N, C, Npad, ws);
     }
-    {
+    if (phases & PH_MIDDLE) {
         const size_t lds = logz_middle_lds_bytes<NB>(C, NSUP);
         if (lds > 160 * 1024) return 2;         // too many chunks for one LDS image
         if (raise_dynamic_lds(reinterpret_cast<const void *>(&logz_middle_kernel<NB, 8>)) ||
@@ -1223,7 +1233,7 @@ static int logz_launch_ch(const float *scores, size_t T, size_t N, float *logz, 
             hipLaunchKernelGGL((logz_middle_kernel<NB, 16>), dim3((unsigned)N), dim3(K2_WAVES * WAVE), lds, stream,
                                (int)N, C, NSUP, Npad, ws, logz, grad != nullptr ? 1 : 0, status);
     }
-    if (grad != nullptr) {
+    if (grad != nullptr && (phases & PH_POSTERIOR)) {
         dim3 grid(ncols, C), block(K3_WAVES * WAVE);
         constexpr bool chain_in_buf =
             ((CH / K3_WAVES) + 2) * F::NS * WAVE <= k3_buf_f4<NB, CH>() * 4;
@@ -1232,7 +1242,7 @@ static int logz_launch_ch(const float *scores, size_t T, size_t N, float *logz, 
         if (raise_dynamic_lds(reinterpret_cast<const void *>(&logz_posterior_kernel<NB, CH, false>)) ||
             raise_dynamic_lds(reinterpret_cast<const void *>(&logz_posterior_kernel<NB, CH, true>)))
             return 4;
-        const int nt_load = (size_t)T * N * F::S * sizeof(float) > ((size_t)200 << 20);
+        const int nt_load = (size_t)T * ws.nstride * F::S * sizeof(float) > ((size_t)200 << 20);
         if (ws.loss_acc != nullptr)
             hipLaunchKernelGGL((logz_posterior_kernel<NB, CH, true>), grid, block, lds, stream, scores, grad,
                                (int)T, (int)N, Npad, ws, status, nt_load);
@@ -1241,6 +1251,81 @@ static int logz_launch_ch(const float *scores, size_t T, size_t N, float *logz, 
                                (int)T, (int)N, Npad, ws, status, nt_load);
     }
     return hipGetLastError() == hipSuccess ? 0 : 4;
+}
+
+// A second hardware queue for the pipeline below: a HIGH-PRIORITY stream per device (HIP keeps a
+// hardware queue per priority level, so it runs beside the caller's stream even when
+// GPU_MAX_HW_QUEUES = 1 keeps the train step's compute on one queue, tools/queue_probe.py).
+struct LogzSide {
+    hipStream_t s = nullptr;
+    hipEvent_t fork = nullptr, t1 = nullptr, join = nullptr;
+    bool ok = false;
+};
+static LogzSide *logz_side_for_current_device() {
+    static std::mutex mu;
+    static LogzSide side[64];
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return nullptr;
+    std::lock_guard<std::mutex> g(mu);
+    LogzSide &sd = side[dev];
+    if (sd.s == nullptr) {
+        int lo = 0, hi = 0;
+        (void)hipDeviceGetStreamPriorityRange(&lo, &hi);       // hi = numerically lowest = highest priority
+        sd.ok = hipStreamCreateWithPriority(&sd.s, hipStreamNonBlocking, hi) == hipSuccess &&
+                hipEventCreateWithFlags(&sd.fork, hipEventDisableTiming) == hipSuccess &&
+                hipEventCreateWithFlags(&sd.t1, hipEventDisableTiming) == hipSuccess &&
+                hipEventCreateWithFlags(&sd.join, hipEventDisableTiming) == hipSuccess;
+        if (!sd.ok) (void)hipGetLastError();
+    }
+    return sd.ok ? &sd : nullptr;
+}
+
+// the workspace and the per-read vectors of a sub-range of the reads starting at read n0 (every
+// per-read array is read-major)
+template <int NB>
+static LogzWs logz_ws_from(const LogzWs &ws, size_t n0, size_t C) {
+    using F = FF<NB>;
+    LogzWs o = ws;
+    o.Pc = ws.Pc + n0 * C * XMat<NB>::NF4;
+    o.Vin = ws.Vin + n0 * C * F::NS;
+    o.Uout = ws.Uout + n0 * C * F::NS;
+    if (ws.loss_acc != nullptr) o.loss_acc = ws.loss_acc + n0;
+    if (ws.grad_scale_vec != nullptr) o.grad_scale_vec = ws.grad_scale_vec + n0;
+    return o;
+}
+
+// TWO-QUEUE PIPELINE over the reads (big tensors): transfer -> middle -> posterior is a strict chain
+// and every launch is a single round of workgroups, so nothing overlaps inside one queue; the middle
+// kernel's ~14 us are pure dependent-step latency with the memory system idle.  The reads are cut in
+// two halves (whole 64-read column groups) and the second half runs one stage behind the first in a
+// second hardware queue:
+//      queue A:  transfer(h1) | middle(h1)   | posterior(h1)              | (join)
+//      queue B:       (wait)  | transfer(h2) | middle(h2) | posterior(h2) |
+// -- middle(h1) runs beside transfer(h2), middle(h2) beside posterior(h1).
+template <int NB, int CH>
+static int logz_launch_split(const float *scores, size_t T, size_t N, float *logz, float *grad, LogzWs ws,
+                             uint32_t *status, hipStream_t stream, LogzSide *sd) {
+    using F = FF<NB>;
+    const size_t C = (T + CH - 1) / CH;
+    const size_t ncols = (N + WAVE - 1) / WAVE, n1 = (ncols / 2) * WAVE, n2 = N - n1;
+    const size_t all = ncols * C;
+    const LogzWs w1 = logz_ws_from<NB>(ws, 0, C), w2 = logz_ws_from<NB>(ws, n1, C);
+    const float *s2 = scores + n1 * F::S;
+    float *g2 = grad + n1 * F::S, *z2 = logz + n1;
+    int rc = 0;
+    if (hipEventRecord(sd->fork, stream) != hipSuccess || hipStreamWaitEvent(sd->s, sd->fork, 0) != hipSuccess) return 4;
+    rc = logz_launch_ch<NB, CH>(scores, T, n1, logz, grad, w1, status, stream, PH_TRANSFER, all);
+    if (rc) return rc;
+    const char *mode = getenv("TK_LOGZ_SPLIT");
+    const bool stagger = !(mode && mode[0] == '2');             // lab: 2 = both halves side by side, no stagger
+    if (stagger && (hipEventRecord(sd->t1, stream) != hipSuccess || hipStreamWaitEvent(sd->s, sd->t1, 0) != hipSuccess))
+        return 4;
+    rc = logz_launch_ch<NB, CH>(s2, T, n2, z2, g2, w2, status, sd->s, PH_ALL, all);
+    if (rc) return rc;
+    if (hipEventRecord(sd->join, sd->s) != hipSuccess) return 4;
+    rc = logz_launch_ch<NB, CH>(scores, T, n1, logz, grad, w1, status, stream, PH_MIDDLE | PH_POSTERIOR, all);
+    if (rc) return rc;
+    return hipStreamWaitEvent(stream, sd->join, 0) == hipSuccess ? 0 : 4;
 }
 
 template <int NB>
@@ -1255,6 +1340,7 @@ static int logz_launch(const float *scores, size_t T, size_t N, float *logz, flo
     ws.acc_scale = acc_scale;
     ws.grad_scale = grad_scale;
     ws.grad_scale_vec = grad_scale_vec;
+    ws.nstride = (int)N;
     int ch = logz_pick_ch(T, N);
     if (const char *e = getenv("TK_LOGZ_CH")) ch = atoi(e);         // tuning override
     // the middle kernel keeps one read's chunk matrices in LDS: fall back to bigger chunks
@@ -1263,6 +1349,23 @@ static int logz_launch(const float *scores, size_t T, size_t N, float *logz, flo
         return logz_middle_lds_bytes<NB>(C, (C + logz_super(C) - 1) / logz_super(C));
     };
     while (ch < 32 && middle_lds(ch) > 160 * 1024) ch *= 2;
+    {
+        // OFF by default -- measured (round 3, T=4000): N=256 134.8 us staggered / 119.4 us side by side
+        // against 101.0 us for the plain chain, N=512 229 / 221 against 204.  A half's kernels do not
+        // take half the time (transfer 25.9 us against 30.6, middle 17.3 against 14.0, posterior 34.6
+        // against 53.0: each wave's work is the same, only the rounds of workgroups shrink) and every
+        // cross-queue event costs ~10 us.  TK_LOGZ_SPLIT=1 (2: no stagger) keeps the experiment
+        // reproducible (tools/logz_sweep.py).
+        const size_t ncols = (N + WAVE - 1) / WAVE;
+        bool split = false;
+        if (const char *e = getenv("TK_LOGZ_SPLIT")) split = atoi(e) != 0 && grad != nullptr && ncols >= 2 && ch == 16;
+        hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+        if (split && (hipStreamIsCapturing(stream, &cap) != hipSuccess || cap != hipStreamCaptureStatusNone)) split = false;
+        if (split) {
+            if (LogzSide *sd = logz_side_for_current_device())
+                return logz_launch_split<NB, 16>(scores, T, N, logz, grad, ws, status, stream, sd);
+        }
+    }
     switch (ch) {
         case 8: return logz_launch_ch<NB, 8>(scores, T, N, logz, grad, ws, status, stream);
         case 16: return logz_launch_ch<NB, 16>(scores, T, N, logz, grad, ws, status, stream);

@@ -217,6 +217,8 @@ class LossOps:
         self.lz_wsb = L.tk_flipflop_logz_workspace_bytes(T, N, 4)
         self.lz_ws = torch.empty(self.lz_wsb, dtype=torch.uint8, device=dev)
         self.status = torch.zeros(1, dtype=torch.int32, device=dev)
+        self.aux_bytes = L.tk_flipflop_loss_fused_aux_bytes(T, N, 4, self.S)
+        self.aux = torch.empty(self.aux_bytes, dtype=torch.uint8, device=dev) if self.aux_bytes else None
 
     def crf(self):
         from taiyaki_amd import _lib
@@ -241,22 +243,20 @@ class LossOps:
 
     def both(self):
         """The loss path as the train step launches it: the fused (A) + (B) / nblk entry point
-        for the plain CRF, the two operators for cat-mod."""
-        if self.mod is not None:
-            self.crf()
-            self.logz_op()
-            return
+        (plain CRF and cat-mod)."""
         from taiyaki_amd import _lib
         L, p = _lib.lib(), _lib.ptr
         st = _lib.stream_ptr()
-        rc = L.tk_flipflop_build_indices_dev(p(self.seqs), p(self.seqlens), self.N, self.seqs.numel(), 4, None, None,
-                                             None, p(self.seqoff), p(self.stay), p(self.move), None, None,
-                                             p(self.status), st)
+        rc = L.tk_flipflop_build_indices_dev(p(self.seqs), p(self.seqlens), self.N, self.seqs.numel(), 4,
+                                             p(self.mod[0]) if self.mod else None, p(self.cmo), p(self.mcw),
+                                             p(self.seqoff), p(self.stay), p(self.move), p(self.modidx),
+                                             p(self.modfact), p(self.status), st)
         _lib.check(rc, "tk_flipflop_build_indices_dev")
-        rc = L.tk_flipflop_loss_fused_dev(p(self.x), self.T, self.N, 4, p(self.stay), p(self.move), p(self.seqlens),
+        rc = L.tk_flipflop_loss_fused_dev(p(self.x), self.T, self.N, 4, self.S, p(self.stay), p(self.move),
+                                          p(self.modidx), p(self.modfact), p(self.seqlens),
                                           p(self.seqoff), self.maxlen, 1.0, 1.0 / self.N, None, p(self.cost), p(self.grad),
                                           p(self.logz), p(self.crf_ws), self.crf_wsb, p(self.lz_ws), self.lz_wsb,
-                                          p(self.status), st)
+                                          p(self.aux), self.aux_bytes, p(self.status), st)
         _lib.check(rc, "tk_flipflop_loss_fused_dev")
 
     def finite(self):
@@ -822,7 +822,8 @@ def main():
         assert step_ops.finite()
         out["loss_path"] = dict(unit="chunks/s through crf grad + logZ fwd-bwd at the step's shape (T=%d, N=%d, "
                                      "S=%d, realistic lengths)" % (T, nbatch, S),
-                                launch=("two operators (cat-mod loss, logZ)" if cat_mod else
+                                launch=("tk_flipflop_loss_fused_dev, cat-mod form: logZ of the canonical columns first, "
+                                        "folded into the cat-mod kernel's writes; one gradient tensor" if cat_mod else
                                         "tk_flipflop_loss_fused_dev: one gradient tensor"),
                                 gpu_ms=round(lp_mean * 1e3, 4), gpu_chunks_per_s=round(nbatch / lp_mean, 1))
         if not no_cpu:

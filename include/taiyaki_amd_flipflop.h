@@ -131,15 +131,24 @@ int tk_crf_flipflop_dev(const float *logprob, size_t ntrans, size_t nblk,
  * lossvector with known weights (`lossvector.mean()` of train_flipflop.py:182:
  * 1 / nbatch) receives the final d loss / d scores and needs no elementwise pass
  * over the tensor in its backward.  1, NULL = d lossvector[n] / d scores[:, n, :].
+ * Cat-mod (`modidx`, `modfact` non-NULL, ntrans = 2 nbase (nbase + 1) + the mod
+ * columns; ctc.pyx:258-312 + logZ of the canonical columns, train_flipflop.py:
+ * 165-176): kernel B runs FIRST on a compact copy of the canonical columns (`aux`,
+ * tk_flipflop_loss_fused_aux_bytes), kernel A folds logZ / nblk and its gradient
+ * into what it writes.  Plain CRF: modidx = modfact = NULL, ntrans = 2 nbase
+ * (nbase + 1), aux may be NULL.
  * ------------------------------------------------------------------------- */
-int tk_flipflop_loss_fused_dev(const float *scores, size_t nblk, size_t nbatch, size_t nbase,
+size_t tk_flipflop_loss_fused_aux_bytes(size_t nblk, size_t nbatch, size_t nbase, size_t ntrans);
+int tk_flipflop_loss_fused_dev(const float *scores, size_t nblk, size_t nbatch, size_t nbase, size_t ntrans,
                                const int32_t *stayidx, const int32_t *moveidx,
+                               const int32_t *modidx, const float *modfact,
                                const int32_t *seqlen, const int64_t *seqoff,
                                size_t max_seqlen, float sharpfact, float grad_scale,
                                const float *grad_scale_per_read, float *lossvector,
                                float *grad, float *logz, void *crf_workspace,
                                size_t crf_workspace_bytes, void *logz_workspace,
-                               size_t logz_workspace_bytes, uint32_t *status, void *stream);
+                               size_t logz_workspace_bytes, void *aux, size_t aux_bytes,
+                               uint32_t *status, void *stream);
 
 /* ------------------------------------------------------------------------- *
  * Hash beam search (replaces taiyaki/decodeutil/c_hashdecode.h:10

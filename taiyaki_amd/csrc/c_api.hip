@@ -26,7 +26,9 @@ int crf_dispatch(const float *logprob, size_t ntrans, size_t nblk, size_t nbatch
                  const float *modfact, const int32_t *seqlen, const int64_t *seqoff,
                  size_t max_seqlen, size_t ncan, float sharp_can, float sharp_mod,
                  float out_scale, float grad_scale, const float *grad_scale_vec, float *cost, float *grad,
-                 void *workspace, size_t workspace_bytes, uint32_t *status, hipStream_t stream);
+                 void *workspace, size_t workspace_bytes, uint32_t *status, hipStream_t stream,
+                 const float *add_grad = nullptr, const float *add_cost = nullptr, int add_S = 0,
+                 float add_scale = 0.f);
 void crf_band_lab_phase(int phase);
 size_t beam_workspace_bytes(size_t T, size_t N, size_t nbase);
 int lattice_dispatch(const float *scores, size_t T, size_t N, size_t nbase, int forward, const float *init,
@@ -78,7 +80,7 @@ static inline bool aligned16(const void *p) { return (reinterpret_cast<uintptr_t
 
 extern "C" {
 
-const char *tk_version(void) { return "taiyaki_amd flipflop gfx950 r1"; }
+const char *tk_version(void) { return "taiyaki_amd flipflop gfx950 r3"; }
 
 int tk_flipflop_build_indices_dev(const int32_t *seqs, const int32_t *seqlen, size_t nbatch,
                                   size_t total_len, size_t nbase, const int32_t *mod_cats,
@@ -200,28 +202,70 @@ int tk_crf_flipflop_dev(const float *logprob, size_t ntrans, size_t nblk, size_t
                             static_cast<hipStream_t>(stream));
 }
 
-int tk_flipflop_loss_fused_dev(const float *scores, size_t nblk, size_t nbatch, size_t nbase,
-                               const int32_t *stayidx, const int32_t *moveidx, const int32_t *seqlen,
+// rows of S floats -> their first S0 columns, contiguous (the canonical block of a cat-mod tensor)
+__global__ void slice_cols_kernel(const float *__restrict__ src, float *__restrict__ dst, size_t nrows, int S, int S0) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= nrows * (size_t)S0) return;
+    const size_t r = i / (size_t)S0;
+    dst[i] = src[r * (size_t)S + (i - r * (size_t)S0)];
+}
+
+size_t tk_flipflop_loss_fused_aux_bytes(size_t nblk, size_t nbatch, size_t nbase, size_t ntrans) {
+    const size_t ncan = 2 * nbase * (nbase + 1);
+    if (ntrans <= ncan) return 0;                               // plain CRF: kernel B works in place
+    const size_t one = (nblk * nbatch * ncan * sizeof(float) + 255) / 256 * 256;
+    return 2 * one;                                             // canonical scores + their logZ gradient
+}
+
+int tk_flipflop_loss_fused_dev(const float *scores, size_t nblk, size_t nbatch, size_t nbase, size_t ntrans,
+                               const int32_t *stayidx, const int32_t *moveidx, const int32_t *modidx,
+                               const float *modfact, const int32_t *seqlen,
                                const int64_t *seqoff, size_t max_seqlen, float sharpfact, float grad_scale,
                                const float *grad_scale_per_read, float *lossvector,
                                float *grad, float *logz, void *crf_workspace, size_t crf_workspace_bytes,
-                               void *logz_workspace, size_t logz_workspace_bytes, uint32_t *status, void *stream) {
+                               void *logz_workspace, size_t logz_workspace_bytes, void *aux, size_t aux_bytes,
+                               uint32_t *status, void *stream) {
     if (!scores || !stayidx || !moveidx || !seqlen || !seqoff || !lossvector || !grad || !logz || !crf_workspace ||
         !logz_workspace || nblk == 0 || nbatch == 0 || nbase == 0 || !(sharpfact > 0.f))
         return TK_ERR_BAD_ARG;
     if (!aligned16(scores) || !aligned16(grad)) return TK_ERR_BAD_ARG;
-    const size_t ntrans = 2 * nbase * (nbase + 1);
+    if ((modidx == nullptr) != (modfact == nullptr)) return TK_ERR_BAD_ARG;
+    const size_t ncan = 2 * nbase * (nbase + 1);
     hipStream_t st = static_cast<hipStream_t>(stream);
-    // (A) first: per-read costs into `lossvector`, its gradient into `grad`; (B) then ADDS
-    // logZ / nblk and (d logZ / d scores) / nblk in place -- in its posterior kernel, whose stores
-    // are whole coalesced row sets (the read-modify-write costs that HBM-bound kernel one more
-    // stream; done in kernel A's row-at-a-time posterior pass it cost ~18 us at the step's shape)
-    int rc = tk::crf_dispatch(scores, ntrans, nblk, nbatch, stayidx, moveidx, nullptr, nullptr, seqlen, seqoff,
-                              max_seqlen, ntrans, sharpfact, sharpfact, 1.0f / sharpfact, grad_scale,
-                              grad_scale_per_read, lossvector, grad, crf_workspace, crf_workspace_bytes, status, st);
+    if (modidx == nullptr) {
+        if (ntrans != ncan) return TK_ERR_BAD_ARG;
+        // (A) first: per-read costs into `lossvector`, its gradient into `grad`; (B) then ADDS
+        // logZ / nblk and (d logZ / d scores) / nblk in place -- in its posterior kernel, whose stores
+        // are whole coalesced row sets (the read-modify-write costs that HBM-bound kernel one more
+        // stream; done in kernel A's row-at-a-time posterior pass it cost ~18 us at the step's shape)
+        int rc = tk::crf_dispatch(scores, ntrans, nblk, nbatch, stayidx, moveidx, nullptr, nullptr, seqlen, seqoff,
+                                  max_seqlen, ntrans, sharpfact, sharpfact, 1.0f / sharpfact, grad_scale,
+                                  grad_scale_per_read, lossvector, grad, crf_workspace, crf_workspace_bytes, status, st);
+        if (rc != 0) return rc;
+        return tk::logz_dispatch(scores, nblk, nbatch, nbase, logz, grad, logz_workspace, logz_workspace_bytes, status,
+                                 st, lossvector, 1.0f / (float)nblk, grad_scale, grad_scale_per_read);
+    }
+    // cat-mod (bin/train_flipflop.py:165-176): kernel B works on the canonical columns only, which are
+    // not contiguous in the (T, N, ntrans) tensor.  (B) FIRST, on a compact copy, into a compact
+    // gradient; (A) then folds logZ / nblk into its costs and (d logZ) / nblk -- times the gradient
+    // multiplier -- into the canonical columns of the rows it writes anyway: still one gradient
+    // tensor and no elementwise pass outside these kernels.
+    if (ntrans <= ncan || ntrans > 62) return TK_ERR_BAD_ARG;
+    if (aux == nullptr || aux_bytes < tk_flipflop_loss_fused_aux_bytes(nblk, nbatch, nbase, ntrans)) return TK_ERR_WORKSPACE;
+    const size_t one = (nblk * nbatch * ncan * sizeof(float) + 255) / 256 * 256;
+    float *x40 = static_cast<float *>(aux), *g40 = reinterpret_cast<float *>(static_cast<char *>(aux) + one);
+    {
+        const size_t n = nblk * nbatch * ncan;
+        hipLaunchKernelGGL(slice_cols_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, scores, x40,
+                           nblk * nbatch, (int)ntrans, (int)ncan);
+        if (hipGetLastError() != hipSuccess) return TK_ERR_LAUNCH;
+    }
+    int rc = tk::logz_dispatch(x40, nblk, nbatch, nbase, logz, g40, logz_workspace, logz_workspace_bytes, status, st);
     if (rc != 0) return rc;
-    return tk::logz_dispatch(scores, nblk, nbatch, nbase, logz, grad, logz_workspace, logz_workspace_bytes, status, st,
-                             lossvector, 1.0f / (float)nblk, grad_scale, grad_scale_per_read);
+    // ctc.pyx:258-303: only the canonical columns are sharpened; cost / sharp
+    return tk::crf_dispatch(scores, ntrans, nblk, nbatch, stayidx, moveidx, modidx, modfact, seqlen, seqoff, max_seqlen,
+                            ncan, sharpfact, 1.0f, 1.0f / sharpfact, grad_scale, grad_scale_per_read, lossvector, grad,
+                            crf_workspace, crf_workspace_bytes, status, st, g40, logz, (int)ncan, 1.0f / (float)nblk);
 }
 
 // lab only (not declared in the public header): see crf_band.hip

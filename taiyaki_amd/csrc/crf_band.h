@@ -22,6 +22,13 @@ struct BandArgs {
     float out_scale;            // cost multiplier (1 / sharpfact)
     float grad_scale;           // gradient multiplier (1 for the reference's operators)
     const float *grad_scale_vec;    // nullable; (N): a further per-read multiplier
+    // fused cat-mod loss: kernel B ran first into a compact buffer; this operator adds
+    // add_scale * add_cost[n] to the cost and add_scale * (gradient multiplier) * add_grad[t][n][s]
+    // (s < add_S) to the gradient it writes.  Null: nothing to add.
+    const float *add_grad;      // (T, N, add_S)
+    const float *add_cost;      // (N)
+    int add_S;
+    float add_scale;
     float *cost;                // (N)
     float *grad;                // (T, N, S) or null (cost only)
     uint32_t *status;

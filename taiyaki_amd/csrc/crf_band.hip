@@ -422,7 +422,7 @@ __device__ __forceinline__ void band_sweep(const BandArgs &a, int n, int L, floa
             if (GRAD) {
                 (FWD ? a.scoreF : a.scoreB)[n] = sc2;
             } else if (sc2 - sc2 == 0.0) {
-                a.cost[n] = (float)(-(sc2 * 0.6931471805599453) / (double)T) * a.out_scale;
+                a.cost[n] = crf_add_cost(a, n, (float)(-(sc2 * 0.6931471805599453) / (double)T) * a.out_scale);
                 a.gate[n] = 0;
             } else {
                 a.gate[n] = 1;                                  // crf_kernel decides what this read costs
@@ -461,7 +461,7 @@ __global__ __launch_bounds__(WCAP *WAVE) void crf_band_sweep_kernel(BandArgs a) 
         // c_crf_flipflop.c:269-272: cost 0 for an empty read (the gradient pass does it when
         // there is one); too long for the launch: flagged
         if (!want_grad && tid == 0) {
-            a.cost[n] = (L == 0) ? 0.f : __builtin_nanf("");
+            a.cost[n] = (L == 0) ? crf_add_cost(a, n, 0.f) : __builtin_nanf("");
             a.gate[n] = 0;
             if (L != 0 && a.status) atomicOr(a.status, 16u);
         }
@@ -567,12 +567,14 @@ __global__ __launch_bounds__(POST_WAVES *WAVE) void crf_band_posterior_kernel(Ba
 
     if (L == 0 || L > a.LP) {
         if (blockIdx.y == 0 && tid == 0) {
-            a.cost[n] = (L == 0) ? 0.f : __builtin_nanf("");     // c_crf_flipflop.c:269-272, 458-464
+            a.cost[n] = (L == 0) ? crf_add_cost(a, n, 0.f) : __builtin_nanf("");   // c_crf_flipflop.c:269-272, 458-464
             if (L != 0 && a.status) atomicOr(a.status, 16u);
         }
-        if (L == 0 && lane < S)
+        if (L == 0 && lane < S) {
+            const float gs0 = a.grad_scale * (a.grad_scale_vec != nullptr ? a.grad_scale_vec[n] : 1.0f);
             for (int t = t0; t < min(t0 + BK, T); ++t)
-                a.grad[(size_t)t * rowstride + (size_t)n * S + lane] = 0.f;
+                a.grad[(size_t)t * rowstride + (size_t)n * S + lane] = crf_add_grad(a, (size_t)t, n, lane, 0.f, gs0);
+        }
         return;
     }
     const double scoreF = a.scoreF[n], scoreB = a.scoreB[n];
@@ -588,7 +590,7 @@ __global__ __launch_bounds__(POST_WAVES *WAVE) void crf_band_posterior_kernel(Ba
     if (blockIdx.y == 0 && tid == 0) {
         // score = mean of the two sweeps (c_crf_flipflop.c:482-491), cost = -score / T
         const double score2 = 0.5 * (scoreF + scoreB);
-        a.cost[n] = (float)(-(score2 * 0.6931471805599453) / (double)T) * a.out_scale;
+        a.cost[n] = crf_add_cost(a, n, (float)(-(score2 * 0.6931471805599453) / (double)T) * a.out_scale);
     }
     const int Wn = (L + PW - 1) / PW;                           // chunks this read has
     float *sP = reinterpret_cast<float *>(smem) + (size_t)wave * RG * EPL * WAVE;
@@ -876,7 +878,7 @@ __global__ __launch_bounds__(POST_WAVES *WAVE) void crf_band_posterior_kernel(Ba
             const float dev = fast_log2(total) - zfrac;
             lost |= !(dev > -ROWZ_TOL && dev < ROWZ_TOL);
             // gradient of -score / T  (ctc.pyx:113)
-            const float g = colacc * (-gsc / (total * (float)T));
+            const float g = crf_add_grad(a, (size_t)(t0 + k), n, lane, colacc * (-gsc / (total * (float)T)), gsc);
             if (lane < S) a.grad[(size_t)(t0 + k) * rowstride + (size_t)n * S + lane] = g;
         }
     }

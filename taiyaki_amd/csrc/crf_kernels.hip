@@ -45,7 +45,13 @@ struct CrfArgs {
     uint32_t *status;
     const int *gate;            // nullable; (N): only reads with gate[n] != 0 are computed (the band path's rejects)
     float grad_scale;           // gradient multiplier (1 for the reference's operators)
-    const float *grad_scale_vec;    // nullable; (N): a further per-read multiplier
+    const float *grad_scale_vec;    // nullable; (N): a further per-read multiplier    // fused cat-mod loss: kernel B ran first into a compact buffer; this operator adds
+    // add_scale * add_cost[n] to the cost and add_scale * (gradient multiplier) * add_grad[t][n][s]
+    // (s < add_S) to the gradient it writes.  Null: nothing to add.
+    const float *add_grad;      // (T, N, add_S)
+    const float *add_cost;      // (N)
+    int add_S;
+    float add_scale;
 };
 
 __host__ __device__ inline int crf_ck(int R, int W, int kinds) {
@@ -119,10 +125,10 @@ __global__ __launch_bounds__(W *WAVE) void crf_kernel(CrfArgs a) {
 
     if (L == 0) {
         // c_crf_flipflop.c:269-272 / 458-464: cost 0, zero gradient rows
-        if (tid == 0) a.cost[n] = 0.f;
+        if (tid == 0) a.cost[n] = crf_add_cost(a, n, 0.f);
         if (want_grad && lane < S) {
             for (int t = wave; t < T; t += W)
-                a.grad[(size_t)t * rowstride + (size_t)n * S + lane] = 0.f;
+                a.grad[(size_t)t * rowstride + (size_t)n * S + lane] = crf_add_grad(a, (size_t)t, n, lane, 0.f, gsc);
         }
         return;
     }
@@ -338,7 +344,7 @@ __global__ __launch_bounds__(W *WAVE) void crf_kernel(CrfArgs a) {
     const double fwd_score2 = offF + (double)misc[0];
     if (!want_grad) {
         if (tid == 0) {
-            const float cst = (float)(-(fwd_score2 * 0.6931471805599453) / (double)T) * a.out_scale;
+            const float cst = crf_add_cost(a, n, (float)(-(fwd_score2 * 0.6931471805599453) / (double)T) * a.out_scale);
             a.cost[n] = cst;
             if (a.status && !isfinite(cst)) atomicOr(a.status, 1u);
         }
@@ -460,7 +466,7 @@ __global__ __launch_bounds__(W *WAVE) void crf_kernel(CrfArgs a) {
                     }
                     wave_lds_fence();
                 }
-                const float g = colval * (-gsc / (total * (float)T));
+                const float g = crf_add_grad(a, (size_t)(t0 + row), n, lane, colval * (-gsc / (total * (float)T)), gsc);
                 if (lane < S) {
                     bad |= !isfinite(g);
                     a.grad[(size_t)(t0 + row) * rowstride + (size_t)n * S + lane] = g;
@@ -477,7 +483,7 @@ __global__ __launch_bounds__(W *WAVE) void crf_kernel(CrfArgs a) {
     if (tid == 0) {
         const double bwd_score2 = offB + (double)b[0];
         const double score2 = 0.5 * (fwd_score2 + bwd_score2);
-        const float cst = (float)(-(score2 * 0.6931471805599453) / (double)T) * a.out_scale;
+        const float cst = crf_add_cost(a, n, (float)(-(score2 * 0.6931471805599453) / (double)T) * a.out_scale);
         a.cost[n] = cst;
         if (a.status && !isfinite(cst)) atomicOr(a.status, 1u);
     }
@@ -672,7 +678,8 @@ int crf_dispatch(const float *logprob, size_t ntrans, size_t nblk, size_t nbatch
                  const float *modfact, const int32_t *seqlen, const int64_t *seqoff,
                  size_t max_seqlen, size_t ncan, float sharp_can, float sharp_mod,
                  float out_scale, float grad_scale, const float *grad_scale_vec, float *cost, float *grad,
-                 void *workspace, size_t workspace_bytes, uint32_t *status, hipStream_t stream) {
+                 void *workspace, size_t workspace_bytes, uint32_t *status, hipStream_t stream,
+                 const float *add_grad, const float *add_cost, int add_S, float add_scale) {
     if (ntrans > 62 || ncan > ntrans || ncan == 0) return 2;
     if (max_seqlen == 0) max_seqlen = nblk + 1;
     const CrfShape sh = crf_pick_shape(max_seqlen);
@@ -696,6 +703,10 @@ int crf_dispatch(const float *logprob, size_t ntrans, size_t nblk, size_t nbatch
     a.out_scale = out_scale;
     a.grad_scale = grad_scale;
     a.grad_scale_vec = grad_scale_vec;
+    a.add_grad = add_grad;
+    a.add_cost = add_cost;
+    a.add_S = add_S;
+    a.add_scale = add_scale;
     a.cost = cost;
     a.grad = grad;
     a.gate = nullptr;
@@ -722,6 +733,10 @@ int crf_dispatch(const float *logprob, size_t ntrans, size_t nblk, size_t nbatch
         b.out_scale = out_scale;
         b.grad_scale = grad_scale;
         b.grad_scale_vec = grad_scale_vec;
+        b.add_grad = add_grad;
+        b.add_cost = add_cost;
+        b.add_S = add_S;
+        b.add_scale = add_scale;
         b.cost = cost;
         b.grad = grad;
         b.status = status;

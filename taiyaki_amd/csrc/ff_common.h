@@ -239,6 +239,19 @@ __device__ __forceinline__ void ff_fwd_step(const float (&in)[2 * NB], const Row
 
 typedef float f2 __attribute__((ext_vector_type(2)));
 
+// kernel A's "add" terms (fused cat-mod loss: kernel B's logZ and gradient, computed first on the
+// canonical columns, folded into kernel A's own writes)
+template <class Args>
+__device__ __forceinline__ float crf_add_cost(const Args &a, int n, float cst) {
+    return a.add_cost != nullptr ? cst + a.add_scale * a.add_cost[n] : cst;
+}
+template <class Args>
+__device__ __forceinline__ float crf_add_grad(const Args &a, size_t t, int n, int lane, float g, float gsc) {
+    if (a.add_grad != nullptr && lane < a.add_S)
+        g = fmaf(a.add_grad[(t * (size_t)a.N + (size_t)n) * a.add_S + lane], a.add_scale * gsc, g);
+    return g;
+}
+
 // One linear-space backward step:
 //   out[from] = sum_{to<NB} w[to*NS + from] * in[to] + w[FLOP0 + from] * in[flop(from)]
 // with flop(from) = NB + (from mod NB).

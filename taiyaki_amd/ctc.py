@@ -182,37 +182,42 @@ cat_mod_flipflop_loss = CatModFlipFlop.apply
 # ---------------------------------------------------------------------------------------------
 # fused train-step loss: (A) + (B) / nblk in one operator, one gradient tensor
 # ---------------------------------------------------------------------------------------------
-def _run_fused(outputs, seqs, seqlen, sharpfact, want_grad, grad_scale=1.0, grad_scale_per_read=None):
+def _run_fused(outputs, seqs, seqlen, sharpfact, want_grad, grad_scale=1.0, grad_scale_per_read=None,
+               mod_cats=None, can_mods_offsets=None, mod_cat_weights=None):
     _lib.require_gpu(outputs, "flip-flop loss")
     L = _lib.lib()
     lp = outputs.detach().float().contiguous()
     if lp.data_ptr() % 16 != 0:
         lp = lp.clone()
     nblk, nbatch, ntrans = lp.shape
-    nbase = flipflopfings.nbase_flipflop(ntrans)
+    ncan = ntrans - (n_mod_columns(can_mods_offsets) if mod_cats is not None else 0)
+    nbase = flipflopfings.nbase_flipflop(ncan)
     dev = lp.device
     with torch.cuda.device(dev):
         status = _lib.status_word(dev)
-        seqlen_d, seqoff, stay, move, _, _, keep = _indices(seqs, seqlen, nbase, dev, status=status)
+        seqlen_d, seqoff, stay, move, mod, fact, keep = _indices(
+            seqs, seqlen, nbase, dev, mod_cats, can_mods_offsets, mod_cat_weights, status=status)
         maxlen = _max_seqlen(seqlen)
         lossvector = torch.empty(nbatch, dtype=torch.float32, device=dev)
         logz = torch.empty(nbatch, dtype=torch.float32, device=dev)
         grad = torch.empty_like(lp)
         wsa = L.tk_crf_flipflop_workspace_bytes(ntrans, nblk, nbatch, maxlen, 1)
         wsb = L.tk_flipflop_logz_workspace_bytes(nblk, nbatch, nbase)
+        wsx = L.tk_flipflop_loss_fused_aux_bytes(nblk, nbatch, nbase, ntrans)
         ws_a = torch.empty(wsa, dtype=torch.uint8, device=dev)
         ws_b = torch.empty(wsb, dtype=torch.uint8, device=dev)
+        ws_x = torch.empty(wsx, dtype=torch.uint8, device=dev) if wsx else None
         gvec = None
         if grad_scale_per_read is not None:
             gvec = grad_scale_per_read.detach().to(device=dev, dtype=torch.float32).contiguous()
         rc = L.tk_flipflop_loss_fused_dev(
-            _lib.ptr(lp), nblk, nbatch, nbase, _lib.ptr(stay), _lib.ptr(move), _lib.ptr(seqlen_d),
-            _lib.ptr(seqoff), maxlen, float(sharpfact), float(grad_scale), _lib.ptr(gvec),
+            _lib.ptr(lp), nblk, nbatch, nbase, ntrans, _lib.ptr(stay), _lib.ptr(move), _lib.ptr(mod), _lib.ptr(fact),
+            _lib.ptr(seqlen_d), _lib.ptr(seqoff), maxlen, float(sharpfact), float(grad_scale), _lib.ptr(gvec),
             _lib.ptr(lossvector), _lib.ptr(grad), _lib.ptr(logz),
-            _lib.ptr(ws_a), wsa, _lib.ptr(ws_b), wsb, _lib.ptr(status), _lib.stream_ptr())
+            _lib.ptr(ws_a), wsa, _lib.ptr(ws_b), wsb, _lib.ptr(ws_x), wsx, _lib.ptr(status), _lib.stream_ptr())
         _lib.check(rc, "tk_flipflop_loss_fused_dev")
         _lib.finish(status)
-    del keep, gvec
+    del keep, gvec, ws_x
     return lossvector, (grad if want_grad else None), logz
 
 
@@ -223,8 +228,11 @@ class FlipFlopLoss(torch.autograd.Function):
     place -- one (T, N, S) gradient tensor instead of two plus autograd's add."""
 
     @staticmethod
-    def forward(ctx, outputs, seqs, seqlen, sharpfact: float):
-        lossvector, grad, _ = _run_fused(outputs, seqs, seqlen, sharpfact, ctx.needs_input_grad[0])
+    def forward(ctx, outputs, seqs, seqlen, sharpfact: float, mod_cats=None, can_mods_offsets=None,
+                mod_cat_weights=None):
+        lossvector, grad, _ = _run_fused(outputs, seqs, seqlen, sharpfact, ctx.needs_input_grad[0],
+                                         mod_cats=mod_cats, can_mods_offsets=can_mods_offsets,
+                                         mod_cat_weights=mod_cat_weights)
         if grad is not None:
             ctx.save_for_backward(grad)
         return lossvector
@@ -232,7 +240,7 @@ class FlipFlopLoss(torch.autograd.Function):
     @staticmethod
     def backward(ctx, output_grads):
         grads, = ctx.saved_tensors
-        return grads * output_grads.unsqueeze(1), None, None, None
+        return grads * output_grads.unsqueeze(1), None, None, None, None, None, None
 
 
 flipflop_loss = FlipFlopLoss.apply
@@ -248,15 +256,19 @@ class FlipFlopMeanLoss(torch.autograd.Function):
     sends grad_output = 1; any other value is honoured by one scaling pass."""
 
     @staticmethod
-    def forward(ctx, outputs, seqs, seqlen, sharpfact: float, weights=None):
+    def forward(ctx, outputs, seqs, seqlen, sharpfact: float, weights=None, mod_cats=None,
+                can_mods_offsets=None, mod_cat_weights=None):
+        """The last three arguments make it the cat-mod loss (ctc.pyx:258-312 on all columns + logZ
+        of the canonical ones, bin/train_flipflop.py:165-176)."""
         nbatch = outputs.shape[1]
+        mods = dict(mod_cats=mod_cats, can_mods_offsets=can_mods_offsets, mod_cat_weights=mod_cat_weights)
         if weights is None:
             lossvector, grad, _ = _run_fused(outputs, seqs, seqlen, sharpfact, ctx.needs_input_grad[0],
-                                             grad_scale=1.0 / nbatch)
+                                             grad_scale=1.0 / nbatch, **mods)
             loss = lossvector.mean()
         else:
             lossvector, grad, _ = _run_fused(outputs, seqs, seqlen, sharpfact, ctx.needs_input_grad[0],
-                                             grad_scale_per_read=weights)
+                                             grad_scale_per_read=weights, **mods)
             loss = (lossvector * weights.to(lossvector.dtype)).sum()
         if grad is not None:
             ctx.save_for_backward(grad)
@@ -266,9 +278,9 @@ class FlipFlopMeanLoss(torch.autograd.Function):
     @staticmethod
     def backward(ctx, grad_loss, _grad_lossvector):
         grads, = ctx.saved_tensors
-        if getattr(grad_loss, "tk_is_one", False) or _ASSUME_UNIT_GRAD:
-            return grads, None, None, None, None
-        return grads * grad_loss, None, None, None, None
+        if _ASSUME_UNIT_GRAD:
+            return grads, None, None, None, None, None, None, None
+        return grads * grad_loss, None, None, None, None, None, None, None
 
 
 # `loss.backward()` on the operator's own output sends grad_output = 1.0; a trainer that does exactly

@@ -7,8 +7,8 @@ import torch
 
 from taiyaki_amd import ctc, layers
 
-# the fused (A) + (B) / nblk operator for the plain CRF (TK_FUSED_LOSS=0: the two reference
-# operators and autograd's add, as bin/train_flipflop.py:172-176 calls them)
+# the fused (A) + (B) / nblk operator, plain CRF and cat-mod (TK_FUSED_LOSS=0: the two reference
+# operators and autograd's add, as bin/train_flipflop.py:165-176 calls them)
 FUSED_LOSS = os.environ.get("TK_FUSED_LOSS", "1") != "0"
 
 
@@ -25,21 +25,22 @@ def calculate_loss(net, indata, seqs, seqlens, sharpen=1.0, mod_cats=None,
     outputs = net(indata)
     nblk = float(outputs.shape[0])
     ntrans = outputs.shape[2]
-    if mod_cats is not None:
-        lossvector = ctc.cat_mod_flipflop_loss(outputs, seqs, seqlens, mod_cats,
-                                               can_mods_offsets, mod_cat_weights, sharpen)
-        ntrans -= ctc.n_mod_columns(can_mods_offsets)
-    elif FUSED_LOSS and outputs.is_cuda:
-        # one operator, one gradient tensor, already d loss / d outputs (ctc.FlipFlopMeanLoss)
+    if FUSED_LOSS and outputs.is_cuda:
+        # one operator, one gradient tensor, already d loss / d outputs (ctc.FlipFlopMeanLoss); cat-mod:
+        # kernel B on the canonical columns first, folded into kernel A's writes
         weights = None
         if ignore_empty:
             live = (seqlens.to(outputs.device) > 0).to(torch.float32)
             weights = live / live.sum().clamp(min=1.0)
-        return ctc.flipflop_mean_loss(outputs, seqs, seqlens, sharpen, weights)
+        return ctc.flipflop_mean_loss(outputs, seqs, seqlens, sharpen, weights, mod_cats, can_mods_offsets,
+                                      mod_cat_weights)
+    if mod_cats is not None:
+        lossvector = ctc.cat_mod_flipflop_loss(outputs, seqs, seqlens, mod_cats,
+                                               can_mods_offsets, mod_cat_weights, sharpen)
+        ntrans -= ctc.n_mod_columns(can_mods_offsets)
     else:
         lossvector = ctc.crf_flipflop_loss(outputs, seqs, seqlens, sharpen)
-    if mod_cats is not None or not (FUSED_LOSS and outputs.is_cuda):
-        lossvector = lossvector + layers.flipflop_logpartition(outputs[:, :, :ntrans]) / nblk
+    lossvector = lossvector + layers.flipflop_logpartition(outputs[:, :, :ntrans]) / nblk
     if ignore_empty:
         live = (seqlens.to(lossvector.device) > 0).to(lossvector.dtype)
         return (lossvector * live).sum() / live.sum().clamp(min=1.0), lossvector

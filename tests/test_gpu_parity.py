@@ -1000,17 +1000,23 @@ def test_fused_loss_at_full_size_against_reference_goldens(gpu_device, name):
     from taiyaki_amd import ctc, layers
     spec = cases.FULLSIZE[name]
     inp = parity.fullsize_inputs(name)
-    if "mod_cats" in inp:
-        pytest.skip("the fused operator is the plain-CRF assembly; cat-mod goes through the two operators")
     gold = load_golden("fullsize.npz")
     x = torch.from_numpy(inp["scores"]).to(gpu_device).requires_grad_()
     seqs, seqlens = torch.from_numpy(inp["seqs"]), torch.from_numpy(inp["seqlens"])
-    lv = ctc.flipflop_loss(x, seqs, seqlens, 1.0)
+    mods = ()
+    if "mod_cats" in inp:
+        # cat-mod form (round 3): logZ of the canonical columns folded into the cat-mod kernel's writes
+        mods = (torch.from_numpy(inp["mod_cats"]), inp["can_mods_offsets"], inp["mod_cat_weights"])
+    lv = ctc.flipflop_loss(x, seqs, seqlens, 1.0, *mods)
     np.testing.assert_allclose(lv.detach().cpu().numpy(), gold[name + "/lossvector"], rtol=1e-4)
     lv.sum().backward()
     g = x.grad.clone()
     x.grad = None
-    two = ctc.crf_flipflop_loss(x, seqs, seqlens, 1.0) + layers.flipflop_logpartition(x) / float(spec["T"])
+    if mods:
+        two = (ctc.cat_mod_flipflop_loss(x, seqs, seqlens, *mods, 1.0)
+               + layers.flipflop_logpartition(x[:, :, :40]) / float(spec["T"]))
+    else:
+        two = ctc.crf_flipflop_loss(x, seqs, seqlens, 1.0) + layers.flipflop_logpartition(x) / float(spec["T"])
     two.sum().backward()
     assert float((lv.detach() - two.detach()).abs().max()) < 2e-6 * float(two.detach().abs().max())
     assert float((g - x.grad).abs().max()) < 1e-7
@@ -1097,3 +1103,38 @@ def test_train_step_has_no_elementwise_pass_between_loss_and_rnn_backward(gpu_de
     with ctc.unit_grad():
         loss.backward()
     assert seen["ptr"] == saved
+
+
+@pytest.mark.parametrize("sharp", [1.0, 2.5])
+def test_fused_catmod_loss_small_against_oracle(oracle_mod, gpu_device, sharp):
+    """Cat-mod form of the fused operator vs the oracle's cat-mod loss + logZ(canonical columns) / nblk,
+    on mod columns that are log-probabilities (what the producer layer emits: the linear band path
+    keeps these reads) -- incl. the reference's sharpening quirk (canonical columns only; the saved
+    gradient unscaled, ctc.pyx:265-267, 306-310), an empty read and the weighted mean."""
+    import torch
+    from taiyaki_amd import ctc, synth
+    T = 90
+    seqlens = np.array([40, 1, 77, 33, 0], dtype=np.int32)
+    inp = synth.normalise_mod_columns(synth.crf_case(T, len(seqlens), 4, seqlens=seqlens, nmods_per_base=(1, 1, 0, 0)))
+    mods = (torch.from_numpy(inp["mod_cats"]), inp["can_mods_offsets"], inp["mod_cat_weights"])
+    oloss, ograd = oracle_mod.cat_mod_flipflop_loss(inp["scores"], inp["seqs"], inp["seqlens"], inp["mod_cats"],
+                                                    inp["can_mods_offsets"], inp["mod_cat_weights"], sharp)
+    olz, olgrad = oracle_mod.flipflop_logz_grad(np.ascontiguousarray(inp["scores"][:, :, :40]))
+    want_lv = oloss + olz / T
+    want_g = ograd.copy()
+    want_g[:, :, :40] += olgrad / T
+    x = torch.from_numpy(inp["scores"]).to(gpu_device).requires_grad_()
+    seqs, sl = torch.from_numpy(inp["seqs"]), torch.from_numpy(inp["seqlens"])
+    lv = ctc.flipflop_loss(x, seqs, sl, sharp, *mods)
+    lv.sum().backward()
+    np.testing.assert_allclose(lv.detach().cpu().numpy(), want_lv, rtol=1e-5, atol=2e-6)
+    np.testing.assert_allclose(x.grad.cpu().numpy(), want_g, atol=2e-5)
+    # ... and as the mean-loss operator with per-read weights
+    x.grad = None
+    live = (seqlens > 0).astype(np.float32)
+    w = torch.from_numpy(live / live.sum()).to(gpu_device)
+    loss, lv2 = ctc.flipflop_mean_loss(x, seqs, sl, sharp, w, *mods)
+    with ctc.unit_grad():
+        loss.backward()
+    np.testing.assert_allclose(lv2.cpu().numpy(), want_lv, rtol=1e-5, atol=2e-6)
+    np.testing.assert_allclose(x.grad.cpu().numpy(), want_g * (live / live.sum())[None, :, None], atol=2e-5)

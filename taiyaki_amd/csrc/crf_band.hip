@@ -134,25 +134,48 @@ __device__ __forceinline__ void band_buffer_store(__amdgpu_buffer_rsrc_t rs, uns
     }
 }
 
-__device__ __forceinline__ int clamp_shift(int d) { return min(max(d, -160), KLIP + 1); }
+constexpr int LEM_MIN = -100;       // cat-mod: the frame slope follows move weights down to 2^-100
+__device__ __forceinline__ int clamp_shift(int d) { return min(max(d, -160), KLIP - LEM_MIN + 1); }
 
 // Frames of a block from the cells' own exponents: see the file header.  Works on the wave's cells
 // in FLOW order (index q = lane R + j, upstream = q - 1); fb = the frame of the cell upstream of
 // q = 0 (NOFRAME: none).  The decayed prefix maximum  f[q] = max_k (own[q - k] - k KLIP)  is a PLAIN
 // prefix maximum of  z[q] = own[q] + KLIP q  (one ramp add, six fused DPP maxima, one ramp
 // subtract).  Rescales m to the new frames; sc[j] = 2^(f[upstream] - f[j]) (0 where no move exists).
-template <int R>
+// SLOPE = false: the envelope falls by KLIP per cell.  SLOPE = true (cat-mod): by KLIP - lem[q] into
+// cell q, lem[q] <= 0 the exponent of the LARGEST weight the move into q has in this block: a move
+// that is weak in every row of the block (a modification the network does not believe in: modfact 8 x
+// a log-probability of -10 is 2^-115) makes a true cliff in the lattice which the frames must follow
+// -- the cells behind it hold ALL the mass of the paths that have passed it.  The inflow a cell can
+// receive per step stays bounded by 2^KLIP of its frame unit (weight <= 2^lem, scale <= 2^(KLIP - lem)).
+template <int R, bool SLOPE>
 __device__ __forceinline__ void band_frames(float (&m)[R], int (&f)[R], float (&sc)[R], const bool (&has)[R],
-                                            int fb, int lane) {
+                                            const int (&lem)[R], int fb, int lane) {
     const int q0 = lane * R;
+    // ramp[j] = sum over the cells up to (q0 + j) of their slope allowance
+    int ramp[R];
+    if constexpr (SLOPE) {
+        int own = 0;
+#pragma unroll
+        for (int j = 0; j < R; ++j) {
+            own += KLIP - lem[j];
+            ramp[j] = own;
+        }
+        const int before = wave_inclusive_scan_int(own) - own;
+#pragma unroll
+        for (int j = 0; j < R; ++j) ramp[j] += before;
+    } else {
+#pragma unroll
+        for (int j = 0; j < R; ++j) ramp[j] = KLIP * (q0 + j + 1);
+    }
     int z[R];
 #pragma unroll
     for (int j = 0; j < R; ++j) {
         // live = positive and finite (a NaN / inf cell keeps its frame and poisons the score)
         const bool live = m[j] > 0.f && m[j] < __builtin_huge_valf();
-        z[j] = live ? f[j] + __builtin_amdgcn_frexp_expf(m[j]) + KLIP * (q0 + j) : NOFRAME;
+        z[j] = live ? f[j] + __builtin_amdgcn_frexp_expf(m[j]) + ramp[j] : NOFRAME;
     }
-    const int zb = (lane == 0 && fb > NOFRAME / 2) ? fb - KLIP : NOFRAME;      // the cell at q = -1
+    const int zb = (lane == 0 && fb > NOFRAME / 2) ? fb : NOFRAME;     // the cell at q = -1 (ramp 0)
     int zl = zb;
 #pragma unroll
     for (int j = 0; j < R; ++j) zl = max(zl, z[j]);
@@ -162,7 +185,7 @@ __device__ __forceinline__ void band_frames(float (&m)[R], int (&f)[R], float (&
 #pragma unroll
     for (int j = 0; j < R; ++j) {
         run = max(run, z[j]);
-        fn[j] = (run > NOFRAME / 2) ? run - KLIP * (q0 + j) : 0;   // dead with nothing upstream: any frame does
+        fn[j] = (run > NOFRAME / 2) ? run - ramp[j] : 0;    // dead with nothing upstream: any frame does
         m[j] = __builtin_amdgcn_ldexpf(m[j], max(f[j] - fn[j], -300));
         f[j] = fn[j];
     }
@@ -349,7 +372,20 @@ __device__ __forceinline__ void band_sweep(const BandArgs &a, int n, int L, floa
         };
         gather_group(0);
         STAMP(1);
-        band_frames<R>(m, f, sc, has, fb, lane);
+        int lem[R];
+#pragma unroll
+        for (int jj = 0; jj < R; ++jj) {
+            lem[jj] = 0;
+            if constexpr (MOD) {
+                float emx = em[0][jj];
+#pragma unroll
+                for (int g = 1; g < GH; ++g) emx = fmaxf(emx, em[g][jj]);
+                // (R = 4 knows the first four steps' weights here: a later, larger one can only make
+                // the block overflow, which the score check catches)
+                lem[jj] = (has[jj] && emx > 0.f) ? min(max(__builtin_amdgcn_frexp_expf(emx), LEM_MIN), 0) : 0;
+            }
+        }
+        band_frames<R, MOD>(m, f, sc, has, lem, fb, lane);
         if (edge_lane) Ef[w * 2 + slot] = f[R - 1];
         if (GRAD) {
             // checkpoint column: forward column 8 j, backward column 8 j + nvalid (positions ascending)
@@ -582,7 +618,7 @@ __global__ __launch_bounds__(POST_WAVES *WAVE) void crf_band_posterior_kernel(Ba
         // the sweeps must have ended finite and agree (c_crf_flipflop.c:482-491 averages them)
         const double dsc = scoreF - scoreB;
         if (!(dsc > -(double)ROWZ_TOL && dsc < (double)ROWZ_TOL)) {
-            if (blockIdx.y == 0 && tid == 0) a.gate[n] = 1;
+            if (blockIdx.y == 0 && tid == 0) a.gate[n] = (dsc == dsc && scoreF - scoreF == 0.0 && scoreB - scoreB == 0.0) ? 4 : 1;
             return;
         }
     }
@@ -882,7 +918,7 @@ __global__ __launch_bounds__(POST_WAVES *WAVE) void crf_band_posterior_kernel(Ba
             if (lane < S) a.grad[(size_t)(t0 + k) * rowstride + (size_t)n * S + lane] = g;
         }
     }
-    if (lost && lane == 0) a.gate[n] = 1;
+    if (lost && lane == 0) a.gate[n] = 2;        // (reason codes, lab dump: 1 non-finite sweep score, 4 sweeps disagree, 2 a row lost mass)
     (void)nskip;
 #ifdef TK_LAB_STAMPS
     if (a.dbg && lane == 0) {

@@ -763,9 +763,13 @@ int crf_dispatch(const float *logprob, size_t ntrans, size_t nblk, size_t nbatch
             static int hostg[1 << 16];
             const size_t ng = nbatch < (1u << 16) ? nbatch : (1u << 16);
             (void)hipMemcpy(hostg, b.gate, ng * sizeof(int), hipMemcpyDeviceToHost);
-            size_t cnt = 0;
-            for (size_t i = 0; i < ng; ++i) cnt += hostg[i] != 0;
-            fprintf(stderr, "crf band: %zu of %zu reads gated\n", cnt, ng);
+            size_t cnt = 0, why[8] = {0};
+            for (size_t i = 0; i < ng; ++i) {
+                cnt += hostg[i] != 0;
+                ++why[hostg[i] & 7];
+            }
+            fprintf(stderr, "crf band: %zu of %zu reads gated (non-finite score %zu, sweeps disagree %zu, row lost mass %zu)\n",
+                    cnt, ng, why[1], why[4], why[2]);
         }
         // the reads the linear path disowned, redone in the log domain
         a.gate = b.gate;

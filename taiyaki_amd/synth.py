@@ -147,14 +147,18 @@ def crf_case(T, N, seed, nbase=4, nmods_per_base=None, seqlens=None):
     return out
 
 
-def normalise_mod_columns(inp, ncan=40):
+def normalise_mod_columns(inp, ncan=40, logit_scale=0.2):
     """Turn the free scores of a cat-mod case's mod columns into what GlobalNormFlipFlopCatMod emits
     there (layers.py:1627-1640): per canonical base a log-softmax over {unmodified, its
-    modifications}.  In place; returns inp."""
+    modifications}.  The free scores (U(-5, 5)) times `logit_scale` are the logits: 0.2 gives the
+    +-1 a freshly initialised layer produces (log-probabilities around log 1/2); 1.0 makes every row
+    disagree violently with its neighbours about every modification (log-probabilities down to -10,
+    times the reference's initial mod_factor of 8) -- a stress case, not a network.  In place;
+    returns inp."""
     offs = np.asarray(inp["can_mods_offsets"])
     sc = inp["scores"]
     for b in range(len(offs) - 1):
-        blk = sc[:, :, ncan + offs[b]:ncan + offs[b + 1]].astype(np.float64)
+        blk = sc[:, :, ncan + offs[b]:ncan + offs[b + 1]].astype(np.float64) * logit_scale
         blk -= np.log(np.exp(blk).sum(axis=2, keepdims=True))
         sc[:, :, ncan + offs[b]:ncan + offs[b + 1]] = blk.astype(np.float32)
     return inp

@@ -97,9 +97,10 @@ def weights(rd, erow, raw, t, sl, forward, c_can, c_mod):
 
 
 KLIP = 6
+LEM_MIN = -100       # cat-mod: the frame slope follows move weights down to 2^-100
 
 
-def block_frame(m, e, forward, e_b):
+def block_frame(m, e, forward, e_b, lem=None):
     """Block-start frames.  Own exponent eo = e + exponent(m) of every live cell; the frame is the
     K-Lipschitz envelope  f[p] = max(eo[p], f[upstream] - KLIP)  (a decayed prefix maximum along the
     flow; the boundary cell starts from the neighbouring chunk's frame e_b).  Then no cell can
@@ -116,7 +117,7 @@ def block_frame(m, e, forward, e_b):
     f = np.zeros(n, dtype=np.int64)
     cur = e_b if e_b is not None else -BIG
     for c in (range(n) if forward else range(n - 1, -1, -1)):
-        cur = max(eo[c], cur - KLIP)
+        cur = max(eo[c], cur - KLIP + (0 if lem is None else int(lem[c])))
         f[c] = cur
     f = np.where(f < -(BIG >> 1), 0, f)                     # nothing upstream and dead: any frame does
     mm = ldexp32(m, np.clip(e - f, -300, 300))
@@ -156,7 +157,13 @@ def run_block(rd, erow, raw, T, KB, NORM, j, w, m, e, forward, pl, ring_m, ring_
         first = (i % NORM == 0) if forward else (i % NORM == NORM - 1 or i == nvalid - 1)
         if first:
             bad |= bool((~np.isfinite(m)).any())
-            m, e, d, nf = block_frame(m, e, forward, int(ring_e[sub]) if pl else None)
+            lem = None
+            if rd.has_mod:
+                steps = [k for k in range(nvalid) if k // NORM == sub]
+                emx = np.max([weights(rd, erow, raw, j * KB + k, sl, forward, c_can, c_mod)[1] for k in steps], axis=0)
+                with np.errstate(all="ignore"):
+                    lem = np.where(emx > 0, np.clip(np.frexp(emx)[1], LEM_MIN, 0), 0)
+            m, e, d, nf = block_frame(m, e, forward, int(ring_e[sub]) if pl else None, lem)
             if waslive is not None:
                 waslive[0] += nf
             sc = ldexp32(np.ones(rd.PW, dtype=f32), d)

@@ -1115,7 +1115,8 @@ def test_fused_catmod_loss_small_against_oracle(oracle_mod, gpu_device, sharp):
     from taiyaki_amd import ctc, synth
     T = 90
     seqlens = np.array([40, 1, 77, 33, 0], dtype=np.int32)
-    inp = synth.normalise_mod_columns(synth.crf_case(T, len(seqlens), 4, seqlens=seqlens, nmods_per_base=(1, 1, 0, 0)))
+    inp = synth.normalise_mod_columns(synth.crf_case(T, len(seqlens), 4, seqlens=seqlens, nmods_per_base=(1, 1, 0, 0)),
+                                      logit_scale=1.0)
     mods = (torch.from_numpy(inp["mod_cats"]), inp["can_mods_offsets"], inp["mod_cat_weights"])
     oloss, ograd = oracle_mod.cat_mod_flipflop_loss(inp["scores"], inp["seqs"], inp["seqlens"], inp["mod_cats"],
                                                     inp["can_mods_offsets"], inp["mod_cat_weights"], sharp)

@@ -25,6 +25,8 @@ SHAPES = {
     "sharp": (800, "speed32", 2.5, None),
     "cfg4": (800, "speed128", 1.0, (1, 1, 0, 0)),
     "cfg4w1": (800, "speed128", 1.0, (1, 1, 0, 0)),
+    "cfg4r": (800, "real128", 1.0, (1, 1, 0, 0)),
+    "cfg4rharsh": (800, "real128", 1.0, (1, 1, 0, 0)),     # log-probabilities down to -10 x weight 8, iid per row
     "cfg4free": (800, "speed128", 1.0, (1, 1, 0, 0)),      # free U(-5, 5) mod scores x weight 8: overflows
     "cfg5": (1600, "speed64", 1.0, None),
     "rowK": (4000, "speed256", 1.0, None),
@@ -49,7 +51,7 @@ def run(x, seqs, seqlens, sharp, extra, env):
 
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument("--shapes", default="tiny,t19,t37,t200,cfg2,cfg2r,narrow,sharp,cfg4,cfg5,rowK")
+    ap.add_argument("--shapes", default="tiny,t19,t37,t200,cfg2,cfg2r,narrow,sharp,cfg4,cfg4r,cfg4rharsh,cfg5,rowK")
     args = ap.parse_args()
     dev = torch.device("cuda:0")
     _lib.set_strict(False)
@@ -62,7 +64,7 @@ def main():
             N, seqlens = len(lens), np.array(lens, dtype=np.int32)
         inp = synth.crf_case(T, N, 1, seqlens=seqlens, nmods_per_base=mods)
         if mods is not None and not sh.endswith("free"):
-            synth.normalise_mod_columns(inp)
+            synth.normalise_mod_columns(inp, logit_scale=1.0 if sh.endswith("harsh") else 0.2)
         x = torch.from_numpy(inp["scores"]).to(dev)
         seqs, sl = torch.from_numpy(inp["seqs"]), torch.from_numpy(inp["seqlens"])
         extra = ()

@@ -5,7 +5,7 @@ layout in `docs/FILE_FORMATS.md:43-75`): root attributes `alphabet`, `collapse_a
 `mod_long_names`, `version`; one group per read under `Reads/` with datasets `Dacs` (int16),
 `Ref_to_signal` (int32), `Reference` (int16) -- gzip + shuffle, chunked -- and five float
 attributes.  This module reads exactly that much of the HDF5 file format, from the format
-specification, for the CLASSIC on-disk layout:
+specification.  The CLASSIC on-disk layout:
 
     superblock version 0/1, version-1 object headers (+ continuation blocks), symbol-table
     groups (version-1 B-tree of group nodes + local heap), data layout message version 3
@@ -16,10 +16,20 @@ specification, for the CLASSIC on-disk layout:
 That is the layout of the mapped-signal files the reference ships with its tests
 (`test/data/mapped_signal_file/*.hdf5`, per-read groups), against which this parser is validated,
 and of what the writers' default, the batch format, produces (`BatchHDF5Writer` opens its file
-with h5py's default `libver`, mapped_signal_files.py:582; read by `reads_of_batches`).  Files
-written with `libver='v108'` or later (version-2 object headers, dense link storage in fractal
-heaps -- the per-read writer of today, mapped_signal_files.py:372) are recognised and refused with a
-clear error; convert those with `tools/mapped_signal_to_npz.py` where h5py exists.
+with h5py's default `libver`, mapped_signal_files.py:582; read by `reads_of_batches`).
+
+And the HDF5 1.8 layout that `libver='v108'` selects (the per-read writer of today,
+mapped_signal_files.py:280, 372):
+
+    superblock version 2/3, version-2 object headers ("OHDR" + "OCHK" continuation chunks; a file
+    may mix them with version-1 headers), groups as link messages in the header (compact) or in a
+    fractal heap (dense: "FRHP" header, direct "FHDB" and indirect "FHIB" blocks of the doubling
+    table -- every managed object is visited in heap order, the name-index B-tree is not needed to
+    list a group), attributes in the header or, beyond 8 of them, in a fractal heap of their own.
+
+validated on the reference's own test files re-written by the HDF5 library's `h5repack` with
+those bounds and on a many-read file written by the library itself
+(tests/golden/mapped_signal/make_v108_fixtures.sh).
 """
 import struct
 import zlib
@@ -128,13 +138,13 @@ def decode_vlen(f, dt, raw):
 
 
 class Group:
-    def __init__(self, f, msgs, btree, heap):
-        self.f, self.attrs, self._btree, self._heap = f, f._attributes(msgs), btree, heap
+    def __init__(self, f, msgs):
+        self.f, self.attrs, self._msgs = f, f._attributes(msgs), msgs
         self._links = None
 
     def _load(self):
         if self._links is None:
-            self._links = dict(self.f._symbol_table(self._btree, self._heap))
+            self._links = dict(self.f._links_of(self._msgs))
         return self._links
 
     def keys(self):
@@ -172,22 +182,27 @@ class File(Group):
         if pos >= len(self.buf):
             raise Hdf5Error("%s is not an HDF5 file" % path)
         ver = self.buf[pos + 8]
+        if ver > 3:
+            raise Hdf5Error("%s has a version-%d superblock (0-3 are known)" % (path, ver))
         if ver >= 2:
-            raise Hdf5Error(
-                "%s has a version-%d superblock (HDF5 1.8+ 'latest' layout: version-2 object headers, links in "
-                "fractal heaps); this reader handles the classic layout only -- convert the file with "
-                "tools/mapped_signal_to_npz.py on a machine that has h5py" % (path, ver))
-        self.offsz, self.lensz = self.buf[pos + 13], self.buf[pos + 14]
-        if self.offsz != 8 or self.lensz != 8:
-            raise Hdf5Error("only 8-byte offsets and lengths are supported")
-        p = pos + 24 + (4 if ver == 1 else 0)
-        self.base = struct.unpack_from("<Q", self.buf, p)[0]
-        root_ste = p + 4 * 8
-        root_hdr = struct.unpack_from("<Q", self.buf, root_ste + 8)[0]
+            # signature(8) version(1) offset size(1) length size(1) flags(1) | base, extension,
+            # end of file, root object header (4 offsets) | checksum
+            self.offsz, self.lensz = self.buf[pos + 9], self.buf[pos + 10]
+            if self.offsz != 8 or self.lensz != 8:
+                raise Hdf5Error("only 8-byte offsets and lengths are supported")
+            self.base = struct.unpack_from("<Q", self.buf, pos + 12)[0]
+            root_hdr = struct.unpack_from("<Q", self.buf, pos + 12 + 24)[0]
+        else:
+            self.offsz, self.lensz = self.buf[pos + 13], self.buf[pos + 14]
+            if self.offsz != 8 or self.lensz != 8:
+                raise Hdf5Error("only 8-byte offsets and lengths are supported")
+            p = pos + 24 + (4 if ver == 1 else 0)
+            self.base = struct.unpack_from("<Q", self.buf, p)[0]
+            root_ste = p + 4 * 8
+            root_hdr = struct.unpack_from("<Q", self.buf, root_ste + 8)[0]
+        self.superblock_version = ver
         self._cache = {}
-        msgs = self._object_header(root_hdr)
-        bt, hp = self._symtab_msg(msgs)
-        Group.__init__(self, self, msgs, bt, hp)
+        Group.__init__(self, self, self._object_header(root_hdr))
 
     # -- primitives ----------------------------------------------------------------------------
     def _off(self, b, o):
@@ -198,20 +213,164 @@ class File(Group):
     def _object(self, addr):
         if addr not in self._cache:
             msgs = self._object_header(addr)
-            st = self._symtab_msg(msgs)
-            self._cache[addr] = Group(self, msgs, *st) if st else Dataset(self, msgs)
+            is_group = any(mtype in (0x11, 0x02, 0x06) for mtype, _ in msgs)
+            self._cache[addr] = Group(self, msgs) if is_group else Dataset(self, msgs)
         return self._cache[addr]
 
-    def _symtab_msg(self, msgs):
+    def _links_of(self, msgs):
+        """(name, object header address) of a group's hard links: symbol table (classic), link
+        messages in the header (1.8 compact) or in a fractal heap (1.8 dense)."""
         for mtype, data in msgs:
-            if mtype == 0x11:
-                return self._off(data, 0), self._off(data, 8)
-        return None
+            if mtype == 0x11:                           # symbol table: B-tree + local heap
+                yield from self._symbol_table(self._off(data, 0), self._off(data, 8))
+            elif mtype == 0x06:
+                link = self._link_message(data, 0)[0]
+                if link is not None:
+                    yield link
+            elif mtype == 0x02:                         # link info: version, flags, [max creation index], heap, B-tree
+                o = 2 + (8 if data[1] & 1 else 0)
+                heap = self._off(data, o)
+                if heap != UNDEF:
+                    for body in self._fractal_heap_objects(heap, self._link_message):
+                        if body is not None:
+                            yield body
+
+    def _link_message(self, d, o):
+        """One link message at d[o:]: ((name, address) or None for a soft / external link, next offset)."""
+        ver, flags = d[o], d[o + 1]
+        if ver != 1:
+            raise Hdf5Error("link message version %d" % ver)
+        q = o + 2
+        ltype = 0
+        if flags & 0x08:
+            ltype = d[q]
+            q += 1
+        if flags & 0x04:
+            q += 8                                      # creation order
+        if flags & 0x10:
+            q += 1                                      # character set of the name
+        nsz = 1 << (flags & 3)
+        nlen = int.from_bytes(bytes(d[q:q + nsz]), "little")
+        q += nsz
+        name = bytes(d[q:q + nlen]).decode("utf-8")
+        q += nlen
+        if ltype == 0:
+            return (name, self._off(d, q)), q + 8
+        if ltype == 1:                                  # soft link: length + path
+            return None, q + 2 + struct.unpack_from("<H", d, q)[0]
+        if ltype == 64:                                 # external link
+            return None, q + 2 + struct.unpack_from("<H", d, q)[0]
+        raise Hdf5Error("link type %d" % ltype)
+
+    def _fractal_heap_objects(self, addr, parse):
+        """Every managed object of the fractal heap at `addr`, in heap order.  `parse(buffer, offset)
+        -> (value, next offset)` decodes one object (link and attribute messages are
+        self-delimiting), so the heap's name-index B-tree is not needed to enumerate them."""
+        b, p = self.buf, self.base + addr
+        if bytes(b[p:p + 4]) != b"FRHP":
+            raise Hdf5Error("fractal heap signature")
+        if b[p + 4] != 0:
+            raise Hdf5Error("fractal heap version %d" % b[p + 4])
+        _idlen, filt_len, flags = struct.unpack_from("<HHB", b, p + 5)
+        if filt_len:
+            raise Hdf5Error("filtered fractal heaps are not supported")
+        q = p + 10 + 4                                  # max size of managed objects
+        q += 8 + 8 + 8 + 8                              # next huge id, huge B-tree, free space, free-space manager
+        q += 8 + 8 + 8                                  # managed space, allocated space, allocation iterator
+        nobj = self._len(b, q)
+        q += 8 + 8 + 8 + 8 + 8                          # (+ huge size / count, tiny size / count)
+        width, = struct.unpack_from("<H", b, q)
+        start = self._len(b, q + 2)
+        maxdirect = self._len(b, q + 10)
+        maxheap_bits, _start_rows = struct.unpack_from("<HH", b, q + 18)
+        root = self._off(b, q + 22)
+        cur_rows, = struct.unpack_from("<H", b, q + 30)
+        offbytes = (maxheap_bits + 7) // 8
+        checksummed = bool(flags & 2)
+        out = []
+
+        def log2(x):
+            return int(x).bit_length() - 1
+
+        max_direct_rows = log2(maxdirect) - log2(start) + 2
+
+        def row_block_size(r):
+            return start if r < 2 else start << (r - 1)
+
+        def direct(a, size):
+            s = self.base + a
+            if bytes(b[s:s + 4]) != b"FHDB":
+                raise Hdf5Error("fractal heap direct block signature")
+            o = s + 5 + 8 + offbytes + (4 if checksummed else 0)
+            end = s + size
+            while len(out) < nobj and o < end and b[o] != 0:
+                val, o = parse(b, o)
+                out.append(val)
+
+        def indirect(a, nrows):
+            s = self.base + a
+            if bytes(b[s:s + 4]) != b"FHIB":
+                raise Hdf5Error("fractal heap indirect block signature")
+            o = s + 5 + 8 + offbytes
+            for r in range(nrows):
+                for _ in range(width):
+                    child = self._off(b, o)
+                    o += 8
+                    if child == UNDEF:
+                        continue
+                    if r < max_direct_rows:
+                        direct(child, row_block_size(r))
+                    else:
+                        indirect(child, log2(row_block_size(r)) - (log2(start) + log2(width)) + 1)
+
+        if root != UNDEF:
+            if cur_rows == 0:
+                direct(root, start)
+            else:
+                indirect(root, cur_rows)
+        if len(out) != nobj:
+            raise Hdf5Error("fractal heap: %d managed objects found, %d announced" % (len(out), nobj))
+        return out
+
+    def _object_header_v2(self, p):
+        """Version-2 object header at buffer position p: "OHDR", version, flags, [times], [attribute
+        phase change], size of chunk 0, messages (type 1 B, size 2 B, flags 1 B, [creation order 2 B]),
+        gap, checksum; continuation chunks "OCHK" ... checksum."""
+        b = self.buf
+        if b[p + 4] != 2:
+            raise Hdf5Error("object header version %d" % b[p + 4])
+        flags = b[p + 5]
+        q = p + 6
+        if flags & 0x20:
+            q += 16
+        if flags & 0x10:
+            q += 4
+        szb = 1 << (flags & 3)
+        chunk0 = int.from_bytes(bytes(b[q:q + szb]), "little")
+        q += szb
+        hdr = 4 + (2 if flags & 0x04 else 0)
+        blocks = [(q, q + chunk0)]
+        msgs = []
+        while blocks:
+            q, end = blocks.pop(0)
+            while q + hdr <= end:
+                mtype = b[q]
+                msize, = struct.unpack_from("<H", b, q + 1)
+                data = bytes(b[q + hdr:q + hdr + msize])
+                q += hdr + msize
+                if mtype == 0x10:                       # continuation: "OCHK" + messages + checksum
+                    coff, clen = self.base + self._off(data, 0), self._len(data, 8)
+                    if bytes(b[coff:coff + 4]) != b"OCHK":
+                        raise Hdf5Error("object header continuation signature")
+                    blocks.append((coff + 4, coff + clen - 4))
+                if mtype != 0:
+                    msgs.append((mtype, data))
+        return msgs
 
     def _object_header(self, addr):
         b, p = self.buf, self.base + addr
         if bytes(b[p:p + 4]) == b"OHDR":
-            raise Hdf5Error("version-2 object header: not a classic-layout file")
+            return self._object_header_v2(p)
         ver, _, nmsgs, _refs, hsize = struct.unpack_from("<BBHII", b, p)
         if ver != 1:
             raise Hdf5Error("object header version %d" % ver)
@@ -345,11 +504,38 @@ class File(Group):
             q += 16 + (osz + 7) // 8 * 8
         raise Hdf5Error("global heap object %d not found" % index)
 
+    def _attribute_size(self, d, o):
+        """(None, next offset) of the attribute message at d[o:] -- the self-delimiting parse the fractal
+        heap walk needs."""
+        ver = d[o]
+        nsz, tsz, ssz = struct.unpack_from("<HHH", d, o + 2)
+        q = o + 8 + (1 if ver == 3 else 0)
+        pad = (lambda n: (n + 7) // 8 * 8) if ver == 1 else (lambda n: n)
+        dto = q + pad(nsz)
+        dt = self._datatype(d, dto)[0]
+        shape = self._dataspace(bytes(d[dto + pad(tsz):dto + pad(tsz) + ssz]))
+        n = int(np.prod(shape)) if shape else 1
+        return None, dto + pad(tsz) + pad(ssz) + n * (16 if dt.cls == 9 else dt.size)
+
     def _attributes(self, msgs):
-        out = {}
+        bodies = []
         for mtype, d in msgs:
-            if mtype != 0x0C:
-                continue
+            if mtype == 0x0C:
+                bodies.append(d)
+            elif mtype == 0x15:                         # attribute info: dense storage in a fractal heap
+                o = 2 + (2 if d[1] & 1 else 0)
+                heap = self._off(d, o)
+                if heap != UNDEF:
+                    spans = []
+
+                    def grab(buf, q, spans=spans):
+                        _, nxt = self._attribute_size(buf, q)
+                        spans.append(bytes(buf[q:nxt]))
+                        return None, nxt
+                    self._fractal_heap_objects(heap, grab)
+                    bodies.extend(spans)
+        out = {}
+        for d in bodies:
             ver = d[0]
             nsz, tsz, ssz = struct.unpack_from("<HHH", d, 2)
             o = 8 + (1 if ver == 3 else 0)

@@ -225,8 +225,8 @@ class MappedSignalStore:
     def from_hdf5(cls, path, device, limit=None):
         """A mapped-signal HDF5 file as the reference's MappedSignalReader reads it
         (mapped_signal_files.py:262-350, docs/FILE_FORMATS.md:43-75), through the built-in
-        classic-layout parser `hdf5_lite` (no h5py needed).  Files in the HDF5 1.8+ "latest"
-        layout are refused with a message that names the converter."""
+        parser `hdf5_lite` (no h5py needed): the classic layout and the HDF5 1.8 layout the per-read
+        writer asks for (libver='v108'), per-read groups or the batch layout."""
         from taiyaki_amd import hdf5_lite
         info, reads = hdf5_lite.read_mapped_signal_file(path, limit=limit)
         store = cls(reads, device)

@@ -52,12 +52,85 @@ def test_dacs_equal_the_raw_fast5_signal_of_the_same_read():
     assert float(ch["digitisation"]) == rd["digitisation"] and ch["channel_number"] == "248"
 
 
-def test_latest_layout_is_refused_with_the_converter_named(tmp_path):
-    """HDF5 1.8+ 'latest' layout (what the per-read writer uses today, libver='v108'): a
-    version-2 superblock is recognised and refused, never mis-parsed."""
+def _generated_id(r):
+    return "%08x-aaaa-4bbb-8ccc-%012x" % ((r * 2654435761) & 0xffffffff, r)
+
+
+def _check_generated_read(q, r):
+    """The formulas of tests/golden/mapped_signal/gen_hdf5_fixtures.c."""
+    ns, nr = 40 + 3 * r, 5 + r
+    assert q["read_id"] == _generated_id(r)
+    np.testing.assert_array_equal(q["Dacs"], ((np.arange(ns) * 7 + r * 13) % 1000 - 300).astype(np.int16))
+    np.testing.assert_array_equal(q["Reference"], ((np.arange(nr) + r) % 4).astype(np.int16))
+    np.testing.assert_array_equal(q["Ref_to_signal"], (np.arange(nr + 1) * ns // nr).astype(np.int32))
+    assert (q["shift_frompA"], q["scale_frompA"], q["range"], q["offset"], q["digitisation"]) == \
+        (1.5 + r, 0.25 * (r + 1), 1400.0 + r, 10.0 - r, 8192.0)
+
+
+def test_hdf5_18_layout_same_reads_as_the_classic_file():
+    """HDF5 1.8 layout -- what the per-read writer of today asks for (libver='v108',
+    mapped_signal_files.py:372): the reference's own test file re-written by the HDF5 library's
+    h5repack with those bounds (superblock 2, version-2 object headers + continuation chunks, link
+    messages) must give exactly the reads of the classic file."""
+    f = hdf5_lite.File(os.path.join(HERE, "mapped_reads_0_v108.hdf5"))
+    assert f.superblock_version == 2
+    info0, reads0 = hdf5_lite.read_mapped_signal_file(os.path.join(HERE, "mapped_reads_0.hdf5"))
+    info1, reads1 = hdf5_lite.read_mapped_signal_file(os.path.join(HERE, "mapped_reads_0_v108.hdf5"))
+    assert info0 == info1 and len(reads0) == len(reads1) == 2
+    by = {r["read_id"]: r for r in reads1}
+    for r in reads0:
+        q = by[r["read_id"]]
+        assert set(q) == set(r)
+        for k, v in r.items():
+            if isinstance(v, np.ndarray):
+                np.testing.assert_array_equal(v, q[k])
+            else:
+                assert v == q[k], k
+
+
+def test_hdf5_18_layout_written_by_the_library_with_the_writers_options():
+    """60 reads written by libhdf5 itself with PerReadHDF5Writer's options (gen_hdf5_fixtures.c: low
+    bound V18, creation order tracked and indexed, gzip + shuffle chunked datasets, variable-length
+    string attributes, `read_ids` in the root): the Reads group is DENSE (links in a fractal heap
+    with an indirect block), every other read has ten attributes (dense attribute storage), and the
+    links come back in creation order."""
+    path = os.path.join(HERE, "generated_v108.hdf5")
+    raw = open(path, "rb").read()
+    assert raw.count(b"FRHP") > 20 and raw.count(b"FHIB") >= 1 and raw.count(b"OHDR") > 200
+    f = hdf5_lite.File(path)
+    assert f.superblock_version == 2 and sorted(f.keys()) == ["Reads", "read_ids"]
+    assert len(f["Reads"]) == 60
+    info, reads = hdf5_lite.read_mapped_signal_file(path)
+    assert info["version"] == 8 and info["alphabet"] == "ACGT" and info["mod_long_names"] == []
+    assert [r["read_id"] for r in reads] == [_generated_id(r) for r in range(60)]
+    for r, q in enumerate(reads):
+        _check_generated_read(q, r)
+        if r % 2 == 0:
+            assert q["mapping_score"] == 100.0 + 0.5 * r and q["mapping_method"] == "generated"
+            assert len(f["Reads"][q["read_id"]].attrs) == 10
+        else:
+            assert "mapping_score" not in q
+    ids = f["read_ids"].read()                  # (variable-length strings decode through the global heap)
+    assert ids == [_generated_id(r) for r in range(60)]
+
+
+def test_batch_layout_written_by_the_library():
+    """BatchHDF5Writer's layout (the writers' default, mapped_signal_files.py:582-650) in a file
+    written by libhdf5 itself: three batches of 10 / 10 / 3 reads, concatenated arrays with
+    `_lengths`, float64 columns, a variable-length string `read_id` column, all gzip-compressed.
+    Pins `reads_of_batches` on a genuine HDF5 file (round 2 could only re-pack arrays in memory)."""
+    info, reads = hdf5_lite.read_mapped_signal_file(os.path.join(HERE, "generated_batch.hdf5"))
+    assert info["version"] == 8 and len(reads) == 23
+    for r, q in enumerate(reads):
+        _check_generated_read(q, r)
+    _, few = hdf5_lite.read_mapped_signal_file(os.path.join(HERE, "generated_batch.hdf5"), limit=12)
+    assert len(few) == 12
+
+
+def test_files_that_are_not_hdf5_or_too_new_are_refused(tmp_path):
     p = tmp_path / "new.hdf5"
-    p.write_bytes(hdf5_lite.SIGNATURE + bytes([2, 8, 8, 0]) + bytes(64))
-    with pytest.raises(hdf5_lite.Hdf5Error, match="mapped_signal_to_npz"):
+    p.write_bytes(hdf5_lite.SIGNATURE + bytes([4, 8, 8, 0]) + bytes(64))
+    with pytest.raises(hdf5_lite.Hdf5Error, match="superblock"):
         hdf5_lite.File(str(p))
     q = tmp_path / "junk.bin"
     q.write_bytes(b"not hdf5" * 100)

@@ -490,7 +490,7 @@ __global__ __launch_bounds__(WCAP *WAVE) void crf_band_sweep_kernel(BandArgs a) 
     const int slot3 = blockIdx.x / N;
     const int role = want_grad ? (slot3 + 2) % 3 : 0;           // 0 forward, 1 backward, 2 rank
     const int n = blockIdx.x - slot3 * N;
-    const int L = a.seqlen[n];
+    const int L = min(a.seqlen[n], (int)(a.seqoff[n + 1] - a.seqoff[n]));      // (offsets are clamped to the label array)
     if (role == 2 && tid == 0) a.gate[n] = 0;
     if (role == 2 && tid < 16) const_cast<float *>(a.zeros)[tid] = 0.f;   // (every rank workgroup: the same zeros)
     if (L == 0 || L > W * PW) {
@@ -595,7 +595,7 @@ __global__ __launch_bounds__(POST_WAVES *WAVE) void crf_band_posterior_kernel(Ba
     const int n = blockIdx.x;
     const int N = a.N, T = a.T, S = a.S, W = a.Wp;              // W: 64-cell chunks per checkpoint row
     const int PWS = a.LP / a.W;                                 // cells per SWEEP chunk
-    const int L = a.seqlen[n];
+    const int L = min(a.seqlen[n], (int)(a.seqoff[n + 1] - a.seqoff[n]));      // (offsets are clamped to the label array)
     const size_t rowstride = (size_t)N * S;
     const int NB = (T + BK - 1) / BK;
     const int jb = blockIdx.y * POST_WAVES + wave;                  // this wave's time block

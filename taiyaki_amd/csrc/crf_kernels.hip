@@ -98,7 +98,7 @@ __global__ __launch_bounds__(W *WAVE) void crf_kernel(CrfArgs a) {
     const int n = blockIdx.x;
     const int T = a.T, N = a.N, S = a.S, SP = S + 2;
     if (a.gate != nullptr && a.gate[n] == 0) return;             // the linear band path owns this read
-    const int L = a.seqlen[n];
+    const int L = min(a.seqlen[n], (int)(a.seqoff[n + 1] - a.seqoff[n]));      // (offsets are clamped to the label array)
     const bool want_grad = a.grad != nullptr;
     const float gsc = a.grad_scale * (a.grad_scale_vec != nullptr ? a.grad_scale_vec[n] : 1.0f);
 
@@ -514,12 +514,15 @@ __global__ void seqoff_kernel(const int32_t *__restrict__ seqlen, int nbatch,
     }
     __syncthreads();
     long long acc = part[tid];
+    // Offsets are CLAMPED to the label array: a batch that announces more labels than it hands over
+    // is flagged, and its reads end where the array ends (the CRF kernels take
+    // min(seqlen, seqoff[n+1] - seqoff[n]) for a read's length): no kernel indexes past `total_len`.
     for (int i = lo; i < hi; ++i) {
-        seqoff[i] = acc;
+        seqoff[i] = min(acc, total_len);
         acc += seqlen[i];
     }
     if (hi == nbatch && lo <= nbatch) {
-        seqoff[nbatch] = acc;       // identical value from every writer
+        seqoff[nbatch] = min(acc, total_len);       // identical value from every writer
         if (acc > total_len && status) atomicOr(status, 8u);    // more labels announced than handed over
     }
 }

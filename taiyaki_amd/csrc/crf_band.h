@@ -37,7 +37,8 @@ struct BandArgs {
     int Wp;                     // 64-cell chunks per checkpoint row = LP / 64 (the gradient pass's chunks)
     // one checkpoint column per time block and sweep: cell = m * 2^f
     float *ckFm, *ckBm;         // [N][NB][LP]  mantissas (forward: column 8 j; backward: column 8 j + nvalid)
-    int *ckFf, *ckBf;           // [N][NB][LP]  frames (exponents), fixed for the block
+    int16_t *ckFf, *ckBf;       // [N][NB][LP]  frames (exponents), fixed for the block: 16-bit offsets from ...
+    int *ckFb, *ckBb;           // [N][NB][W]   ... a base per (sweep chunk, block)
     float *bndF, *bndB;         // [N][NB][Wp][8]  forward: the LAST cell of a 64-cell chunk before every step of the
                                 // block; backward: its FIRST cell
     double *scoreF, *scoreB;    // [N]  log2 scores of the two sweeps
@@ -51,7 +52,7 @@ struct BandArgs {
 struct BandLayout {
     int R, W;
     size_t LP;
-    size_t ckFm, ckBm, ckFf, ckBf, bndF, bndB, scoreF, scoreB, rec, segend, gate, zeros, total;
+    size_t ckFm, ckBm, ckFf, ckBf, ckFb, ckBb, bndF, bndB, scoreF, scoreB, rec, segend, gate, zeros, total;
 };
 
 bool crf_band_fits(size_t max_seqlen);

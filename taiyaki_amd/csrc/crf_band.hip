@@ -135,6 +135,22 @@ __device__ __forceinline__ void band_buffer_store(__amdgpu_buffer_rsrc_t rs, uns
 }
 
 constexpr int LEM_MIN = -100;       // cat-mod: the frame slope follows move weights down to 2^-100
+// R 16-bit values per lane (the frames of a checkpoint column as offsets from the chunk's base)
+template <int R>
+__device__ __forceinline__ void band_buffer_store16(__amdgpu_buffer_rsrc_t rs, unsigned voff, const int (&x)[R]) {
+    typedef unsigned u2 __attribute__((ext_vector_type(2)));
+    // (v_perm_b32: the low halves of two registers in one instruction)
+    if constexpr (R == 4) {
+        __builtin_amdgcn_raw_buffer_store_b64(u2{__builtin_amdgcn_perm((unsigned)x[1], (unsigned)x[0], 0x05040100u),
+                                                 __builtin_amdgcn_perm((unsigned)x[3], (unsigned)x[2], 0x05040100u)},
+                                              rs, voff, 0, 0);
+    } else if constexpr (R == 2) {
+        __builtin_amdgcn_raw_buffer_store_b32(__builtin_amdgcn_perm((unsigned)x[1], (unsigned)x[0], 0x05040100u), rs, voff, 0, 0);
+    } else {
+        __builtin_amdgcn_raw_buffer_store_b16((unsigned short)x[0], rs, voff, 0, 0);
+    }
+}
+
 __device__ __forceinline__ int clamp_shift(int d) { return min(max(d, -160), KLIP - LEM_MIN + 1); }
 
 // Frames of a block from the cells' own exponents: see the file header.  Works on the wave's cells
@@ -248,7 +264,10 @@ __device__ __forceinline__ void band_sweep(const BandArgs &a, int n, int L, floa
 
     const unsigned rs4 = 4u * (unsigned)rowstride;
     float *ckm = GRAD ? (FWD ? a.ckFm : a.ckBm) + (size_t)n * NB * a.LP + a0 : nullptr;
-    int *ckf = GRAD ? (FWD ? a.ckFf : a.ckBf) + (size_t)n * NB * a.LP + a0 : nullptr;
+    int16_t *ckf = GRAD ? (FWD ? a.ckFf : a.ckBf) + (size_t)n * NB * a.LP + a0 : nullptr;
+    int *ckb = GRAD ? (FWD ? a.ckFb : a.ckBb) + (size_t)n * NB * W + w : nullptr;
+    int fbase_prev = 0;
+    bool have_base = false;
     // the gradient pass works on 64-cell chunks whatever R is: the lanes that hold the last cell (in
     // flow order) of a 64-cell run hand their cell of every step over.  Forward that is the LAST
     // cell of sub-chunk w R + k - 1, backward the FIRST cell of sub-chunk w R + R - k  (k = 1 .. R).
@@ -391,14 +410,27 @@ __device__ __forceinline__ void band_sweep(const BandArgs &a, int n, int L, floa
             // checkpoint column: forward column 8 j, backward column 8 j + nvalid (positions ascending)
             const __amdgpu_buffer_rsrc_t rm = __builtin_amdgcn_make_buffer_rsrc(ckm + (size_t)j * a.LP, 0, 0x7fffffff, BUF_WORD3);
             const __amdgpu_buffer_rsrc_t rf = __builtin_amdgcn_make_buffer_rsrc(ckf + (size_t)j * a.LP, 0, 0x7fffffff, BUF_WORD3);
-            unsigned xm[R], xf[R];
+            // frames as 16-bit offsets from a per-(chunk, block) base (the envelope falls by KLIP per
+            // cell and rises with the cells' own exponents: a few thousand across a chunk at most.  An
+            // offset that does not fit -- scores far outside the network's range -- is NOT checked here:
+            // a wrapped frame puts its cell 2^65536 off, and the gradient pass verifies every row's
+            // total against the partition function anyway: such a read is disowned there)
+            // (the base is the PREVIOUS block's first frame -- frames drift by a few bits per block -- so
+            // that no cross-lane read sits between this block's frames and its stores; a chunk's first
+            // block starts from the neighbour's edge frame)
+            const int fbase = have_base ? fbase_prev : (pl ? __builtin_amdgcn_readfirstlane(fb) : 0);
+            fbase_prev = __builtin_amdgcn_readfirstlane(f[0]);
+            have_base = true;
+            unsigned xm[R];
+            int xf[R];
 #pragma unroll
             for (int jj = 0; jj < R; ++jj) {
                 xm[jj] = __float_as_uint(m[FWD ? jj : R - 1 - jj]);
-                xf[jj] = (unsigned)f[FWD ? jj : R - 1 - jj];
+                xf[jj] = f[FWD ? jj : R - 1 - jj] - fbase;      // (kept to 16 bits: see the base's comment)
             }
             band_buffer_store<R>(rm, lane_cell4, xm);
-            band_buffer_store<R>(rf, lane_cell4, xf);
+            band_buffer_store16<R>(rf, lane_cell4 / 2, xf);
+            ckb[(size_t)j * W] = fbase;                         // (every lane, the same word: no exec-mask detour)
         }
         STAMP(2);
         if (nvalid == BK) {
@@ -661,6 +693,9 @@ __global__ __launch_bounds__(POST_WAVES *WAVE) void crf_band_posterior_kernel(Ba
 #pragma unroll
     for (int k = 0; k < BK; ++k) pacc[k] = 0.f;
     const size_t ckrow = ((size_t)n * NB + jb) * a.LP;
+    const size_t ckbase = ((size_t)n * NB + jb) * a.W;           // the block's frame bases, one per sweep chunk
+    const int pws_sh = 31 - __builtin_clz(PWS);                  // (PWS = 64, 128 or 256 cells)
+    auto frame_at = [&](const int16_t *ff, const int *fbase, int p) { return fbase[ckbase + (p >> pws_sh)] + (int)ff[ckrow + p]; };
     const float *bndFn = a.bndF + ((size_t)n * NB + jb) * W * BK;
     const float *bndBn = a.bndB + ((size_t)n * NB + jb) * W * BK;
 
@@ -672,11 +707,12 @@ __global__ __launch_bounds__(POST_WAVES *WAVE) void crf_band_posterior_kernel(Ba
         constexpr bool FULL = decltype(full_tag)::value;
         const int a0 = ck * PW;
         // the neighbouring cells exist as boundary cells iff their SWEEP chunk ran this block
-        const Win wl = band_window((a0 - 1) / PWS, PWS, L, T), wr = band_window((a0 + PW) / PWS, PWS, L, T);
+        const Win wl = band_window((a0 - 1) >> pws_sh, PWS, L, T), wr = band_window((a0 + PW) >> pws_sh, PWS, L, T);
         const bool plF = ck > 0 && jb >= wl.j0 && jb <= wl.j1;
         const bool plB = ck + 1 < Wn && jb >= wr.j0 && jb <= wr.j1;
 
         // ---- ids, checkpoints, boundary cells, frames
+        const int baseF = a.ckFb[ckbase + (a0 >> pws_sh)], baseB = a.ckBb[ckbase + (a0 >> pws_sh)];
         int st4[R], mi4[R], mo4[R], di4[MOD ? R : 1], do4[MOD ? R : 1];
         float fwi[MOD ? R : 1], fwo[MOD ? R : 1], mfi[MOD ? R : 1];
         bool hasi[R], haso[R];
@@ -698,9 +734,9 @@ __global__ __launch_bounds__(POST_WAVES *WAVE) void crf_band_posterior_kernel(Ba
                 fwo[MOD ? j : 0] = haso[j] ? a.modfact[off + p] * a.c_mod : 0.f;
             }
             fv[j] = a.ckFm[ckrow + a0 + lane * R + j];
-            fF[j] = a.ckFf[ckrow + a0 + lane * R + j];
+            fF[j] = baseF + (int)a.ckFf[ckrow + a0 + lane * R + j];
             bv[BK - 1][j] = a.ckBm[ckrow + a0 + lane * R + j];
-            fB[j] = a.ckBf[ckrow + a0 + lane * R + j];
+            fB[j] = baseB + (int)a.ckBf[ckrow + a0 + lane * R + j];
         }
         // boundary cells: forward from chunk ck-1 into lane 0, backward from chunk ck+1 into lane 63
         float einF[BK], einB[BK];
@@ -722,9 +758,9 @@ __global__ __launch_bounds__(POST_WAVES *WAVE) void crf_band_posterior_kernel(Ba
         int kx[R];
         {
             int fupF = __builtin_amdgcn_update_dpp(0, fF[R - 1], 0x138, 0xF, 0xF, false);       // wave_shr:1
-            if (lane == 0) fupF = plF ? a.ckFf[ckrow + max(a0 - 1, 0)] : fF[0];
+            if (lane == 0) fupF = plF ? frame_at(a.ckFf, a.ckFb, max(a0 - 1, 0)) : fF[0];
             int fupB = __builtin_amdgcn_update_dpp(0, fB[0], 0x130, 0xF, 0xF, false);           // wave_shl:1
-            if (lane == WAVE - 1) fupB = plB ? a.ckBf[ckrow + min(a0 + PW, (int)a.LP - 1)] : fB[R - 1];
+            if (lane == WAVE - 1) fupB = plB ? frame_at(a.ckBf, a.ckBb, min(a0 + PW, (int)a.LP - 1)) : fB[R - 1];
 #pragma unroll
             for (int j = 0; j < R; ++j) {
                 const int dF = clamp_shift((j == 0 ? fupF : fF[j > 0 ? j - 1 : 0]) - fF[j]);
@@ -874,7 +910,7 @@ __global__ __launch_bounds__(POST_WAVES *WAVE) void crf_band_posterior_kernel(Ba
 
     int nskip = 0;
     for (int ck = cmin; ck <= cmax; ++ck) {
-        const Win wme = band_window(ck * PW / PWS, PWS, L, T);  // the sweep chunk that holds these cells
+        const Win wme = band_window((ck * PW) >> pws_sh, PWS, L, T);    // the sweep chunk that holds these cells
         if (jb < wme.j0 || jb > wme.j1) continue;               // (never for a live row: the windows cover the band)
         {
             // A cell's posterior is (mF es) (mB) 2^(fF + fB - zexp) with mantissas that start the
@@ -887,7 +923,7 @@ __global__ __launch_bounds__(POST_WAVES *WAVE) void crf_band_posterior_kernel(Ba
             // alignment that carry the posterior mass: 43 % of the chunk-blocks at the train step's
             // shape, 77 % at T = 4000 are skipped.
             const int p = ck * PW + lane;
-            const int kxl = (p < L) ? a.ckFf[ckrow + p] + a.ckBf[ckrow + p] - zexp : -(1 << 20);
+            const int kxl = (p < L) ? frame_at(a.ckFf, a.ckFb, p) + frame_at(a.ckBf, a.ckBb, p) - zexp : -(1 << 20);
             const float kmax = wave_allmax_dpp((float)kxl);
             if (kmax < (float)POST_SKIP_BELOW) {
                 ++nskip;
@@ -962,8 +998,10 @@ BandLayout crf_band_layout(size_t ntrans, size_t nblk, size_t nbatch, size_t max
     };
     l.ckFm = take(nbatch * NB * l.LP * sizeof(float));
     l.ckBm = take(nbatch * NB * l.LP * sizeof(float));
-    l.ckFf = take(nbatch * NB * l.LP * sizeof(int));
-    l.ckBf = take(nbatch * NB * l.LP * sizeof(int));
+    l.ckFf = take(nbatch * NB * l.LP * sizeof(int16_t));
+    l.ckBf = take(nbatch * NB * l.LP * sizeof(int16_t));
+    l.ckFb = take(nbatch * NB * l.W * sizeof(int));
+    l.ckBb = take(nbatch * NB * l.W * sizeof(int));
     l.bndF = take(nbatch * NB * Wp * BK * sizeof(float));
     l.bndB = take(nbatch * NB * Wp * BK * sizeof(float));
     l.scoreF = take(nbatch * sizeof(double));

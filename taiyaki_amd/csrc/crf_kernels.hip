@@ -529,7 +529,7 @@ __global__ void seqoff_kernel(const int32_t *__restrict__ seqlen, int nbatch,
 
 __global__ void build_indices_kernel(const int32_t *__restrict__ seqs,
                                      const int32_t *__restrict__ seqlen,
-                                     const int64_t *__restrict__ seqoff, int nbase,
+                                     int64_t *__restrict__ seqoff, int nbatch, int nbase,
                                      const int32_t *__restrict__ mod_cats,
                                      const int32_t *__restrict__ can_mods_offsets,
                                      const float *__restrict__ mod_cat_weights,
@@ -537,7 +537,46 @@ __global__ void build_indices_kernel(const int32_t *__restrict__ seqs,
                                      int32_t *__restrict__ mod, float *__restrict__ fact,
                                      long long total_len, uint32_t *__restrict__ status) {
     const int n = blockIdx.x;
-    const int64_t off = seqoff[n];
+    // this read's offset = the sum of the lengths before it, clamped to the label array (see
+    // seqoff_kernel): every workgroup sums for itself -- a batch is a few hundred reads, and it saves
+    // the separate prefix-sum launch (~5 us of a 170 us loss path)
+    __shared__ long long part[128];
+    __shared__ long long off_sh, tot_sh;
+    if (nbatch == 0) {                  // (offsets already there: seqoff_kernel ran)
+        if (threadIdx.x == 0) off_sh = seqoff[n];
+        __syncthreads();
+    } else {
+        long long mine = 0, all = 0;
+        for (int i = threadIdx.x; i < nbatch; i += blockDim.x) {
+            const long long v = seqlen[i];
+            all += v;
+            if (i < n) mine += v;
+        }
+        part[threadIdx.x] = mine;
+        __syncthreads();
+        for (int st = blockDim.x / 2; st > 0; st >>= 1) {
+            if ((int)threadIdx.x < st) part[threadIdx.x] += part[threadIdx.x + st];
+            __syncthreads();
+        }
+        if (threadIdx.x == 0) off_sh = part[0];
+        __syncthreads();
+        part[threadIdx.x] = all;
+        __syncthreads();
+        for (int st = blockDim.x / 2; st > 0; st >>= 1) {
+            if ((int)threadIdx.x < st) part[threadIdx.x] += part[threadIdx.x + st];
+            __syncthreads();
+        }
+        if (threadIdx.x == 0) {
+            tot_sh = part[0];
+            seqoff[n] = min(off_sh, total_len);
+            if (n == nbatch - 1) {
+                seqoff[nbatch] = min(tot_sh, total_len);
+                if (tot_sh > total_len && status) atomicOr(status, 8u);     // more labels announced than handed over
+            }
+        }
+        __syncthreads();
+    }
+    const int64_t off = min(off_sh, total_len);
     // (a batch that announces more labels than were handed over is flagged by seqoff_kernel;
     // here its reads are cut at the end of the label array)
     const int L = (int)max(0ll, min((long long)seqlen[n], total_len - (long long)off));
@@ -581,10 +620,13 @@ int build_indices_dispatch(const int32_t *seqs, const int32_t *seqlen, size_t nb
                            const int32_t *can_mods_offsets, const float *mod_cat_weights,
                            int64_t *seqoff, int32_t *stay, int32_t *move, int32_t *mod,
                            float *fact, size_t total_len, uint32_t *status, hipStream_t stream) {
-    hipLaunchKernelGGL(seqoff_kernel, dim3(1), dim3(256), 0, stream, seqlen, (int)nbatch, seqoff,
-                       (long long)total_len, status);
+    // (one launch: every workgroup computes its read's offset itself; seqoff_kernel is kept for
+    // batches of more than 8192 reads, where the redundant sums would cost more than a launch)
+    if (nbatch > 8192)
+        hipLaunchKernelGGL(seqoff_kernel, dim3(1), dim3(256), 0, stream, seqlen, (int)nbatch, seqoff,
+                           (long long)total_len, status);
     hipLaunchKernelGGL(build_indices_kernel, dim3((unsigned)nbatch), dim3(128), 0, stream, seqs,
-                       seqlen, seqoff, (int)nbase, mod_cats, can_mods_offsets, mod_cat_weights,
+                       seqlen, seqoff, (int)(nbatch > 8192 ? 0 : nbatch), (int)nbase, mod_cats, can_mods_offsets, mod_cat_weights,
                        stay, move, mod, fact, (long long)total_len, status);
     return hipGetLastError() == hipSuccess ? 0 : 4;
 }
@@ -748,8 +790,10 @@ int crf_dispatch(const float *logprob, size_t ntrans, size_t nblk, size_t nbatch
         b.Wp = (int)(l.LP / WAVE);
         b.ckFm = g ? reinterpret_cast<float *>(wb + l.ckFm) : nullptr;
         b.ckBm = g ? reinterpret_cast<float *>(wb + l.ckBm) : nullptr;
-        b.ckFf = g ? reinterpret_cast<int *>(wb + l.ckFf) : nullptr;
-        b.ckBf = g ? reinterpret_cast<int *>(wb + l.ckBf) : nullptr;
+        b.ckFf = g ? reinterpret_cast<int16_t *>(wb + l.ckFf) : nullptr;
+        b.ckBf = g ? reinterpret_cast<int16_t *>(wb + l.ckBf) : nullptr;
+        b.ckFb = g ? reinterpret_cast<int *>(wb + l.ckFb) : nullptr;
+        b.ckBb = g ? reinterpret_cast<int *>(wb + l.ckBb) : nullptr;
         b.bndF = g ? reinterpret_cast<float *>(wb + l.bndF) : nullptr;
         b.bndB = g ? reinterpret_cast<float *>(wb + l.bndB) : nullptr;
         b.scoreF = g ? reinterpret_cast<double *>(wb + l.scoreF) : nullptr;

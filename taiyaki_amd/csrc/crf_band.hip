@@ -678,13 +678,14 @@ __global__ __launch_bounds__(POST_WAVES *WAVE) void crf_band_posterior_kernel(Ba
         er[k] = fast_exp2(raw[k] * c);
     }
 
-    // live chunks of row t: chunk [a, b] holds a cell of some complete path through row t iff
-    // a <= t  and  b + 1 >= L - T + t
+    // live chunks of row t (column t -> t + 1): chunk [a, b] holds an instance of some complete path
+    // through row t iff  a <= t + 1  (the move INTO position t + 1 is the fastest path's)  and
+    // b + 1 >= L - T + t
     auto chunk_lo = [&](int t) {
         const int need = L - T + t;
         return (trim && need > 0) ? max(0, (need + PW - 1) / PW - 1) : 0;
     };
-    auto chunk_hi = [&](int t) { return trim ? min(Wn - 1, t / PW) : Wn - 1; };
+    auto chunk_hi = [&](int t) { return trim ? min(Wn - 1, (t + 1) / PW) : Wn - 1; };
     const int cmin = chunk_lo(t0), cmax = chunk_hi(t0 + nrows - 1);       // both bounds grow with t
     // (a row of the block that a chunk is not live for only adds exact zeros: its forward or its
     // backward cells are all dead there)
@@ -949,6 +950,10 @@ __global__ __launch_bounds__(POST_WAVES *WAVE) void crf_band_posterior_kernel(Ba
             const float total = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(pacc[k]), a.ncan - 1));
             const float dev = fast_log2(total) - zfrac;
             lost |= !(dev > -ROWZ_TOL && dev < ROWZ_TOL);
+#ifdef TK_LAB_ROWDEV
+            if (!(dev > -ROWZ_TOL && dev < ROWZ_TOL) && lane == 0)
+                printf("rowdev n %d t %d L %d total %g dev %g cmin %d cmax %d nskip %d\n", n, t0 + k, L, total, dev, cmin, cmax, nskip);
+#endif
             // gradient of -score / T  (ctc.pyx:113)
             const float g = crf_add_grad(a, (size_t)(t0 + k), n, lane, colacc * (-gsc / (total * (float)T)), gsc);
             if (lane < S) a.grad[(size_t)(t0 + k) * rowstride + (size_t)n * S + lane] = g;

@@ -817,6 +817,8 @@ int crf_dispatch(const float *logprob, size_t ntrans, size_t nblk, size_t nbatch
             }
             fprintf(stderr, "crf band: %zu of %zu reads gated (non-finite score %zu, sweeps disagree %zu, row lost mass %zu)\n",
                     cnt, ng, why[1], why[4], why[2]);
+            for (size_t i = 0, shown = 0; i < ng && shown < 16; ++i)
+                if (hostg[i]) fprintf(stderr, "crf band:   read %zu (reason %d)\n", i, hostg[i]), ++shown;
         }
         // the reads the linear path disowned, redone in the log domain
         a.gate = b.gate;

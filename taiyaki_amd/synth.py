@@ -147,6 +147,41 @@ def crf_case(T, N, seed, nbase=4, nmods_per_base=None, seqlens=None):
     return out
 
 
+def confident_scores(inp, seed, on=4.0, off=-3.0, noise=1.0, nbase=4, bursty=False):
+    """Scores of a TRAINED network, not of a freshly initialised one: every read follows one alignment
+    (its L - 1 moves at random block positions, `bursty`: in runs, as a strand that speeds up and
+    stalls), the transition the alignment takes at a block scores `on` (+- noise), every other one
+    `off` (+- noise) -- the 5 tanh range used to its ends.  Replaces inp["scores"] in place."""
+    T, N, S = inp["scores"].shape
+    rng = np.random.RandomState(seed)
+    sc = (off + noise * rng.uniform(-1, 1, size=(T, N, S))).astype(np.float32)
+    ns = 2 * nbase
+    off_seq = np.concatenate([[0], np.cumsum(inp["seqlens"])])
+    for n in range(N):
+        L = int(inp["seqlens"][n])
+        if L == 0 or L - 1 > T:
+            continue
+        codes = inp["seqs"][off_seq[n]:off_seq[n] + L].astype(int)
+        if bursty:
+            w = np.repeat(rng.uniform(0.05, 1.0, size=T // 40 + 1) ** 3, 40)[:T]
+            moves = np.sort(rng.choice(T, size=L - 1, replace=False, p=w / w.sum()))
+        else:
+            moves = np.sort(rng.choice(T, size=L - 1, replace=False))
+        is_move = np.zeros(T, dtype=bool)
+        is_move[moves] = True
+        p = 0
+        for t in range(T):
+            c = codes[p]
+            if is_move[t]:
+                tid = c + min(codes[p + 1], nbase) * ns            # flipflopfings.py:6-17
+                p += 1
+            else:
+                tid = c + min(c, nbase) * ns                       # flipflopfings.py:20-31
+            sc[t, n, tid] = on + noise * rng.uniform(-1, 1)
+    inp["scores"][:, :, :S] = sc
+    return inp
+
+
 def normalise_mod_columns(inp, ncan=40, logit_scale=0.2):
     """Turn the free scores of a cat-mod case's mod columns into what GlobalNormFlipFlopCatMod emits
     there (layers.py:1627-1640): per canonical base a log-softmax over {unmodified, its

@@ -585,6 +585,48 @@ def test_crf_linear_band_path_disowns_reads_and_the_log_domain_kernel_redoes_the
     assert 401 not in kept and 399 not in kept, kept
 
 
+@pytest.mark.parametrize("bursty", [False, True])
+def test_crf_linear_band_path_keeps_confident_reads(oracle_mod, gpu_device, bursty, monkeypatch):
+    """Scores of a trained network (synth.confident_scores: the alignment's transition at +4, every
+    other at -3) put the whole posterior on one path; a strand that starts in a burst runs that path
+    along the band's diagonal edge (position = block + 1), where the move into the first cell of the
+    next 64-cell chunk is the row's only instance with mass.  The linear path alone
+    (TK_CRF_NO_FALLBACK=1, outputs poisoned) must own every such read and match the oracle."""
+    import torch
+    from taiyaki_amd import ctc, synth
+    monkeypatch.setenv("TK_CRF_MODE", "band")
+    monkeypatch.setenv("TK_CRF_NO_FALLBACK", "1")
+    T, Ls = 400, [250, 130, 64, 65, 66, 200, 301, 129, 193, 180, 90, 257]
+    inp = synth.crf_case(T, len(Ls), 11, seqlens=np.array(Ls, dtype=np.int32))
+    synth.confident_scores(inp, 3, bursty=bursty)
+    if bursty:
+        # reads 0 .. 3 open with one move per block for as long as they have labels: the diagonal
+        S = inp["scores"].shape[2]
+        off0 = np.concatenate([[0], np.cumsum(Ls)])
+        rng = np.random.RandomState(4)
+        for n in range(4):
+            codes = inp["seqs"][off0[n]:off0[n + 1]].astype(int)
+            sc = (-3.0 + rng.uniform(-1, 1, size=(T, S))).astype(np.float32)
+            for t in range(T):
+                p = min(t, Ls[n] - 1)
+                tid = codes[p] + min(codes[p + 1] if t < Ls[n] - 1 else codes[p], 4) * 8
+                sc[t, tid] = 4.0 + rng.uniform(-1, 1)
+            inp["scores"][:, n, :] = sc
+    off = np.concatenate([[0], np.cumsum(Ls)])
+    x = torch.from_numpy(inp["scores"]).to(gpu_device)
+    seqs, sl = torch.from_numpy(inp["seqs"]), torch.from_numpy(inp["seqlens"])
+    junk = [torch.full_like(x, float("nan")), torch.full((len(Ls),), float("nan"), device=gpu_device)]
+    del junk
+    c, g = ctc._run(x, seqs, sl, 1.0, 1.0, 1.0, 40, True)
+    torch.cuda.synchronize()
+    cost, grad = c.cpu().numpy(), g.cpu().numpy()
+    assert np.isfinite(cost).all() and np.isfinite(grad).all(), np.nonzero(~np.isfinite(cost))[0]
+    for n, L in enumerate(Ls):
+        oloss, ograd = parity.oracle_crf(oracle_mod, _crf_alone(inp, n, L, off), 1.0)
+        assert parity.rel_err(cost[n:n + 1], oloss) < LOSS_RTOL, (L, cost[n], oloss)
+        assert parity.abs_err(grad[:, n:n + 1], ograd) < GRAD_ATOL, L
+
+
 def test_crf_sharpened_scores_take_the_log_domain_kernel(oracle_mod, gpu_device, monkeypatch):
     """sharp = 2.5 puts weights of 2^(+-18) on a step: eight of them overflow a block of the linear
     path, which must notice (non-finite sweep score) and hand the read over."""

@@ -31,6 +31,10 @@ SHAPES = {
     "cfg5": (1600, "speed64", 1.0, None),
     "rowK": (4000, "speed256", 1.0, None),
     "t19": (19, [20, 3], 1.0, None),
+    # a trained network: one alignment per read scores +4, everything else -3
+    "conf": (800, "real128", 1.0, None),
+    "confburst": (800, "real128", 1.0, None),
+    "confK": (4000, "speed64", 1.0, None),
 }
 
 
@@ -51,7 +55,7 @@ def run(x, seqs, seqlens, sharp, extra, env):
 
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument("--shapes", default="tiny,t19,t37,t200,cfg2,cfg2r,narrow,sharp,cfg4,cfg4r,cfg4rharsh,cfg5,rowK")
+    ap.add_argument("--shapes", default="tiny,t19,t37,t200,cfg2,cfg2r,narrow,sharp,cfg4,cfg4r,cfg4rharsh,cfg5,rowK,conf,confburst,confK")
     args = ap.parse_args()
     dev = torch.device("cuda:0")
     _lib.set_strict(False)
@@ -63,6 +67,8 @@ def main():
         else:
             N, seqlens = len(lens), np.array(lens, dtype=np.int32)
         inp = synth.crf_case(T, N, 1, seqlens=seqlens, nmods_per_base=mods)
+        if sh.startswith("conf"):
+            synth.confident_scores(inp, 7, bursty="burst" in sh)
         if mods is not None and not sh.endswith("free"):
             synth.normalise_mod_columns(inp, logit_scale=1.0 if sh.endswith("harsh") else 0.2)
         x = torch.from_numpy(inp["scores"]).to(dev)

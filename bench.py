@@ -621,8 +621,14 @@ def main():
     for m in net.modules():
         if hasattr(m, "use_gemm"):
             m.use_gemm = args.conv == "gemm"
-    parallel.broadcast_parameters(net)
-    arena = parallel.FlatGradArena(net, overlap_buckets=args.overlap_buckets)
+    # TK_RCCL_DIRECT=1: the gradient collectives through this repo's own C ABI over RCCL
+    # (libtaiyaki_amd_rccl.so) instead of ProcessGroupNCCL; the process group stays up for the
+    # rendezvous (it carries RCCL's unique id) and the bench's own barriers
+    collective = None
+    if os.environ.get("TK_RCCL_DIRECT") and dev.type == "cuda" and (world > 1 or os.environ.get("TK_FORCE_PROCESS_GROUP")):
+        collective = parallel.DirectRccl(rank, world, device=dev)
+    parallel.broadcast_parameters(net, collective=collective)
+    arena = parallel.FlatGradArena(net, overlap_buckets=args.overlap_buckets, collective=collective)
     # the reference's default adaptive clipping (--gradient_clip_num_mads 0, window 1000):
     # gradient maxima every step, clamp once 1000 steps have been seen
     trainer = train.Trainer(net, arena, clip_num_mads=0)
@@ -732,7 +738,20 @@ def main():
                 evb.append((a, b))
             torch.cuda.synchronize()
             bucket_us.append(round(float(np.mean([a.elapsed_time(b) * 1e3 for a, b in evb])), 1))
+        direct_us = None
+        if arena.collective is not None:
+            evd = []
+            for _ in range(20):
+                a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                a.record()
+                arena.collective.all_reduce(arena.flat).wait()
+                b.record()
+                evd.append((a, b))
+            torch.cuda.synchronize()
+            direct_us = round(float(np.mean(sorted(a.elapsed_time(b) * 1e3 for a, b in evd)[:-2])), 1)
         rccl = dict(ranks=world, backend=dist.get_backend(), bytes=arena.flat.numel() * 4,
+                    collective=("tk_allreduce_f32_dev (C ABI over RCCL)" if arena.collective is not None
+                                else "torch.distributed ProcessGroupNCCL"), c_abi_allreduce_us=direct_us,
                     allreduce_us=round(float(np.mean(us)), 1), allreduce_min_us=round(us[0], 1),
                     overlap_buckets=len(arena._buckets),
                     bucket_bytes=[(hi - lo) * 4 for lo, hi in arena.slices()], bucket_us=bucket_us,

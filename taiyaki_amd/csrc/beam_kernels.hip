@@ -44,11 +44,58 @@ __device__ __forceinline__ unsigned long long beam_chain(unsigned long long h, u
     h *= 0x880355f21e6d1965ULL;
     return beam_mix(h);
 }
+// expf(-a) for a in [0, 17), correctly rounded: exp in double to ~2^-50 (range reduction by ln 2 in two
+// parts, Taylor polynomial of degree 13 on |r| <= 0.347), rounded once to float.  ocml's generic
+// double exp + log1p made a log-sum-exp ~165 instructions, most of them half-rate; these two are ~60.
+__device__ __forceinline__ float beam_expf_neg(float a) {
+    const double x = -(double)a;
+    const double k = __builtin_rint(x * 1.4426950408889634074);
+    double r = __builtin_fma(k, -6.93147180369123816490e-01, x);
+    r = __builtin_fma(k, -1.90821492927058770002e-10, r);
+    double p = 1.6059043836821613e-10;                  // 1 / 13!
+    p = __builtin_fma(p, r, 2.08767569878681e-09);      // 1 / 12!
+    p = __builtin_fma(p, r, 2.505210838544172e-08);     // 1 / 11!
+    p = __builtin_fma(p, r, 2.755731922398589e-07);     // 1 / 10!
+    p = __builtin_fma(p, r, 2.7557319223985893e-06);    // 1 / 9!
+    p = __builtin_fma(p, r, 2.48015873015873e-05);      // 1 / 8!
+    p = __builtin_fma(p, r, 1.984126984126984e-04);     // 1 / 7!
+    p = __builtin_fma(p, r, 1.388888888888889e-03);     // 1 / 6!
+    p = __builtin_fma(p, r, 8.333333333333333e-03);     // 1 / 5!
+    p = __builtin_fma(p, r, 4.1666666666666664e-02);    // 1 / 4!
+    p = __builtin_fma(p, r, 1.6666666666666666e-01);    // 1 / 3!
+    p = __builtin_fma(p, r, 0.5);
+    p = __builtin_fma(p, r, 1.0);
+    p = __builtin_fma(p, r, 1.0);
+    return (float)__builtin_ldexp(p, (int)k);
+}
+// log1pf(e) for e in (0, 1], correctly rounded: 1 + e is exact in double, folded to (1/sqrt 2, sqrt 2],
+// log t = 2 atanh((t - 1) / (t + 1)) with the series to s^21 (|s| <= 0.1716: remainder < 2^-60).
+__device__ __forceinline__ float beam_log1pf_unit(float e) {
+    const double t0 = 1.0 + (double)e;
+    const bool fold = t0 > 1.4142135623730951;
+    const double t = fold ? 0.5 * t0 : t0;
+    const double s = (t - 1.0) / (t + 1.0);
+    const double z = s * s;
+    double q = 1.0 / 21.0;
+    q = __builtin_fma(q, z, 1.0 / 19.0);
+    q = __builtin_fma(q, z, 1.0 / 17.0);
+    q = __builtin_fma(q, z, 1.0 / 15.0);
+    q = __builtin_fma(q, z, 1.0 / 13.0);
+    q = __builtin_fma(q, z, 1.0 / 11.0);
+    q = __builtin_fma(q, z, 1.0 / 9.0);
+    q = __builtin_fma(q, z, 1.0 / 7.0);
+    q = __builtin_fma(q, z, 1.0 / 5.0);
+    q = __builtin_fma(q, z, 1.0 / 3.0);
+    q = __builtin_fma(q, z, 1.0);
+    const double l = 2.0 * s * q;
+    return (float)(fold ? l + 6.93147180559945309417e-01 : l);
+}
 // c_hashdecode.c:50-54
 __device__ __forceinline__ float beam_lse(float x, float y) {
     const float absdif = fabsf(x - y);
-    const float tail = (absdif < 17.0f) ? (float)log1p((double)(float)exp(-(double)absdif)) : 0.0f;
-    return fmaxf(x, y) + tail;
+    // (clamped argument: both functions run unconditionally, a lane outside the range drops the result)
+    const float tail = beam_log1pf_unit(beam_expf_neg(fminf(absdif, 17.0f)));
+    return fmaxf(x, y) + ((absdif < 17.0f) ? tail : 0.0f);
 }
 __device__ __forceinline__ float rdl(float v, int l) {
     return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), l));
@@ -153,16 +200,32 @@ __global__ __launch_bounds__(WAVE) void beam_kernel(BeamArgs a) {
 
     // ---- guiding backward pass (c_flipflopfwdbwd.c:55-91): lane = from-state ----------------
     if (lane < ns) bwd[(size_t)T * ns + lane] = 0.f;
+    // (score rows are requested PF blocks ahead of their use: a block is a serial chain of nbase + 1
+    // log-sum-exps, and a load issued where it is needed adds a memory round trip to every one)
+    constexpr int PF = 4;
+    auto load_row = [&](int blk) { return sc[(size_t)min(max(blk, 0), T - 1) * rowstride + col]; };
     if (a.guided) {
         float p = 0.f;                                  // pbwd[lane]
-        for (int blk = T; blk > 0; --blk) {
-            const float row = sc[(size_t)(blk - 1) * rowstride + col];
-            const int fr = min(lane, ns - 1);
-            // to the flop of this state's base
-            float c = bpf(row, ns * nb + fr) + bpf(p, nb + fr % nb);
-            for (int to = 0; to < nb; ++to) c = beam_lse(c, bpf(row, to * ns + fr) + rdl(p, to));
-            p = c;
-            if (lane < ns) bwd[(size_t)(blk - 1) * ns + lane] = c;
+        float cur[PF], nxt[PF];
+#pragma unroll
+        for (int q = 0; q < PF; ++q) cur[q] = load_row(T - 1 - q);
+        for (int b0 = T; b0 > 0; b0 -= PF) {
+#pragma unroll
+            for (int q = 0; q < PF; ++q) nxt[q] = load_row(b0 - 1 - PF - q);
+#pragma unroll
+            for (int q = 0; q < PF; ++q) {
+                const int blk = b0 - q;
+                if (blk <= 0) break;
+                const float row = cur[q];
+                const int fr = min(lane, ns - 1);
+                // to the flop of this state's base
+                float c = bpf(row, ns * nb + fr) + bpf(p, nb + fr % nb);
+                for (int to = 0; to < nb; ++to) c = beam_lse(c, bpf(row, to * ns + fr) + rdl(p, to));
+                p = c;
+                if (lane < ns) bwd[(size_t)(blk - 1) * ns + lane] = c;
+            }
+#pragma unroll
+            for (int q = 0; q < PF; ++q) cur[q] = nxt[q];
         }
     } else {
         for (int i = lane; i < T * ns; i += WAVE) bwd[i] = 0.f;
@@ -176,9 +239,26 @@ __global__ __launch_bounds__(WAVE) void beam_kernel(BeamArgs a) {
     float es = 0.f;
     int el = min(lane, nb - 1);
     int W = nb;
-    for (int blk = 0; blk < T; ++blk) {
-        const float row = sc[(size_t)blk * rowstride + col];
-        const float bsv = (lane < ns) ? bwd[(size_t)(blk + 1) * ns + lane] : 0.f;     // bwdscore[lane]
+    auto load_bwd = [&](int blk) { return bwd[(size_t)min(blk + 1, T) * ns + min(lane, ns - 1)]; };
+    float rowc[PF], bsvc[PF], rown[PF], bsvn[PF];
+#pragma unroll
+    for (int q = 0; q < PF; ++q) {
+        rowc[q] = load_row(q);
+        bsvc[q] = load_bwd(q);
+    }
+    for (int b0 = 0; b0 < T; b0 += PF) {
+      // (this group's rows and backward scores were requested a group ago)
+#pragma unroll
+      for (int q = 0; q < PF; ++q) {
+          rown[q] = load_row(b0 + PF + q);
+          bsvn[q] = load_bwd(b0 + PF + q);
+      }
+#pragma unroll
+      for (int q = 0; q < PF; ++q) {
+        const int blk = b0 + q;
+        if (blk >= T) break;
+        const float row = rowc[q];
+        const float bsv = (lane < ns) ? bsvc[q] : 0.f;                                  // bwdscore[lane]
         const int next = W * nb, ncand = next + W;
         // candidate of this lane
         const bool is_ext = lane < next, is_cand = lane < ncand;
@@ -276,6 +356,12 @@ __global__ __launch_bounds__(WAVE) void beam_kernel(BeamArgs a) {
         }
         W = newW;
         __syncthreads();
+      }
+#pragma unroll
+      for (int q = 0; q < PF; ++q) {
+          rowc[q] = rown[q];
+          bsvc[q] = bsvn[q];
+      }
     }
     // ---- walk the best element's sequence back -----------------------------------------------
     if (lane == 0) {

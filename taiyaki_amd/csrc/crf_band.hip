@@ -285,14 +285,19 @@ __device__ __forceinline__ void band_sweep(const BandArgs &a, int n, int L, floa
     // it in between, so the load latency never sits in a phase; the live loop is unrolled three
     // times to keep the rotation in register NAMES (a copy would have to wait for the load).
     float row0[BK], row1[BK], row2[BK];
+    // (row offsets inside a block are loop-invariant scalars; the descriptor covers exactly the rows
+    // of the block that exist, so a row past the end of the tensor is out of range and reads 0 --
+    // its step is never taken -- without a clamp per row)
+    unsigned rowoff[BK];
+#pragma unroll
+    for (int i = 0; i < BK; ++i) rowoff[i] = rs4 * (unsigned)i;
     auto load_block = [&](int j, float (&dst)[BK]) {
         j = min(max(j, 0), NB - 1);
         const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(
-            const_cast<float *>(lpn + (size_t)(j * BK) * rowstride), 0, 0x7fffffff, BUF_WORD3);
-        const int last = T - 1 - j * BK;                        // rows past the end re-read the last one
+            const_cast<float *>(lpn + (size_t)(j * BK) * rowstride), 0, (int)(rs4 * (unsigned)min(BK, T - j * BK)), BUF_WORD3);
 #pragma unroll
         for (int i = 0; i < BK; ++i) {
-            dst[i] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rs, col4, rs4 * (unsigned)min(i, last), 0));
+            dst[i] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rs, col4, rowoff[i], 0));
         }
     };
 

@@ -80,6 +80,90 @@ def _trace(msg):
         print("[arena rank %s] %s" % (os.environ.get("RANK", "?"), msg), file=sys.stderr, flush=True)
 
 
+class _StreamWork:
+    """What `DirectRccl.all_reduce` returns: `wait()` makes the CURRENT stream wait for the
+    collective (the contract of a torch.distributed async work object on a GPU backend)."""
+
+    def __init__(self, event):
+        self.event = event
+
+    def wait(self):
+        torch.cuda.current_stream().wait_event(self.event)
+
+
+class DirectRccl:
+    """The arena's collectives straight on RCCL through this repo's C ABI
+    (csrc/rccl_api.cpp -> libtaiyaki_amd_rccl.so: `tk_rccl_comm_init`, `tk_allreduce_f32_dev`,
+    `tk_broadcast_f32_dev`) instead of ProcessGroupNCCL -- the path a host without
+    torch.distributed binds, and `TK_RCCL_DIRECT=1` for the Python trainers.  One communicator per
+    process; the collectives are enqueued on a high-priority side stream of this class (a hardware
+    queue of its own, like ProcessGroupNCCL's, tools/queue_probe.py) behind an event of the stream
+    that produced the gradients.
+
+    `exchange(id_bytes_or_None) -> id_bytes` hands rank 0's RCCL unique id to every rank (the
+    reference's TCP store, bin/train_flipflop.py:255-268); the default uses the torch.distributed
+    group that is already up (gloo or nccl) and is the identity for a single rank."""
+
+    def __init__(self, rank, world, exchange=None, device=None):
+        import ctypes
+        from . import _lib
+        self._lib = _lib.rccl_lib()
+        self.rank, self.world = rank, world
+        if device is not None:
+            torch.cuda.set_device(device)
+        nb = int(self._lib.tk_rccl_unique_id_bytes())
+        buf = ctypes.create_string_buffer(nb)
+        if rank == 0:
+            _lib.check(self._lib.tk_rccl_unique_id(buf, nb), "tk_rccl_unique_id")
+        if exchange is None:
+            exchange = self._exchange_over_process_group
+        idbytes = exchange(buf.raw if rank == 0 else None)
+        if idbytes is None or len(idbytes) != nb:
+            raise RuntimeError("DirectRccl: the unique id did not arrive (%r)" % (idbytes,))
+        comm = ctypes.c_void_p()
+        _lib.check(self._lib.tk_rccl_comm_init(ctypes.byref(comm), world, idbytes, rank), "tk_rccl_comm_init")
+        self._comm = comm
+        self.stream = torch.cuda.Stream(priority=-1)
+
+    def _exchange_over_process_group(self, idbytes):
+        if self.world == 1:
+            return idbytes
+        box = [idbytes]
+        dist.broadcast_object_list(box, src=0)
+        return box[0]
+
+    def _enqueue(self, fn, what):
+        from . import _lib
+        ready = torch.cuda.Event()
+        ready.record(torch.cuda.current_stream())
+        self.stream.wait_event(ready)
+        _lib.check(fn(_lib._vp(self.stream.cuda_stream)), what)
+        done = torch.cuda.Event()
+        done.record(self.stream)
+        return _StreamWork(done)
+
+    def all_reduce(self, t):
+        """SUM over ranks, in place, asynchronously; `t`: contiguous float32 on this device."""
+        from . import _lib
+        assert t.is_cuda and t.dtype == torch.float32 and t.is_contiguous()
+        t.record_stream(self.stream)
+        return self._enqueue(lambda st: self._lib.tk_allreduce_f32_dev(self._comm, _lib.ptr(t), t.numel(), st),
+                             "tk_allreduce_f32_dev")
+
+    def broadcast(self, t, src=0):
+        from . import _lib
+        assert t.is_cuda and t.dtype == torch.float32 and t.is_contiguous()
+        t.record_stream(self.stream)
+        return self._enqueue(lambda st: self._lib.tk_broadcast_f32_dev(self._comm, _lib.ptr(t), t.numel(), src, st),
+                             "tk_broadcast_f32_dev")
+
+    def close(self):
+        if self._comm is not None:
+            torch.cuda.synchronize()
+            self._lib.tk_rccl_comm_destroy(self._comm)
+            self._comm = None
+
+
 class FlatGradArena:
     """All trainable gradients as views into one contiguous fp32 buffer.
 
@@ -91,7 +175,11 @@ class FlatGradArena:
     10.9 MB).  `finish()` waits for every slice, reduces whatever was not ready (unused
     parameters) and applies the 1/world factor."""
 
-    def __init__(self, module, overlap_buckets=0):
+    def __init__(self, module, overlap_buckets=0, collective=None):
+        """`collective`: a `DirectRccl` (this repo's C ABI over RCCL) instead of torch.distributed's
+        process group; with it the arena reduces even for a single rank (a one-rank communicator
+        is how a 1-GPU box exercises the path)."""
+        self.collective = collective
         self.params = [p for p in module.parameters() if p.requires_grad]
         n = sum(p.numel() for p in self.params)
         dev = self.params[0].device
@@ -104,6 +192,8 @@ class FlatGradArena:
             off += p.numel()
         self.world = dist.get_world_size() if dist.is_initialized() else 1
         self._always = dist.is_initialized() and bool(os.environ.get("TK_FORCE_PROCESS_GROUP"))
+        if collective is not None:
+            self.world, self._always = collective.world, True
         self._work = []
         self._buckets = []          # [lo, hi, params still missing this step, issued]
         self._hooks = []
@@ -139,8 +229,13 @@ class FlatGradArena:
             if b[2] == 0 and not b[3]:
                 b[3] = True
                 _trace("hook bucket %d [%d:%d]" % (k, b[0], b[1]))
-                self._work.append(dist.all_reduce(self.flat[b[0]:b[1]], op=dist.ReduceOp.SUM, async_op=True))
+                self._work.append(self._all_reduce(self.flat[b[0]:b[1]]))
         return hook
+
+    def _all_reduce(self, t):
+        if self.collective is not None:
+            return self.collective.all_reduce(t)
+        return dist.all_reduce(t, op=dist.ReduceOp.SUM, async_op=True)
 
     @property
     def overlapped(self):
@@ -165,11 +260,10 @@ class FlatGradArena:
                 if not b[3]:
                     b[3] = True
                     _trace("late bucket %d [%d:%d] missing %d" % (k, b[0], b[1], b[2]))
-                    self._work.append(dist.all_reduce(self.flat[b[0]:b[1]], op=dist.ReduceOp.SUM,
-                                                      async_op=True))
+                    self._work.append(self._all_reduce(self.flat[b[0]:b[1]]))
         else:
             _trace("whole arena")
-            self._work.append(dist.all_reduce(self.flat, op=dist.ReduceOp.SUM, async_op=True))
+            self._work.append(self._all_reduce(self.flat))
 
     def finish(self, scale=1.0):
         """Wait for the slices, apply 1 / world (x `scale`: 1 / number of accumulated sub-batches)."""
@@ -185,9 +279,17 @@ class FlatGradArena:
             b[2], b[3] = c, False
 
 
-def broadcast_parameters(module, src=0):
+def broadcast_parameters(module, src=0, collective=None):
     """Replaces the checkpoint-file + barrier handshake of the reference
-    (bin/train_flipflop.py:380-392): rank 0's weights go out over RCCL."""
+    (bin/train_flipflop.py:380-392): rank 0's weights go out over RCCL (`collective`: through the
+    C ABI's `tk_broadcast_f32_dev`; float32 tensors only, which is every parameter and every
+    floating-point buffer of the models here)."""
+    if collective is not None:
+        work = [collective.broadcast(t.data, src=src) for t in list(module.parameters()) + list(module.buffers())
+                if t.dtype == torch.float32 and t.is_cuda and t.is_contiguous()]
+        for w in work:
+            w.wait()
+        return
     if dist.is_initialized() and dist.get_world_size() > 1:
         for t in list(module.parameters()) + list(module.buffers()):
             dist.broadcast(t.data, src=src)

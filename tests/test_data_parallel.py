@@ -227,3 +227,44 @@ def test_torchrun_env_rendezvous_single_process():
     for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK"):
         os.environ.pop(k, None)
     assert parallel.init_from_env() == (0, 0, 1)
+
+
+@pytest.mark.gpu
+def test_direct_rccl_collectives_through_the_c_abi_single_rank():
+    """`libtaiyaki_amd_rccl.so` on a real GPU: a one-rank RCCL communicator (the most a 1-GPU box
+    can build) created through `tk_rccl_unique_id` / `tk_rccl_comm_init`, `tk_allreduce_f32_dev` and
+    `tk_broadcast_f32_dev` enqueued on the collective's own stream and joined by events -- SUM over
+    one rank and a broadcast from rank 0 must leave the buffer as it was -- and the gradient arena
+    reducing through it from its backward hooks gives the gradients of the plain step."""
+    import torch
+    from taiyaki_amd import parallel
+    dev = torch.device("cuda:0")
+    coll = parallel.DirectRccl(0, 1, device=dev)
+    try:
+        x = torch.randn(1 << 20, device=dev)
+        ref = x.clone()
+        coll.all_reduce(x).wait()
+        coll.broadcast(x, src=0).wait()
+        torch.cuda.synchronize()
+        assert torch.equal(x, ref)
+
+        def grads(collective):
+            torch.manual_seed(3)
+            net = torch.nn.Sequential(torch.nn.Linear(64, 128), torch.nn.Tanh(), torch.nn.Linear(128, 128),
+                                      torch.nn.Tanh(), torch.nn.Linear(128, 40)).to(dev)
+            parallel.broadcast_parameters(net, collective=collective)
+            arena = parallel.FlatGradArena(net, overlap_buckets=3, collective=collective)
+            assert arena.overlapped == (collective is not None)
+            arena.zero()
+            torch.manual_seed(4)
+            net(torch.randn(256, 64, device=dev)).square().mean().backward()
+            arena.allreduce_async()
+            arena.finish()
+            torch.cuda.synchronize()
+            return arena.flat.clone()
+
+        g_direct, g_plain = grads(coll), grads(None)
+        assert torch.isfinite(g_direct).all() and g_direct.abs().max() > 0
+        assert torch.equal(g_direct, g_plain)
+    finally:
+        coll.close()

@@ -28,7 +28,8 @@ int crf_dispatch(const float *logprob, size_t ntrans, size_t nblk, size_t nbatch
                  float out_scale, float grad_scale, const float *grad_scale_vec, float *cost, float *grad,
                  void *workspace, size_t workspace_bytes, uint32_t *status, hipStream_t stream,
                  const float *add_grad = nullptr, const float *add_cost = nullptr, int add_S = 0,
-                 float add_scale = 0.f);
+                 float add_scale = 0.f, hipEvent_t add_ready = nullptr);
+bool logz_side_stream(hipStream_t *s, hipEvent_t *fork, hipEvent_t *join);
 void crf_band_lab_phase(int phase);
 size_t beam_workspace_bytes(size_t T, size_t N, size_t nbase);
 int lattice_dispatch(const float *scores, size_t T, size_t N, size_t nbase, int forward, const float *init,
@@ -210,10 +211,31 @@ __global__ void slice_cols_kernel(const float *__restrict__ src, float *__restri
     dst[i] = src[r * (size_t)S + (i - r * (size_t)S0)];
 }
 
+// Kernel B beside kernel A's sweeps -- an experiment, OFF unless TK_LOSS_OVERLAP=1.  The sweeps are one
+// workgroup per CU issuing one instruction every ~5 cycles: they leave the chip's memory system and most
+// of its issue slots idle for ~90 us at the train step's shape, and kernel B's three launches (~30 us) do
+// not depend on them.  With an aux buffer for kernel B's gradient, B runs on a second hardware queue
+// (the high-priority side stream of logz_kernels.hip) while the sweeps run, and kernel A's gradient
+// pass, which waits for it, folds logZ / nblk and (d logZ) / nblk into the rows it writes anyway.
+// Measured: the loss path goes from 0.176 to 0.171 ms (plain; the sweeps slow down
+// by most of what the overlap hides) and from 0.245 to 0.223 ms (cat-mod) -- and capturing the fork /
+// join into a hipGraph crashes inside the HIP runtime of this PyTorch build, which is how the train
+// step runs.  So: off, and never while the caller's stream is capturing.
+static bool loss_overlap_enabled(hipStream_t st) {
+    static const int on = [] {
+        const char *e = getenv("TK_LOSS_OVERLAP");
+        return (e != nullptr && e[0] == '1') ? 1 : 0;
+    }();
+    if (on == 0) return false;
+    hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+    if (st != nullptr && hipStreamIsCapturing(st, &cs) == hipSuccess && cs != hipStreamCaptureStatusNone) return false;
+    return true;
+}
+
 size_t tk_flipflop_loss_fused_aux_bytes(size_t nblk, size_t nbatch, size_t nbase, size_t ntrans) {
     const size_t ncan = 2 * nbase * (nbase + 1);
-    if (ntrans <= ncan) return 0;                               // plain CRF: kernel B works in place
     const size_t one = (nblk * nbatch * ncan * sizeof(float) + 255) / 256 * 256;
+    if (ntrans <= ncan) return loss_overlap_enabled(nullptr) ? one : 0;    // plain CRF: in place (the experiment: kernel B's gradient)
     return 2 * one;                                             // canonical scores + their logZ gradient
 }
 
@@ -231,13 +253,17 @@ int tk_flipflop_loss_fused_dev(const float *scores, size_t nblk, size_t nbatch, 
     if (!aligned16(scores) || !aligned16(grad)) return TK_ERR_BAD_ARG;
     if ((modidx == nullptr) != (modfact == nullptr)) return TK_ERR_BAD_ARG;
     const size_t ncan = 2 * nbase * (nbase + 1);
+    const size_t one = (nblk * nbatch * ncan * sizeof(float) + 255) / 256 * 256;
     hipStream_t st = static_cast<hipStream_t>(stream);
-    if (modidx == nullptr) {
-        if (ntrans != ncan) return TK_ERR_BAD_ARG;
+    const bool catmod = modidx != nullptr;
+    if (!catmod && ntrans != ncan) return TK_ERR_BAD_ARG;
+    if (catmod && (ntrans <= ncan || ntrans > 62)) return TK_ERR_BAD_ARG;
+    if (catmod && (aux == nullptr || aux_bytes < 2 * one)) return TK_ERR_WORKSPACE;
+
+    if (!catmod && (aux == nullptr || aux_bytes < one || !loss_overlap_enabled(st))) {
         // (A) first: per-read costs into `lossvector`, its gradient into `grad`; (B) then ADDS
         // logZ / nblk and (d logZ / d scores) / nblk in place -- in its posterior kernel, whose stores
-        // are whole coalesced row sets (the read-modify-write costs that HBM-bound kernel one more
-        // stream; done in kernel A's row-at-a-time posterior pass it cost ~18 us at the step's shape)
+        // are whole coalesced row sets
         int rc = tk::crf_dispatch(scores, ntrans, nblk, nbatch, stayidx, moveidx, nullptr, nullptr, seqlen, seqoff,
                                   max_seqlen, ntrans, sharpfact, sharpfact, 1.0f / sharpfact, grad_scale,
                                   grad_scale_per_read, lossvector, grad, crf_workspace, crf_workspace_bytes, status, st);
@@ -245,27 +271,40 @@ int tk_flipflop_loss_fused_dev(const float *scores, size_t nblk, size_t nbatch, 
         return tk::logz_dispatch(scores, nblk, nbatch, nbase, logz, grad, logz_workspace, logz_workspace_bytes, status,
                                  st, lossvector, 1.0f / (float)nblk, grad_scale, grad_scale_per_read);
     }
-    // cat-mod (bin/train_flipflop.py:165-176): kernel B works on the canonical columns only, which are
-    // not contiguous in the (T, N, ntrans) tensor.  (B) FIRST, on a compact copy, into a compact
-    // gradient; (A) then folds logZ / nblk into its costs and (d logZ) / nblk -- times the gradient
-    // multiplier -- into the canonical columns of the rows it writes anyway: still one gradient
-    // tensor and no elementwise pass outside these kernels.
-    if (ntrans <= ncan || ntrans > 62) return TK_ERR_BAD_ARG;
-    if (aux == nullptr || aux_bytes < tk_flipflop_loss_fused_aux_bytes(nblk, nbatch, nbase, ntrans)) return TK_ERR_WORKSPACE;
-    const size_t one = (nblk * nbatch * ncan * sizeof(float) + 255) / 256 * 256;
-    float *x40 = static_cast<float *>(aux), *g40 = reinterpret_cast<float *>(static_cast<char *>(aux) + one);
-    {
+    // (B) into a compact gradient of its own -- for cat-mod (bin/train_flipflop.py:165-176) on a compact
+    // copy of the canonical columns, which are not contiguous in the (T, N, ntrans) tensor --, (A) folds
+    // logZ / nblk into its costs and (d logZ) / nblk, times the gradient multiplier, into the canonical
+    // columns of the rows it writes anyway: one gradient tensor, no elementwise pass outside these kernels.
+    float *x40 = catmod ? static_cast<float *>(aux) : nullptr;
+    float *g40 = reinterpret_cast<float *>(static_cast<char *>(aux) + (catmod ? one : 0));
+    hipStream_t sb = st;
+    hipEvent_t fork = nullptr, join = nullptr;
+    const bool side = loss_overlap_enabled(st) && tk::logz_side_stream(&sb, &fork, &join);
+    if (side) {
+        if (hipEventRecord(fork, st) != hipSuccess || hipStreamWaitEvent(sb, fork, 0) != hipSuccess) return TK_ERR_LAUNCH;
+    } else {
+        sb = st;
+    }
+    if (catmod) {
         const size_t n = nblk * nbatch * ncan;
-        hipLaunchKernelGGL(slice_cols_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, scores, x40,
+        hipLaunchKernelGGL(slice_cols_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, sb, scores, x40,
                            nblk * nbatch, (int)ntrans, (int)ncan);
         if (hipGetLastError() != hipSuccess) return TK_ERR_LAUNCH;
     }
-    int rc = tk::logz_dispatch(x40, nblk, nbatch, nbase, logz, g40, logz_workspace, logz_workspace_bytes, status, st);
-    if (rc != 0) return rc;
+    int rc = tk::logz_dispatch(catmod ? x40 : scores, nblk, nbatch, nbase, logz, g40, logz_workspace, logz_workspace_bytes,
+                               status, sb);
+    if (side && hipEventRecord(join, sb) != hipSuccess) rc = rc != 0 ? rc : TK_ERR_LAUNCH;
+    if (rc != 0) {
+        if (side) (void)hipStreamWaitEvent(st, join, 0);        // (never leave the side queue dangling in a capture)
+        return rc;
+    }
     // ctc.pyx:258-303: only the canonical columns are sharpened; cost / sharp
-    return tk::crf_dispatch(scores, ntrans, nblk, nbatch, stayidx, moveidx, modidx, modfact, seqlen, seqoff, max_seqlen,
-                            ncan, sharpfact, 1.0f, 1.0f / sharpfact, grad_scale, grad_scale_per_read, lossvector, grad,
-                            crf_workspace, crf_workspace_bytes, status, st, g40, logz, (int)ncan, 1.0f / (float)nblk);
+    rc = tk::crf_dispatch(scores, ntrans, nblk, nbatch, stayidx, moveidx, modidx, modfact, seqlen, seqoff, max_seqlen,
+                          ncan, sharpfact, catmod ? 1.0f : sharpfact, 1.0f / sharpfact, grad_scale, grad_scale_per_read,
+                          lossvector, grad, crf_workspace, crf_workspace_bytes, status, st, g40, logz, (int)ncan,
+                          1.0f / (float)nblk, side ? join : nullptr);
+    if (rc != 0 && side) (void)hipStreamWaitEvent(st, join, 0);
+    return rc;
 }
 
 // lab only (not declared in the public header): see crf_band.hip

@@ -1044,6 +1044,7 @@ static int band_launch(const BandArgs &a, hipStream_t stream) {
     }
     if (hipGetLastError() != hipSuccess) return 4;
     if (!want_grad || g_band_lab_phase == 1) return 0;
+    if (a.before_gradient != nullptr && hipStreamWaitEvent(stream, a.before_gradient, 0) != hipSuccess) return 4;
     const int NB = (a.T + BK - 1) / BK;
     hipLaunchKernelGGL((crf_band_posterior_kernel<MOD>), dim3(a.N, (NB + POST_WAVES - 1) / POST_WAVES),
                        dim3(POST_WAVES * WAVE), band_post_lds_bytes(MOD), stream, a);

@@ -724,7 +724,8 @@ int crf_dispatch(const float *logprob, size_t ntrans, size_t nblk, size_t nbatch
                  size_t max_seqlen, size_t ncan, float sharp_can, float sharp_mod,
                  float out_scale, float grad_scale, const float *grad_scale_vec, float *cost, float *grad,
                  void *workspace, size_t workspace_bytes, uint32_t *status, hipStream_t stream,
-                 const float *add_grad, const float *add_cost, int add_S, float add_scale) {
+                 const float *add_grad, const float *add_cost, int add_S, float add_scale,
+                 hipEvent_t add_ready) {
     if (ntrans > 62 || ncan > ntrans || ncan == 0) return 2;
     if (max_seqlen == 0) max_seqlen = nblk + 1;
     const CrfShape sh = crf_pick_shape(max_seqlen);
@@ -758,6 +759,10 @@ int crf_dispatch(const float *logprob, size_t ntrans, size_t nblk, size_t nbatch
     a.status = status;
     const bool mod = modidx != nullptr;
     char *wb = static_cast<char *>(workspace);
+    const bool band = crf_pick_mode(ntrans, nblk, nbatch, max_seqlen, grad != nullptr) == CRF_BAND;
+    // (what add_grad / add_cost hold may come from another stream: the band path waits between its sweeps
+    // and its gradient pass, the single-launch form before it starts)
+    if (add_ready != nullptr && !(band && grad != nullptr) && hipStreamWaitEvent(stream, add_ready, 0) != hipSuccess) return 4;
     if (crf_pick_mode(ntrans, nblk, nbatch, max_seqlen, grad != nullptr) == CRF_BAND) {
         const bool g = grad != nullptr;
         const BandLayout l = crf_band_layout(ntrans, nblk, nbatch, max_seqlen, mod, g);
@@ -803,6 +808,7 @@ int crf_dispatch(const float *logprob, size_t ntrans, size_t nblk, size_t nbatch
         b.gate = reinterpret_cast<int *>(wb + l.gate);
         b.zeros = reinterpret_cast<const float *>(wb + l.zeros);
         b.dbg = nullptr;
+        b.before_gradient = add_ready;
         const int rc = crf_band_dispatch(b, l.R, mod, stream);
         if (rc != 0) return rc;
         if (getenv("TK_CRF_GATE_DUMP")) {                       // lab: how many reads did the band path disown?

@@ -1280,6 +1280,16 @@ static LogzSide *logz_side_for_current_device() {
     return sd.ok ? &sd : nullptr;
 }
 
+// (for the fused loss, c_api.hip: kernel B on this queue beside kernel A's sweeps)
+bool logz_side_stream(hipStream_t *s, hipEvent_t *fork, hipEvent_t *join) {
+    LogzSide *sd = logz_side_for_current_device();
+    if (sd == nullptr) return false;
+    *s = sd->s;
+    *fork = sd->fork;
+    *join = sd->join;
+    return true;
+}
+
 // the workspace and the per-read vectors of a sub-range of the reads starting at read n0 (every
 // per-read array is read-major)
 template <int NB>

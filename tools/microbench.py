@@ -16,7 +16,8 @@ import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from taiyaki_amd import _lib, ctc, decode, layers, qscores, synth  # noqa: E402
 
-SHAPES = {"rowK": (4000, 256), "cfg2": (800, 128), "cfg5": (1600, 64), "big": (4000, 1024)}
+SHAPES = {"rowK": (4000, 256), "cfg2": (800, 128), "cfg5": (1600, 64), "big": (4000, 1024), "big2k": (4000, 2048),
+          "big4k": (4000, 4096), "bigshort": (800, 8192)}
 
 
 def timed(fn, reps):

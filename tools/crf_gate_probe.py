@@ -22,6 +22,12 @@ SHAPES = {
     "cfg2": (800, "speed128", 1.0, None),
     "cfg2r": (800, "real128", 1.0, None),
     "narrow": (800, [400, 533, 380, 700, 780, 800, 801, 790, 760, 100, 5, 1], 1.0, None),
+    # around the reference's path-buffer filter (signal_mapping.py:699-703: a chunk needs T / L > 1.1, L <= 727 at T = 800)
+    "pathbuf": (800, [700, 710, 720, 727, 735, 745, 750, 755], 1.0, None),
+    "lenramp": (800, [560, 600, 640, 660, 680, 690, 700, 705, 710, 715], 1.0, None),
+    "conframp": (800, [560, 600, 640, 660, 680, 700, 710, 720, 727, 740, 760, 780], 1.0, None),
+    # a freshly initialised network: 5 tanh of small activations, |score| <= 1
+    "initramp": (800, [560, 640, 680, 700, 710, 720, 727, 740, 760, 780, 795, 801], 1.0, None),
     "sharp": (800, "speed32", 2.5, None),
     "cfg4": (800, "speed128", 1.0, (1, 1, 0, 0)),
     "cfg4w1": (800, "speed128", 1.0, (1, 1, 0, 0)),
@@ -67,6 +73,8 @@ def main():
         else:
             N, seqlens = len(lens), np.array(lens, dtype=np.int32)
         inp = synth.crf_case(T, N, 1, seqlens=seqlens, nmods_per_base=mods)
+        if sh.startswith("init"):
+            inp["scores"] *= np.float32(0.2)
         if sh.startswith("conf"):
             synth.confident_scores(inp, 7, bursty="burst" in sh)
         if mods is not None and not sh.endswith("free"):

@@ -65,8 +65,11 @@ __device__ __forceinline__ uint64_t readlane_u64(uint64_t v, int lane) {
 // be as small as one wave (20 for K = 40); R = 8 / 16 blocks have at least 257 / 513 threads.
 __host__ __device__ constexpr int remap_prefetch_regs(int R) { return R == 2 ? 24 : 8; }
 
-template <int R>
-__global__ __launch_bounds__(1024) void remap_kernel(RemapArgs a) {
+// NT: the launch bound.  Sixteen float64 cells per thread do not fit the 128 registers a 1024-thread
+// workgroup leaves (54 spills, 2 us per step); sequences up to 12288 bases need at most 768 threads,
+// which leaves 170: no spills (round 3).
+template <int R, int NT>
+__global__ __launch_bounds__(NT) void remap_kernel(RemapArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int read = blockIdx.x;
     const int tid = threadIdx.x, lane = lane_id(), wave = tid >> 6;
@@ -341,9 +344,14 @@ int remap_dispatch(const RemapArgs &a, size_t nread, size_t max_M, hipStream_t s
     if ((RM_ROWS * a.K + threads - 1) / threads > remap_prefetch_regs(R)) return TK_ERR_UNSUPPORTED;
     const size_t lds = remap_lds_bytes(a.K);
     switch (R) {
-    case 2: hipLaunchKernelGGL(remap_kernel<2>, dim3((unsigned)nread), dim3(threads), lds, stream, a); break;
-    case 8: hipLaunchKernelGGL(remap_kernel<8>, dim3((unsigned)nread), dim3(threads), lds, stream, a); break;
-    default: hipLaunchKernelGGL(remap_kernel<16>, dim3((unsigned)nread), dim3(threads), lds, stream, a); break;
+    case 2: hipLaunchKernelGGL((remap_kernel<2, 1024>), dim3((unsigned)nread), dim3(threads), lds, stream, a); break;
+    case 8: hipLaunchKernelGGL((remap_kernel<8, 1024>), dim3((unsigned)nread), dim3(threads), lds, stream, a); break;
+    default:
+        if (threads <= 768)
+            hipLaunchKernelGGL((remap_kernel<16, 768>), dim3((unsigned)nread), dim3(threads), lds, stream, a);
+        else
+            hipLaunchKernelGGL((remap_kernel<16, 1024>), dim3((unsigned)nread), dim3(threads), lds, stream, a);
+        break;
     }
     return hipGetLastError() == hipSuccess ? TK_OK : TK_ERR_LAUNCH;
 }

@@ -43,9 +43,14 @@ def main():
     scs = [sc] * n
     fr.map_to_crf_viterbi_batch(scs[:2], [step] * 2, [stay] * 2, 3.0)
     torch.cuda.synchronize()
-    t0 = time.time()
-    s, p = fr.map_to_crf_viterbi_batch(scs, [step] * n, [stay] * n, 3.0)
-    bt = time.time() - t0
+    bts = []
+    for _ in range(3):                  # (the first full-size call also pays for its workspaces)
+        torch.cuda.synchronize()
+        t0 = time.time()
+        s, p = fr.map_to_crf_viterbi_batch(scs, [step] * n, [stay] * n, 3.0)
+        bts.append(time.time() - t0)
+    print("batch of %d, call by call: %s ms" % (n, ", ".join("%.1f" % (b * 1e3) for b in bts)))
+    bt = min(bts)
     assert np.all(s == score) and all(np.array_equal(x, path) for x in p[:4])
     print("batch of %d: %8.2f ms = %.2f ms per read = %.0f reads/s (%.1f M blocks/s)"
           % (n, bt * 1e3, bt / n * 1e3, n / bt, n * T / bt / 1e6))

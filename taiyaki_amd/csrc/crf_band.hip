@@ -214,8 +214,18 @@ __device__ __forceinline__ void band_frames(float (&m)[R], int (&f)[R], float (&
     }
 }
 
-template <int R, bool MOD, bool FWD, bool GRAD>
-__device__ __forceinline__ void band_sweep(const BandArgs &a, int n, int L, float *E, int *Ef, const float *Ezero) {
+// LDS image of a block's step weights, written by a helper wave and read by the chunk's own wave
+// (HELP mode, see band_helper): value v = (kind R + cell) BK + row of (chunk, slot) sits in component
+// v & 3 of float4  ((chunk 2 + slot) 4 R + (v >> 2)) 64 + lane  -- lanes are 16 bytes apart, so both
+// sides move it with conflict-free ds_*_b128.
+template <int R>
+__device__ __forceinline__ int wt_f4(int chunk, int slot, int g, int lane) {
+    return ((chunk * 2 + slot) * (4 * R) + g) * WAVE + lane;
+}
+
+template <int R, bool MOD, bool FWD, bool GRAD, bool HELP>
+__device__ __forceinline__ void band_sweep(const BandArgs &a, int n, int L, float *E, int *Ef, const float *Ezero,
+                                           const f4 *Wt) {
     constexpr int PW = R * WAVE;
     // the wave index is wave-uniform: keep everything derived from it in SGPRs
     const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & (WAVE - 1);
@@ -228,7 +238,7 @@ __device__ __forceinline__ void band_sweep(const BandArgs &a, int n, int L, floa
     const Win wsrc = (src >= 0 && src < W) ? band_window(src, PW, L, T) : Win{1, 0};
     if (win.j0 > win.j1) {
         // a chunk past the end of this read: keep the workgroup's barriers company
-        for (int ph = 0; ph < NPH; ++ph) band_barrier();
+        for (int ph = 0; ph < NPH + (HELP ? 1 : 0); ++ph) band_barrier();
         return;
     }
     const size_t rowstride = (size_t)N * S;
@@ -322,7 +332,7 @@ __device__ __forceinline__ void band_sweep(const BandArgs &a, int n, int L, floa
     //   4. the edge lane hands its BK boundary cells to the ring (and to HBM for the gradient pass).
     auto body = [&](int j, const float (&cur)[BK], float (&fill)[BK]) {
         STAMP(0);
-        load_block(FWD ? j + 2 : j - 2, fill);
+        if constexpr (!HELP) load_block(FWD ? j + 2 : j - 2, fill);
         const bool pl = j >= wsrc.j0 && j <= wsrc.j1;           // the neighbour ran this block one phase ago
         const int slot = j & 1;
         const int srcc = min(max(src, 0), W - 1);
@@ -341,6 +351,30 @@ __device__ __forceinline__ void band_sweep(const BandArgs &a, int n, int L, floa
         constexpr int GH = (R == 4) ? 4 : BK;
         float es[GH][R], em[GH][R];
         auto gather_group = [&](int ii0) {
+            if constexpr (HELP) {
+                // the helper wave left this block's weights in LDS one phase ago, rows in TIME order
+                // (GH = 8: both float4 of a cell and kind; GH = 4: the half this group consumes)
+#pragma unroll
+                for (int jj = 0; jj < R; ++jj) {
+#pragma unroll
+                    for (int kind = 0; kind < 2; ++kind) {
+#pragma unroll
+                        for (int h4 = 0; h4 < GH / 4; ++h4) {
+                            // steps ii0 + 4 h4 .. + 3 in sweep order = rows i0 .. i0 + 3 (forward) / i0 .. i0 - 3
+                            const int first = ii0 + 4 * h4;
+                            const int lowrow = FWD ? first : BK - 4 - first;       // the float4 that holds them
+                            const f4 v = Wt[wt_f4<R>(w, slot, ((kind * R + jj) * BK + lowrow) >> 2, lane)];
+#pragma unroll
+                            for (int q = 0; q < 4; ++q) {
+                                const float x = FWD ? v[q] : v[3 - q];
+                                if (kind == 0) es[4 * h4 + q][jj] = x;
+                                else em[4 * h4 + q][jj] = x;
+                            }
+                        }
+                    }
+                }
+                return;
+            }
 #pragma unroll
             for (int g = 0; g < GH; ++g) {
                 const int i = FWD ? ii0 + g : BK - 1 - (ii0 + g);
@@ -475,8 +509,12 @@ __device__ __forceinline__ void band_sweep(const BandArgs &a, int n, int L, floa
     const int jfirst = FWD ? win.j0 : win.j1, nlive = win.j1 - win.j0 + 1;
     const int ph0 = FWD ? win.j0 + w : (NB - 1 - win.j1) + (W - 1 - w);
     const int dj = FWD ? 1 : -1;
-    load_block(jfirst, row0);
-    load_block(jfirst + dj, row1);
+    if constexpr (!HELP) {
+        load_block(jfirst, row0);
+        load_block(jfirst + dj, row1);
+    } else {
+        band_barrier();                                         // the helpers' lead phase
+    }
     for (int ph = 0; ph < ph0; ++ph) band_barrier();
     for (int k = 0; k < nlive; k += 3) {
         body(jfirst + dj * k, row0, row2);
@@ -505,14 +543,125 @@ __device__ __forceinline__ void band_sweep(const BandArgs &a, int n, int L, floa
 }
 
 // ===========================================================================
+// HELPER WAVES (round 3).  At the train step's shape a sweep is ONE workgroup per CU and the time of a
+// phase is the instruction stream of ONE wave (~260 instructions at one per ~5 cycles) while three of
+// the CU's four SIMDs idle.  About 100 of those instructions do not depend on the lattice at all: the
+// block's row loads, their exponentials and the 16 R gathers of the step weights.  In HELP mode a
+// helper wave per TWO chunks does them one phase ahead and leaves the weights in LDS (wt_f4), where the
+// chunk's own wave picks them up with 4 R ds_read_b128: the same arithmetic on the same values (the
+// results are bit for bit those of the plain mode), a phase ~40 % shorter.  The two chunks of a helper
+// run consecutive blocks in consecutive phases (the skew), so the rows it loads for the leading chunk
+// serve the trailing one a phase later.  Used when every sweep workgroup has a CU to itself and
+// W + ceil(W / 2) waves fit a workgroup; the weights take W R 8 KiB of LDS.
+// ===========================================================================
+template <int R, bool MOD, bool FWD>
+__device__ __forceinline__ void band_helper(const BandArgs &a, int n, int L, int h, f4 *Wt) {
+    constexpr int PW = R * WAVE;
+    const int lane = threadIdx.x & (WAVE - 1);
+    const int N = a.N, T = a.T, S = a.S, W = a.W;
+    const int64_t off = a.seqoff[n];
+    const int NB = (T + BK - 1) / BK, NPH = NB + W - 1;
+    const size_t rowstride = (size_t)N * S;
+    const float *lpn = a.lp + (size_t)n * S;
+    const unsigned col4 = 4u * (unsigned)min(lane, S - 1);
+    const unsigned rs4 = 4u * (unsigned)rowstride;
+    const float c = a.c_can;
+    // the leading chunk runs block j in the phase before the trailing one does
+    const int cl = FWD ? 2 * h : 2 * h + 1, ct = FWD ? 2 * h + 1 : 2 * h;
+    const int cc[2] = {cl, ct};
+    Win win[2];
+    int st4[2][R], mv4[2][R], md4[2][MOD ? R : 1];
+    float fw[2][MOD ? R : 1];
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+        win[u] = (cc[u] >= 0 && cc[u] < W) ? band_window(cc[u], PW, L, T) : Win{1, 0};
+#pragma unroll
+        for (int j = 0; j < R; ++j) {
+            const int q = lane * R + j, p = FWD ? cc[u] * PW + q : cc[u] * PW + PW - 1 - q;
+            const int ms = FWD ? p - 1 : p;
+            const bool has = ms >= 0 && ms < L - 1;
+            st4[u][j] = 4 * ((p >= 0 && p < L) ? a.stay[off + p] : 0);
+            mv4[u][j] = 4 * (has ? a.move[off + ms] : 0);
+            if (MOD) {
+                md4[u][MOD ? j : 0] = 4 * (has ? a.mod[off + ms] : 0);
+                fw[u][MOD ? j : 0] = has ? a.modfact[off + ms] * a.c_mod : 0.f;
+            }
+        }
+    }
+    unsigned rowoff[BK];
+#pragma unroll
+    for (int i = 0; i < BK; ++i) rowoff[i] = rs4 * (unsigned)i;
+    auto load_block = [&](int j, float (&dst)[BK]) {
+        j = min(max(j, 0), NB - 1);
+        const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(
+            const_cast<float *>(lpn + (size_t)(j * BK) * rowstride), 0, (int)(rs4 * (unsigned)min(BK, T - j * BK)), BUF_WORD3);
+#pragma unroll
+        for (int i = 0; i < BK; ++i)
+            dst[i] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rs, col4, rowoff[i], 0));
+    };
+    // weights of block j of chunk cc[u] from its rows -> LDS, rows in time order
+    auto emit = [&](int u, int j, const float (&row)[BK]) {
+        if (j < win[u].j0 || j > win[u].j1) return;             // (wave-uniform)
+        const int slot = j & 1;
+        float er[BK];
+#pragma unroll
+        for (int i = 0; i < BK; ++i) er[i] = fast_exp2(row[i] * c);
+#pragma unroll
+        for (int jj = 0; jj < R; ++jj) {
+            float es[BK], em[BK];
+#pragma unroll
+            for (int i = 0; i < BK; ++i) {
+                es[i] = bperm(st4[u][jj], er[i]);
+                if constexpr (MOD)
+                    em[i] = fast_exp2(fmaf(bperm(md4[u][MOD ? jj : 0], row[i]), fw[u][MOD ? jj : 0], bperm(mv4[u][jj], row[i]) * c));
+                else
+                    em[i] = bperm(mv4[u][jj], er[i]);
+            }
+#pragma unroll
+            for (int h4 = 0; h4 < BK / 4; ++h4) {
+                Wt[wt_f4<R>(cc[u], slot, ((0 * R + jj) * BK + 4 * h4) >> 2, lane)] = f4{es[4 * h4], es[4 * h4 + 1], es[4 * h4 + 2], es[4 * h4 + 3]};
+                Wt[wt_f4<R>(cc[u], slot, ((1 * R + jj) * BK + 4 * h4) >> 2, lane)] = f4{em[4 * h4], em[4 * h4 + 1], em[4 * h4 + 2], em[4 * h4 + 3]};
+            }
+        }
+    };
+    // In the phase before phase ph (ph = 0 .. NPH - 1; the lead phase prepares phase 0) the helper emits
+    // the blocks its chunks run IN phase ph: forward chunk c runs block ph - c, backward
+    // NB - 1 - (ph - (W - 1 - c)).  The leading chunk's block index moves one per phase; four register
+    // sets rotate by NAME (current, previous = the trailing chunk's, and two in flight).
+    auto block_of = [&](int cidx, int ph) { return FWD ? ph - cidx : NB - 1 - (ph - (W - 1 - cidx)); };
+    const int dj = FWD ? 1 : -1;
+    float r0[BK], r1[BK], r2[BK], r3[BK];
+    const int jl0 = block_of(cl, 0);
+    load_block(jl0 - dj, r3);                                   // "previous" of the first round (never live)
+    load_block(jl0, r0);
+    load_block(jl0 + dj, r1);
+    load_block(jl0 + 2 * dj, r2);
+    auto round = [&](int ph, const float (&cur)[BK], const float (&prev)[BK], float (&fill)[BK]) {
+        const int jl = block_of(cl, ph);
+        emit(0, jl, cur);
+        emit(1, block_of(ct, ph), prev);                       // (= jl - dj: the leader's block of the round before)
+        load_block(jl + 3 * dj, fill);                          // `prev` is free now: the set three rounds ahead
+        band_barrier();
+    };
+    for (int ph = 0; ph < NPH; ph += 4) {
+        round(ph, r0, r3, r3);
+        if (ph + 1 < NPH) round(ph + 1, r1, r0, r0);
+        if (ph + 2 < NPH) round(ph + 2, r2, r1, r1);
+        if (ph + 3 < NPH) round(ph + 3, r3, r2, r2);
+    }
+    band_barrier();                                             // the chunks' last phase
+}
+
+// ===========================================================================
 // sweep + rank launch.  blockIdx.x in [0, N): sorted-instance records for the gradient pass;
 // [N, 2N): forward sweep of read n; [2N, 3N): backward sweep.  Cost-only calls launch N
 // workgroups: the forward sweeps.
 // ===========================================================================
 // WCAP = the most waves a launch of this instantiation may have: the register budget of a lane is
 // 512 / ceil(WCAP / 4) (R = 4 wants more than the 128 that 16 waves leave).
-template <int R, bool MOD, int WCAP>
+template <int R, bool MOD, int WCAP, bool HELP>
 __global__ __launch_bounds__(WCAP *WAVE) void crf_band_sweep_kernel(BandArgs a) {
+    extern __shared__ __attribute__((aligned(16))) char band_dyn_lds[];     // HELP: the weights image (wt_f4)
     constexpr int PW = R * WAVE;
     constexpr int KINDS = MOD ? 3 : 2;
     __shared__ __attribute__((aligned(16))) float E[BAND_MAXW * 2 * BK];
@@ -550,7 +699,7 @@ __global__ __launch_bounds__(WCAP *WAVE) void crf_band_sweep_kernel(BandArgs a) 
         // id (the three kinds use disjoint id ranges), padding last.  Ranks come from ballots in a
         // fixed order, so the permutation -- and with it every floating-point sum of the gradient
         // pass -- is the same from run to run.
-        for (int ck = w; ck * WAVE < L; ck += W) {
+        for (int ck = w; ck * WAVE < L; ck += (int)(blockDim.x >> 6)) {
             int key[KINDS];
             const int p = ck * WAVE + lane;
             const bool has = p >= 1 && p < L;
@@ -588,12 +737,21 @@ __global__ __launch_bounds__(WCAP *WAVE) void crf_band_sweep_kernel(BandArgs a) 
 
     if (tid < BK) Ezero[tid] = 0.f;
     __syncthreads();
+    f4 *Wt = reinterpret_cast<f4 *>(band_dyn_lds);
+    if (HELP && w >= W) {
+        // helper waves (gradient calls only): the weights of two chunks each, a phase ahead
+        if (role == 0)
+            band_helper<R, MOD, true>(a, n, L, w - W, Wt);
+        else
+            band_helper<R, MOD, false>(a, n, L, w - W, Wt);
+        return;
+    }
     if (!want_grad)
-        band_sweep<R, MOD, true, false>(a, n, L, E, Ef, Ezero);
+        band_sweep<R, MOD, true, false, false>(a, n, L, E, Ef, Ezero, Wt);
     else if (role == 0)
-        band_sweep<R, MOD, true, true>(a, n, L, E, Ef, Ezero);
+        band_sweep<R, MOD, true, true, HELP>(a, n, L, E, Ef, Ezero, Wt);
     else
-        band_sweep<R, MOD, false, true>(a, n, L, E, Ef, Ezero);
+        band_sweep<R, MOD, false, true, HELP>(a, n, L, E, Ef, Ezero, Wt);
 }
 
 // Inclusive wave prefix sum in six fused DPP adds (the row_bcast steps write only the rows they
@@ -1030,17 +1188,47 @@ BandLayout crf_band_layout(size_t ntrans, size_t nblk, size_t nbatch, size_t max
 static int g_band_lab_phase = 0;
 void crf_band_lab_phase(int phase) { g_band_lab_phase = phase; }
 
+// Helper waves (band_helper) pay when a sweep is latency-bound: every sweep workgroup has a CU to itself
+// (2 N workgroups <= CUs), its chunks' waves plus one helper per two chunks fit a workgroup, and the
+// weights image fits LDS.  TK_CRF_HELPER=0 / 1 overrides the first condition (lab).
+static bool band_use_helpers(const BandArgs &a, int R, bool mod) {
+    if (a.grad == nullptr || R > 2) return false;
+    if (a.W + (a.W + 1) / 2 > BAND_MAXW || (size_t)a.W * R * 8192 > 144 * 1024) return false;
+    if (const char *e = getenv("TK_CRF_HELPER")) return e[0] == '1';
+    // measured (kernel A): -3.5 % for the plain CRF at R = 1; cat-mod (whose helpers also carry the
+    // per-cell exponentials) +4 %, R = 2 +-0: those stay in the plain mode
+    if (R != 1 || mod) return false;
+    static int ncu[64] = {0};
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return false;
+    if (ncu[dev] == 0) {
+        int v = 0;
+        if (hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || v <= 0) v = -1;
+        ncu[dev] = v;
+    }
+    return ncu[dev] > 0 && 2 * a.N <= ncu[dev];
+}
+
 template <int R, bool MOD>
 static int band_launch(const BandArgs &a, hipStream_t stream) {
     const bool want_grad = a.grad != nullptr;
     if (g_band_lab_phase != 2) {
         const dim3 grid((want_grad ? 3 : 1) * a.N), block(a.W * WAVE);
-        if (R == 4 && a.W <= 8)
-            hipLaunchKernelGGL((crf_band_sweep_kernel<R, MOD, (R == 4 ? 8 : BAND_MAXW)>), grid, block, 0, stream, a);
-        else if (R == 4 && a.W <= 12)
-            hipLaunchKernelGGL((crf_band_sweep_kernel<R, MOD, (R == 4 ? 12 : BAND_MAXW)>), grid, block, 0, stream, a);
+        if constexpr (R <= 2) {
+            if (band_use_helpers(a, R, MOD)) {
+                const size_t lds = (size_t)a.W * R * 8192;
+                const dim3 hblock((a.W + (a.W + 1) / 2) * WAVE);
+                if (raise_dynamic_lds(reinterpret_cast<const void *>(&crf_band_sweep_kernel<R, MOD, BAND_MAXW, true>), 152 * 1024)) return 4;
+                hipLaunchKernelGGL((crf_band_sweep_kernel<R, MOD, BAND_MAXW, true>), grid, hblock, lds, stream, a);
+            } else {
+                hipLaunchKernelGGL((crf_band_sweep_kernel<R, MOD, BAND_MAXW, false>), grid, block, 0, stream, a);
+            }
+        } else if (a.W <= 8)
+            hipLaunchKernelGGL((crf_band_sweep_kernel<R, MOD, (R == 4 ? 8 : BAND_MAXW), false>), grid, block, 0, stream, a);
+        else if (a.W <= 12)
+            hipLaunchKernelGGL((crf_band_sweep_kernel<R, MOD, (R == 4 ? 12 : BAND_MAXW), false>), grid, block, 0, stream, a);
         else
-            hipLaunchKernelGGL((crf_band_sweep_kernel<R, MOD, BAND_MAXW>), grid, block, 0, stream, a);
+            hipLaunchKernelGGL((crf_band_sweep_kernel<R, MOD, BAND_MAXW, false>), grid, block, 0, stream, a);
     }
     if (hipGetLastError() != hipSuccess) return 4;
     if (!want_grad || g_band_lab_phase == 1) return 0;

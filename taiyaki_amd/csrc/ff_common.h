@@ -14,14 +14,15 @@ namespace tk {
 // Dynamic LDS beyond 64 KiB needs hipFuncAttributeMaxDynamicSharedMemorySize on the kernel, PER
 // DEVICE: raised once per (kernel, device) the first time a process launches it there (outside
 // the steady-state launch path, so launches stay capturable into a hipGraph).
-inline int raise_dynamic_lds(const void *fn) {
+inline int raise_dynamic_lds(const void *fn, int bytes = 160 * 1024) {
     static std::mutex mu;
     static std::set<std::pair<const void *, int>> done;
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess) return 4;
     std::lock_guard<std::mutex> g(mu);
     if (done.count({fn, dev})) return 0;
-    if (hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) return 4;
+    // (a kernel that also has static LDS asks for less: the two together must fit the CU's 160 KiB)
+    if (hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, bytes) != hipSuccess) return 4;
     done.insert({fn, dev});
     return 0;
 }

@@ -627,6 +627,40 @@ def test_crf_linear_band_path_keeps_confident_reads(oracle_mod, gpu_device, burs
         assert parity.abs_err(grad[:, n:n + 1], ograd) < GRAD_ATOL, L
 
 
+@pytest.mark.parametrize("case", ["step", "ragged", "r2", "catmod", "lastblock"])
+def test_crf_helper_waves_change_no_bit(gpu_device, case, monkeypatch):
+    """Round 3: in small launches a helper wave per two chunks prepares the step weights (row loads,
+    exponentials, gathers) a phase ahead and hands them over through LDS (crf_band.hip: band_helper).
+    The arithmetic and its order are those of the plain mode, so costs and gradients must agree BIT FOR
+    BIT: for the train step's shape, ragged / degenerate lengths, two cells per lane, cat-mod (whose
+    helpers also carry the per-cell exponentials) and a last block of three rows."""
+    import torch
+    from taiyaki_amd import ctc, synth
+    monkeypatch.setenv("TK_CRF_MODE", "band")
+    T, N, lens, mods = {"step": (800, 64, "real", None), "ragged": (200, 7, [90, 150, 201, 30, 195, 64, 65], None),
+                        "r2": (1600, 16, "real", None), "catmod": (400, 24, "real", (1, 1, 0, 0)),
+                        "lastblock": (803, 9, "real", None)}[case]
+    seqlens = synth.realistic_seqlens(T, N, 17000, T * 5, 9.0) if lens == "real" else np.array(lens, dtype=np.int32)
+    inp = synth.crf_case(T, N, 3, seqlens=seqlens, nmods_per_base=mods)
+    extra = ()
+    if mods is not None:
+        synth.normalise_mod_columns(inp, logit_scale=0.2)
+        extra = (torch.from_numpy(inp["mod_cats"]), inp["can_mods_offsets"], inp["mod_cat_weights"])
+    x = torch.from_numpy(inp["scores"]).to(gpu_device)
+    seqs, sl = torch.from_numpy(inp["seqs"]), torch.from_numpy(inp["seqlens"])
+    out = {}
+    for helper in ("0", "1"):
+        monkeypatch.setenv("TK_CRF_HELPER", helper)
+        if extra:
+            c, g = ctc._run(x, seqs, sl, 1.0, 1.0, 1.0, 40, True, *extra)
+        else:
+            c, g = ctc._run(x, seqs, sl, 1.0, 1.0, 1.0, x.shape[2], True)
+        torch.cuda.synchronize()
+        out[helper] = (c.cpu().numpy(), g.cpu().numpy())
+    assert np.isfinite(out["0"][0]).all()
+    assert np.array_equal(out["0"][0], out["1"][0]) and np.array_equal(out["0"][1], out["1"][1])
+
+
 def test_crf_sharpened_scores_take_the_log_domain_kernel(oracle_mod, gpu_device, monkeypatch):
     """sharp = 2.5 puts weights of 2^(+-18) on a step: eight of them overflow a block of the linear
     path, which must notice (non-finite sweep score) and hand the read over."""

@@ -61,7 +61,7 @@ def run(x, seqs, seqlens, sharp, extra, env):
 
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument("--shapes", default="tiny,t19,t37,t200,cfg2,cfg2r,narrow,sharp,cfg4,cfg4r,cfg4rharsh,cfg5,rowK,conf,confburst,confK")
+    ap.add_argument("--shapes", default="tiny,t19,t37,t200,cfg2,cfg2r,narrow,pathbuf,lenramp,initramp,conframp,sharp,cfg4,cfg4r,cfg4rharsh,cfg5,rowK,conf,confburst,confK")
     args = ap.parse_args()
     dev = torch.device("cuda:0")
     _lib.set_strict(False)

@@ -119,35 +119,37 @@ __device__ __forceinline__ int wave_prefix_max_fused(int x) {
 constexpr int BUF_WORD3 = 0x00027000;       // raw buffer descriptor, 32-bit data (gfx9 family)
 
 template <int R>
-__device__ __forceinline__ void band_buffer_store(__amdgpu_buffer_rsrc_t rs, unsigned voff, const unsigned (&x)[R]) {
+__device__ __forceinline__ void band_buffer_store(__amdgpu_buffer_rsrc_t rs, unsigned voff, const unsigned (&x)[R],
+                                                  unsigned soff = 0) {
     typedef unsigned u2 __attribute__((ext_vector_type(2)));
     if constexpr (R == 4) {
         // two 8-byte stores, not one 16-byte store: a buffer store of more than 64 bits whose data
         // registers are overwritten by the next VALU instruction stores the NEW value of a dword on
         // gfx950 (observed in round 2; hipcc only guards the immediate-soffset form of that hazard)
-        __builtin_amdgcn_raw_buffer_store_b64(u2{x[0], x[1]}, rs, voff, 0, 0);
-        __builtin_amdgcn_raw_buffer_store_b64(u2{x[2], x[3]}, rs, voff + 8u, 0, 0);
+        __builtin_amdgcn_raw_buffer_store_b64(u2{x[0], x[1]}, rs, voff, soff, 0);
+        __builtin_amdgcn_raw_buffer_store_b64(u2{x[2], x[3]}, rs, voff + 8u, soff, 0);
     } else if constexpr (R == 2) {
-        __builtin_amdgcn_raw_buffer_store_b64(u2{x[0], x[1]}, rs, voff, 0, 0);
+        __builtin_amdgcn_raw_buffer_store_b64(u2{x[0], x[1]}, rs, voff, soff, 0);
     } else {
-        __builtin_amdgcn_raw_buffer_store_b32(x[0], rs, voff, 0, 0);
+        __builtin_amdgcn_raw_buffer_store_b32(x[0], rs, voff, soff, 0);
     }
 }
 
 constexpr int LEM_MIN = -100;       // cat-mod: the frame slope follows move weights down to 2^-100
 // R 16-bit values per lane (the frames of a checkpoint column as offsets from the chunk's base)
 template <int R>
-__device__ __forceinline__ void band_buffer_store16(__amdgpu_buffer_rsrc_t rs, unsigned voff, const int (&x)[R]) {
+__device__ __forceinline__ void band_buffer_store16(__amdgpu_buffer_rsrc_t rs, unsigned voff, const int (&x)[R],
+                                                    unsigned soff = 0) {
     typedef unsigned u2 __attribute__((ext_vector_type(2)));
     // (v_perm_b32: the low halves of two registers in one instruction)
     if constexpr (R == 4) {
         __builtin_amdgcn_raw_buffer_store_b64(u2{__builtin_amdgcn_perm((unsigned)x[1], (unsigned)x[0], 0x05040100u),
                                                  __builtin_amdgcn_perm((unsigned)x[3], (unsigned)x[2], 0x05040100u)},
-                                              rs, voff, 0, 0);
+                                              rs, voff, soff, 0);
     } else if constexpr (R == 2) {
-        __builtin_amdgcn_raw_buffer_store_b32(__builtin_amdgcn_perm((unsigned)x[1], (unsigned)x[0], 0x05040100u), rs, voff, 0, 0);
+        __builtin_amdgcn_raw_buffer_store_b32(__builtin_amdgcn_perm((unsigned)x[1], (unsigned)x[0], 0x05040100u), rs, voff, soff, 0);
     } else {
-        __builtin_amdgcn_raw_buffer_store_b16((unsigned short)x[0], rs, voff, 0, 0);
+        __builtin_amdgcn_raw_buffer_store_b16((unsigned short)x[0], rs, voff, soff, 0);
     }
 }
 
@@ -164,6 +166,46 @@ __device__ __forceinline__ int clamp_shift(int d) { return min(max(d, -160), KLI
 // a log-probability of -10 is 2^-115) makes a true cliff in the lattice which the frames must follow
 // -- the cells behind it hold ALL the mass of the paths that have passed it.  The inflow a cell can
 // receive per step stays bounded by 2^KLIP of its frame unit (weight <= 2^lem, scale <= 2^(KLIP - lem)).
+// The part of band_frames that needs only the wave's OWN cells (constant slope): their ramp-domain
+// exponents and the exclusive prefix maximum over the lanes.  It runs at the END of a block, between the
+// ring write and the barrier, so that its ~25 dependent instructions sit in the shadow of the LDS
+// round trip and the barrier instead of behind them; band_frames_finish folds in the neighbour's edge
+// frame (one maximum: the cell at q = -1 precedes every lane) when the ring has delivered it.
+template <int R>
+__device__ __forceinline__ void band_frames_own(const float (&m)[R], const int (&f)[R], int (&z)[R], int &run_excl, int lane) {
+    const int q0 = lane * R;
+    int zl = NOFRAME;
+#pragma unroll
+    for (int j = 0; j < R; ++j) {
+        const bool live = m[j] > 0.f && m[j] < __builtin_huge_valf();
+        z[j] = live ? f[j] + __builtin_amdgcn_frexp_expf(m[j]) + KLIP * (q0 + j + 1) : NOFRAME;
+        zl = max(zl, z[j]);
+    }
+    const int zi = wave_prefix_max_fused(zl);
+    run_excl = __builtin_amdgcn_update_dpp(NOFRAME, zi, 0x138, 0xF, 0xF, false);       // wave_shr:1; lane 0: nothing
+}
+template <int R>
+__device__ __forceinline__ void band_frames_finish(float (&m)[R], int (&f)[R], float (&sc)[R], const bool (&has)[R],
+                                                   const int (&z)[R], int run_excl, int fb, int lane) {
+    const int q0 = lane * R;
+    int run = max(run_excl, (fb > NOFRAME / 2) ? fb : NOFRAME);
+    int fn[R];
+#pragma unroll
+    for (int j = 0; j < R; ++j) {
+        run = max(run, z[j]);
+        fn[j] = (run > NOFRAME / 2) ? run - KLIP * (q0 + j + 1) : 0;
+        m[j] = __builtin_amdgcn_ldexpf(m[j], max(f[j] - fn[j], -300));
+        f[j] = fn[j];
+    }
+    int fup = __builtin_amdgcn_update_dpp(0, fn[R - 1], 0x138, 0xF, 0xF, false);       // wave_shr:1
+    if (lane == 0) fup = (fb > NOFRAME / 2) ? fb : fn[0];
+#pragma unroll
+    for (int j = 0; j < R; ++j) {
+        const int d = clamp_shift((j == 0 ? fup : fn[j > 0 ? j - 1 : 0]) - fn[j]);
+        sc[j] = has[j] ? __builtin_amdgcn_ldexpf(1.f, d) : 0.f;
+    }
+}
+
 template <int R, bool SLOPE>
 __device__ __forceinline__ void band_frames(float (&m)[R], int (&f)[R], float (&sc)[R], const bool (&has)[R],
                                             const int (&lem)[R], int fb, int lane) {
@@ -276,6 +318,10 @@ __device__ __forceinline__ void band_sweep(const BandArgs &a, int n, int L, floa
     float *ckm = GRAD ? (FWD ? a.ckFm : a.ckBm) + (size_t)n * NB * a.LP + a0 : nullptr;
     int16_t *ckf = GRAD ? (FWD ? a.ckFf : a.ckBf) + (size_t)n * NB * a.LP + a0 : nullptr;
     int *ckb = GRAD ? (FWD ? a.ckFb : a.ckBb) + (size_t)n * NB * W + w : nullptr;
+    const __amdgpu_buffer_rsrc_t rm_all = __builtin_amdgcn_make_buffer_rsrc(ckm, 0, 0x7fffffff, BUF_WORD3);
+    const __amdgpu_buffer_rsrc_t rf_all = __builtin_amdgcn_make_buffer_rsrc(ckf, 0, 0x7fffffff, BUF_WORD3);
+    const __amdgpu_buffer_rsrc_t rb_all = __builtin_amdgcn_make_buffer_rsrc(ckb, 0, 0x7fffffff, BUF_WORD3);
+    const unsigned lp4 = 4u * (unsigned)a.LP, w4 = 4u * (unsigned)W;
     int fbase_prev = 0;
     bool have_base = false;
     // the gradient pass works on 64-cell chunks whatever R is: the lanes that hold the last cell (in
@@ -311,6 +357,13 @@ __device__ __forceinline__ void band_sweep(const BandArgs &a, int n, int L, floa
         }
     };
 
+    // the frames' own-cells half ahead of the barrier: constant slope only (cat-mod's slope needs the NEXT block's
+    // move weights), and not at four cells per lane, whose sweep is bound by registers and VALU throughput, not by
+    // this chain (measured: -2 % at the train step's shape, +3 % at T = 4000 / N = 256 with it)
+    constexpr bool SPLIT_FRAMES = !MOD && R <= 2;
+    int zown[R], zrun_excl = NOFRAME;           // band_frames_own's results, carried from block to block
+#pragma unroll
+    for (int j = 0; j < R; ++j) zown[j] = NOFRAME;
     int stamp_k = 0;
 #ifdef TK_LAB_STAMPS
 #define STAMP(q)                                                                            \
@@ -443,12 +496,18 @@ __device__ __forceinline__ void band_sweep(const BandArgs &a, int n, int L, floa
                 lem[jj] = (has[jj] && emx > 0.f) ? min(max(__builtin_amdgcn_frexp_expf(emx), LEM_MIN), 0) : 0;
             }
         }
-        band_frames<R, MOD>(m, f, sc, has, lem, fb, lane);
+        if constexpr (!SPLIT_FRAMES) {
+            band_frames<R, MOD>(m, f, sc, has, lem, fb, lane);
+        } else {
+            // (the own-cells half ran at the end of the previous block, or before the first one)
+            band_frames_finish<R>(m, f, sc, has, zown, zrun_excl, fb, lane);
+        }
         if (edge_lane) Ef[w * 2 + slot] = f[R - 1];
         if (GRAD) {
             // checkpoint column: forward column 8 j, backward column 8 j + nvalid (positions ascending)
-            const __amdgpu_buffer_rsrc_t rm = __builtin_amdgcn_make_buffer_rsrc(ckm + (size_t)j * a.LP, 0, 0x7fffffff, BUF_WORD3);
-            const __amdgpu_buffer_rsrc_t rf = __builtin_amdgcn_make_buffer_rsrc(ckf + (size_t)j * a.LP, 0, 0x7fffffff, BUF_WORD3);
+            // (one descriptor per array for the whole read, built before the loop; the block is a scalar offset:
+            // NB LP 4 bytes stay far below 2^31)
+            const unsigned soff_m = (unsigned)j * lp4;
             // frames as 16-bit offsets from a per-(chunk, block) base (the envelope falls by KLIP per
             // cell and rises with the cells' own exponents: a few thousand across a chunk at most.  An
             // offset that does not fit -- scores far outside the network's range -- is NOT checked here:
@@ -467,9 +526,9 @@ __device__ __forceinline__ void band_sweep(const BandArgs &a, int n, int L, floa
                 xm[jj] = __float_as_uint(m[FWD ? jj : R - 1 - jj]);
                 xf[jj] = f[FWD ? jj : R - 1 - jj] - fbase;      // (kept to 16 bits: see the base's comment)
             }
-            band_buffer_store<R>(rm, lane_cell4, xm);
-            band_buffer_store16<R>(rf, lane_cell4 / 2, xf);
-            ckb[(size_t)j * W] = fbase;                         // (every lane, the same word: no exec-mask detour)
+            band_buffer_store<R>(rm_all, lane_cell4, xm, soff_m);
+            band_buffer_store16<R>(rf_all, lane_cell4 / 2, xf, soff_m / 2);
+            __builtin_amdgcn_raw_buffer_store_b32((unsigned)fbase, rb_all, 0, (unsigned)j * w4, 0);   // (every lane, the same word)
         }
         STAMP(2);
         if (nvalid == BK) {
@@ -499,6 +558,7 @@ __device__ __forceinline__ void band_sweep(const BandArgs &a, int n, int L, floa
             Bo[0] = f4{edge[0], edge[1], edge[2], edge[3]};
             Bo[1] = f4{edge[4], edge[5], edge[6], edge[7]};
         }
+        if constexpr (SPLIT_FRAMES) band_frames_own<R>(m, f, zown, zrun_excl, lane);      // (for the next block)
         band_barrier();
         STAMP(4);
         ++stamp_k;
@@ -509,6 +569,7 @@ __device__ __forceinline__ void band_sweep(const BandArgs &a, int n, int L, floa
     const int jfirst = FWD ? win.j0 : win.j1, nlive = win.j1 - win.j0 + 1;
     const int ph0 = FWD ? win.j0 + w : (NB - 1 - win.j1) + (W - 1 - w);
     const int dj = FWD ? 1 : -1;
+    if constexpr (SPLIT_FRAMES) band_frames_own<R>(m, f, zown, zrun_excl, lane);
     if constexpr (!HELP) {
         load_block(jfirst, row0);
         load_block(jfirst + dj, row1);

@@ -86,6 +86,12 @@ __device__ __forceinline__ void band_barrier() {
     asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
 }
 
+// ... and the same with a register pinned in front of it: what computes `v` is issued BEFORE the barrier
+// (hipcc is free to sink register-only work past an asm with a memory clobber, and did)
+__device__ __forceinline__ void band_barrier_after(int &v) {
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" : "+v"(v) : : "memory");
+}
+
 __device__ __forceinline__ float bperm(int byteaddr, float v) {
     return __int_as_float(__builtin_amdgcn_ds_bpermute(byteaddr, __float_as_int(v)));
 }
@@ -452,7 +458,24 @@ __device__ __forceinline__ void band_sweep(const BandArgs &a, int n, int L, floa
             // (R = 4 has no registers to spare for that: 16 waves leave 128 per lane)
             constexpr bool PRE = R < 4;
             float mt[PRE ? GH : 1][R], u[PRE ? GH : 1];
-            if constexpr (PRE) {
+            if constexpr (PRE && !MOD) {
+                // (two steps per instruction: v_pk_mul_f32 -- -1 % for the plain CRF; cat-mod, whose weights
+                // come out of a v_exp_f32 each, measured +2 % with the pairing and keeps single multiplies)
+                typedef float f2 __attribute__((ext_vector_type(2)));
+#pragma unroll
+                for (int g = 0; g < GH; g += 2) {
+                    const int i0 = FWD ? ii0 + g : BK - 1 - (ii0 + g), i1 = FWD ? i0 + 1 : i0 - 1;
+#pragma unroll
+                    for (int jj = 0; jj < R; ++jj) {
+                        const f2 p = f2{em[g][jj], em[g + 1][jj]} * f2{sc[jj], sc[jj]};
+                        mt[g][jj] = p.x;
+                        mt[g + 1][jj] = p.y;
+                    }
+                    const f2 q = f2{ein[i0], ein[i1]} * f2{mt[g][0], mt[g + 1][0]};
+                    u[g] = q.x;
+                    u[g + 1] = q.y;
+                }
+            } else if constexpr (PRE) {
 #pragma unroll
                 for (int g = 0; g < GH; ++g) {
                     const int i = FWD ? ii0 + g : BK - 1 - (ii0 + g);
@@ -558,8 +581,12 @@ __device__ __forceinline__ void band_sweep(const BandArgs &a, int n, int L, floa
             Bo[0] = f4{edge[0], edge[1], edge[2], edge[3]};
             Bo[1] = f4{edge[4], edge[5], edge[6], edge[7]};
         }
-        if constexpr (SPLIT_FRAMES) band_frames_own<R>(m, f, zown, zrun_excl, lane);      // (for the next block)
-        band_barrier();
+        if constexpr (SPLIT_FRAMES) {
+            band_frames_own<R>(m, f, zown, zrun_excl, lane);    // (for the next block)
+            band_barrier_after(zrun_excl);
+        } else {
+            band_barrier();
+        }
         STAMP(4);
         ++stamp_k;
     };

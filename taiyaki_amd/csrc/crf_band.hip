@@ -854,6 +854,26 @@ __device__ __forceinline__ float wave_scan_fused(float x) {
     return x;
 }
 
+// The same for EIGHT independent values at once, level by level: the eight adds of a level do not depend
+// on each other, so the two wait states a DPP read needs after the write of its source are filled with
+// the other rows' adds instead of an s_nop per add (48 issue slots per chunk-block of the gradient pass,
+// which is bound by its instruction count).  One s_nop in front covers whatever wrote the inputs.
+__device__ __forceinline__ void wave_scan_fused8(float (&x)[8]) {
+#define TK_SCAN8_LEVEL(PRE, CTRL)                                                                   \
+    asm(PRE "v_add_f32_dpp %0, %0, %0 " CTRL "\n\tv_add_f32_dpp %1, %1, %1 " CTRL "\n\t"             \
+            "v_add_f32_dpp %2, %2, %2 " CTRL "\n\tv_add_f32_dpp %3, %3, %3 " CTRL "\n\t"             \
+            "v_add_f32_dpp %4, %4, %4 " CTRL "\n\tv_add_f32_dpp %5, %5, %5 " CTRL "\n\t"             \
+            "v_add_f32_dpp %6, %6, %6 " CTRL "\n\tv_add_f32_dpp %7, %7, %7 " CTRL                      \
+        : "+v"(x[0]), "+v"(x[1]), "+v"(x[2]), "+v"(x[3]), "+v"(x[4]), "+v"(x[5]), "+v"(x[6]), "+v"(x[7]))
+    TK_SCAN8_LEVEL("s_nop 1\n\t", "row_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:1");
+    TK_SCAN8_LEVEL("", "row_shr:2 row_mask:0xf bank_mask:0xf bound_ctrl:1");
+    TK_SCAN8_LEVEL("", "row_shr:4 row_mask:0xf bank_mask:0xf bound_ctrl:1");
+    TK_SCAN8_LEVEL("", "row_shr:8 row_mask:0xf bank_mask:0xf bound_ctrl:1");
+    TK_SCAN8_LEVEL("", "row_bcast:15 row_mask:0xa bank_mask:0xf");
+    TK_SCAN8_LEVEL("", "row_bcast:31 row_mask:0xc bank_mask:0xf");
+#undef TK_SCAN8_LEVEL
+}
+
 // ===========================================================================
 // gradient pass: grid (N, ceil(NB / POST_WAVES)), wave = one time block (BK rows) of read n,
 // looping over the block's live chunks.  Per chunk: the two checkpoint columns, the boundary
@@ -1135,8 +1155,15 @@ __global__ __launch_bounds__(POST_WAVES *WAVE) void crf_band_posterior_kernel(Ba
                 }
             }
             float base[RG];
+            static_assert(RG == 8, "wave_scan_fused8");
+            {
+                float incl[RG];
 #pragma unroll
-            for (int kk = 0; kk < RG; ++kk) base[kk] = wave_scan_fused(v[kk][EPL - 1]) - v[kk][EPL - 1];
+                for (int kk = 0; kk < RG; ++kk) incl[kk] = v[kk][EPL - 1];
+                wave_scan_fused8(incl);
+#pragma unroll
+                for (int kk = 0; kk < RG; ++kk) base[kk] = incl[kk] - v[kk][EPL - 1];
+            }
             if constexpr (true) {
                 // the inclusive prefixes go back to LDS in sorted order (the rows' regions are free
                 // again: every lane has read its values), the segment ends are one read each

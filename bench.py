@@ -231,7 +231,8 @@ class LossOps:
         _lib.check(rc, "tk_flipflop_build_indices_dev")
         rc = L.tk_crf_flipflop_dev(p(self.x), self.S, self.T, self.N, p(self.stay), p(self.move), p(self.modidx),
                                    p(self.modfact), p(self.seqlens), p(self.seqoff), self.maxlen, 40, 1.0, 1.0, 1.0,
-                                   p(self.cost), p(self.grad), p(self.crf_ws), self.crf_wsb, p(self.status), st)
+                                   p(self.cost), p(self.grad), p(self.crf_ws), self.crf_wsb, p(self.status), st,
+                                   p(self.mcw) if self.mod else None)
         _lib.check(rc, "tk_crf_flipflop_dev")
 
     def logz_op(self):
@@ -256,7 +257,8 @@ class LossOps:
                                           p(self.modidx), p(self.modfact), p(self.seqlens),
                                           p(self.seqoff), self.maxlen, 1.0, 1.0 / self.N, None, p(self.cost), p(self.grad),
                                           p(self.logz), p(self.crf_ws), self.crf_wsb, p(self.lz_ws), self.lz_wsb,
-                                          p(self.aux), self.aux_bytes, p(self.status), st)
+                                          p(self.aux), self.aux_bytes, p(self.status), st,
+                                          p(self.mcw) if self.mod else None)
         _lib.check(rc, "tk_flipflop_loss_fused_dev")
 
     def finite(self):

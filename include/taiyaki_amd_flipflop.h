@@ -101,6 +101,13 @@ int tk_flipflop_build_indices_dev(const int32_t *seqs, const int32_t *seqlen,
  *                 in which case score is the forward score, c_crf_flipflop.c:255-290)
  *   seqlen[n]==0 => cost 0, zero gradient rows        (c_crf_flipflop.c:269-272,458-464)
  *   max_seqlen: an upper bound of seqlen (0 = unknown => nblk+1 is assumed)
+ *   mod_col_weights (nullable, cat-mod only; (ntrans - ncan) floats on the device): the caller's PROMISE
+ *     that modfact[p] == mod_col_weights[modidx[p] - ncan] for every move, i.e. that the factor is a property
+ *     of the modification column -- which is what `mod_cat_weights` of the reference's operator is
+ *     (ctc.pyx:288-292; tk_flipflop_build_indices_dev fills modfact from it).  A move weight
+ *     exp(sharp s[move] + modfact s[mod]) then factors into two GATHERS from one row that was exponentiated
+ *     once per wave (lane = column, exponent multiplier per column), as in the plain CRF, instead of one
+ *     exponential per lattice cell and step.  NULL: the general form (any per-position factors).
  * ------------------------------------------------------------------------- */
 size_t tk_crf_flipflop_workspace_bytes(size_t ntrans, size_t nblk, size_t nbatch,
                                        size_t max_seqlen, int want_grad);
@@ -112,7 +119,8 @@ int tk_crf_flipflop_dev(const float *logprob, size_t ntrans, size_t nblk,
                         const int64_t *seqoff, size_t max_seqlen, size_t ncan,
                         float sharp_can, float sharp_mod, float out_scale,
                         float *cost, float *grad, void *workspace,
-                        size_t workspace_bytes, uint32_t *status, void *stream);
+                        size_t workspace_bytes, uint32_t *status, void *stream,
+                        const float *mod_col_weights);
 
 /* ------------------------------------------------------------------------- *
  * Fused train-step loss (replaces the assembly in `calculate_loss`,
@@ -150,7 +158,8 @@ int tk_flipflop_loss_fused_dev(const float *scores, size_t nblk, size_t nbatch, 
                                float *grad, float *logz, void *crf_workspace,
                                size_t crf_workspace_bytes, void *logz_workspace,
                                size_t logz_workspace_bytes, void *aux, size_t aux_bytes,
-                               uint32_t *status, void *stream);
+                               uint32_t *status, void *stream,
+                               const float *mod_col_weights);
 
 /* ------------------------------------------------------------------------- *
  * Hash beam search (replaces taiyaki/decodeutil/c_hashdecode.h:10

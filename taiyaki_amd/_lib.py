@@ -27,10 +27,10 @@ SIGNATURES = {
                                           _vp, _vp, _vp, _vp, _vp]),
     "tk_crf_flipflop_workspace_bytes": (_sz, [_sz, _sz, _sz, _sz, _i]),
     "tk_crf_flipflop_dev": (_i, [_vp, _sz, _sz, _sz, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _sz,
-                                 _f, _f, _f, _vp, _vp, _vp, _sz, _vp, _vp]),
+                                 _f, _f, _f, _vp, _vp, _vp, _sz, _vp, _vp, _vp]),
     "tk_flipflop_loss_fused_aux_bytes": (_sz, [_sz, _sz, _sz, _sz]),
     "tk_flipflop_loss_fused_dev": (_i, [_vp, _sz, _sz, _sz, _sz, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _f, _f, _vp, _vp,
-                                       _vp, _vp, _vp, _sz, _vp, _sz, _vp, _sz, _vp, _vp]),
+                                       _vp, _vp, _vp, _sz, _vp, _sz, _vp, _sz, _vp, _vp, _vp]),
     "tk_flipflop_lattice_dev": (_i, [_vp, _sz, _sz, _sz, _i, _vp, _vp, _vp, _vp]),
     "tk_flipflop_beamsearch_workspace_bytes": (_sz, [_sz, _sz, _sz]),
     "tk_flipflop_beamsearch_dev": (_i, [_vp, _sz, _sz, _sz, _i, _f, _i, _vp, _vp, _vp, _vp, _sz, _vp]),

@@ -28,7 +28,7 @@ int crf_dispatch(const float *logprob, size_t ntrans, size_t nblk, size_t nbatch
                  float out_scale, float grad_scale, const float *grad_scale_vec, float *cost, float *grad,
                  void *workspace, size_t workspace_bytes, uint32_t *status, hipStream_t stream,
                  const float *add_grad = nullptr, const float *add_cost = nullptr, int add_S = 0,
-                 float add_scale = 0.f, hipEvent_t add_ready = nullptr);
+                 float add_scale = 0.f, hipEvent_t add_ready = nullptr, const float *mod_col_weights = nullptr);
 bool logz_side_stream(hipStream_t *s, hipEvent_t *fork, hipEvent_t *join);
 void crf_band_lab_phase(int phase);
 size_t beam_workspace_bytes(size_t T, size_t N, size_t nbase);
@@ -193,14 +193,15 @@ int tk_crf_flipflop_dev(const float *logprob, size_t ntrans, size_t nblk, size_t
                         const float *modfact, const int32_t *seqlen, const int64_t *seqoff,
                         size_t max_seqlen, size_t ncan, float sharp_can, float sharp_mod,
                         float out_scale, float *cost, float *grad, void *workspace,
-                        size_t workspace_bytes, uint32_t *status, void *stream) {
+                        size_t workspace_bytes, uint32_t *status, void *stream, const float *mod_col_weights) {
     if (!logprob || !stayidx || !moveidx || !seqlen || !seqoff || !cost || !workspace) return TK_ERR_BAD_ARG;
     if (ntrans == 0 || nblk == 0 || nbatch == 0) return TK_ERR_BAD_ARG;
     if ((modidx == nullptr) != (modfact == nullptr)) return TK_ERR_BAD_ARG;
     return tk::crf_dispatch(logprob, ntrans, nblk, nbatch, stayidx, moveidx, modidx, modfact,
                             seqlen, seqoff, max_seqlen, ncan, sharp_can, sharp_mod, out_scale, 1.0f, nullptr,
                             cost, grad, workspace, workspace_bytes, status,
-                            static_cast<hipStream_t>(stream));
+                            static_cast<hipStream_t>(stream), nullptr, nullptr, 0, 0.f, nullptr,
+                            modidx != nullptr ? mod_col_weights : nullptr);
 }
 
 // rows of S floats -> their first S0 columns, contiguous (the canonical block of a cat-mod tensor)
@@ -246,7 +247,7 @@ int tk_flipflop_loss_fused_dev(const float *scores, size_t nblk, size_t nbatch, 
                                const float *grad_scale_per_read, float *lossvector,
                                float *grad, float *logz, void *crf_workspace, size_t crf_workspace_bytes,
                                void *logz_workspace, size_t logz_workspace_bytes, void *aux, size_t aux_bytes,
-                               uint32_t *status, void *stream) {
+                               uint32_t *status, void *stream, const float *mod_col_weights) {
     if (!scores || !stayidx || !moveidx || !seqlen || !seqoff || !lossvector || !grad || !logz || !crf_workspace ||
         !logz_workspace || nblk == 0 || nbatch == 0 || nbase == 0 || !(sharpfact > 0.f))
         return TK_ERR_BAD_ARG;
@@ -302,7 +303,7 @@ int tk_flipflop_loss_fused_dev(const float *scores, size_t nblk, size_t nbatch, 
     rc = tk::crf_dispatch(scores, ntrans, nblk, nbatch, stayidx, moveidx, modidx, modfact, seqlen, seqoff, max_seqlen,
                           ncan, sharpfact, catmod ? 1.0f : sharpfact, 1.0f / sharpfact, grad_scale, grad_scale_per_read,
                           lossvector, grad, crf_workspace, crf_workspace_bytes, status, st, g40, logz, (int)ncan,
-                          1.0f / (float)nblk, side ? join : nullptr);
+                          1.0f / (float)nblk, side ? join : nullptr, catmod ? mod_col_weights : nullptr);
     if (rc != 0 && side) (void)hipStreamWaitEvent(st, join, 0);
     return rc;
 }

@@ -47,6 +47,7 @@ struct BandArgs {
     const float *zeros;         // 64 B of zeros (the boundary row of lanes that take none)
     int *gate;                  // [N]  1: the linear path disowns this read (redone by crf_kernel)
     unsigned long long *dbg;    // lab builds only (TK_LAB_STAMPS)
+    const float *colw;          // nullable (cat-mod): (S - ncan) per-COLUMN factors; promise that modfact[p] = colw[mod[p] - ncan]
     hipEvent_t before_gradient; // host side: the stream waits for this event between the sweeps and the gradient
                                 // pass (what `add_grad` / `add_cost` hold was produced on another stream); null: none
 };

@@ -271,7 +271,7 @@ __device__ __forceinline__ int wt_f4(int chunk, int slot, int g, int lane) {
     return ((chunk * 2 + slot) * (4 * R) + g) * WAVE + lane;
 }
 
-template <int R, bool MOD, bool FWD, bool GRAD, bool HELP>
+template <int R, bool MOD, bool FWD, bool GRAD, bool HELP, bool CW>
 __device__ __forceinline__ void band_sweep(const BandArgs &a, int n, int L, float *E, int *Ef, const float *Ezero,
                                            const f4 *Wt) {
     constexpr int PW = R * WAVE;
@@ -293,6 +293,11 @@ __device__ __forceinline__ void band_sweep(const BandArgs &a, int n, int L, floa
     const float *lpn = a.lp + (size_t)n * S;
     const unsigned col4 = 4u * (unsigned)min(lane, S - 1);
     const float c = a.c_can;
+    // cat-mod with per-COLUMN factors (BandArgs::colw): the row is exponentiated once per wave with a
+    // multiplier per lane = column (sharp log2 e on the canonical columns, factor x sharp_mod x log2 e on a
+    // modification's), and a move's weight is the product of two gathers from it
+    constexpr bool colw_mode = MOD && CW;       // (a template parameter: a per-step runtime branch cost both forms 10 %)
+    const float cw_lane = colw_mode ? ((int)lane < a.ncan ? c : a.colw[min(max((int)lane - a.ncan, 0), S - a.ncan - 1)] * a.c_mod) : c;
 
     // The wave's cells in FLOW order: index q = lane R + j, upstream = q - 1, i.e. position
     // a0 + q forward and a0 + PW - 1 - q backward (the backward sweep runs on mirrored lanes, so
@@ -437,13 +442,16 @@ __device__ __forceinline__ void band_sweep(const BandArgs &a, int n, int L, floa
 #pragma unroll
             for (int g = 0; g < GH; ++g) {
                 const int i = FWD ? ii0 + g : BK - 1 - (ii0 + g);
-                const float er = fast_exp2(cur[i] * c);
+                const float er = fast_exp2(cur[i] * cw_lane);
 #pragma unroll
                 for (int jj = 0; jj < R; ++jj) {
                     es[g][jj] = bperm(st4[jj], er);
                     if constexpr (MOD) {
                         // c_cat_mod_flipflop.c:64-66: move score + modfact * mod score
-                        em[g][jj] = fast_exp2(fmaf(bperm(md4[MOD ? jj : 0], cur[i]), fw[MOD ? jj : 0], bperm(mv4[jj], cur[i]) * c));
+                        if constexpr (colw_mode)
+                            em[g][jj] = bperm(mv4[jj], er) * bperm(md4[MOD ? jj : 0], er);
+                        else
+                            em[g][jj] = fast_exp2(fmaf(bperm(md4[MOD ? jj : 0], cur[i]), fw[MOD ? jj : 0], bperm(mv4[jj], cur[i]) * c));
                     } else {
                         em[g][jj] = bperm(mv4[jj], er);
                     }
@@ -642,7 +650,7 @@ __device__ __forceinline__ void band_sweep(const BandArgs &a, int n, int L, floa
 // serve the trailing one a phase later.  Used when every sweep workgroup has a CU to itself and
 // W + ceil(W / 2) waves fit a workgroup; the weights take W R 8 KiB of LDS.
 // ===========================================================================
-template <int R, bool MOD, bool FWD>
+template <int R, bool MOD, bool FWD, bool CW>
 __device__ __forceinline__ void band_helper(const BandArgs &a, int n, int L, int h, f4 *Wt) {
     constexpr int PW = R * WAVE;
     const int lane = threadIdx.x & (WAVE - 1);
@@ -654,6 +662,7 @@ __device__ __forceinline__ void band_helper(const BandArgs &a, int n, int L, int
     const unsigned col4 = 4u * (unsigned)min(lane, S - 1);
     const unsigned rs4 = 4u * (unsigned)rowstride;
     const float c = a.c_can;
+    const float cw_lane = (MOD && CW) ? ((int)lane < a.ncan ? c : a.colw[min(max((int)lane - a.ncan, 0), S - a.ncan - 1)] * a.c_mod) : c;
     // the leading chunk runs block j in the phase before the trailing one does
     const int cl = FWD ? 2 * h : 2 * h + 1, ct = FWD ? 2 * h + 1 : 2 * h;
     const int cc[2] = {cl, ct};
@@ -693,14 +702,16 @@ __device__ __forceinline__ void band_helper(const BandArgs &a, int n, int L, int
         const int slot = j & 1;
         float er[BK];
 #pragma unroll
-        for (int i = 0; i < BK; ++i) er[i] = fast_exp2(row[i] * c);
+        for (int i = 0; i < BK; ++i) er[i] = fast_exp2(row[i] * cw_lane);
 #pragma unroll
         for (int jj = 0; jj < R; ++jj) {
             float es[BK], em[BK];
 #pragma unroll
             for (int i = 0; i < BK; ++i) {
                 es[i] = bperm(st4[u][jj], er[i]);
-                if constexpr (MOD)
+                if constexpr (MOD && CW)
+                    em[i] = bperm(mv4[u][jj], er[i]) * bperm(md4[u][MOD ? jj : 0], er[i]);
+                else if constexpr (MOD)
                     em[i] = fast_exp2(fmaf(bperm(md4[u][MOD ? jj : 0], row[i]), fw[u][MOD ? jj : 0], bperm(mv4[u][jj], row[i]) * c));
                 else
                     em[i] = bperm(mv4[u][jj], er[i]);
@@ -747,7 +758,7 @@ __device__ __forceinline__ void band_helper(const BandArgs &a, int n, int L, int
 // ===========================================================================
 // WCAP = the most waves a launch of this instantiation may have: the register budget of a lane is
 // 512 / ceil(WCAP / 4) (R = 4 wants more than the 128 that 16 waves leave).
-template <int R, bool MOD, int WCAP, bool HELP>
+template <int R, bool MOD, int WCAP, bool HELP, bool CW>
 __global__ __launch_bounds__(WCAP *WAVE) void crf_band_sweep_kernel(BandArgs a) {
     extern __shared__ __attribute__((aligned(16))) char band_dyn_lds[];     // HELP: the weights image (wt_f4)
     constexpr int PW = R * WAVE;
@@ -829,17 +840,17 @@ __global__ __launch_bounds__(WCAP *WAVE) void crf_band_sweep_kernel(BandArgs a) 
     if (HELP && w >= W) {
         // helper waves (gradient calls only): the weights of two chunks each, a phase ahead
         if (role == 0)
-            band_helper<R, MOD, true>(a, n, L, w - W, Wt);
+            band_helper<R, MOD, true, CW>(a, n, L, w - W, Wt);
         else
-            band_helper<R, MOD, false>(a, n, L, w - W, Wt);
+            band_helper<R, MOD, false, CW>(a, n, L, w - W, Wt);
         return;
     }
     if (!want_grad)
-        band_sweep<R, MOD, true, false, false>(a, n, L, E, Ef, Ezero, Wt);
+        band_sweep<R, MOD, true, false, false, CW>(a, n, L, E, Ef, Ezero, Wt);
     else if (role == 0)
-        band_sweep<R, MOD, true, true, HELP>(a, n, L, E, Ef, Ezero, Wt);
+        band_sweep<R, MOD, true, true, HELP, CW>(a, n, L, E, Ef, Ezero, Wt);
     else
-        band_sweep<R, MOD, false, true, HELP>(a, n, L, E, Ef, Ezero, Wt);
+        band_sweep<R, MOD, false, true, HELP, CW>(a, n, L, E, Ef, Ezero, Wt);
 }
 
 // Inclusive wave prefix sum in six fused DPP adds (the row_bcast steps write only the rows they
@@ -885,7 +896,7 @@ __host__ __device__ inline size_t band_post_lds_bytes(bool mod) {
     return (size_t)POST_WAVES * BK * (mod ? 3 : 2) * WAVE * 4;
 }
 
-template <bool MOD>
+template <bool MOD, bool CW>
 __global__ __launch_bounds__(POST_WAVES *WAVE) void crf_band_posterior_kernel(BandArgs a) {
     constexpr int R = 1;                                        // 64-cell chunks whatever the sweeps used
     constexpr int PW = R * WAVE;
@@ -941,12 +952,15 @@ __global__ __launch_bounds__(POST_WAVES *WAVE) void crf_band_posterior_kernel(Ba
     const int64_t off = a.seqoff[n];
     const int zexp = (int)floor(scoreF);
 
+    // (cat-mod with per-column factors: see band_sweep)
+    constexpr bool colw_mode = MOD && CW;
+    const float cw_lane = colw_mode ? ((int)lane < a.ncan ? c : a.colw[min(max((int)lane - a.ncan, 0), S - a.ncan - 1)] * a.c_mod) : c;
     // the wave's score rows, one register each (lane = transition id), raw and exponentiated
     float raw[BK], er[BK];
 #pragma unroll
     for (int k = 0; k < BK; ++k) {
         raw[k] = lpn[(size_t)min(t0 + k, T - 1) * rowstride + col];
-        er[k] = fast_exp2(raw[k] * c);
+        er[k] = fast_exp2(raw[k] * cw_lane);
     }
 
     // live chunks of row t (column t -> t + 1): chunk [a, b] holds an instance of some complete path
@@ -1070,7 +1084,8 @@ __global__ __launch_bounds__(POST_WAVES *WAVE) void crf_band_posterior_kernel(Ba
 #pragma unroll
                 for (int j = 0; j < R; ++j) {
                     if constexpr (MOD)
-                        emo[i][j] = fast_exp2(fmaf(bperm(do4[MOD ? j : 0], raw[i]), fwo[MOD ? j : 0], bperm(mo4[j], raw[i]) * c)) * scB[j];
+                        emo[i][j] = (colw_mode ? bperm(mo4[j], er[i]) * bperm(do4[MOD ? j : 0], er[i])
+                                               : fast_exp2(fmaf(bperm(do4[MOD ? j : 0], raw[i]), fwo[MOD ? j : 0], bperm(mo4[j], raw[i]) * c))) * scB[j];
                     else
                         emo[i][j] = bperm(mo4[j], er[i]) * scB[j];
                 }
@@ -1105,7 +1120,8 @@ __global__ __launch_bounds__(POST_WAVES *WAVE) void crf_band_posterior_kernel(Ba
                 for (int j = 0; j < R; ++j) {
                     float em;
                     if constexpr (MOD)
-                        em = fast_exp2(fmaf(bperm(di4[MOD ? j : 0], raw[k]), fwi[MOD ? j : 0], bperm(mi4[j], raw[k]) * c));
+                        em = colw_mode ? bperm(mi4[j], er[k]) * bperm(di4[MOD ? j : 0], er[k])
+                                       : fast_exp2(fmaf(bperm(di4[MOD ? j : 0], raw[k]), fwi[MOD ? j : 0], bperm(mi4[j], raw[k]) * c));
                     else
                         em = bperm(mi4[j], er[k]);
                     const float up = (j == 0) ? upl : fv[j > 0 ? j - 1 : 0];
@@ -1324,7 +1340,7 @@ static bool band_use_helpers(const BandArgs &a, int R, bool mod) {
     return ncu[dev] > 0 && 2 * a.N <= ncu[dev];
 }
 
-template <int R, bool MOD>
+template <int R, bool MOD, bool CW>
 static int band_launch(const BandArgs &a, hipStream_t stream) {
     const bool want_grad = a.grad != nullptr;
     if (g_band_lab_phase != 2) {
@@ -1333,23 +1349,23 @@ static int band_launch(const BandArgs &a, hipStream_t stream) {
             if (band_use_helpers(a, R, MOD)) {
                 const size_t lds = (size_t)a.W * R * 8192;
                 const dim3 hblock((a.W + (a.W + 1) / 2) * WAVE);
-                if (raise_dynamic_lds(reinterpret_cast<const void *>(&crf_band_sweep_kernel<R, MOD, BAND_MAXW, true>), 152 * 1024)) return 4;
-                hipLaunchKernelGGL((crf_band_sweep_kernel<R, MOD, BAND_MAXW, true>), grid, hblock, lds, stream, a);
+                if (raise_dynamic_lds(reinterpret_cast<const void *>(&crf_band_sweep_kernel<R, MOD, BAND_MAXW, true, CW>), 152 * 1024)) return 4;
+                hipLaunchKernelGGL((crf_band_sweep_kernel<R, MOD, BAND_MAXW, true, CW>), grid, hblock, lds, stream, a);
             } else {
-                hipLaunchKernelGGL((crf_band_sweep_kernel<R, MOD, BAND_MAXW, false>), grid, block, 0, stream, a);
+                hipLaunchKernelGGL((crf_band_sweep_kernel<R, MOD, BAND_MAXW, false, CW>), grid, block, 0, stream, a);
             }
         } else if (a.W <= 8)
-            hipLaunchKernelGGL((crf_band_sweep_kernel<R, MOD, (R == 4 ? 8 : BAND_MAXW), false>), grid, block, 0, stream, a);
+            hipLaunchKernelGGL((crf_band_sweep_kernel<R, MOD, (R == 4 ? 8 : BAND_MAXW), false, CW>), grid, block, 0, stream, a);
         else if (a.W <= 12)
-            hipLaunchKernelGGL((crf_band_sweep_kernel<R, MOD, (R == 4 ? 12 : BAND_MAXW), false>), grid, block, 0, stream, a);
+            hipLaunchKernelGGL((crf_band_sweep_kernel<R, MOD, (R == 4 ? 12 : BAND_MAXW), false, CW>), grid, block, 0, stream, a);
         else
-            hipLaunchKernelGGL((crf_band_sweep_kernel<R, MOD, BAND_MAXW, false>), grid, block, 0, stream, a);
+            hipLaunchKernelGGL((crf_band_sweep_kernel<R, MOD, BAND_MAXW, false, CW>), grid, block, 0, stream, a);
     }
     if (hipGetLastError() != hipSuccess) return 4;
     if (!want_grad || g_band_lab_phase == 1) return 0;
     if (a.before_gradient != nullptr && hipStreamWaitEvent(stream, a.before_gradient, 0) != hipSuccess) return 4;
     const int NB = (a.T + BK - 1) / BK;
-    hipLaunchKernelGGL((crf_band_posterior_kernel<MOD>), dim3(a.N, (NB + POST_WAVES - 1) / POST_WAVES),
+    hipLaunchKernelGGL((crf_band_posterior_kernel<MOD, CW>), dim3(a.N, (NB + POST_WAVES - 1) / POST_WAVES),
                        dim3(POST_WAVES * WAVE), band_post_lds_bytes(MOD), stream, a);
     return hipGetLastError() == hipSuccess ? 0 : 4;
 }
@@ -1382,12 +1398,12 @@ int crf_band_dispatch(const BandArgs &a0, int R, bool mod, hipStream_t stream) {
 #endif
     if (a.W < 1 || a.W > BAND_MAXW) return 2;
     switch (R * 2 + (mod ? 1 : 0)) {
-        case 2: return band_launch<1, false>(a, stream);
-        case 3: return band_launch<1, true>(a, stream);
-        case 4: return band_launch<2, false>(a, stream);
-        case 5: return band_launch<2, true>(a, stream);
-        case 8: return band_launch<4, false>(a, stream);
-        case 9: return band_launch<4, true>(a, stream);
+        case 2: return band_launch<1, false, false>(a, stream);
+        case 3: return a.colw ? band_launch<1, true, true>(a, stream) : band_launch<1, true, false>(a, stream);
+        case 4: return band_launch<2, false, false>(a, stream);
+        case 5: return a.colw ? band_launch<2, true, true>(a, stream) : band_launch<2, true, false>(a, stream);
+        case 8: return band_launch<4, false, false>(a, stream);
+        case 9: return a.colw ? band_launch<4, true, true>(a, stream) : band_launch<4, true, false>(a, stream);
         default: return 2;
     }
 }

@@ -725,7 +725,7 @@ int crf_dispatch(const float *logprob, size_t ntrans, size_t nblk, size_t nbatch
                  float out_scale, float grad_scale, const float *grad_scale_vec, float *cost, float *grad,
                  void *workspace, size_t workspace_bytes, uint32_t *status, hipStream_t stream,
                  const float *add_grad, const float *add_cost, int add_S, float add_scale,
-                 hipEvent_t add_ready) {
+                 hipEvent_t add_ready, const float *mod_col_weights) {
     if (ntrans > 62 || ncan > ntrans || ncan == 0) return 2;
     if (max_seqlen == 0) max_seqlen = nblk + 1;
     const CrfShape sh = crf_pick_shape(max_seqlen);
@@ -809,6 +809,7 @@ int crf_dispatch(const float *logprob, size_t ntrans, size_t nblk, size_t nbatch
         b.zeros = reinterpret_cast<const float *>(wb + l.zeros);
         b.dbg = nullptr;
         b.before_gradient = add_ready;
+        b.colw = mod ? mod_col_weights : nullptr;
         const int rc = crf_band_dispatch(b, l.R, mod, stream);
         if (rc != 0) return rc;
         if (getenv("TK_CRF_GATE_DUMP")) {                       // lab: how many reads did the band path disown?

@@ -6,6 +6,8 @@ kernels through the C ABI on ``torch.cuda.current_stream()``: no device->host co
 of the score tensor, no Python index building, no host->device copy of the
 gradient (ctc.pyx:119, 127-132, 139-141 in the reference).
 """
+import os
+
 import numpy as np
 import torch
 
@@ -69,6 +71,16 @@ def n_mod_columns(can_mods_offsets):
     return int(np.asarray(can_mods_offsets)[-1])
 
 
+def _col_weights(keep, mod):
+    """The `mod_col_weights` argument of the C entry points: the device copy of `mod_cat_weights` that
+    `tk_flipflop_build_indices_dev` filled `modfact` from -- the promise that a move's factor is a
+    property of its modification column, which lets the kernels exponentiate a row once per wave.
+    TK_CATMOD_GENERAL=1 withholds it (lab / tests: the general per-position form)."""
+    if mod is None or os.environ.get("TK_CATMOD_GENERAL"):
+        return None
+    return _lib.ptr(keep[3])
+
+
 _KEEP_WS = None      # debugging aid: set to a list to keep the kernels' workspaces alive
 
 
@@ -120,7 +132,8 @@ def _run(logprob, seqs, seqlen, sharp_can, sharp_mod, out_scale, ncan, want_grad
             _lib.ptr(lp), ntrans, nblk, nbatch, _lib.ptr(stay), _lib.ptr(move), _lib.ptr(mod),
             _lib.ptr(fact), _lib.ptr(seqlen_d), _lib.ptr(seqoff), maxlen, ncan,
             float(sharp_can), float(sharp_mod), float(out_scale), _lib.ptr(cost),
-            _lib.ptr(grad), _lib.ptr(ws), wsb, _lib.ptr(status), _lib.stream_ptr())
+            _lib.ptr(grad), _lib.ptr(ws), wsb, _lib.ptr(status), _lib.stream_ptr(),
+            _col_weights(keep, mod))     # (the per-column factors modfact was filled from)
         _lib.check(rc, "tk_crf_flipflop_dev")
         _lib.finish(status)
     del keep
@@ -214,7 +227,8 @@ def _run_fused(outputs, seqs, seqlen, sharpfact, want_grad, grad_scale=1.0, grad
             _lib.ptr(lp), nblk, nbatch, nbase, ntrans, _lib.ptr(stay), _lib.ptr(move), _lib.ptr(mod), _lib.ptr(fact),
             _lib.ptr(seqlen_d), _lib.ptr(seqoff), maxlen, float(sharpfact), float(grad_scale), _lib.ptr(gvec),
             _lib.ptr(lossvector), _lib.ptr(grad), _lib.ptr(logz),
-            _lib.ptr(ws_a), wsa, _lib.ptr(ws_b), wsb, _lib.ptr(ws_x), wsx, _lib.ptr(status), _lib.stream_ptr())
+            _lib.ptr(ws_a), wsa, _lib.ptr(ws_b), wsb, _lib.ptr(ws_x), wsx, _lib.ptr(status), _lib.stream_ptr(),
+            _col_weights(keep, mod))
         _lib.check(rc, "tk_flipflop_loss_fused_dev")
         _lib.finish(status)
     del keep, gvec, ws_x

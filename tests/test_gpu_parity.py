@@ -661,6 +661,37 @@ def test_crf_helper_waves_change_no_bit(gpu_device, case, monkeypatch):
     assert np.array_equal(out["0"][0], out["1"][0]) and np.array_equal(out["0"][1], out["1"][1])
 
 
+def test_catmod_column_weights_form_agrees_with_the_general_form(oracle_mod, gpu_device, monkeypatch):
+    """Round 3: when the caller passes `mod_col_weights` (the Python operator always does: modfact is
+    mod_cat_weights gathered by column) a cat-mod move weight exp(sharp s[move] + factor s[mod]) is the
+    product of two gathers from a row exponentiated once per wave; without it (arbitrary per-position
+    factors: the reference's C prototype) every cell and step takes its own exponential.  Same
+    mathematics, different rounding: both must match the oracle, and each other far inside the tolerance."""
+    import torch
+    from taiyaki_amd import ctc, synth
+    monkeypatch.setenv("TK_CRF_MODE", "band")
+    T, N = 400, 24
+    seqlens = synth.realistic_seqlens(T, N, 17000, T * 5, 9.0)
+    inp = synth.crf_case(T, N, 8, seqlens=seqlens, nmods_per_base=(1, 1, 0, 0))
+    synth.normalise_mod_columns(inp, logit_scale=0.2)
+    x = torch.from_numpy(inp["scores"]).to(gpu_device)
+    seqs, sl = torch.from_numpy(inp["seqs"]), torch.from_numpy(inp["seqlens"])
+    extra = (torch.from_numpy(inp["mod_cats"]), inp["can_mods_offsets"], inp["mod_cat_weights"])
+    out = {}
+    for general in ("", "1"):
+        if general:
+            monkeypatch.setenv("TK_CATMOD_GENERAL", "1")
+        c, g = ctc._run(x, seqs, sl, 1.0, 1.0, 1.0, 40, True, *extra)
+        torch.cuda.synchronize()
+        out[general] = (c.cpu().numpy(), g.cpu().numpy())
+    oloss, ograd = parity.oracle_crf(oracle_mod, inp, 1.0)
+    for c, g in out.values():
+        assert np.isfinite(c).all() and np.isfinite(g).all()
+        assert parity.rel_err(c, oloss) < LOSS_RTOL and parity.abs_err(g, ograd) < 5e-5
+    assert not np.array_equal(out[""][1], out["1"][1])          # (really two code paths)
+    assert parity.rel_err(out[""][0], out["1"][0]) < 1e-5 and parity.abs_err(out[""][1], out["1"][1]) < 5e-6
+
+
 def test_crf_sharpened_scores_take_the_log_domain_kernel(oracle_mod, gpu_device, monkeypatch):
     """sharp = 2.5 puts weights of 2^(+-18) on a step: eight of them overflow a block of the linear
     path, which must notice (non-finite sweep score) and hand the read over."""

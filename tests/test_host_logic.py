@@ -157,7 +157,7 @@ def test_c_abi_rejects_bad_arguments_before_touching_the_gpu():
     assert L.tk_flipflop_errprobs_dev(one, one, 0, 2, 4, one, None) == BAD
     assert L.tk_grad_maxabs_clip_dev(None, None, 3, 10, None, None, None) == BAD
     assert L.tk_crf_flipflop_dev(None, 40, 10, 2, None, None, None, None, None, None, 0, 40,
-                                 1.0, 1.0, 1.0, None, None, None, 0, None, None) == BAD
+                                 1.0, 1.0, 1.0, None, None, None, 0, None, None, None) == BAD
     assert L.tk_flipflop_build_indices_dev(None, None, 0, 0, 4, None, None, None, None, None, None,
                                            None, None, None, None) == BAD
 

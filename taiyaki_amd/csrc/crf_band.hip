@@ -1326,9 +1326,10 @@ static bool band_use_helpers(const BandArgs &a, int R, bool mod) {
     if (a.grad == nullptr || R > 2) return false;
     if (a.W + (a.W + 1) / 2 > BAND_MAXW || (size_t)a.W * R * 8192 > 144 * 1024) return false;
     if (const char *e = getenv("TK_CRF_HELPER")) return e[0] == '1';
-    // measured (kernel A): -3.5 % for the plain CRF at R = 1; cat-mod (whose helpers also carry the
-    // per-cell exponentials) +4 %, R = 2 +-0: those stay in the plain mode
-    if (R != 1 || mod) return false;
+    // measured (kernel A): -3.5 % for the plain CRF at R = 1, -7 % for cat-mod with per-column
+    // factors; cat-mod in its general form (whose helpers also carry the per-cell exponentials) +4 %,
+    // R = 2 +-0: those stay in the plain mode
+    if (R != 1 || (mod && a.colw == nullptr)) return false;
     static int ncu[64] = {0};
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return false;

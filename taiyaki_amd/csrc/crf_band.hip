@@ -466,9 +466,10 @@ __device__ __forceinline__ void band_sweep(const BandArgs &a, int n, int L, floa
             // (R = 4 has no registers to spare for that: 16 waves leave 128 per lane)
             constexpr bool PRE = R < 4;
             float mt[PRE ? GH : 1][R], u[PRE ? GH : 1];
-            if constexpr (PRE && !MOD) {
-                // (two steps per instruction: v_pk_mul_f32 -- -1 % for the plain CRF; cat-mod, whose weights
-                // come out of a v_exp_f32 each, measured +2 % with the pairing and keeps single multiplies)
+            if constexpr (PRE && (!MOD || CW)) {
+                // (two steps per instruction: v_pk_mul_f32 -- -1 % for the plain CRF, -2 % for cat-mod with
+                // per-column factors; cat-mod's general form, whose weights come out of a v_exp_f32 each,
+                // measured +2 % with the pairing and keeps single multiplies)
                 typedef float f2 __attribute__((ext_vector_type(2)));
 #pragma unroll
                 for (int g = 0; g < GH; g += 2) {

@@ -10,7 +10,8 @@
 //     (forward sweep) resp. (NB-1-j) + (W-1-w) (backward sweep): the boundary cell a chunk needs
 //     from its neighbour for every step of a block was written to a two-slot LDS ring one phase
 //     earlier, so a workgroup executes ONE s_barrier per BK time steps.
-//   * A cell is m * 2^f: float mantissa, int32 FRAME per cell, fixed for the steps of a block.
+//   * A cell is m * 2^f: float mantissa, integer FRAME per cell (int32 in registers, a 16-bit offset from
+//     a per-chunk base in the checkpoint columns), fixed for the steps of a block.
 //     The score row is exponentiated once per row and wave (one VGPR, lane = transition id); a
 //     step is two ds_bpermute gathers and  m' = m es + m_up (em 2^(f_up - f))  -- an fma and a
 //     DPP-fed v_fmac, no exp / log on the serial chain (round 2: max + log2(1 + 2^-|d|), ~15
@@ -38,6 +39,12 @@
 //     sweep launch), so the per-id sums of the reference's scatter-add (c_crf_flipflop.c:403-412)
 //     are differences of ONE prefix scan held in registers: no atomics, no cross-wave reduction,
 //     fixed summation order -> bitwise reproducible.
+//   * Round 3 also: HELPER WAVES prepare a block's step weights a phase ahead through LDS in launches where
+//     every sweep workgroup has a CU to itself (band_helper); the frames' own-cells half runs ahead of the
+//     barrier (band_frames_own / _finish); cat-mod with per-COLUMN factors exponentiates a row once per wave
+//     like the plain CRF (CW); the gradient pass runs two waves per workgroup and interleaves its eight
+//     prefix scans.  Each of these is bit-identical to the form it replaced except CW (different rounding,
+//     tested against the general form and the oracle).
 //   * The linear path is exact or says so: a read whose sweeps end non-finite (overflow: scores
 //     beyond the bound above, e.g. sharpening factors > 1; underflow of everything: no complete
 //     path, log-probabilities far below zero), whose two sweeps disagree, or ANY of whose rows'

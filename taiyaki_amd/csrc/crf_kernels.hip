@@ -665,9 +665,25 @@ static size_t crf_ckpt_bytes(size_t nblk, size_t nbatch, CrfShape sh) {
 //            three serial passes per read (workspace-bound batches, and the band path's safety net)
 enum CrfMode { CRF_BAND, CRF_CKPT };
 static size_t crf_lattice_cap_bytes() {
-    size_t cap_mb = 40960;          // 40 GiB of the 288 GB
-    if (const char *e = getenv("TK_CRF_LATTICE_MB")) cap_mb = (size_t)atoll(e);
-    return cap_mb * 1024 * 1024;
+    // TK_CRF_LATTICE_MB, else a quarter of THIS device's memory (72 GB of an MI355X's 288; round 3's checkpoint
+    // columns are 3.9 GB at T = 4000 / N = 256, so the cap is about smaller devices and partitions, and about
+    // callers that do not know their longest sequence).  No device (the build container): 40 GiB.
+    if (const char *e = getenv("TK_CRF_LATTICE_MB")) return (size_t)atoll(e) * 1024 * 1024;
+    static size_t cap[64] = {0};
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) {
+        (void)hipGetLastError();
+        return (size_t)40960 * 1024 * 1024;
+    }
+    if (cap[dev] == 0) {
+        size_t total = 0;
+        if (hipDeviceTotalMem(&total, dev) != hipSuccess || total == 0) {
+            (void)hipGetLastError();
+            total = (size_t)160 * 1024 * 1024 * 1024;
+        }
+        cap[dev] = total / 4;
+    }
+    return cap[dev];
 }
 static CrfMode crf_pick_mode(size_t ntrans, size_t nblk, size_t nbatch, size_t max_seqlen, bool want_grad) {
     const char *e = getenv("TK_CRF_MODE");

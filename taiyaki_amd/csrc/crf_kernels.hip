@@ -540,8 +540,8 @@ __global__ void build_indices_kernel(const int32_t *__restrict__ seqs,
     // this read's offset = the sum of the lengths before it, clamped to the label array (see
     // seqoff_kernel): every workgroup sums for itself -- a batch is a few hundred reads, and it saves
     // the separate prefix-sum launch (~5 us of a 170 us loss path)
-    __shared__ long long part[128];
-    __shared__ long long off_sh, tot_sh;
+    __shared__ long long off_sh;
+    __shared__ long long wsum[2][2];    // [wave][mine | all]: the block is two wavefronts
     if (nbatch == 0) {                  // (offsets already there: seqoff_kernel ran)
         if (threadIdx.x == 0) off_sh = seqoff[n];
         __syncthreads();
@@ -552,26 +552,30 @@ __global__ void build_indices_kernel(const int32_t *__restrict__ seqs,
             all += v;
             if (i < n) mine += v;
         }
-        part[threadIdx.x] = mine;
-        __syncthreads();
-        for (int st = blockDim.x / 2; st > 0; st >>= 1) {
-            if ((int)threadIdx.x < st) part[threadIdx.x] += part[threadIdx.x + st];
-            __syncthreads();
+        // wave sums by butterfly, one hand-over through LDS -- the tree of fourteen barriers this replaces was
+        // most of the kernel
+        auto wave_sum = [&](long long v) {
+#pragma unroll
+            for (int m = 32; m >= 1; m >>= 1) v += __shfl_xor(v, m, WAVE);
+            return v;
+        };
+        const long long wm = wave_sum(mine), wa = wave_sum(all);
+        if ((threadIdx.x & (WAVE - 1)) == 0) {
+            wsum[threadIdx.x >> 6][0] = wm;
+            wsum[threadIdx.x >> 6][1] = wa;
         }
-        if (threadIdx.x == 0) off_sh = part[0];
         __syncthreads();
-        part[threadIdx.x] = all;
-        __syncthreads();
-        for (int st = blockDim.x / 2; st > 0; st >>= 1) {
-            if ((int)threadIdx.x < st) part[threadIdx.x] += part[threadIdx.x + st];
-            __syncthreads();
-        }
         if (threadIdx.x == 0) {
-            tot_sh = part[0];
-            seqoff[n] = min(off_sh, total_len);
+            long long m = 0, t = 0;
+            for (unsigned w = 0; w < (blockDim.x + WAVE - 1) / WAVE && w < 2; ++w) {
+                m += wsum[w][0];
+                t += wsum[w][1];
+            }
+            off_sh = m;
+            seqoff[n] = min(m, total_len);
             if (n == nbatch - 1) {
-                seqoff[nbatch] = min(tot_sh, total_len);
-                if (tot_sh > total_len && status) atomicOr(status, 8u);     // more labels announced than handed over
+                seqoff[nbatch] = min(t, total_len);
+                if (t > total_len && status) atomicOr(status, 8u);      // more labels announced than handed over
             }
         }
         __syncthreads();

@@ -361,7 +361,9 @@ __device__ __forceinline__ void band_sweep(const BandArgs &a, int n, int L, floa
     float row0[BK], row1[BK], row2[BK];
     // (row offsets inside a block are loop-invariant scalars; the descriptor covers exactly the rows
     // of the block that exist, so a row past the end of the tensor is out of range and reads 0 --
-    // its step is never taken -- without a clamp per row)
+    // its step is never taken -- without a clamp per row.  The SCALAR offset takes part in the range
+    // check on gfx950: tools/bufrange_probe.hip, profiles/r3_bufrange_probe.txt.  Clamping instead
+    // costs 3 % as selects and 6 % at T = 4000 as a branch around the loads.)
     unsigned rowoff[BK];
 #pragma unroll
     for (int i = 0; i < BK; ++i) rowoff[i] = rs4 * (unsigned)i;

@@ -994,6 +994,18 @@ __global__ __launch_bounds__(POST_WAVES *WAVE) void crf_band_posterior_kernel(Ba
     auto frame_at = [&](const int16_t *ff, const int *fbase, int p) { return fbase[ckbase + (p >> pws_sh)] + (int)ff[ckrow + p]; };
     const float *bndFn = a.bndF + ((size_t)n * NB + jb) * W * BK;
     const float *bndBn = a.bndB + ((size_t)n * NB + jb) * W * BK;
+    // Per-wave buffer descriptors for everything a chunk loads: the chunk is then a SCALAR offset and the lane a
+    // constant vector offset -- no 64-bit address arithmetic per load -- and the descriptors' bounds return the
+    // 0 that cells past the end of the read take (stay ids at p >= L, move ids at p - 1 < 0 or p >= L - 1).
+    const __amdgpu_buffer_rsrc_t rFm = __builtin_amdgcn_make_buffer_rsrc(a.ckFm + ckrow, 0, (int)(a.LP * 4), BUF_WORD3);
+    const __amdgpu_buffer_rsrc_t rBm = __builtin_amdgcn_make_buffer_rsrc(a.ckBm + ckrow, 0, (int)(a.LP * 4), BUF_WORD3);
+    const __amdgpu_buffer_rsrc_t rFf = __builtin_amdgcn_make_buffer_rsrc(a.ckFf + ckrow, 0, (int)(a.LP * 2), BUF_WORD3);
+    const __amdgpu_buffer_rsrc_t rBf = __builtin_amdgcn_make_buffer_rsrc(a.ckBf + ckrow, 0, (int)(a.LP * 2), BUF_WORD3);
+    const __amdgpu_buffer_rsrc_t rSt = __builtin_amdgcn_make_buffer_rsrc(const_cast<int32_t *>(a.stay + off), 0, L * 4, BUF_WORD3);
+    const __amdgpu_buffer_rsrc_t rMv = __builtin_amdgcn_make_buffer_rsrc(const_cast<int32_t *>(a.move + off), 0, (L - 1) * 4, BUF_WORD3);
+    const __amdgpu_buffer_rsrc_t rRec = __builtin_amdgcn_make_buffer_rsrc(a.rec + (size_t)n * W * EPL * WAVE, 0, (int)(W * EPL * WAVE * 4), BUF_WORD3);
+    const __amdgpu_buffer_rsrc_t rSeg = __builtin_amdgcn_make_buffer_rsrc(a.segend + (size_t)n * W * WAVE, 0, (int)(W * WAVE * 4), BUF_WORD3);
+    const unsigned lane4 = 4u * (unsigned)lane;
 
     // One chunk of the wave's time block.  Everything is straight-line and branch-free so that the
     // LDS round trips, the two recurrence chains and the RG prefix scans of a row group overlap
@@ -1019,9 +1031,11 @@ __global__ __launch_bounds__(POST_WAVES *WAVE) void crf_band_posterior_kernel(Ba
             const int p = a0 + lane * R + j;
             hasi[j] = p >= 1 && p < L;
             haso[j] = p < L - 1;
-            st4[j] = 4 * ((p < L) ? a.stay[off + p] : 0);
-            mi4[j] = 4 * (hasi[j] ? a.move[off + p - 1] : 0);
-            mo4[j] = 4 * (haso[j] ? a.move[off + p] : 0);
+            // (R = 1: p = a0 + lane; the moves' descriptor ends at L - 1, the vector offset of p - 1 wraps to
+            // "far out of range" at p = 0)
+            st4[j] = 4 * (int)__builtin_amdgcn_raw_buffer_load_b32(rSt, lane4, 4u * (unsigned)a0, 0);
+            mi4[j] = 4 * (int)__builtin_amdgcn_raw_buffer_load_b32(rMv, 4u * (unsigned)p - 4u, 0, 0);
+            mo4[j] = 4 * (int)__builtin_amdgcn_raw_buffer_load_b32(rMv, lane4, 4u * (unsigned)a0, 0);
             if (MOD) {
                 di4[MOD ? j : 0] = 4 * (hasi[j] ? a.mod[off + p - 1] : 0);
                 do4[MOD ? j : 0] = 4 * (haso[j] ? a.mod[off + p] : 0);
@@ -1029,10 +1043,10 @@ __global__ __launch_bounds__(POST_WAVES *WAVE) void crf_band_posterior_kernel(Ba
                 fwi[MOD ? j : 0] = mfi[MOD ? j : 0] * a.c_mod;
                 fwo[MOD ? j : 0] = haso[j] ? a.modfact[off + p] * a.c_mod : 0.f;
             }
-            fv[j] = a.ckFm[ckrow + a0 + lane * R + j];
-            fF[j] = baseF + (int)a.ckFf[ckrow + a0 + lane * R + j];
-            bv[BK - 1][j] = a.ckBm[ckrow + a0 + lane * R + j];
-            fB[j] = baseB + (int)a.ckBf[ckrow + a0 + lane * R + j];
+            fv[j] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rFm, lane4, 4u * (unsigned)a0, 0));
+            fF[j] = baseF + (int)(short)__builtin_amdgcn_raw_buffer_load_b16(rFf, lane4 / 2, 2u * (unsigned)a0, 0);
+            bv[BK - 1][j] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rBm, lane4, 4u * (unsigned)a0, 0));
+            fB[j] = baseB + (int)(short)__builtin_amdgcn_raw_buffer_load_b16(rBf, lane4 / 2, 2u * (unsigned)a0, 0);
         }
         // boundary cells: forward from chunk ck-1 into lane 0, backward from chunk ck+1 into lane 63
         float einF[BK], einB[BK];
@@ -1069,8 +1083,9 @@ __global__ __launch_bounds__(POST_WAVES *WAVE) void crf_band_posterior_kernel(Ba
         // ---- sorted order of this chunk: LDS word of every sorted position, segment-end look-up
         int addr[EPL];
 #pragma unroll
-        for (int r = 0; r < EPL; ++r) addr[r] = (int)a.rec[(((size_t)n * W + ck) * EPL + r) * WAVE + lane];
-        const int sidx = a.segend[((size_t)n * W + ck) * WAVE + lane] - 1;
+        for (int r = 0; r < EPL; ++r)
+            addr[r] = (int)__builtin_amdgcn_raw_buffer_load_b32(rRec, lane4, 4u * (unsigned)((ck * EPL + r) * WAVE), 0);
+        const int sidx = (int)__builtin_amdgcn_raw_buffer_load_b32(rSeg, lane4, 4u * (unsigned)(ck * WAVE), 0) - 1;
 
         // ---- backward columns t0+1 .. t0+nrows: bv[i] = column t0+i+1 (bv[nrows-1] = the checkpoint)
         if (!FULL) {

@@ -1005,6 +1005,10 @@ __global__ __launch_bounds__(POST_WAVES *WAVE) void crf_band_posterior_kernel(Ba
     const __amdgpu_buffer_rsrc_t rMv = __builtin_amdgcn_make_buffer_rsrc(const_cast<int32_t *>(a.move + off), 0, (L - 1) * 4, BUF_WORD3);
     const __amdgpu_buffer_rsrc_t rRec = __builtin_amdgcn_make_buffer_rsrc(a.rec + (size_t)n * W * EPL * WAVE, 0, (int)(W * EPL * WAVE * 4), BUF_WORD3);
     const __amdgpu_buffer_rsrc_t rSeg = __builtin_amdgcn_make_buffer_rsrc(a.segend + (size_t)n * W * WAVE, 0, (int)(W * WAVE * 4), BUF_WORD3);
+    const __amdgpu_buffer_rsrc_t rMd = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<int32_t *>(MOD ? a.mod + off : a.move + off), 0, (L - 1) * 4, BUF_WORD3);
+    const __amdgpu_buffer_rsrc_t rMf = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<float *>(MOD ? a.modfact + off : a.zeros), 0, MOD ? (L - 1) * 4 : 0, BUF_WORD3);
     const unsigned lane4 = 4u * (unsigned)lane;
 
     // One chunk of the wave's time block.  Everything is straight-line and branch-free so that the
@@ -1037,11 +1041,11 @@ __global__ __launch_bounds__(POST_WAVES *WAVE) void crf_band_posterior_kernel(Ba
             mi4[j] = 4 * (int)__builtin_amdgcn_raw_buffer_load_b32(rMv, 4u * (unsigned)p - 4u, 0, 0);
             mo4[j] = 4 * (int)__builtin_amdgcn_raw_buffer_load_b32(rMv, lane4, 4u * (unsigned)a0, 0);
             if (MOD) {
-                di4[MOD ? j : 0] = 4 * (hasi[j] ? a.mod[off + p - 1] : 0);
-                do4[MOD ? j : 0] = 4 * (haso[j] ? a.mod[off + p] : 0);
-                mfi[MOD ? j : 0] = hasi[j] ? a.modfact[off + p - 1] : 0.f;
+                di4[MOD ? j : 0] = 4 * (int)__builtin_amdgcn_raw_buffer_load_b32(rMd, 4u * (unsigned)p - 4u, 0, 0);
+                do4[MOD ? j : 0] = 4 * (int)__builtin_amdgcn_raw_buffer_load_b32(rMd, lane4, 4u * (unsigned)a0, 0);
+                mfi[MOD ? j : 0] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rMf, 4u * (unsigned)p - 4u, 0, 0));
                 fwi[MOD ? j : 0] = mfi[MOD ? j : 0] * a.c_mod;
-                fwo[MOD ? j : 0] = haso[j] ? a.modfact[off + p] * a.c_mod : 0.f;
+                fwo[MOD ? j : 0] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rMf, lane4, 4u * (unsigned)a0, 0)) * a.c_mod;
             }
             fv[j] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rFm, lane4, 4u * (unsigned)a0, 0));
             fF[j] = baseF + (int)(short)__builtin_amdgcn_raw_buffer_load_b16(rFf, lane4 / 2, 2u * (unsigned)a0, 0);

@@ -991,6 +991,16 @@ __global__ __launch_bounds__(POST_WAVES *WAVE) void crf_band_posterior_kernel(Ba
     const size_t ckrow = ((size_t)n * NB + jb) * a.LP;
     const size_t ckbase = ((size_t)n * NB + jb) * a.W;           // the block's frame bases, one per sweep chunk
     const int pws_sh = 31 - __builtin_clz(PWS);                  // (PWS = 64, 128 or 256 cells)
+    // Did the SWEEP chunk that holds cell p run this time block?  band_window(w) solved for the block once per
+    // wave: chunk start a = w PWS is live in block jb iff  a <= t0 + BK  and  a + PWS - 1 >= t0 - (T - L + 1)
+    // (reads without a complete path, L > T + 1, keep every block) -- two scalars per wave and three compares
+    // per chunk instead of three window evaluations per chunk.
+    const bool notrim = L > T + 1;
+    const int live_hi = t0 + BK, live_lo = t0 - (T - L + 1) - PWS + 1;
+    auto sweep_live = [&](int p) {
+        const int as = (p >> pws_sh) << pws_sh;
+        return p >= 0 && as < L && (notrim || (as <= live_hi && as >= live_lo));
+    };
     auto frame_at = [&](const int16_t *ff, const int *fbase, int p) { return fbase[ckbase + (p >> pws_sh)] + (int)ff[ckrow + p]; };
     const float *bndFn = a.bndF + ((size_t)n * NB + jb) * W * BK;
     const float *bndBn = a.bndB + ((size_t)n * NB + jb) * W * BK;
@@ -1019,9 +1029,8 @@ __global__ __launch_bounds__(POST_WAVES *WAVE) void crf_band_posterior_kernel(Ba
         constexpr bool FULL = decltype(full_tag)::value;
         const int a0 = ck * PW;
         // the neighbouring cells exist as boundary cells iff their SWEEP chunk ran this block
-        const Win wl = band_window((a0 - 1) >> pws_sh, PWS, L, T), wr = band_window((a0 + PW) >> pws_sh, PWS, L, T);
-        const bool plF = ck > 0 && jb >= wl.j0 && jb <= wl.j1;
-        const bool plB = ck + 1 < Wn && jb >= wr.j0 && jb <= wr.j1;
+        const bool plF = ck > 0 && sweep_live(a0 - 1);
+        const bool plB = ck + 1 < Wn && sweep_live(a0 + PW);
 
         // ---- ids, checkpoints, boundary cells, frames
         const int baseF = a.ckFb[ckbase + (a0 >> pws_sh)], baseB = a.ckBb[ckbase + (a0 >> pws_sh)];
@@ -1234,8 +1243,7 @@ __global__ __launch_bounds__(POST_WAVES *WAVE) void crf_band_posterior_kernel(Ba
 
     int nskip = 0;
     for (int ck = cmin; ck <= cmax; ++ck) {
-        const Win wme = band_window((ck * PW) >> pws_sh, PWS, L, T);    // the sweep chunk that holds these cells
-        if (jb < wme.j0 || jb > wme.j1) continue;               // (never for a live row: the windows cover the band)
+        if (!sweep_live(ck * PW)) continue;                     // (never for a live row: the windows cover the band)
         {
             // A cell's posterior is (mF es) (mB) 2^(fF + fB - zexp) with mantissas that start the
             // block below 1 and grow by at most (1 + 2^KLIP) 2^7.2 per step for |sharp score| <= 5:

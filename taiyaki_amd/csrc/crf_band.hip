@@ -1025,7 +1025,7 @@ __global__ __launch_bounds__(POST_WAVES *WAVE) void crf_band_posterior_kernel(Ba
     // LDS round trips, the two recurrence chains and the RG prefix scans of a row group overlap
     // (FULL = all BK rows exist; the last block of a T that is not a multiple of BK runs the
     // guarded form).
-    auto chunk_body = [&](int ck, auto full_tag) {
+    auto chunk_body = [&](int ck, int fF0, int fB0, auto full_tag) {
         constexpr bool FULL = decltype(full_tag)::value;
         const int a0 = ck * PW;
         // the neighbouring cells exist as boundary cells iff their SWEEP chunk ran this block
@@ -1033,7 +1033,6 @@ __global__ __launch_bounds__(POST_WAVES *WAVE) void crf_band_posterior_kernel(Ba
         const bool plB = ck + 1 < Wn && sweep_live(a0 + PW);
 
         // ---- ids, checkpoints, boundary cells, frames
-        const int baseF = a.ckFb[ckbase + (a0 >> pws_sh)], baseB = a.ckBb[ckbase + (a0 >> pws_sh)];
         int st4[R], mi4[R], mo4[R], di4[MOD ? R : 1], do4[MOD ? R : 1];
         float fwi[MOD ? R : 1], fwo[MOD ? R : 1], mfi[MOD ? R : 1];
         bool hasi[R], haso[R];
@@ -1057,9 +1056,9 @@ __global__ __launch_bounds__(POST_WAVES *WAVE) void crf_band_posterior_kernel(Ba
                 fwo[MOD ? j : 0] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rMf, lane4, 4u * (unsigned)a0, 0)) * a.c_mod;
             }
             fv[j] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rFm, lane4, 4u * (unsigned)a0, 0));
-            fF[j] = baseF + (int)(short)__builtin_amdgcn_raw_buffer_load_b16(rFf, lane4 / 2, 2u * (unsigned)a0, 0);
+            fF[j] = fF0;                                            // (the loop loaded them for its skip test)
             bv[BK - 1][j] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rBm, lane4, 4u * (unsigned)a0, 0));
-            fB[j] = baseB + (int)(short)__builtin_amdgcn_raw_buffer_load_b16(rBf, lane4 / 2, 2u * (unsigned)a0, 0);
+            fB[j] = fB0;
         }
         // boundary cells: forward from chunk ck-1 into lane 0, backward from chunk ck+1 into lane 63
         float einF[BK], einB[BK];
@@ -1244,6 +1243,10 @@ __global__ __launch_bounds__(POST_WAVES *WAVE) void crf_band_posterior_kernel(Ba
     int nskip = 0;
     for (int ck = cmin; ck <= cmax; ++ck) {
         if (!sweep_live(ck * PW)) continue;                     // (never for a live row: the windows cover the band)
+        // the chunk's frames: 16-bit offsets from the base of the sweep chunk that stored them
+        const int a0l = ck * PW;
+        const int fF0 = a.ckFb[ckbase + (a0l >> pws_sh)] + (int)(short)__builtin_amdgcn_raw_buffer_load_b16(rFf, lane4 / 2, 2u * (unsigned)a0l, 0);
+        const int fB0 = a.ckBb[ckbase + (a0l >> pws_sh)] + (int)(short)__builtin_amdgcn_raw_buffer_load_b16(rBf, lane4 / 2, 2u * (unsigned)a0l, 0);
         {
             // A cell's posterior is (mF es) (mB) 2^(fF + fB - zexp) with mantissas that start the
             // block below 1 and grow by at most (1 + 2^KLIP) 2^7.2 per step for |sharp score| <= 5:
@@ -1254,8 +1257,7 @@ __global__ __launch_bounds__(POST_WAVES *WAVE) void crf_band_posterior_kernel(Ba
             // goes to the log-domain kernel.  Most of the band lies outside the few chunks around the
             // alignment that carry the posterior mass: 43 % of the chunk-blocks at the train step's
             // shape, 77 % at T = 4000 are skipped.
-            const int p = ck * PW + lane;
-            const int kxl = (p < L) ? frame_at(a.ckFf, a.ckFb, p) + frame_at(a.ckBf, a.ckBb, p) - zexp : -(1 << 20);
+            const int kxl = (ck * PW + lane < L) ? fF0 + fB0 - zexp : -(1 << 20);
             const float kmax = wave_allmax_dpp((float)kxl);
             if (kmax < (float)POST_SKIP_BELOW) {
                 ++nskip;
@@ -1263,9 +1265,9 @@ __global__ __launch_bounds__(POST_WAVES *WAVE) void crf_band_posterior_kernel(Ba
             }
         }
         if (nrows == BK)
-            chunk_body(ck, std::true_type{});
+            chunk_body(ck, fF0, fB0, std::true_type{});
         else
-            chunk_body(ck, std::false_type{});
+            chunk_body(ck, fF0, fB0, std::false_type{});
     }
     // every row's total is Z 2^-zexp: a row that lost mass (or everything) disowns the read
     const float zfrac = (float)(scoreF - (double)zexp);

@@ -256,3 +256,22 @@ def test_shim_patches_an_importable_reference_package(tmp_path, monkeypatch):
     assert tl2.flipflop_logpartition(None) == "torch-loop"
     for k in [k for k in sys.modules if k == "taiyaki" or k.startswith("taiyaki.")]:
         sys.modules.pop(k, None)
+
+
+def test_beam_lse_tables_in_the_kernel_are_the_generators():
+    """The 162 table entries and the three reduction constants of the beam search's log-sum-exp
+    (csrc/beam_kernels.hip: BEAM_TAB, LN2_32_HI / _LO, INV_LN2_32) are exactly what
+    tools/beam_lse_tables.py derives from 60-digit decimals -- an edited digit would still pass every
+    parity test with a tolerance and quietly lose the bit-for-bit agreement with glibc."""
+    import re
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    gen = subprocess.run([sys.executable, os.path.join(root, "tools", "beam_lse_tables.py")], capture_output=True,
+                         text=True, check=True).stdout
+    want = re.findall(r"-?0x[0-9a-f.]+p[+-]\d+", gen)
+    src = open(os.path.join(root, "taiyaki_amd", "csrc", "beam_kernels.hip")).read()
+    tab = src[src.index("__constant__ double BEAM_TAB"):]
+    tab = tab[:tab.index("// tables into LDS")]
+    have = re.findall(r"-?0x[0-9a-f.]+p[+-]\d+", tab)
+    assert len(want) == 162 + 3 and have == want

@@ -275,3 +275,20 @@ def test_beam_lse_tables_in_the_kernel_are_the_generators():
     tab = tab[:tab.index("// tables into LDS")]
     have = re.findall(r"-?0x[0-9a-f.]+p[+-]\d+", tab)
     assert len(want) == 162 + 3 and have == want
+
+
+def test_beam_lse_host_twin_matches_glibc(tmp_path):
+    """tools/beam_lse_check.c is the host twin of the kernel's table-driven expf / log1pf: on every 101st
+    float in [0, 17) (11 M arguments; the full every-third sweep is a 16 s run of the same program) it
+    must give bit for bit what glibc's double exp / log1p give after rounding to float."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    hdr = subprocess.run([sys.executable, os.path.join(root, "tools", "beam_lse_tables.py")], capture_output=True,
+                         text=True, check=True).stdout
+    (tmp_path / "beam_lse_tables.h").write_text(hdr)
+    exe = str(tmp_path / "beam_lse_check")
+    subprocess.run(["gcc", "-O2", "-ffp-contract=off", "-DSTRIDE=101", "-I", str(tmp_path), "-o", exe,
+                    os.path.join(root, "tools", "beam_lse_check.c"), "-lm"], check=True)
+    out = subprocess.run([exe], capture_output=True, text=True, check=True).stdout
+    assert "expf mismatches 0, log1pf mismatches 0" in out, out

@@ -119,3 +119,28 @@ def test_linear_band_model_catmod(oracle_mod):
         assert not info["bad"]
         assert abs(cost - oloss[n]) <= 2e-6 * abs(oloss[n])
         assert np.abs(grad - ograd[:, n]).max() < 2e-6
+
+
+def test_sweep_liveness_closed_form_equals_the_windows():
+    """The gradient pass asks, per 64-cell chunk, whether the SWEEP chunk holding a cell ran the wave's time
+    block; crf_band.hip answers with band_window solved for the block once per wave (`sweep_live`: chunk
+    start a is live in block jb iff a <= t0 + BK and a + PWS - 1 >= t0 - (T - L + 1), every block for reads
+    without a complete path).  Here: that closed form against the schedule model's windows, exhaustively
+    over small shapes (the kernel's bit-for-bit regression runs cover the real ones)."""
+    from tests.helpers import crf_skew_model as sk
+    KB = 8
+    for T in (1, 7, 8, 9, 23, 40, 64, 65, 100):
+        for L in list(range(1, min(T + 4, 70))) + [T + 1, T + 2, 2 * T + 5]:
+            for PWS in (4, 8, 16):
+                win = sk.windows(L, T, PWS, KB)
+                NB = (T + KB - 1) // KB
+                notrim = L > T + 1
+                for jb in range(NB):
+                    t0 = jb * KB
+                    hi, lo = t0 + KB, t0 - (T - L + 1) - PWS + 1
+                    for p in range(-1, len(win) * PWS + PWS):
+                        a = (p // PWS) * PWS
+                        closed = p >= 0 and a < L and (notrim or (a <= hi and a >= lo))
+                        w = p // PWS
+                        ref = 0 <= w < len(win) and win[w][0] <= jb <= win[w][1]
+                        assert closed == ref, (T, L, PWS, jb, p)

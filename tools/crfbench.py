@@ -17,7 +17,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from taiyaki_amd import _lib, ctc, synth  # noqa: E402
 
 SHAPES = {"cfg2": (800, 128, None), "cfg2r": (800, 128, 4000), "cfg5": (1600, 64, None),
-          "cfg5r": (1600, 64, 8000), "rowK": (4000, 256, None), "cfg4": (800, 128, None), "cfg4r": (800, 128, 4000),
+          "cfg5r": (1600, 64, 8000), "rowK": (4000, 256, None), "rowK8": (4000, 256, "short"), "cfg4": (800, 128, None), "cfg4r": (800, 128, 4000),
           "one": (800, 1, 4000), "short": (800, 128, 450), "short1": (800, 1, 450), "mid": (800, 128, 1100)}
 MODES = {"band1": dict(TK_CRF_MODE="band", TK_CRF_BAND_R="1"), "band2": dict(TK_CRF_MODE="band", TK_CRF_BAND_R="2"),
          "band4": dict(TK_CRF_MODE="band", TK_CRF_BAND_R="4"), "band": dict(TK_CRF_MODE="band"),
@@ -52,7 +52,11 @@ def main():
     _lib.set_strict(False)
     for sh in args.shapes.split(","):
         T, N, chunk_len = SHAPES[sh]
-        seqlens = None if chunk_len is None else synth.realistic_seqlens(T, N, 17000, chunk_len, 9.0)
+        if chunk_len == "short":
+            # SPEED_TEST lengths scaled to at most 2048 cells: eight 256-cell chunks at four cells per lane
+            seqlens = np.minimum((synth.speedtest_seqlens(T, N) * 0.93).astype(np.int32), 2048)
+        else:
+            seqlens = None if chunk_len is None else synth.realistic_seqlens(T, N, 17000, chunk_len, 9.0)
         mods = (1, 1, 0, 0) if sh.startswith("cfg4") else None
         inp = synth.crf_case(T, N, 1, seqlens=seqlens, nmods_per_base=mods)
         if mods is not None:

@@ -678,6 +678,7 @@ def test_catmod_column_weights_form_agrees_with_the_general_form(oracle_mod, gpu
     seqs, sl = torch.from_numpy(inp["seqs"]), torch.from_numpy(inp["seqlens"])
     extra = (torch.from_numpy(inp["mod_cats"]), inp["can_mods_offsets"], inp["mod_cat_weights"])
     out = {}
+    monkeypatch.delenv("TK_CATMOD_GENERAL", raising=False)
     for general in ("", "1"):
         if general:
             monkeypatch.setenv("TK_CATMOD_GENERAL", "1")

@@ -379,6 +379,41 @@ def reference_copies_ms(T, N, S, dev, reps=10):
     return (time.perf_counter() - t0) / reps * 1e3
 
 
+def forced_group_overhead(args, argv, plain_ms):
+    """N = 1 only: what the data-parallel machinery costs before any wire is involved.  A child runs
+    the same step with a forced ONE-rank RCCL process group (TK_FORCE_PROCESS_GROUP=1: communicator,
+    watchdog, the arena's all-reduce and its stream joins, the 1 / world pass) while this process
+    idles; overhead_ms = its ms/step - the plain step's.  The part of north_star's 1 -> 8 target
+    that a one-GPU box can measure."""
+    keep = []
+    skip = 0
+    for a in argv:
+        if skip:
+            skip -= 1
+        elif a in ("--gpus",):
+            skip = 1
+        elif a not in ("--no-cpu-baseline", "--no-pmc", "--no-rowk", "--no-kernel-records"):
+            keep.append(a)
+    cmd = [sys.executable, os.path.abspath(__file__)] + keep + ["--gpus", "1", "--no-kernel-records",
+                                                               "--steps", str(args.steps), "--warmup", str(args.warmup)]
+    env = dict(os.environ, RANK="0", LOCAL_RANK="0", WORLD_SIZE="1", TK_FORCE_PROCESS_GROUP="1",
+               MASTER_ADDR="127.0.0.1", MASTER_PORT=str(_free_port()))
+    try:
+        pr = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
+        line = [ln for ln in pr.stdout.splitlines() if ln.startswith("{")]
+        if pr.returncode != 0 or not line:
+            return dict(forced_group="failed (rc %d): %s" % (pr.returncode, pr.stderr[-300:]))
+        d = json.loads(line[-1])
+    except subprocess.TimeoutExpired:
+        return dict(forced_group="timed out")
+    r = d.get("rccl") or {}
+    r.update(forced_group_ms_per_step=d["ms_per_step"], plain_ms_per_step=round(plain_ms, 3),
+             overhead_ms=round(d["ms_per_step"] - plain_ms, 3),
+             how="child process, same command with a forced one-rank RCCL process group "
+                 "(TK_FORCE_PROCESS_GROUP=1); box-to-box and run-to-run spread of the plain step is about +-0.5 ms")
+    return r
+
+
 # ---------------------------------------------------------------------------------------------
 def dry_launch(args):
     """Launcher check without GPUs (tests/test_data_parallel.py): the ranks rendezvous over gloo,
@@ -477,6 +512,82 @@ def variable_length_bench(args, cfg, trainer, dev, rank, use_graph):
                     distinct_graphs=len(getattr(stepper, "entries", {}))))), flush=True)
 
 
+def kernel_records(out, args, cfg, dev, world, T, nbatch, chunk_len, cat_mod, S):
+    """The loss-path kernel records of the JSON line (`roofline*`, `loss_path`, `cpu_baseline`)."""
+    # ---- loss-path kernels, HIP events on the launching stream, right after the timed steps
+    #      (the step itself may be a hipGraph replay, so per-launch events cannot be
+    #      interleaved with it) -----------------------------------------------------------
+    step_ops = LossOps(T, nbatch, dev, realistic_chunk_len=chunk_len, spb=cfg["spb"], cat_mod=cat_mod)
+    specs = [("logz", T, nbatch, 0), ("crf", T, nbatch, chunk_len)]
+    rowk = None
+    if not args.no_rowk:
+        rowk = LossOps(4000, 256, dev)
+        specs = [("logz", 4000, 256, 0), ("crf", 4000, 256, 0)] + specs
+    # N > 1: the other ranks wait in a barrier while rank 0 fills in the kernel records -- no
+    # rocprofv3 passes and no CPU leg there (both belong to the N = 1 line; `traffic` then
+    # comes from the committed profile of the same kernel hash)
+    no_pmc = args.no_pmc or world > 1
+    no_cpu = args.no_cpu_baseline or world > 1
+    measured = {} if no_pmc else measure_traffic_now(specs)
+    khash = kernel_hash()
+
+    def traffic_of(op, t, n, realistic):
+        key = "%s:%d:%d:%d" % (op, t, n, realistic)
+        if key in measured:
+            return measured[key], dict(measured="in this run (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, "
+                                                "separate passes, tools/pmc_traffic.py)", kernel_hash=khash,
+                                       current=True)
+        return committed_traffic(op, t, n)
+
+    def logz_roofline(ops, reps, label):
+        mean_s, min_s = _events_mean_min(ops.logz_op, reps)
+        tr, src = traffic_of("logz", ops.T, ops.N, 0)
+        return roofline_record("logZ forward-backward op (logz_transfer + logz_middle + logz_posterior), "
+                               "T=%d N=%d (%s)" % (ops.T, ops.N, label), 3.0 * ops.T * ops.N * 40 * 4,
+                               mean_s, min_s, reps, tr, src)
+
+    def crf_roofline(ops, reps, label, realistic):
+        mean_s, min_s = _events_mean_min(ops.crf, reps, warm=5)
+        tr, src = traffic_of("crf", ops.T, ops.N, realistic)
+        return roofline_record("sequence CRF op (build_indices + crf_band_sweep + crf_band_posterior + gated crf_kernel), "
+                               "T=%d N=%d S=%d, max L %d (%s)" % (ops.T, ops.N, ops.S, ops.maxlen, label),
+                               3.0 * ops.T * ops.N * ops.S * 4, mean_s, min_s, reps, tr, src)
+
+    if rowk is not None:
+        out["roofline"] = logz_roofline(rowk, 50, "north_star kernel shape")
+        out["roofline_in_step"] = logz_roofline(step_ops, 30, "the train step's own launch")
+        out["roofline_crf"] = dict(
+            in_step=crf_roofline(step_ops, 20, "the train step's own launch, realistic lengths", chunk_len),
+            rowK=crf_roofline(rowk, 5, "north_star shape, SPEED_TEST lengths 0.45-0.55 T", 0),
+            note="linear-domain band sweeps (per-cell power-of-two frames) + recomputing gradient pass: both are "
+                 "bound by instruction issue -- T serial steps per read, all of a read's waves on one CU -- "
+                 "not by HBM; `traffic` = scores read three times, one checkpoint column + boundary cells per "
+                 "8-step block written and read, the gradient written once; achieved is the algorithmic "
+                 "3*T*N*S*4 bytes over the op's duration (build_indices + sweeps + gradient pass + the gated "
+                 "log-domain launch, which finds nothing to redo on these inputs)")
+    else:
+        out["roofline"] = logz_roofline(step_ops, 30, "the train step's own launch")
+    # ---- the whole loss path in one unit ------------------------------------------------
+    lp_mean, _ = _events_mean_min(step_ops.both, 20, warm=5)
+    assert step_ops.finite()
+    out["loss_path"] = dict(unit="chunks/s through crf grad + logZ fwd-bwd at the step's shape (T=%d, N=%d, "
+                                 "S=%d, realistic lengths)" % (T, nbatch, S),
+                            launch=("tk_flipflop_loss_fused_dev, cat-mod form: logZ of the canonical columns first, "
+                                    "folded into the cat-mod kernel's writes; one gradient tensor" if cat_mod else
+                                    "tk_flipflop_loss_fused_dev: one gradient tensor"),
+                            gpu_ms=round(lp_mean * 1e3, 4), gpu_chunks_per_s=round(nbatch / lp_mean, 1))
+    if not no_cpu:
+        cb = cpu_baseline(T, nbatch)
+        out["cpu_baseline"] = cb
+        copies = reference_copies_ms(T, nbatch, S, dev)
+        cpu_ms = nbatch / cb["value"] * 1e3
+        out["loss_path"].update(
+            cpu_chunks_per_s=cb["value"], cpu_ms=round(cpu_ms, 3), copies_ms=round(copies, 3),
+            cpu_with_copies_chunks_per_s=round(nbatch / ((cpu_ms + copies) * 1e-3), 2),
+            note="cpu = %s on %d host threads; copies = score tensor D->H + gradient H->D (pinned), what "
+                 "the reference's CPU extension adds per call (ctc.pyx:119, 139-141)" % (cb["kind"], cb["cores"]))
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=None)
@@ -512,9 +623,13 @@ def main():
                     help="with --data store: take the reads from this mapped-signal HDF5 (classic layout, read by "
                          "taiyaki_amd.hdf5_lite) or packed .npz file instead of synthetic reads, e.g. "
                          "tests/golden/mapped_signal/mapped_reads_0.hdf5 (real r9.4.1 reads)")
-    ap.add_argument("--overlap-buckets", type=int, default=4,
-                    help="gradient all-reduce slices issued from backward hooks (N > 1); 0 = one all-reduce "
-                         "after backward")
+    ap.add_argument("--overlap-buckets", type=int, default=0,
+                    help="gradient all-reduce slices issued from backward hooks (N > 1); 0 (default) = ONE flat "
+                         "all-reduce after backward -- measured: slices issued inside the eager RNN backward cost "
+                         "3-4 ms each (profiles/r4_forced_group_bisect.txt), the one flat call nothing")
+    ap.add_argument("--no-forced-group", action="store_true",
+                    help="N = 1: skip the child run that repeats the step with a one-rank RCCL process group "
+                         "(the `rccl.overhead_ms` field)")
     ap.add_argument("--chunk-len-range", type=int, nargs=2, default=None, metavar=("MIN", "MAX"),
                     help="the reference's own schedule (bin/train_flipflop.py:554-563, defaults 3000 8000): every "
                          "step draws a chunk length in [MIN, MAX] and rescales the batch to batch * chunk_len / "
@@ -523,6 +638,8 @@ def main():
     ap.add_argument("--len-bucket", type=int, default=100, help="grid of --chunk-len-range in blocks (strides)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-rowk", action="store_true")
+    ap.add_argument("--no-kernel-records", action="store_true",
+                    help="the train-step line only (no roofline / loss_path / cpu_baseline records)")
     ap.add_argument("--no-pmc", action="store_true", help="do not run the rocprofv3 PMC passes")
     ap.add_argument("--probe-graph", action="store_true", help=argparse.SUPPRESS)
     ap.add_argument("--dry-launch", action="store_true", help=argparse.SUPPRESS)
@@ -628,7 +745,7 @@ def main():
     # rendezvous (it carries RCCL's unique id) and the bench's own barriers
     collective = None
     if os.environ.get("TK_RCCL_DIRECT") and dev.type == "cuda" and (world > 1 or os.environ.get("TK_FORCE_PROCESS_GROUP")):
-        collective = parallel.DirectRccl(rank, world, device=dev)
+        collective = parallel.DirectRccl(rank, world, device=dev, in_stream=bool(os.environ.get("TK_RCCL_INSTREAM")))
     parallel.broadcast_parameters(net, collective=collective)
     arena = parallel.FlatGradArena(net, overlap_buckets=args.overlap_buckets, collective=collective)
     # the reference's default adaptive clipping (--gradient_clip_num_mads 0, window 1000):
@@ -757,8 +874,9 @@ def main():
                     allreduce_us=round(float(np.mean(us)), 1), allreduce_min_us=round(us[0], 1),
                     overlap_buckets=len(arena._buckets),
                     bucket_bytes=[(hi - lo) * 4 for lo, hi in arena.slices()], bucket_us=bucket_us,
-                    note="one flat fp32 gradient arena; in the step it is reduced in %d slices issued from "
-                         "backward hooks on RCCL's high-priority stream" % max(1, len(arena._buckets)))
+                    note=("one flat fp32 gradient arena; in the step it is reduced in %d slices issued from backward "
+                          "hooks on RCCL's high-priority stream" % len(arena._buckets) if arena._buckets else
+                          "one flat fp32 gradient arena, reduced by ONE all-reduce after backward"))
 
     if rank == 0:
         nglobal = nbatch * world
@@ -779,84 +897,17 @@ def main():
                                conv=args.conv, lstm=args.lstm,
                                batches=("assembled on the device every step from a mapped-signal set in HBM"
                                         if args.data == "store" else "pre-assembled, cycled from HBM"),
-                               parallelism="dp%d (reads sharded, bucketed RCCL all-reduce overlapped with backward)"
-                               % world))
+                               parallelism="dp%d (reads sharded; %s)" % (
+                                   world, "gradient all-reduce in %d slices from backward hooks" % args.overlap_buckets
+                                   if args.overlap_buckets > 1 else "one flat RCCL gradient all-reduce after backward")))
         if rccl is not None:
             out["rccl"] = rccl
             out["per_rank_ms"] = per_rank
             out["cores_per_rank"] = len(cores)
-        # ---- loss-path kernels, HIP events on the launching stream, right after the timed steps
-        #      (the step itself may be a hipGraph replay, so per-launch events cannot be
-        #      interleaved with it) -----------------------------------------------------------
-        step_ops = LossOps(T, nbatch, dev, realistic_chunk_len=chunk_len, spb=cfg["spb"], cat_mod=cat_mod)
-        specs = [("logz", T, nbatch, 0), ("crf", T, nbatch, chunk_len)]
-        rowk = None
-        if not args.no_rowk:
-            rowk = LossOps(4000, 256, dev)
-            specs = [("logz", 4000, 256, 0), ("crf", 4000, 256, 0)] + specs
-        # N > 1: the other ranks wait in a barrier while rank 0 fills in the kernel records -- no
-        # rocprofv3 passes and no CPU leg there (both belong to the N = 1 line; `traffic` then
-        # comes from the committed profile of the same kernel hash)
-        no_pmc = args.no_pmc or world > 1
-        no_cpu = args.no_cpu_baseline or world > 1
-        measured = {} if no_pmc else measure_traffic_now(specs)
-        khash = kernel_hash()
-
-        def traffic_of(op, t, n, realistic):
-            key = "%s:%d:%d:%d" % (op, t, n, realistic)
-            if key in measured:
-                return measured[key], dict(measured="in this run (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, "
-                                                    "separate passes, tools/pmc_traffic.py)", kernel_hash=khash,
-                                           current=True)
-            return committed_traffic(op, t, n)
-
-        def logz_roofline(ops, reps, label):
-            mean_s, min_s = _events_mean_min(ops.logz_op, reps)
-            tr, src = traffic_of("logz", ops.T, ops.N, 0)
-            return roofline_record("logZ forward-backward op (logz_transfer + logz_middle + logz_posterior), "
-                                   "T=%d N=%d (%s)" % (ops.T, ops.N, label), 3.0 * ops.T * ops.N * 40 * 4,
-                                   mean_s, min_s, reps, tr, src)
-
-        def crf_roofline(ops, reps, label, realistic):
-            mean_s, min_s = _events_mean_min(ops.crf, reps, warm=5)
-            tr, src = traffic_of("crf", ops.T, ops.N, realistic)
-            return roofline_record("sequence CRF op (build_indices + crf_band_sweep + crf_band_posterior + gated crf_kernel), "
-                                   "T=%d N=%d S=%d, max L %d (%s)" % (ops.T, ops.N, ops.S, ops.maxlen, label),
-                                   3.0 * ops.T * ops.N * ops.S * 4, mean_s, min_s, reps, tr, src)
-
-        if rowk is not None:
-            out["roofline"] = logz_roofline(rowk, 50, "north_star kernel shape")
-            out["roofline_in_step"] = logz_roofline(step_ops, 30, "the train step's own launch")
-            out["roofline_crf"] = dict(
-                in_step=crf_roofline(step_ops, 20, "the train step's own launch, realistic lengths", chunk_len),
-                rowK=crf_roofline(rowk, 5, "north_star shape, SPEED_TEST lengths 0.45-0.55 T", 0),
-                note="linear-domain band sweeps (per-cell power-of-two frames) + recomputing gradient pass: both are "
-                     "bound by instruction issue -- T serial steps per read, all of a read's waves on one CU -- "
-                     "not by HBM; `traffic` = scores read three times, one checkpoint column + boundary cells per "
-                     "8-step block written and read, the gradient written once; achieved is the algorithmic "
-                     "3*T*N*S*4 bytes over the op's duration (build_indices + sweeps + gradient pass + the gated "
-                     "log-domain launch, which finds nothing to redo on these inputs)")
-        else:
-            out["roofline"] = logz_roofline(step_ops, 30, "the train step's own launch")
-        # ---- the whole loss path in one unit ------------------------------------------------
-        lp_mean, _ = _events_mean_min(step_ops.both, 20, warm=5)
-        assert step_ops.finite()
-        out["loss_path"] = dict(unit="chunks/s through crf grad + logZ fwd-bwd at the step's shape (T=%d, N=%d, "
-                                     "S=%d, realistic lengths)" % (T, nbatch, S),
-                                launch=("tk_flipflop_loss_fused_dev, cat-mod form: logZ of the canonical columns first, "
-                                        "folded into the cat-mod kernel's writes; one gradient tensor" if cat_mod else
-                                        "tk_flipflop_loss_fused_dev: one gradient tensor"),
-                                gpu_ms=round(lp_mean * 1e3, 4), gpu_chunks_per_s=round(nbatch / lp_mean, 1))
-        if not no_cpu:
-            cb = cpu_baseline(T, nbatch)
-            out["cpu_baseline"] = cb
-            copies = reference_copies_ms(T, nbatch, S, dev)
-            cpu_ms = nbatch / cb["value"] * 1e3
-            out["loss_path"].update(
-                cpu_chunks_per_s=cb["value"], cpu_ms=round(cpu_ms, 3), copies_ms=round(copies, 3),
-                cpu_with_copies_chunks_per_s=round(nbatch / ((cpu_ms + copies) * 1e-3), 2),
-                note="cpu = %s on %d host threads; copies = score tensor D->H + gradient H->D (pinned), what "
-                     "the reference's CPU extension adds per call (ctc.pyx:119, 139-141)" % (cb["kind"], cb["cores"]))
+        elif world == 1 and not args.no_forced_group and not dist.is_initialized():
+            out["rccl"] = forced_group_overhead(args, argv, elapsed / args.steps * 1e3)
+        if not args.no_kernel_records:
+            kernel_records(out, args, cfg, dev, world, T, nbatch, chunk_len, cat_mod, S)
     else:
         out = None
     if dist.is_initialized():

@@ -23,6 +23,7 @@ _i = ctypes.c_int
 # symbol -> (restype, argtypes); mirrors include/taiyaki_amd_flipflop.h
 SIGNATURES = {
     "tk_version": (ctypes.c_char_p, []),
+    "tk_lab_crf_band_phase": (None, [_i]),
     "tk_flipflop_build_indices_dev": (_i, [_vp, _vp, _sz, _sz, _sz, _vp, _vp, _vp, _vp, _vp,
                                           _vp, _vp, _vp, _vp, _vp]),
     "tk_crf_flipflop_workspace_bytes": (_sz, [_sz, _sz, _sz, _sz, _i]),

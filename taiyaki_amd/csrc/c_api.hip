@@ -308,7 +308,7 @@ int tk_flipflop_loss_fused_dev(const float *scores, size_t nblk, size_t nbatch, 
     return rc;
 }
 
-// lab only (not declared in the public header): see crf_band.hip
+// lab hook: see crf_band.hip
 void tk_lab_crf_band_phase(int phase) { tk::crf_band_lab_phase(phase); }
 
 int tk_flipflop_lattice_dev(const float *scores, size_t nblk, size_t nbatch, size_t nbase, int forward,

@@ -142,6 +142,109 @@ def _run(logprob, seqs, seqlen, sharp_can, sharp_mod, out_scale, ncan, want_grad
     return cost, grad
 
 
+# ---------------------------------------------------------------------------------------------
+# the numpy-level functions of taiyaki.ctc (ctc.pyx:13-113, 162-255) on the exact C prototypes
+# ---------------------------------------------------------------------------------------------
+def nstate_to_nbase(nstate):
+    """ctc.pyx:13-21: number of bases of a flip-flop model with `nstate` transition scores;
+    AssertionError when nstate is not 2 nb (nb + 1)."""
+    nbase_f = np.float32(np.sqrt(0.25 + (0.5 * nstate)) - 0.5)
+    assert np.mod(nbase_f, 1) == 0, (
+        'Number of states not valid for flip-flop model. ' +
+        'nstates: {}\tconverted nbases: {}').format(nstate, nbase_f)
+    return int(nbase_f)
+
+
+def _host_call(name, logprob, idx_arrays, seqlen, want_grad, pin, check_states):
+    """One call of an exact-prototype entry point (`crf_flipflop_cost` ... in
+    include/taiyaki_amd_flipflop.h: host pointers in the reference's layout, staged through device
+    memory by the library) with the Cython layer's contract around it: C-contiguous typed arrays,
+    finite input, finite output, outputs allocated here (pinned on request), -x / nblk returned.
+    `idx_arrays`: (array, dtype, argument name) in prototype order."""
+    logprob = _typed(logprob, np.float32, 3, "logprob")
+    seqlen = _typed(seqlen, np.int32, 1, "seqlen")
+    idx = [_typed(a, dt, 1, nm) for a, dt, nm in idx_arrays]
+    assert np.all(np.isfinite(logprob)), "Input not finite"
+    nblk, nbatch, nstate = logprob.shape
+    if check_states:
+        nstate_to_nbase(nstate)
+    if seqlen.shape[0] != nbatch:
+        raise ValueError("seqlen has %d entries for a batch of %d" % (seqlen.shape[0], nbatch))
+    # the C layer trusts the index arrays' lengths (c_crf_flipflop.c:446-451); a short array would be
+    # read past its end by the staging loop, so check here what Cython's bounds checks cannot
+    nstay = int(seqlen.sum())
+    nmove = int(np.maximum(seqlen.astype(np.int64) - 1, 0).sum())
+    for a, (_, _, nm) in zip(idx, idx_arrays):
+        need = nstay if nm == "stayidxs" else nmove
+        if a.shape[0] < need:
+            raise ValueError("%s has %d entries, the sequence lengths need %d" % (nm, a.shape[0], need))
+    costs = torch.zeros(nbatch, device='cpu', dtype=torch.float)
+    grads = torch.zeros(nblk, nbatch, nstate, device='cpu', dtype=torch.float) if want_grad else None
+    if pin:
+        costs = costs.pin_memory()
+        grads = grads.pin_memory() if want_grad else None
+    args = [_lib._vp(logprob.ctypes.data), nstate, nblk, nbatch] + [_lib._vp(a.ctypes.data) for a in idx]
+    args += [_lib._vp(seqlen.ctypes.data), _lib._vp(costs.data_ptr())]
+    if want_grad:
+        args.append(_lib._vp(grads.data_ptr()))
+    getattr(_lib.lib(), name)(*args)
+    costs_np = costs.numpy()
+    assert np.all(np.isfinite(costs_np)), (
+        "Error: all costs must be finite, got {}.\n"
+        "Try restarting from a checkpoint with a lower learning rate."
+    ).format(costs_np)
+    if not want_grad:
+        return -costs / nblk
+    assert np.all(np.isfinite(grads.numpy())), ("Error: Gradients not finite.\n"
+                                                "Try restarting from a checkpoint with a lower learning rate.")
+    return -costs / nblk, -grads / nblk
+
+
+def _typed(a, dtype, ndim, name):
+    """The typed-buffer check of a Cython signature (`np.ndarray[np.float32_t, ndim=3, mode="c"]`):
+    wrong dtype / rank / layout is an error there, not a silent conversion."""
+    if not isinstance(a, np.ndarray):
+        raise TypeError("Argument '%s' has incorrect type (expected numpy.ndarray, got %s)" % (name, type(a).__name__))
+    if a.dtype != np.dtype(dtype):
+        raise ValueError("Buffer dtype mismatch for '%s', expected '%s' but got '%s'" % (name, np.dtype(dtype), a.dtype))
+    if a.ndim != ndim:
+        raise ValueError("Buffer has wrong number of dimensions for '%s' (expected %d, got %d)" % (name, ndim, a.ndim))
+    if not a.flags.c_contiguous:
+        raise ValueError("ndarray is not C-contiguous ('%s')" % name)
+    return a
+
+
+def crf_flipflop_cost(logprob, moveidxs, stayidxs, seqlen, pin=False):
+    """ctc.pyx:31-66.  logprob (nblk, nbatch, nstate) float32, moveidxs (sum(seqlen) - nseq) and
+    stayidxs (sum(seqlen)) uintp transition ids, seqlen (nseq) int32, all C-contiguous numpy
+    arrays; returns the costs -score / nblk as a CPU tensor (nbatch,)."""
+    return _host_call("crf_flipflop_cost", logprob, [(moveidxs, np.uintp, "moveidxs"), (stayidxs, np.uintp, "stayidxs")],
+                      seqlen, False, pin, True)
+
+
+def crf_flipflop_grad(logprob, moveidxs, stayidxs, seqlen, pin=False):
+    """ctc.pyx:69-113: (costs (nbatch,), d cost / d logprob (nblk, nbatch, nstate)) as CPU tensors."""
+    return _host_call("crf_flipflop_grad", logprob, [(moveidxs, np.uintp, "moveidxs"), (stayidxs, np.uintp, "stayidxs")],
+                      seqlen, True, pin, True)
+
+
+def cat_mod_flipflop_cost(logprob, moveidxs, stayidxs, modmoveidxs, modmovefacts, seqlen, pin=False):
+    """ctc.pyx:162-204: as `crf_flipflop_cost` with a modification column id (uintp) and factor
+    (float32) per move."""
+    return _host_call("cat_mod_flipflop_cost", logprob,
+                      [(moveidxs, np.uintp, "moveidxs"), (stayidxs, np.uintp, "stayidxs"),
+                       (modmoveidxs, np.uintp, "modmoveidxs"), (modmovefacts, np.float32, "modmovefacts")],
+                      seqlen, False, pin, False)
+
+
+def cat_mod_flipflop_grad(logprob, moveidxs, stayidxs, modmoveidxs, modmovefacts, seqlen, pin=False):
+    """ctc.pyx:207-255"""
+    return _host_call("cat_mod_flipflop_grad", logprob,
+                      [(moveidxs, np.uintp, "moveidxs"), (stayidxs, np.uintp, "stayidxs"),
+                       (modmoveidxs, np.uintp, "modmoveidxs"), (modmovefacts, np.float32, "modmovefacts")],
+                      seqlen, True, pin, False)
+
+
 class FlipFlopCRF(torch.autograd.Function):
     """taiyaki/ctc/ctc.pyx:116-151"""
 

@@ -65,6 +65,12 @@ def flipflop_logpartition(x, _never_use_cupy=False):
     return LogZ.apply(x)
 
 
+def log_partition_flipflop(scores):
+    """layers.py:1277-1299, the reference's torch statement of the same quantity: (N, 1).  Here it
+    is the same HIP operator (differentiable through `LogZ`), not a T-step loop."""
+    return flipflop_logpartition(scores).unsqueeze(1)
+
+
 def global_norm_flipflop(scores):
     """layers.py:1302-1313"""
     T = scores.shape[0]

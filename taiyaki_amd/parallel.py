@@ -80,6 +80,11 @@ def _trace(msg):
         print("[arena rank %s] %s" % (os.environ.get("RANK", "?"), msg), file=sys.stderr, flush=True)
 
 
+class _NoWork:
+    def wait(self):
+        pass
+
+
 class _StreamWork:
     """What `DirectRccl.all_reduce` returns: `wait()` makes the CURRENT stream wait for the
     collective (the contract of a torch.distributed async work object on a GPU backend)."""
@@ -104,7 +109,11 @@ class DirectRccl:
     reference's TCP store, bin/train_flipflop.py:255-268); the default uses the torch.distributed
     group that is already up (gloo or nccl) and is the identity for a single rank."""
 
-    def __init__(self, rank, world, exchange=None, device=None):
+    def __init__(self, rank, world, exchange=None, device=None, in_stream=False):
+        """`in_stream`: enqueue every collective on the CALLER's current stream -- in order with the
+        kernels that produced the gradients and with the optimiser behind them: no side stream, no
+        events, no cross-queue signal.  Nothing is overlapped then; for this path's 10.9 MB payload
+        there is nothing worth overlapping."""
         import ctypes
         from . import _lib
         self._lib = _lib.rccl_lib()
@@ -123,7 +132,8 @@ class DirectRccl:
         comm = ctypes.c_void_p()
         _lib.check(self._lib.tk_rccl_comm_init(ctypes.byref(comm), world, idbytes, rank), "tk_rccl_comm_init")
         self._comm = comm
-        self.stream = torch.cuda.Stream(priority=-1)
+        self.in_stream = bool(in_stream)
+        self.stream = None if self.in_stream else torch.cuda.Stream(priority=-1)
 
     def _exchange_over_process_group(self, idbytes):
         if self.world == 1:
@@ -132,8 +142,12 @@ class DirectRccl:
         dist.broadcast_object_list(box, src=0)
         return box[0]
 
-    def _enqueue(self, fn, what):
+    def _enqueue(self, fn, what, t):
         from . import _lib
+        if self.in_stream:
+            _lib.check(fn(_lib.stream_ptr()), what)
+            return _NoWork()
+        t.record_stream(self.stream)
         ready = torch.cuda.Event()
         ready.record(torch.cuda.current_stream())
         self.stream.wait_event(ready)
@@ -146,16 +160,14 @@ class DirectRccl:
         """SUM over ranks, in place, asynchronously; `t`: contiguous float32 on this device."""
         from . import _lib
         assert t.is_cuda and t.dtype == torch.float32 and t.is_contiguous()
-        t.record_stream(self.stream)
         return self._enqueue(lambda st: self._lib.tk_allreduce_f32_dev(self._comm, _lib.ptr(t), t.numel(), st),
-                             "tk_allreduce_f32_dev")
+                             "tk_allreduce_f32_dev", t)
 
     def broadcast(self, t, src=0):
         from . import _lib
         assert t.is_cuda and t.dtype == torch.float32 and t.is_contiguous()
-        t.record_stream(self.stream)
         return self._enqueue(lambda st: self._lib.tk_broadcast_f32_dev(self._comm, _lib.ptr(t), t.numel(), src, st),
-                             "tk_broadcast_f32_dev")
+                             "tk_broadcast_f32_dev", t)
 
     def close(self):
         if self._comm is not None:
@@ -167,13 +179,19 @@ class DirectRccl:
 class FlatGradArena:
     """All trainable gradients as views into one contiguous fp32 buffer.
 
-    `overlap_buckets=k` (k > 1, world > 1) cuts the arena into k contiguous slices and all-reduces
-    a slice as soon as autograd has accumulated the last gradient that lives in it (post-
-    accumulate hooks): backward produces the gradients of the last layers first, so their
-    reduction runs on RCCL's own stream while the RNN backward of the earlier layers is still
-    computing (the reference's DDP does the same with 25 MiB buckets; here the whole payload is
-    10.9 MB).  `finish()` waits for every slice, reduces whatever was not ready (unused
-    parameters) and applies the 1/world factor."""
+    Default (`overlap_buckets=0`): ONE all-reduce of the whole arena after backward.  That is the
+    measured choice (profiles/r4_forced_group_bisect.txt, a one-rank RCCL group on one MI355X): the
+    process group, its watchdog and one flat all-reduce cost the 109.4 ms step 0.1 ms; the same
+    10.9 MB issued as 4-5 slices from backward hooks cost 16-19 ms, because every slice is a
+    collective enqueued on a side queue in the middle of the host-bound eager RNN backward.  The
+    payload needs ~0.1 ms on xGMI: there is nothing for an overlap to hide.
+
+    `overlap_buckets=k` (k > 1, world > 1; kept for larger models) cuts the arena into k contiguous
+    slices and all-reduces a slice as soon as autograd has accumulated the last gradient that lives
+    in it (post-accumulate hooks): backward produces the gradients of the last layers first, so
+    their reduction runs on RCCL's own stream while the RNN backward of the earlier layers is still
+    computing (the reference's DDP does the same with 25 MiB buckets).  `finish()` waits for every
+    slice, reduces whatever was not ready (unused parameters) and applies the 1/world factor."""
 
     def __init__(self, module, overlap_buckets=0, collective=None):
         """`collective`: a `DirectRccl` (this repo's C ABI over RCCL) instead of torch.distributed's
@@ -195,6 +213,9 @@ class FlatGradArena:
         if collective is not None:
             self.world, self._always = collective.world, True
         self._work = []
+        # TK_ARENA_LAB (tools/forced_group_bisect.py): "noop" = issue nothing (what the mere existence
+        # of the process group costs), "hooks" = hooks installed and counted but no collective
+        self._lab = os.environ.get("TK_ARENA_LAB", "")
         self._buckets = []          # [lo, hi, params still missing this step, issued]
         self._hooks = []
         self.hooks_enabled = True   # (switched off around a whole-step graph capture)
@@ -233,8 +254,13 @@ class FlatGradArena:
         return hook
 
     def _all_reduce(self, t):
+        if self._lab in ("noop", "hooks"):
+            return _NoWork()
         if self.collective is not None:
             return self.collective.all_reduce(t)
+        if self._lab == "sync":     # ProcessGroupNCCL on the CURRENT stream (torch >= 2.8: async_op=False)
+            dist.all_reduce(t, op=dist.ReduceOp.SUM)
+            return _NoWork()
         return dist.all_reduce(t, op=dist.ReduceOp.SUM, async_op=True)
 
     @property
@@ -281,15 +307,26 @@ class FlatGradArena:
 
 def broadcast_parameters(module, src=0, collective=None):
     """Replaces the checkpoint-file + barrier handshake of the reference
-    (bin/train_flipflop.py:380-392): rank 0's weights go out over RCCL (`collective`: through the
-    C ABI's `tk_broadcast_f32_dev`; float32 tensors only, which is every parameter and every
-    floating-point buffer of the models here)."""
+    (bin/train_flipflop.py:380-392): rank 0's weights and buffers go out over RCCL.  With
+    `collective` the contiguous float32 device tensors (every parameter and floating-point buffer
+    of the models here) travel through the C ABI's `tk_broadcast_f32_dev`; anything else (integer
+    buffers, other dtypes, non-contiguous storage) goes through torch.distributed when a group is
+    up and is an ERROR otherwise -- never skipped: ranks must not start from different values."""
+    tensors = list(module.parameters()) + list(module.buffers())
     if collective is not None:
-        work = [collective.broadcast(t.data, src=src) for t in list(module.parameters()) + list(module.buffers())
-                if t.dtype == torch.float32 and t.is_cuda and t.is_contiguous()]
+        direct = [t for t in tensors if t.dtype == torch.float32 and t.is_cuda and t.is_contiguous()]
+        rest = [t for t in tensors if not (t.dtype == torch.float32 and t.is_cuda and t.is_contiguous())]
+        work = [collective.broadcast(t.data, src=src) for t in direct]
         for w in work:
             w.wait()
+        if rest and collective.world > 1:
+            if not (dist.is_initialized() and dist.get_world_size() == collective.world):
+                raise RuntimeError("broadcast_parameters: %d tensor(s) are not contiguous float32 device tensors "
+                                   "(%s) and no torch.distributed group is up to carry them"
+                                   % (len(rest), ", ".join(sorted({str(t.dtype) for t in rest}))))
+            for t in rest:
+                dist.broadcast(t.data, src=src)
         return
     if dist.is_initialized() and dist.get_world_size() > 1:
-        for t in list(module.parameters()) + list(module.buffers()):
+        for t in tensors:
             dist.broadcast(t.data, src=src)

@@ -8,7 +8,7 @@
 * the reference package `taiyaki` is importable (its Python layers, file readers and CLI are
   wanted as they are): its hot-path entry points are re-pointed --
   `taiyaki.ctc` (the Cython extension module, taiyaki/ctc/__init__.py:1) is replaced by
-  `taiyaki_amd.ctc`, `taiyaki.layers.flipflop_logpartition` (layers.py:1875-1890),
+  `taiyaki_amd.ctc`, `taiyaki.layers.flipflop_logpartition` / `log_partition_flipflop` (layers.py:1875-1890, 1277-1299),
   `taiyaki.decode.flipflop_viterbi` / `flipflop_make_trans` (decode.py:15-72),
   `taiyaki.qscores.errprobs_from_trans` (qscores.py:88-142),
   `taiyaki.flipflop_remap.flipflop_remap` (flipflop_remap.py:6-88) and
@@ -42,6 +42,7 @@ _SUBMODULES = {
 }
 _FUNCTIONS = [
     ("layers", "flipflop_logpartition", "taiyaki_amd.layers"),
+    ("layers", "log_partition_flipflop", "taiyaki_amd.layers"),
     ("layers", "global_norm_flipflop", "taiyaki_amd.layers"),
     ("decode", "flipflop_viterbi", "taiyaki_amd.decode"),
     ("decode", "flipflop_make_trans", "taiyaki_amd.decode"),

@@ -230,16 +230,18 @@ def test_torchrun_env_rendezvous_single_process():
 
 
 @pytest.mark.gpu
-def test_direct_rccl_collectives_through_the_c_abi_single_rank():
+@pytest.mark.parametrize("in_stream,buckets", [(False, 3), (False, 0), (True, 0)])
+def test_direct_rccl_collectives_through_the_c_abi_single_rank(in_stream, buckets):
     """`libtaiyaki_amd_rccl.so` on a real GPU: a one-rank RCCL communicator (the most a 1-GPU box
     can build) created through `tk_rccl_unique_id` / `tk_rccl_comm_init`, `tk_allreduce_f32_dev` and
     `tk_broadcast_f32_dev` enqueued on the collective's own stream and joined by events -- SUM over
     one rank and a broadcast from rank 0 must leave the buffer as it was -- and the gradient arena
-    reducing through it from its backward hooks gives the gradients of the plain step."""
+    reducing through it (from its backward hooks; as the one flat call after backward that the bench
+    ships; on the caller's own stream) gives the gradients of the plain step."""
     import torch
     from taiyaki_amd import parallel
     dev = torch.device("cuda:0")
-    coll = parallel.DirectRccl(0, 1, device=dev)
+    coll = parallel.DirectRccl(0, 1, device=dev, in_stream=in_stream)
     try:
         x = torch.randn(1 << 20, device=dev)
         ref = x.clone()
@@ -253,8 +255,8 @@ def test_direct_rccl_collectives_through_the_c_abi_single_rank():
             net = torch.nn.Sequential(torch.nn.Linear(64, 128), torch.nn.Tanh(), torch.nn.Linear(128, 128),
                                       torch.nn.Tanh(), torch.nn.Linear(128, 40)).to(dev)
             parallel.broadcast_parameters(net, collective=collective)
-            arena = parallel.FlatGradArena(net, overlap_buckets=3, collective=collective)
-            assert arena.overlapped == (collective is not None)
+            arena = parallel.FlatGradArena(net, overlap_buckets=buckets, collective=collective)
+            assert arena.overlapped == (collective is not None and buckets > 1)
             arena.zero()
             torch.manual_seed(4)
             net(torch.randn(256, 64, device=dev)).square().mean().backward()

@@ -156,6 +156,72 @@ def test_c_harness_known_answers_host_abi(oracle_mod, gpu_device):
         assert float(np.abs(rgrad[:, :, 40:]).max()) > 0        # the mod columns do receive gradient
 
 
+def test_numpy_level_ctc_functions_on_known_answers(oracle_mod, gpu_device):
+    """`taiyaki.ctc.crf_flipflop_cost / _grad`, `cat_mod_flipflop_cost / _grad` (ctc.pyx:31-113,
+    162-255) and `taiyaki.layers.log_partition_flipflop` (layers.py:1277-1299) under the REFERENCE's
+    names after `shim.install()`: the C harness data give -score / nblk of the reference's known
+    answers, the move / stay ids of `flipflopfings` reproduce the operator, and the way the
+    reference's own `FlipFlopCRF.forward` calls them (ctc.pyx:119-145) gives the operator's loss."""
+    from taiyaki_amd import shim
+    ka = load_golden("known_answers.npz")
+    assert shim.install(force_standalone=True) == "standalone"
+    try:
+        from taiyaki import ctc as tctc, flipflopfings as tff, layers as tlayers
+        lp = np.ascontiguousarray(ka["ccrf/logprob"], dtype=np.float32)
+        move = np.ascontiguousarray(ka["ccrf/move"], dtype=np.uintp)
+        stay = np.ascontiguousarray(ka["ccrf/stay"], dtype=np.uintp)
+        seqlen = np.ascontiguousarray(ka["ccrf/seqlen"], dtype=np.int32)
+        nblk = lp.shape[0]
+        cost = tctc.crf_flipflop_cost(lp, move, stay, seqlen)
+        assert torch.is_tensor(cost) and cost.device.type == "cpu" and cost.shape == (2,)
+        np.testing.assert_allclose(-cost.numpy() * nblk, ka["ccrf/score"], atol=5e-6)     # -2.378088
+        cost2, grads = tctc.crf_flipflop_grad(lp, move, stay, seqlen, pin=True)
+        assert grads.shape == lp.shape and grads.is_pinned() and cost2.is_pinned()
+        np.testing.assert_allclose(cost2.numpy(), cost.numpy(), atol=1e-7)
+        np.testing.assert_allclose(-grads.numpy().sum(axis=2) * nblk, 1.0, atol=1e-5)
+        lpm = np.ascontiguousarray(ka["ccm/logprob"], dtype=np.float32)
+        mm = np.ascontiguousarray(ka["ccm/modmoveidx"], dtype=np.uintp)
+        mf = np.ascontiguousarray(ka["ccm/modmovefact"], dtype=np.float32)
+        mmove = np.ascontiguousarray(ka["ccm/move"], dtype=np.uintp)
+        mstay = np.ascontiguousarray(ka["ccm/stay"], dtype=np.uintp)
+        mcost = tctc.cat_mod_flipflop_cost(lpm, mmove, mstay, mm, mf, seqlen)
+        np.testing.assert_allclose(-mcost.numpy() * nblk, ka["ccm/score"], rtol=2e-6)     # -52.35, -195.4
+        mcost2, mgrads = tctc.cat_mod_flipflop_grad(lpm, mmove, mstay, mm, mf, seqlen)
+        np.testing.assert_allclose(mcost2.numpy(), mcost.numpy(), rtol=1e-6)
+        assert mgrads.shape == lpm.shape and float(mgrads[:, :, 40:].abs().max()) > 0
+        # the reference's own forward (ctc.pyx:119-145) written against these names == the operator
+        spec = cases.CRF_SMALL["t64n8"]
+        inp = cases.crf_inputs(spec)
+        sharp = 1.0
+        lp2 = np.ascontiguousarray(inp["scores"] * sharp, dtype=np.float32)
+        sl = inp["seqlens"].astype(np.int32)
+        off = np.concatenate([[0], np.cumsum(sl)])
+        seqs = [inp["seqs"][off[i]:off[i + 1]] for i in range(len(sl))]
+        mv = np.concatenate([tff.move_indices(s) for s in seqs if len(s)]).astype(np.uintp)
+        st = np.concatenate([tff.stay_indices(s) for s in seqs]).astype(np.uintp)
+        c3, g3 = tctc.crf_flipflop_grad(lp2, mv, st, sl)
+        x = torch.tensor(inp["scores"], device=gpu_device, requires_grad=True)
+        lv = tctc.crf_flipflop_loss(x, torch.tensor(inp["seqs"]), torch.tensor(inp["seqlens"]), sharp)
+        lv.sum().backward()
+        np.testing.assert_allclose(c3.numpy() / sharp, lv.detach().cpu().numpy(), rtol=LOSS_RTOL, atol=2e-6)
+        T = lp2.shape[0]
+        assert float(np.abs(g3.numpy() - x.grad.cpu().numpy()).max()) * T < 5e-4
+        oloss, ograd = oracle_mod.crf_flipflop_loss(inp["scores"], inp["seqs"], inp["seqlens"], sharp)
+        np.testing.assert_allclose(c3.numpy(), oloss, rtol=LOSS_RTOL, atol=2e-6)
+        assert float(np.abs(g3.numpy() - ograd).max()) * T < 5e-4
+        # logZ with the reference's (N, 1) shape: test_ctc_loss.py:85, test_decodeutil.py:20
+        outputs = torch.tensor(ka["ctcloss/outputs"], device=gpu_device)
+        lz = tlayers.log_partition_flipflop(outputs)
+        assert lz.shape == (outputs.shape[1], 1) and abs(float(lz)) < 1e-5
+        assert torch.equal(lz.squeeze(1), tlayers.flipflop_logpartition(outputs))
+        # a path the labels cannot take gives -inf scores in the reference: same AssertionError
+        bad = np.full_like(lp, -3e38)
+        with pytest.raises(AssertionError, match="costs must be finite|Gradients not finite"):
+            tctc.crf_flipflop_grad(bad, move, stay, seqlen)
+    finally:
+        shim.uninstall()
+
+
 # ---------------------------------------------------------- (B) logZ --------
 @pytest.mark.parametrize("name", list(cases.LOGZ_SMALL))
 def test_logz_small(oracle_mod, gpu_device, name):

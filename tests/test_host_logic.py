@@ -292,3 +292,84 @@ def test_beam_lse_host_twin_matches_glibc(tmp_path):
                     os.path.join(root, "tools", "beam_lse_check.c"), "-lm"], check=True)
     out = subprocess.run([exe], capture_output=True, text=True, check=True).stdout
     assert "expf mismatches 0, log1pf mismatches 0" in out, out
+
+
+def test_shim_offers_every_hot_path_name_of_the_reference_modules():
+    """tests/golden/reference_names.json lists the public names of the reference modules the shim
+    stands in for (read from their source by make_reference_names.py).  After install() every name
+    SURVEY.md section 8 puts on the path resolves -- `taiyaki.ctc` and `taiyaki.decodeutil`, the two
+    compiled extensions, completely (ctc.pyx:13-312: the numpy-level cost / grad functions too)."""
+    import json
+    from taiyaki_amd import shim
+    root = os.path.dirname(os.path.abspath(__file__))
+    names = json.load(open(os.path.join(root, "golden", "reference_names.json")))
+    assert shim.install(force_standalone=True) == "standalone"
+    try:
+        import importlib
+        for mod, d in names.items():
+            m = importlib.import_module("taiyaki." + mod)
+            missing = [n for n in d["hot_path"] if not hasattr(m, n)]
+            assert not missing, "taiyaki.%s lacks %s" % (mod, missing)
+        import taiyaki.ctc as tctc
+        assert sorted(n for n in names["ctc"]["public"] if not hasattr(tctc, n)) == []
+        # (N, 1) like the reference's torch statement of logZ, (N,) for the dispatcher
+        import inspect
+        import taiyaki.layers as tl
+        assert list(inspect.signature(tl.log_partition_flipflop).parameters) == ["scores"]
+        assert list(inspect.signature(tctc.crf_flipflop_grad).parameters) == [
+            "logprob", "moveidxs", "stayidxs", "seqlen", "pin"]
+        assert list(inspect.signature(tctc.cat_mod_flipflop_cost).parameters) == [
+            "logprob", "moveidxs", "stayidxs", "modmoveidxs", "modmovefacts", "seqlen", "pin"]
+    finally:
+        shim.uninstall()
+
+
+def test_library_exports_exactly_what_the_header_declares():
+    """`nm -D` of libtaiyaki_amd_flipflop.so == the functions include/taiyaki_amd_flipflop.h declares
+    (minus the RCCL ones, which live in libtaiyaki_amd_rccl.so): no dispatcher, kernel stub or helper
+    leaks into the drop-in's symbol namespace (csrc/exports.map)."""
+    import re
+    import subprocess
+    from taiyaki_amd import _lib
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    hdr = open(os.path.join(root, "include", "taiyaki_amd_flipflop.h")).read()
+    hdr = re.sub(r"/\*.*?\*/", "", hdr, flags=re.S)
+    declared = set(re.findall(r"^(?:const\s+)?[a-z_0-9]+\s+\*?\s*([a-z_0-9]+)\(", hdr, flags=re.M))
+    assert {"tk_version", "crf_flipflop_grad", "tk_allreduce_f32_dev", "tk_flipflop_loss_fused_dev"} <= declared
+
+    def exported(path):
+        out = subprocess.run(["nm", "-D", "--defined-only", path], capture_output=True, text=True, check=True).stdout
+        return {ln.split()[2] for ln in out.splitlines() if len(ln.split()) == 3 and ln.split()[1] in "TDBW"}
+
+    rccl = {n for n in declared if n in _lib.RCCL_SIGNATURES}
+    assert exported(_lib.LIBPATH) == declared - rccl
+    assert exported(os.path.join(_lib.CSRC, _lib.RCCL_LIBNAME)) == rccl
+    assert set(_lib.SIGNATURES) <= declared
+
+
+def test_numpy_level_ctc_functions_keep_the_cython_layers_contract():
+    """ctc.pyx:31-113: typed C-contiguous buffers or an error, finite input or AssertionError,
+    a state count that is no flip-flop model is an AssertionError -- all before anything is launched
+    (so checkable without a GPU)."""
+    from taiyaki_amd import ctc
+    lp = np.zeros((5, 2, 40), dtype=np.float32)
+    mv = np.zeros(3, dtype=np.uintp)
+    st = np.zeros(5, dtype=np.uintp)
+    sl = np.array([3, 2], dtype=np.int32)
+    with pytest.raises(ValueError, match="dtype mismatch"):
+        ctc.crf_flipflop_cost(lp.astype(np.float64), mv, st, sl)
+    with pytest.raises(ValueError, match="dtype mismatch"):
+        ctc.crf_flipflop_cost(lp, mv.astype(np.int32), st, sl)
+    with pytest.raises(ValueError, match="C-contiguous"):
+        ctc.crf_flipflop_grad(np.zeros((5, 40, 2), dtype=np.float32).transpose(0, 2, 1), mv, st, sl)
+    with pytest.raises(TypeError):
+        ctc.crf_flipflop_grad(torch.zeros(5, 2, 40), mv, st, sl)
+    bad = lp.copy()
+    bad[2, 1, 7] = np.inf
+    with pytest.raises(AssertionError, match="Input not finite"):
+        ctc.crf_flipflop_grad(bad, mv, st, sl)
+    with pytest.raises(AssertionError, match="not valid for flip-flop"):
+        ctc.crf_flipflop_cost(np.zeros((5, 2, 41), dtype=np.float32), mv, st, sl)
+    with pytest.raises(ValueError, match="stayidxs has 4 entries"):
+        ctc.crf_flipflop_cost(lp, mv, st[:4], sl)
+    assert ctc.nstate_to_nbase(40) == 4 and ctc.nstate_to_nbase(12) == 2

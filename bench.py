@@ -321,43 +321,55 @@ def roofline_record(kernel, alg, mean_s, min_s, reps, traffic, source):
 # ---------------------------------------------------------------------------------------------
 # CPU legs (the only part of this file that touches oracle/)
 # ---------------------------------------------------------------------------------------------
-def cpu_baseline(T, N, budget_s=12.0):
-    """The loss path (A: crf grad, B: logZ fwd-bwd) on the host cores, same shape
-    as one GPU's share of a train step.  A runs on the genuine reference C when
-    oracle/_ref was built (kind = "reference"), else on the oracle port."""
+def cpu_baseline(inp, budget_s=12.0):
+    """The loss path (A: crf / cat-mod grad, B: logZ fwd-bwd) on the host cores, on the SAME host
+    arrays `loss_path.gpu_ms` is measured on (`LossOps.host`: the step's shape, realistic sequence
+    lengths, same seed).  A runs on the genuine reference C when oracle/_ref was built (kind =
+    "reference"), else on the oracle port.  BASELINE.md section 3's protocol: one warm-up, then the
+    MEDIAN of >= 5 repetitions (as many as fit the time budget)."""
     import oracle
-    from taiyaki_amd import synth
     oracle.build()
     cores = os.cpu_count() or 1
-    inp = synth.crf_case(T, N, 1)
     use_ref = oracle.ref_available()
+    T, N, S = inp["scores"].shape
+    cat_mod = "mod_cats" in inp
+    sc40 = np.ascontiguousarray(inp["scores"][:, :, :40]) if cat_mod else inp["scores"]
+
+    def once():
+        if cat_mod:
+            oracle.cat_mod_flipflop_loss(inp["scores"], inp["seqs"], inp["seqlens"], inp["mod_cats"],
+                                         inp["can_mods_offsets"], inp["mod_cat_weights"], 1.0, use_ref=use_ref)
+        else:
+            oracle.crf_flipflop_loss(inp["scores"], inp["seqs"], inp["seqlens"], 1.0, use_ref=use_ref)
+        oracle.flipflop_logz_grad(sc40)
 
     def run(threads, budget):
         oracle.set_threads(threads)
-        oracle.crf_flipflop_loss(inp["scores"], inp["seqs"], inp["seqlens"], 1.0, use_ref=use_ref)
-        reps, t0 = 0, time.perf_counter()
-        while True:
-            oracle.crf_flipflop_loss(inp["scores"], inp["seqs"], inp["seqlens"], 1.0, use_ref=use_ref)
-            oracle.flipflop_logz_grad(inp["scores"])
-            reps += 1
-            el = time.perf_counter() - t0
-            if el > budget:
-                return reps, el
+        once()                                          # warm-up
+        times, t_start = [], time.perf_counter()
+        while len(times) < 5 or time.perf_counter() - t_start < budget:
+            t0 = time.perf_counter()
+            once()
+            times.append(time.perf_counter() - t0)
+        return times, time.perf_counter() - t_start
 
     threads = min(cores, 8)     # the reference's own advice: OMP_NUM_THREADS=8 (README.md:362-372)
-    reps, el = run(threads, budget_s)
-    out = dict(value=round(N * reps / el, 2),
-               unit="chunks/s (loss path only: crf grad + logZ fwd-bwd; compare with loss_path.gpu_chunks_per_s, "
-                    "not with value)",
+    times, el = run(threads, budget_s)
+    med = float(np.median(times))
+    out = dict(value=round(N / med, 2),
+               unit="chunks/s (loss path only: %s grad + logZ fwd-bwd; compare with loss_path.gpu_chunks_per_s, "
+                    "not with value)" % ("cat-mod" if cat_mod else "crf"),
                cores=threads, kind="reference" if use_ref else "port",
-               sample="%d reps of T=%d N=%d (the step's shape, SPEED_TEST inputs), %.1f s; host has %d "
-                      "cores; A = %s, B = oracle port" % (
-                          reps, T, N, el, cores,
-                          "genuine reference C (oracle/_ref)" if use_ref else "oracle port"))
+               sample="median of %d reps (after 1 warm-up, %.1f s) of T=%d N=%d S=%d, the SAME host arrays as "
+                      "loss_path.gpu_ms (the step's shape, realistic sequence lengths up to %d); host has %d "
+                      "cores; A = %s, B = oracle port (the reference's B is a T-step torch loop, layers.py:1277-1299)"
+                      % (len(times), el, T, N, S, int(np.max(inp["seqlens"])), cores,
+                         "genuine reference C (oracle/_ref)" if use_ref else "oracle port"),
+               median_ms=round(med * 1e3, 3), min_ms=round(min(times) * 1e3, 3), reps=len(times))
     if cores > threads:
         allc = min(cores, N)
-        reps2, el2 = run(allc, budget_s / 2)
-        out["value_all_cores"] = round(N * reps2 / el2, 2)
+        times2, _ = run(allc, budget_s / 2)
+        out["value_all_cores"] = round(N / float(np.median(times2)), 2)
         out["cores_all"] = allc
     return out
 
@@ -577,14 +589,15 @@ def kernel_records(out, args, cfg, dev, world, T, nbatch, chunk_len, cat_mod, S)
                                     "tk_flipflop_loss_fused_dev: one gradient tensor"),
                             gpu_ms=round(lp_mean * 1e3, 4), gpu_chunks_per_s=round(nbatch / lp_mean, 1))
     if not no_cpu:
-        cb = cpu_baseline(T, nbatch)
+        cb = cpu_baseline(step_ops.host)
         out["cpu_baseline"] = cb
         copies = reference_copies_ms(T, nbatch, S, dev)
         cpu_ms = nbatch / cb["value"] * 1e3
         out["loss_path"].update(
             cpu_chunks_per_s=cb["value"], cpu_ms=round(cpu_ms, 3), copies_ms=round(copies, 3),
             cpu_with_copies_chunks_per_s=round(nbatch / ((cpu_ms + copies) * 1e-3), 2),
-            note="cpu = %s on %d host threads; copies = score tensor D->H + gradient H->D (pinned), what "
+            same_inputs=True,
+            note="cpu = %s on %d host threads, same arrays as gpu_ms; copies = score tensor D->H + gradient H->D (pinned), what "
                  "the reference's CPU extension adds per call (ctc.pyx:119, 139-141)" % (cb["kind"], cb["cores"]))
 
 

@@ -17,44 +17,96 @@ from taiyaki_amd import _lib
 MAD_SD_FACTOR = 1.4826      # maths.py:5
 
 
+def _middle(values, axis):
+    """Median along `axis` by selection (np.partition at the one or two middle ranks); the mean of
+    the two middle values is taken in the array's own floating type, which is what np.median gives."""
+    x = np.asarray(values)
+    if not np.issubdtype(x.dtype, np.floating):
+        x = x.astype(np.float64)
+    n = x.shape[axis]
+    lo, hi = (n - 1) // 2, n // 2
+    part = np.partition(x, (lo, hi) if hi != lo else lo, axis=axis)
+    low = np.take(part, lo, axis=axis)
+    return low if hi == lo else (low + np.take(part, hi, axis=axis)) * x.dtype.type(0.5)
+
+
 def med_mad(data, factor=None, axis=None):
-    """maths.py:8-32: median and scaled median absolute deviation."""
-    factor = MAD_SD_FACTOR if factor is None else factor
-    dmed = np.median(data, axis=axis, keepdims=True)
-    dmad = factor * np.median(np.abs(data - dmed), axis=axis, keepdims=True)
+    """Robust location / scale of `data` (the interface of taiyaki/maths.py:8-32, which
+    chunk_selection.py:98-131 and the clipping below call): the median, and the median distance
+    from it times `factor` (default 1.4826: the MAD of a normal sample then estimates its standard
+    deviation).  Over everything (`axis=None`: two scalars) or along one axis."""
+    scale = MAD_SD_FACTOR if factor is None else factor
+    x = np.asarray(data)
     if axis is None:
-        return dmed.flatten()[0], dmad.flatten()[0]
-    return dmed.squeeze(axis), dmad.squeeze(axis)
+        x, axis = x.reshape(-1), 0
+    centre = _middle(x, axis)
+    spread = _middle(np.abs(x - np.expand_dims(centre, axis)), axis)
+    return centre, scale * spread
 
 
 class RollingMAD:
-    """maths.py:138-195: per-parameter `median + n_mads * MAD` over the last `window` values;
-    `default_to` until `window` values have been seen."""
+    """Clipping thresholds `median + n_mads * MAD` per parameter tensor over the last `window`
+    gradient maxima (the interface of taiyaki/maths.py:138-195; `update` returns `default_to` until
+    the window has filled).
+
+    The window of every parameter is kept twice: as a ring in arrival order (which value expires
+    next) and SORTED, updated per step by taking the expiring value out and putting the new one
+    in -- two rank counts and a shift over (nparams, window) instead of re-sorting.  The median is
+    then read off the middle of the sorted rows; only the deviations from it need one selection
+    pass.  Values are float32 like the reference's window, so thresholds agree with it bit for bit
+    (tests/golden/basecall_small.npz `rollingmad/*`).  A non-finite maximum (a diverged step) is
+    kept in the ring, sorts last, and makes that parameter's threshold NaN for as long as it is in
+    the window -- what a median over the raw window would give."""
 
     def __init__(self, nparams, n_mads=0, window=1000, default_to=None):
         self.n_mads = n_mads
         self.default_to = default_to
-        self._window_data = np.empty((nparams, window), dtype="f4")
-        self._curr_iter = 0
+        self._ring = np.zeros((nparams, window), dtype=np.float32)
+        self._sorted = np.full((nparams, window), np.inf, dtype=np.float32)   # unfilled slots sort last
+        self._seen = 0
 
     @property
     def nparams(self):
-        return self._window_data.shape[0]
+        return self._ring.shape[0]
 
     @property
     def window(self):
-        return self._window_data.shape[1]
+        return self._ring.shape[1]
+
+    def _swap_in(self, leaving, entering):
+        """One value per row leaves the sorted rows, one enters; rows stay ascending."""
+        rows = self._sorted
+        width = rows.shape[1]
+        col = np.arange(width)[None, :]
+        at = (rows < leaving[:, None]).sum(axis=1)[:, None]             # rank of the value that leaves
+        closed = np.where(col >= at, np.roll(rows, -1, axis=1), rows)    # gap closed; last column is free
+        to = (closed[:, :width - 1] < entering[:, None]).sum(axis=1)[:, None]
+        self._sorted = np.where(col < to, closed, np.where(col == to, entering[:, None], np.roll(closed, 1, axis=1)))
 
     def update(self, vals):
-        if len(vals) != self.nparams:
-            raise AssertionError("Number of values (%d) provided does not match number of parameters "
-                                 "(%d)." % (len(vals), self.nparams))
-        self._window_data[:, self._curr_iter % self.window] = vals
-        self._curr_iter += 1
-        if self._curr_iter < self.window:
+        vals = np.asarray(vals, dtype=np.float32).reshape(-1)
+        if vals.shape[0] != self.nparams:
+            raise AssertionError("RollingMAD.update: got %d values for %d parameters" % (vals.shape[0], self.nparams))
+        key = np.where(np.isfinite(vals), vals, np.float32(np.inf))     # sort key: non-finite last
+        slot = self._seen % self.window
+        # before the window has filled the slot holds no value yet: an +inf placeholder leaves
+        leaving = np.where(np.isfinite(self._ring[:, slot]), self._ring[:, slot], np.float32(np.inf)) \
+            if self._seen >= self.window else np.full(self.nparams, np.inf, dtype=np.float32)
+        self._swap_in(leaving, key)
+        self._ring[:, slot] = vals
+        self._seen += 1
+        if self._seen < self.window:
             return self.default_to
-        med, mad = med_mad(self._window_data, axis=1)
-        return med + mad * self.n_mads
+        width = self.window
+        lo, hi = (width - 1) // 2, width // 2
+        centre = self._sorted[:, lo] if lo == hi else (self._sorted[:, lo] + self._sorted[:, hi]) * np.float32(0.5)
+        with np.errstate(invalid="ignore"):
+            spread = _middle(np.abs(self._sorted - centre[:, None]), 1) * np.float32(MAD_SD_FACTOR)
+            out = centre + spread * self.n_mads
+        dirty = ~np.isfinite(self._sorted[:, -1])
+        if dirty.any():
+            out = np.where(dirty, np.float32(np.nan), out)
+        return out
 
 
 class DeviceClipper:

@@ -15,18 +15,20 @@ LARGE_VAL = 1e30
 
 
 def remap_indices(sequence, alphabet=DEFAULT_ALPHABET):
-    """flipflop_remap.py:131-140: (step_index (M-1), stay_index (M)) of a sequence (str, or an
-    integer array of base indices)."""
+    """The transition-score columns the alignment of `sequence` (str, or an array of base numbers)
+    walks through: `(step_index (M-1), stay_index (M))`, what flipflop_remap.py:131-140 hands to
+    `map_to_crf_viterbi`.  They are the loss's own transition ids (csrc/crf_kernels.hip
+    `build_indices_kernel`, flipflopfings.py:6-31): flip-flop code the bases (second, fourth, ...
+    base of a homopolymer run = flop), then stay = the code's self transition and step = the
+    transition from one code into the next."""
     nbase = len(alphabet)
     if isinstance(sequence, str):
-        bases = np.array([alphabet.find(b) for b in sequence])
+        lookup = {ch: k for k, ch in enumerate(alphabet)}
+        bases = np.fromiter((lookup.get(ch, -1) for ch in sequence), dtype=np.int64, count=len(sequence))
     else:
         bases = np.asarray(sequence, dtype=np.int64)
-    flops = flipflopfings.flopmask(bases)
-    stay_index = np.where(flops, bases + (2 * nbase + 1) * nbase, bases + 2 * nbase * bases)
-    from_base = (bases + flops * nbase)[:-1]
-    to_base = np.maximum(bases, nbase * flops)[1:]
-    return from_base + 2 * nbase * to_base, stay_index
+    codes = flipflopfings.flipflop_code(bases, nbase)
+    return flipflopfings.move_indices(codes, nbase), flipflopfings.stay_indices(codes, nbase)
 
 
 def map_to_crf_viterbi_batch(scores, step_indices, stay_indices, localpen=LARGE_VAL, device=None):

@@ -28,12 +28,13 @@ def qchar_from_errprob(errprob, qscore_scale, qscore_offset):
 
 
 def transitions_into_base(b, nbases, device=None):
-    """qscores.py:58-85: indices of every transition into base b (flip or flop): the 2nb
-    transitions into b_flip, b_flip -> b_flop and the b_flop stay."""
-    toflip = torch.arange(2 * nbases * b, 2 * nbases * (b + 1), dtype=torch.long, device=device)
-    fliptoflop = 2 * nbases * nbases + b
-    toflop = torch.tensor([fliptoflop, fliptoflop + nbases], dtype=torch.long, device=device)
-    return torch.cat((toflip, toflop))
+    """Columns of the transition-score vector that END in base b (the interface of
+    qscores.py:58-85; csrc/qscore_kernels.hip sums exactly these per block).  The vector is the
+    (nbases + 1) x 2 nbases table `[to][from]` of layers.py:1253-1274 read row by row: row b holds
+    every transition into b's flip state, and the last row (the flops) holds flip b -> flop b and
+    the flop b stay in its columns b and b + nbases."""
+    table = torch.arange(2 * nbases * (nbases + 1), dtype=torch.long, device=device).view(nbases + 1, 2 * nbases)
+    return torch.cat((table[b], table[nbases, [b, b + nbases]]))
 
 
 def errprobs_from_trans(trans, path):

@@ -2,7 +2,8 @@
 against the pinned CPU oracle and the reference-generated golden fixtures.
 
 Tolerances (BASELINE.json north_star): loss / logZ <= 1e-4 relative (asserted at
-1e-5, observed ~1e-6); gradients <= 2e-5 absolute on values in [0, 1/T];
+1e-5, observed ~1e-6); logZ gradients (posteriors) <= 2e-5 absolute; CRF / cat-mod gradients
+(posteriors / T) <= 5e-4 / T absolute, i.e. 5e-4 of full scale whatever T is;
 Viterbi fwd / traceback / path bit-exact.
 """
 import ctypes
@@ -18,7 +19,10 @@ from tests.golden import cases
 pytestmark = pytest.mark.gpu
 
 LOSS_RTOL = 1e-5
-GRAD_ATOL = 2e-5
+GRAD_ATOL = 2e-5        # logZ gradients (posteriors in [0, 1]); an outer bound for CRF gradients
+# CRF / cat-mod gradients are posteriors / T: the element-wise bound that means something is on
+# gradient x T (5e-4 of a posterior's full scale at EVERY T; the kernels deliver ~1e-5)
+GRAD_T_ATOL = 5e-4
 
 
 def _check_grad_golden(gold, prefix, grad, atol):
@@ -40,10 +44,11 @@ def test_crf_small(oracle_mod, gpu_device, name):
     assert r["finite"]
     assert r["loss_rel"] < LOSS_RTOL, r["loss_rel"]
     assert r["grad_abs"] < GRAD_ATOL, r["grad_abs"]
+    assert r["grad_scaled_abs"] < GRAD_T_ATOL, r["grad_scaled_abs"]     # posterior scale: gradient x T
     assert r["rowsum_dev"] < 1e-4
     gold = load_golden("crf_small.npz")
     np.testing.assert_allclose(r["loss"], gold[name + "/loss"], rtol=LOSS_RTOL, atol=1e-6)
-    _check_grad_golden(gold, name + "/grad", r["grad"], GRAD_ATOL)
+    _check_grad_golden(gold, name + "/grad", r["grad"], GRAD_T_ATOL / spec["T"])
     # forward-only path (no requires_grad): reference returns the forward score
     loss_ng, _ = parity.run_crf(inp, spec["sharp"], gpu_device, want_grad=False)
     np.testing.assert_allclose(loss_ng, gold[name + "/loss_nograd"], rtol=LOSS_RTOL, atol=1e-6)
@@ -57,9 +62,10 @@ def test_catmod_small(oracle_mod, gpu_device, name):
     assert r["finite"]
     assert r["loss_rel"] < LOSS_RTOL, r["loss_rel"]
     assert r["grad_abs"] < 4 * GRAD_ATOL, r["grad_abs"]     # mod bins carry p * 8.0
+    assert r["grad_scaled_abs"] < GRAD_T_ATOL, r["grad_scaled_abs"]     # posterior scale: gradient x T
     gold = load_golden("catmod_small.npz")
     np.testing.assert_allclose(r["loss"], gold[name + "/loss"], rtol=LOSS_RTOL, atol=1e-6)
-    _check_grad_golden(gold, name + "/grad", r["grad"], 4 * GRAD_ATOL)
+    _check_grad_golden(gold, name + "/grad", r["grad"], GRAD_T_ATOL / spec["T"])
 
 
 def test_crf_seqs_on_device(oracle_mod, gpu_device):
@@ -319,7 +325,7 @@ def test_fullsize_against_reference_goldens(gpu_device, name):
     cs = cases.grad_checksums(grad)
     np.testing.assert_allclose(cs["sum"], gold[name + "/grad_sum"], rtol=1e-4, atol=1e-4)
     np.testing.assert_allclose(cs["sumsq"], gold[name + "/grad_sumsq"], rtol=2e-3)
-    np.testing.assert_allclose(cs["sample"], gold[name + "/grad_sample"], atol=GRAD_ATOL)
+    np.testing.assert_allclose(cs["sample"], gold[name + "/grad_sample"], atol=2e-4 / spec["T"], rtol=0)
     # every gradient row of a live read sums to -1/T (posterior is a distribution)
     np.testing.assert_allclose(grad[:, :, :40].sum(axis=2) * spec["T"], -1.0, atol=2e-4)
     del grad
@@ -387,6 +393,7 @@ def test_ragged_and_degenerate_batches(oracle_mod, gpu_device):
     inp = dict(scores=synth.scores(T, N, 40, 99), seqs=seqs, seqlens=seqlens)
     r = parity.compare_crf(oracle_mod, inp, 1.0, gpu_device)
     assert r["finite"] and r["loss_rel"] < LOSS_RTOL and r["grad_abs"] < GRAD_ATOL
+    assert r["grad_scaled_abs"] < GRAD_T_ATOL, r["grad_scaled_abs"]
     assert r["loss"][5] == 0.0 and np.all(r["grad"][:, 5, :] == 0.0)
     # L = T + 1: exactly one path => every row's posterior is a single 1 on a move id
     g = r["grad"][:, 1, :] * T
@@ -512,6 +519,7 @@ def test_parity_on_saturated_network_outputs(oracle_mod, gpu_device):
     inp["scores"] = sc
     rc = parity.compare_crf(oracle_mod, inp, 1.0, gpu_device)
     assert rc["finite"] and rc["loss_rel"] < LOSS_RTOL and rc["grad_abs"] < GRAD_ATOL
+    assert rc["grad_scaled_abs"] < GRAD_T_ATOL, rc["grad_scaled_abs"]
 
 
 def test_logz_above_the_streaming_threshold(gpu_device):
@@ -565,6 +573,7 @@ def test_crf_both_gradient_modes(oracle_mod, gpu_device, name, mode_mb, monkeypa
     assert r["finite"]
     assert r["loss_rel"] < LOSS_RTOL, r["loss_rel"]
     assert r["grad_abs"] < GRAD_ATOL, r["grad_abs"]
+    assert r["grad_scaled_abs"] < GRAD_T_ATOL, r["grad_scaled_abs"]     # posterior scale: gradient x T
     assert r["rowsum_dev"] < 1e-4
 
 
@@ -595,7 +604,7 @@ def test_crf_band_shapes_against_oracle(oracle_mod, gpu_device, R, monkeypatch):
             # (a loss that is itself ~0 is a cancelled sum: bound its absolute error instead)
             assert (parity.rel_err(loss[n:n + 1], oloss) < LOSS_RTOL
                     or parity.abs_err(loss[n:n + 1], oloss) < 2e-6), (T, L, loss[n], oloss)
-            assert parity.abs_err(grad[:, n:n + 1], ograd) < GRAD_ATOL, (T, L)
+            assert parity.abs_err(grad[:, n:n + 1], ograd) * T < GRAD_T_ATOL, (T, L)
 
 
 def _crf_alone(inp, n, L, off):
@@ -641,7 +650,7 @@ def test_crf_linear_band_path_disowns_reads_and_the_log_domain_kernel_redoes_the
         # (a loss that is itself ~0 is a cancelled sum: bound its absolute error instead)
         assert (parity.rel_err(cost[n:n + 1], oloss) < LOSS_RTOL
                 or parity.abs_err(cost[n:n + 1], oloss) < 2e-6), (L, cost[n], oloss)
-        assert parity.abs_err(grad[:, n:n + 1], ograd) < GRAD_ATOL, L
+        assert parity.abs_err(grad[:, n:n + 1], ograd) * grad.shape[0] < GRAD_T_ATOL, L
         own = np.isfinite(cost_nf[n]) and np.isfinite(grad_nf[:, n]).all()
         if own:
             kept.append(L)
@@ -690,7 +699,7 @@ def test_crf_linear_band_path_keeps_confident_reads(oracle_mod, gpu_device, burs
     for n, L in enumerate(Ls):
         oloss, ograd = parity.oracle_crf(oracle_mod, _crf_alone(inp, n, L, off), 1.0)
         assert parity.rel_err(cost[n:n + 1], oloss) < LOSS_RTOL, (L, cost[n], oloss)
-        assert parity.abs_err(grad[:, n:n + 1], ograd) < GRAD_ATOL, L
+        assert parity.abs_err(grad[:, n:n + 1], ograd) * grad.shape[0] < GRAD_T_ATOL, L
 
 
 @pytest.mark.parametrize("case", ["step", "ragged", "r2", "catmod", "lastblock"])
@@ -770,6 +779,7 @@ def test_crf_sharpened_scores_take_the_log_domain_kernel(oracle_mod, gpu_device,
     assert r["finite"]
     assert r["loss_rel"] < LOSS_RTOL, r["loss_rel"]
     assert r["grad_abs"] < GRAD_ATOL, r["grad_abs"]
+    assert r["grad_scaled_abs"] < GRAD_T_ATOL, r["grad_scaled_abs"]     # posterior scale: gradient x T
 
 
 def test_crf_log_probability_inputs(oracle_mod, gpu_device, monkeypatch):
@@ -787,6 +797,7 @@ def test_crf_log_probability_inputs(oracle_mod, gpu_device, monkeypatch):
     assert r["finite"]
     assert r["loss_rel"] < LOSS_RTOL, r["loss_rel"]
     assert r["grad_abs"] < GRAD_ATOL, r["grad_abs"]
+    assert r["grad_scaled_abs"] < GRAD_T_ATOL, r["grad_scaled_abs"]     # posterior scale: gradient x T
 
 
 @pytest.mark.parametrize("R", ["1", "2", "4"])
@@ -907,6 +918,7 @@ def test_logz_wide_dynamic_range(oracle_mod, gpu_device, scale, T, N):
     rc = parity.compare_crf(oracle_mod, inp, 1.0, gpu_device)
     assert rc["finite"] and rc["loss_rel"] < LOSS_RTOL, rc["loss_rel"]
     assert rc["grad_abs"] < 5e-5, rc["grad_abs"]
+    assert rc["grad_scaled_abs"] < GRAD_T_ATOL, rc["grad_scaled_abs"]     # posterior scale: gradient x T
 
 
 def test_bench_contract_with_live_rccl_group(gpu_device):
@@ -985,6 +997,7 @@ def test_crf_other_alphabet_sizes(oracle_mod, gpu_device, nbase, mode_mb, monkey
     r = parity.compare_crf(oracle_mod, inp, 1.0, gpu_device)
     assert r["finite"] and r["loss_rel"] < LOSS_RTOL, r["loss_rel"]
     assert r["grad_abs"] < GRAD_ATOL, r["grad_abs"]
+    assert r["grad_scaled_abs"] < GRAD_T_ATOL, r["grad_scaled_abs"]     # posterior scale: gradient x T
     assert r["rowsum_dev"] < 1e-4
 
 

@@ -93,6 +93,7 @@ CONFIGS = {
 }
 CAN_NMODS = (1, 1, 0, 0)        # alphabet ACGTZY: 6mA on A, 5mC on C (layers.py:1441-1460)
 MOD_FACTOR = 8.0                # --mod_factor start value (bin/_bin_argparse.py:178)
+PATH_BUFFER = 1.1               # --filter_path_buffer default (bin/_bin_argparse.py)
 
 
 def make_batches(nbatch, chunk_len, stride, seed, dev, n=4, spb=9.0, cat_mod=False):
@@ -776,9 +777,12 @@ def main():
     if use_graph:
         try:
             cls = train.HybridGraphTrainer if hybrid else train.GraphedTrainer
-            maxlen = None
-            if args.data != "store":    # (device-assembled batches: lengths unknown to the host)
-                maxlen = max(b["seqlens"].tk_max_seqlen for b in batches)
+            maxlen = max(b["seqlens"].tk_max_seqlen for b in batches)
+            if args.data == "store":
+                # device-assembled batches: the host does not see the lengths, but chunks that pass the
+                # path-buffer filter (1.1 below) have fewer than chunk_len / (stride * 1.1) bases --
+                # mapped_signal.sample_chunks hangs that bound on the seqlens tensor it returns
+                maxlen = max(maxlen, int(chunk_len / (stride * PATH_BUFFER)) + 1)
             g = cls(trainer, batches[0], seq_capacity=nbatch * (T + 1), max_seqlen=maxlen)
             g.load(batches[0])
             g.capture()
@@ -816,7 +820,7 @@ def main():
                 synth.mapped_reads(1500, 31 + rank, mean_reflen=max(900, chunk_len // 4),
                                    long_dwell_prob=0.0003), dev)
         torch.manual_seed(99 + rank)
-        fparams = store.sample_filter_parameters(1000, chunk_len, 3.0, 10.0, 0.5, stride, 1.1)
+        fparams = store.sample_filter_parameters(1000, chunk_len, 3.0, 10.0, 0.5, stride, PATH_BUFFER)
 
         def next_batch(i):
             b = store.sample_chunks(nbatch, chunk_len, fparams, max_bases_per_chunk=T + 1)

@@ -930,10 +930,13 @@ __global__ __launch_bounds__(POST_WAVES *WAVE) void crf_band_posterior_kernel(Ba
             a.cost[n] = (L == 0) ? crf_add_cost(a, n, 0.f) : __builtin_nanf("");   // c_crf_flipflop.c:269-272, 458-464
             if (L != 0 && a.status) atomicOr(a.status, 16u);
         }
-        if (L == 0 && lane < S) {
+        if (lane < S) {
+            // empty read: zero rows; a read too long for the launch: NaN rows next to its NaN cost and
+            // the status bit -- never uninitialised memory on its way to an optimiser
             const float gs0 = a.grad_scale * (a.grad_scale_vec != nullptr ? a.grad_scale_vec[n] : 1.0f);
             for (int t = t0; t < min(t0 + BK, T); ++t)
-                a.grad[(size_t)t * rowstride + (size_t)n * S + lane] = crf_add_grad(a, (size_t)t, n, lane, 0.f, gs0);
+                a.grad[(size_t)t * rowstride + (size_t)n * S + lane] =
+                    (L == 0) ? crf_add_grad(a, (size_t)t, n, lane, 0.f, gs0) : __builtin_nanf("");
         }
         return;
     }

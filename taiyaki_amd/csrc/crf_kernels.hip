@@ -137,6 +137,10 @@ __global__ __launch_bounds__(W *WAVE) void crf_kernel(CrfArgs a) {
             a.cost[n] = __builtin_nanf("");
             if (a.status) atomicOr(a.status, 16u);
         }
+        if (want_grad && lane < S) {        // NaN rows, not uninitialised memory (see crf_band_posterior_kernel)
+            for (int t = wave; t < T; t += W)
+                a.grad[(size_t)t * rowstride + (size_t)n * S + lane] = __builtin_nanf("");
+        }
         return;
     }
 

@@ -395,29 +395,29 @@ class FlipFlopMeanLoss(torch.autograd.Function):
     @staticmethod
     def backward(ctx, grad_loss, _grad_lossvector):
         grads, = ctx.saved_tensors
-        if _ASSUME_UNIT_GRAD:
+        if getattr(ctx, "tk_unit_grad", False):     # (set by `backward_unit` on THIS node only)
             return grads, None, None, None, None, None, None, None
         return grads * grad_loss, None, None, None, None, None, None, None
 
 
-# `loss.backward()` on the operator's own output sends grad_output = 1.0; a trainer that does exactly
-# that (train.Trainer, the graph trainers) says so and saves the scaling pass.  Off by default:
-# anything else (loss * 2, a sum of losses) stays correct.
-_ASSUME_UNIT_GRAD = False
-
-
-class unit_grad:
-    """Context manager: inside it, `FlipFlopMeanLoss.backward` trusts that the loss is
-    differentiated with grad_output = 1 (a bare `loss.backward()`)."""
-
-    def __enter__(self):
-        global _ASSUME_UNIT_GRAD
-        self.prev = _ASSUME_UNIT_GRAD
-        _ASSUME_UNIT_GRAD = True
-
-    def __exit__(self, *exc):
-        global _ASSUME_UNIT_GRAD
-        _ASSUME_UNIT_GRAD = self.prev
+def backward_unit(loss, **kwargs):
+    """`loss.backward(**kwargs)` for a trainer that differentiates the mean loss as it came out of
+    `flipflop_mean_loss`.  autograd then sends grad_output = 1 and the scaling pass over the
+    (T, N, S) tensor is pointless: `backward` hands the kernels' tensor on untouched.  The shortcut
+    is tied to the node, not to a mode: it is taken only when `loss` IS the operator's own output
+    (its grad_fn is this operator's node).  A loss that went through anything else first --
+    `loss * 2`, `loss / n_sub_batches`, a GradScaler, a sum of losses -- has another grad_fn, the
+    flag is not set and the incoming gradient is honoured.  Nothing global, nothing another thread
+    differentiating another loss can see."""
+    node = loss.grad_fn
+    ours = node is not None and type(node).__name__ == FlipFlopMeanLoss.__name__ + "Backward"
+    if ours:
+        node.tk_unit_grad = True
+    try:
+        loss.backward(**kwargs)
+    finally:
+        if ours:
+            node.tk_unit_grad = False
 
 
 flipflop_mean_loss = FlipFlopMeanLoss.apply

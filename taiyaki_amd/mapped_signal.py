@@ -332,6 +332,14 @@ class MappedSignalStore:
                 _lib.ptr(indata), _lib.ptr(seqs), cap, _lib.ptr(seqlens), _lib.ptr(mc), _lib.ptr(status),
                 _lib.stream_ptr())
             _lib.check(rc, "tk_chunks_gather_dev")
+            # the host knows a bound on every sequence of the batch without looking at it: a chunk
+            # that passed the path-buffer filter has chunk_len / (L * stride) > path_buffer
+            # (signal_mapping.py:699-703).  The tensor carries it (ctc.set_max_seqlen): the CRF launch
+            # is sized by it and a captured step can check the batch against its capacity, no sync
+            if filter_params.model_stride is not None and filter_params.path_buffer is not None \
+                    and filter_params.median_meandwell is not None and filter_params.mad_meandwell is not None:
+                bound = int(chunk_len / (float(filter_params.model_stride) * float(filter_params.path_buffer))) + 1
+                seqlens.tk_max_seqlen = min(bound, max(int(chunk_len), 1))
             return ChunkBatch(indata, seqs, seqlens, seqoff, mc, counts, sel, cr, loc["dacstart"],
                               loc["seqlen"], status)
 

@@ -82,8 +82,7 @@ class Trainer:
         for k, sub in enumerate(subs):
             self.arena.hooks_enabled = hooks and k == len(subs) - 1
             loss, _ = calculate_loss(self.net, **sub)
-            with ctc.unit_grad():
-                loss.backward()
+            ctc.backward_unit(loss)
             total = loss.detach() if total is None else total + loss.detach()
         self.arena.hooks_enabled = hooks
         self.arena.allreduce_async()
@@ -145,10 +144,26 @@ class GraphedTrainer:
         self.graph = None
 
     def load(self, batch):
-        hint = getattr(batch["seqlens"], "tk_max_seqlen", None)
-        if self.max_seqlen is not None and hint is not None and hint > self.max_seqlen:
-            raise ValueError("batch with sequences up to %d bases for a step captured for at most %d"
-                             % (hint, self.max_seqlen))
+        """Copy a batch into the static buffers.  When the captured CRF launch was sized for
+        `max_seqlen`, every batch must PROVE that it fits before it is copied in: by the hint its
+        `seqlens` tensor carries (`ctc.set_max_seqlen`: bench.make_batches, mapped_signal.sample_chunks
+        with `max_bases_per_chunk`), or -- `seqlens` on the host, as bin/train_flipflop.py:133-138
+        builds them -- by looking.  A device tensor without a hint (it lost the attribute in a
+        `.to()` / slice, or never had one) is refused: checking it would be a sync per step, and
+        copying it in unchecked lets a longer read reach a launch that cannot hold it (the kernels
+        then flag it and write NaN for that read -- loud, but a lost step)."""
+        if self.max_seqlen is not None:
+            sl = batch["seqlens"]
+            hint = getattr(sl, "tk_max_seqlen", None)
+            if hint is None:
+                if torch.is_tensor(sl) and sl.is_cuda:
+                    raise ValueError("this step was captured for sequences of at most %d bases: a `seqlens` tensor on "
+                                     "the device must carry its maximum (ctc.set_max_seqlen(seqlens, max)) -- keep it "
+                                     "on the host or set the hint where the batch is assembled" % self.max_seqlen)
+                hint = int(sl.max()) if len(sl) else 0
+            if hint > self.max_seqlen:
+                raise ValueError("batch with sequences up to %d bases for a step captured for at most %d"
+                                 % (hint, self.max_seqlen))
         self.static["indata"].copy_(batch["indata"], non_blocking=True)
         n = batch["seqs"].numel()
         self.static["seqs"][:n].copy_(batch["seqs"], non_blocking=True)
@@ -189,6 +204,37 @@ class GraphedTrainer:
         return self.loss
 
 
+def _aliased_adamw(trainer):
+    """The optimiser of the hybrid trainers.  The captured autograd graph saved (views of) the
+    parameters; an in-place optimiser update of the parameters themselves would trip autograd's
+    version check on the next eager backward.  The optimiser therefore updates ALIASES of the
+    parameters (same storage, own version counters) -- the replayed forward and the eager backward of
+    one step always see the same, current weights.  The learning rate lives in a DEVICE scalar
+    (capturable AdamW reads it at replay time): `_set_lr` between replays is what a per-iteration
+    schedule needs.  Returns (aliases, optimiser)."""
+    arena = trainer.arena
+    alias = []
+    for p in arena.params:
+        a = p.data.requires_grad_(True)
+        a.grad = p.grad
+        alias.append(a)
+    g = trainer.opt.param_groups[0]
+    lr = g["lr"]
+    lr = lr.detach().clone().to(arena.flat.device) if torch.is_tensor(lr) else \
+        torch.tensor(float(lr), dtype=torch.float32, device=arena.flat.device)
+    opt = torch.optim.AdamW(alias, lr=lr, weight_decay=g["weight_decay"], eps=g["eps"], betas=g["betas"],
+                            capturable=True)
+    return alias, opt
+
+
+def _set_lr(opt, lr):
+    for g in opt.param_groups:
+        if torch.is_tensor(g["lr"]):
+            g["lr"].fill_(float(lr))
+        else:
+            g["lr"] = float(lr)
+
+
 class HybridGraphTrainer(GraphedTrainer):
     """Forward + loss replayed from a hipGraph, backward launched eagerly, AdamW replayed.
 
@@ -203,27 +249,19 @@ class HybridGraphTrainer(GraphedTrainer):
 
     def __init__(self, trainer, example_batch, seq_capacity, max_seqlen=None):
         super().__init__(trainer, example_batch, seq_capacity, max_seqlen)
-        # The captured autograd graph saved (views of) the parameters; an in-place optimiser
-        # update of the parameters themselves would trip autograd's version check on the next
-        # eager backward.  The optimiser therefore updates ALIASES of the parameters (same
-        # storage, own version counters) -- the replayed forward and the eager backward of one
-        # step always see the same, current weights.
-        arena = trainer.arena
-        self.alias = []
-        for p in arena.params:
-            a = p.data.requires_grad_(True)
-            a.grad = p.grad
-            self.alias.append(a)
-        g = trainer.opt.param_groups[0]
-        self.opt = torch.optim.AdamW(self.alias, lr=g["lr"], weight_decay=g["weight_decay"],
-                                     eps=g["eps"], betas=g["betas"], capturable=True)
+        self.alias, self.opt = _aliased_adamw(trainer)
+
+    def set_lr(self, lr):
+        """The reference steps its learning-rate schedule every iteration
+        (bin/train_flipflop.py:605-607); the replayed optimiser graph reads the rate from a device
+        scalar, so a new value is one tiny fill between replays."""
+        _set_lr(self.opt, lr)
 
     def _eager_step(self):
         tr = self.trainer
         tr.arena.zero()
         loss, _ = calculate_loss(tr.net, **self.static)
-        with ctc.unit_grad():
-            loss.backward()
+        ctc.backward_unit(loss)
         tr.arena.allreduce_async()
         tr.arena.finish()
         self._clip_and_step()
@@ -257,8 +295,7 @@ class HybridGraphTrainer(GraphedTrainer):
         self.opt.step()
 
     def _tail_eager(self):
-        with ctc.unit_grad():
-            self.loss.backward(retain_graph=True)
+        ctc.backward_unit(self.loss, retain_graph=True)
         self.trainer.arena.allreduce_async()
         self.trainer.arena.finish()
         self._clip_and_step()
@@ -266,8 +303,7 @@ class HybridGraphTrainer(GraphedTrainer):
     def step(self, batch):
         self.load(batch)
         self.graph.replay()
-        with ctc.unit_grad():
-            self.loss.backward(retain_graph=True)
+        ctc.backward_unit(self.loss, retain_graph=True)
         self.trainer.arena.allreduce_async()
         self.trainer.arena.finish()
         self.trainer.clip()         # eager: two tiny launches + an async copy of the maxima
@@ -275,8 +311,8 @@ class HybridGraphTrainer(GraphedTrainer):
         return self.loss
 
 
-class GraphCacheTrainer(HybridGraphTrainer):
-    """`HybridGraphTrainer` for the reference's own schedule, which draws a new chunk length for
+class GraphCacheTrainer:
+    """The hybrid scheme (`HybridGraphTrainer`) for the reference's own schedule, which draws a new chunk length for
     every iteration and rescales the batch with it (bin/train_flipflop.py:554-563:
     batch_chunk_len in [chunk_len_min, chunk_len_max], sub_batch_size = min_sub_batch_size *
     chunk_len_max / batch_chunk_len): one captured forward + loss graph PER SHAPE
@@ -298,15 +334,10 @@ class GraphCacheTrainer(HybridGraphTrainer):
         self.entries = {}
         self.opt_graph = None
         self.nsteps = 0
-        arena = trainer.arena
-        self.alias = []
-        for p in arena.params:
-            a = p.data.requires_grad_(True)
-            a.grad = p.grad
-            self.alias.append(a)
-        g = trainer.opt.param_groups[0]
-        self.opt = torch.optim.AdamW(self.alias, lr=g["lr"], weight_decay=g["weight_decay"],
-                                     eps=g["eps"], betas=g["betas"], capturable=True)
+        self.alias, self.opt = _aliased_adamw(trainer)
+
+    def set_lr(self, lr):
+        _set_lr(self.opt, lr)
 
     @staticmethod
     def key_of(batch):
@@ -332,8 +363,7 @@ class GraphCacheTrainer(HybridGraphTrainer):
                 tr.arena.hooks_enabled = False
                 try:
                     loss, _ = calculate_loss(tr.net, **one.static)
-                    with ctc.unit_grad():
-                        loss.backward()
+                    ctc.backward_unit(loss)
                 finally:
                     tr.arena.hooks_enabled = hooks
         torch.cuda.current_stream().wait_stream(side)
@@ -352,8 +382,7 @@ class GraphCacheTrainer(HybridGraphTrainer):
             one = self.entries[key] = self._capture_shape(batch)
         one.load(batch)
         one.graph.replay()
-        with ctc.unit_grad():
-            one.loss.backward(retain_graph=True)
+        ctc.backward_unit(one.loss, retain_graph=True)
         self.trainer.arena.allreduce_async()
         self.trainer.arena.finish()
         self.trainer.clip()

@@ -1232,7 +1232,8 @@ def test_mean_loss_operator_hands_over_the_final_gradient(oracle_mod, gpu_device
     """ctc.flipflop_mean_loss = calculate_loss's lossvector + its reduction in one operator: the
     kernels scale the gradient per read (1 / nbatch for `lossvector.mean()`, any weight vector
     for the padded-batch mean), so backward returns the saved tensor -- with grad_output = 1 under
-    `ctc.unit_grad()` untouched (same storage), otherwise scaled once."""
+    `ctc.backward_unit(loss)` untouched (same storage), otherwise scaled once -- also when the SAME
+    graph is differentiated through a scaled loss right after a unit backward."""
     import torch
     from taiyaki_amd import ctc, synth
     T = 120
@@ -1258,8 +1259,7 @@ def test_mean_loss_operator_hands_over_the_final_gradient(oracle_mod, gpu_device
     assert not lv.requires_grad
     np.testing.assert_allclose(lv.cpu().numpy(), olv, rtol=1e-5, atol=2e-6)
     assert abs(float(loss) - want_loss) < 1e-5 * abs(want_loss) + 2e-6
-    with ctc.unit_grad():
-        loss.backward(retain_graph=True)
+    ctc.backward_unit(loss, retain_graph=True)
     g1 = x.grad.clone()
     np.testing.assert_allclose(g1.cpu().numpy(), want_grad, atol=2e-5 / N)
     # a grad_output other than 1 is honoured (one scaling pass)
@@ -1287,8 +1287,7 @@ def test_train_step_has_no_elementwise_pass_between_loss_and_rnn_backward(gpu_de
     loss, _ = train.calculate_loss(Net(), None, torch.from_numpy(inp["seqs"]).to(gpu_device), seqlens)
     fn = loss.grad_fn
     saved = fn.saved_tensors[0].data_ptr()
-    with ctc.unit_grad():
-        loss.backward()
+    ctc.backward_unit(loss)
     assert seen["ptr"] == saved
 
 
@@ -1322,7 +1321,6 @@ def test_fused_catmod_loss_small_against_oracle(oracle_mod, gpu_device, sharp):
     live = (seqlens > 0).astype(np.float32)
     w = torch.from_numpy(live / live.sum()).to(gpu_device)
     loss, lv2 = ctc.flipflop_mean_loss(x, seqs, sl, sharp, w, *mods)
-    with ctc.unit_grad():
-        loss.backward()
+    ctc.backward_unit(loss)
     np.testing.assert_allclose(lv2.cpu().numpy(), want_lv, rtol=1e-5, atol=2e-6)
     np.testing.assert_allclose(x.grad.cpu().numpy(), want_g * (live / live.sum())[None, :, None], atol=2e-5)

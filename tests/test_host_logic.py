@@ -373,3 +373,26 @@ def test_numpy_level_ctc_functions_keep_the_cython_layers_contract():
     with pytest.raises(ValueError, match="stayidxs has 4 entries"):
         ctc.crf_flipflop_cost(lp, mv, st[:4], sl)
     assert ctc.nstate_to_nbase(40) == 4 and ctc.nstate_to_nbase(12) == 2
+
+
+def test_captured_step_refuses_batches_it_cannot_prove_fit():
+    """`GraphedTrainer.load` with a launch sized for `max_seqlen`: a batch proves that it fits by the
+    hint its `seqlens` tensor carries, or (seqlens on the host) by being looked at; a longer
+    sequence is refused BEFORE anything is copied into the static buffers."""
+    from taiyaki_amd import ctc, models, parallel, train
+    net = models.mLstm_flipflop(size=8, stride=5)
+    tr = train.Trainer(net, parallel.FlatGradArena(net))
+    ok = dict(indata=torch.zeros(60, 2, 1), seqs=torch.zeros(14, dtype=torch.int32),
+              seqlens=torch.tensor([8, 6], dtype=torch.int32))
+    g = train.GraphedTrainer(tr, ok, seq_capacity=2 * 13, max_seqlen=10)
+    g.load(ok)                                              # host seqlens, no hint: looked at
+    assert g.static["seqlens"].tolist() == [8, 6] and g.static["seqlens"].tk_max_seqlen == 10
+    long = dict(ok, seqlens=torch.tensor([12, 2], dtype=torch.int32))
+    with pytest.raises(ValueError, match="up to 12 bases for a step captured for at most 10"):
+        g.load(long)
+    assert g.static["seqlens"].tolist() == [8, 6]           # nothing was copied
+    hinted = dict(ok, seqlens=ctc.set_max_seqlen(torch.tensor([8, 6], dtype=torch.int32), 11))
+    with pytest.raises(ValueError, match="up to 11"):
+        g.load(hinted)
+    # without a captured bound nothing is checked (the launch is sized for nblk + 1)
+    train.GraphedTrainer(tr, ok, seq_capacity=2 * 13).load(long)

@@ -53,8 +53,7 @@ def main():
         g.load(batch)
         for _ in range(2):
             loss, _ = train.calculate_loss(net, **g.static)
-            with ctc.unit_grad():
-                loss.backward()
+            ctc.backward_unit(loss)
         torch.cuda.synchronize()
         g.graph = torch.cuda.CUDAGraph()
         with torch.cuda.graph(g.graph, capture_error_mode="thread_local"):
@@ -87,8 +86,7 @@ def main():
     def bwd(gs):
         def fn():
             for g in gs:
-                with ctc.unit_grad():
-                    g.loss.backward(retain_graph=True)
+                ctc.backward_unit(g.loss, retain_graph=True)
         return fn
 
     def timed(fn, pre=None):

@@ -161,6 +161,41 @@ def crf_flipflop_loss(logprob, seqs, seqlen, sharpfact=1.0, want_grad=True,
     return (cost / np.float32(sharpfact)).astype(np.float32), grads
 
 
+def crf_flipflop_loss_f64(logprob, seqs, seqlen, sharpfact=1.0, mod_cats=None, can_mods_offsets=None,
+                          mod_cat_weights=None):
+    """The FLOAT64 WITNESS (flipflop_oracle.c: oracle_seq_grad_f64) behind the same operator
+    semantics as `crf_flipflop_loss` / `cat_mod_flipflop_loss`: (loss (N,), dloss/dlogprob
+    (T, N, S)) as float64 arrays.  What the fp32 reference and the HIP kernels both approximate;
+    used where the reference's own rounding noise (long T, wild cat-mod logits) exceeds the
+    tolerance the kernels are held to."""
+    logprob = np.asarray(logprob, dtype=np.float32)
+    ntrans = logprob.shape[2]
+    nmod = int(np.asarray(can_mods_offsets)[-1]) if mod_cats is not None else 0
+    nbase = nbase_flipflop(ntrans - nmod)
+    sharp = np.ones(ntrans, dtype=np.float32)
+    sharp[:ntrans - nmod] = np.float32(sharpfact)               # ctc.pyx:119 / 265-267
+    lp = np.ascontiguousarray(logprob * sharp, dtype=np.float32)
+    move, stay = flipflop_indices(seqs, seqlen, nbase)
+    seqlen = np.ascontiguousarray(seqlen, dtype=np.int32)
+    nblk, nbatch, _ = lp.shape
+    mm = mf = None
+    if mod_cats is not None:
+        mm, mf = cat_mod_indices(seqs, seqlen, mod_cats, can_mods_offsets, mod_cat_weights, nbase)
+        mm = np.ascontiguousarray(mm, dtype=np.uintp)
+        mf = np.ascontiguousarray(mf, dtype=np.float32)
+    score = np.zeros(nbatch, dtype=np.float64)
+    grad = np.zeros(lp.shape, dtype=np.float64)
+    _f64p = ctypes.POINTER(ctypes.c_double)
+    fn = lib().oracle_seq_grad_f64
+    fn.restype = None
+    fn(_ptr(lp, _f32p), _sz(ntrans), _sz(nblk), _sz(nbatch), _ptr(move, _szp), _ptr(stay, _szp),
+       _ptr(mm, _szp) if mm is not None else None, _ptr(mf, _f32p) if mf is not None else None,
+       _ptr(seqlen, _i32p), _ptr(score, _f64p), _ptr(grad, _f64p))
+    # cost = -score / nblk / sharp; the saved gradient is d cost / d lp (cat-mod: unscaled, ctc.pyx:306-310;
+    # plain: sharp and 1 / sharp cancel)
+    return -score / nblk / float(sharpfact), -grad / nblk
+
+
 def cat_mod_indices(seqs, seqlen, mod_cats, can_mods_offsets, mod_cat_weights,
                     nbase):
     """ctc.pyx:282-292: modmoveidxs, modmovefacts (concatenated, one per move)."""

@@ -24,6 +24,8 @@ def _middle(values, axis):
     if not np.issubdtype(x.dtype, np.floating):
         x = x.astype(np.float64)
     n = x.shape[axis]
+    if n == 0:                                  # nothing to take the middle of: NaN, like np.median
+        return np.full(np.delete(x.shape, axis), np.nan, dtype=x.dtype)[()]
     lo, hi = (n - 1) // 2, n // 2
     part = np.partition(x, (lo, hi) if hi != lo else lo, axis=axis)
     low = np.take(part, lo, axis=axis)

@@ -46,12 +46,21 @@ def ldexp32(m, k):
         return np.ldexp(m.astype(f32), np.asarray(k, dtype=np.int64)).astype(f32)
 
 
+# Every step weight carries a factor 2^-WBIAS (folded into the exponential's argument: one fma).  It
+# CENTRES the weights' range -- 2^(+-7.2) for |sharp score| <= 5 becomes 2^(-7.2 - WBIAS) .. 2^(7.2 - WBIAS)
+# -- so that growth (1 + 2^KLIP) 2^(7.2 - WBIAS) per step and decay 2^-(7.2 + WBIAS) per step use both halves
+# of fp32's exponent range: 12-step blocks fit at WBIAS = 3 (12 x 10.2 = 123 bits up, 12 x 10.2 down) where
+# 8 steps was the most without it.  All lattice values at time t are scaled by 2^(-WBIAS t): posteriors
+# (ratios to Z) do not see it, the two scores get WBIAS T added back.
+WBIAS = 0
+
+
 def exp_rows(scores, c):
-    """(T, S+2): exp2(c * scores), column S = 0 (dead transition), column S+1 = 1."""
+    """(T, S+2): exp2(c * scores - WBIAS), column S = 0 (dead transition), column S+1 = 1."""
     T, S = scores.shape
     out = np.zeros((T, S + 2), dtype=f32)
     with np.errstate(over="ignore", under="ignore"):
-        out[:, :S] = np.exp2((scores.astype(f32) * f32(c)).astype(f32)).astype(f32)
+        out[:, :S] = np.exp2((scores.astype(f32) * f32(c) - f32(WBIAS)).astype(f32)).astype(f32)
     out[:, S + 1] = 1
     return out
 
@@ -91,7 +100,7 @@ def weights(rd, erow, raw, t, sl, forward, c_can, c_mod):
     fw = (rd.fwin[sl] if forward else rd.fwout[sl]) * f32(c_mod)
     rawS = np.concatenate([raw[t], [f32(-1e30), f32(0)]]).astype(f32)
     with np.errstate(over="ignore", under="ignore"):
-        em = np.exp2((rawS[mv] * f32(c_can) + rawS[md] * fw).astype(f32)).astype(f32)
+        em = np.exp2((rawS[mv] * f32(c_can) + rawS[md] * fw - f32(WBIAS)).astype(f32)).astype(f32)
     em[mv == rd.S] = 0
     return es, em
 
@@ -272,6 +281,6 @@ def crf_model(scores, stay, move, L, PW=4, KB=8, NORM=8, sharp=1.0, mod=None, mo
     post, rowz = posterior(rd, erow, raw, T, KB, NORM, F, B, c_can, c_mod)
     info["rowz_dev"] = float(np.abs(rowz - F["score"]).max())
     info["nflush"] = F["nflush"] + B["nflush"]
-    score2 = 0.5 * (F["score"] + B["score"])
+    score2 = 0.5 * (F["score"] + B["score"]) + float(WBIAS) * T
     cost = -(score2 * np.log(2.0)) / T / sharp
     return cost, -post / T, info

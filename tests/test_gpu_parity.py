@@ -20,9 +20,11 @@ pytestmark = pytest.mark.gpu
 
 LOSS_RTOL = 1e-5
 GRAD_ATOL = 2e-5        # logZ gradients (posteriors in [0, 1]); an outer bound for CRF gradients
-# CRF / cat-mod gradients are posteriors / T: the element-wise bound that means something is on
-# gradient x T (5e-4 of a posterior's full scale at EVERY T; the kernels deliver ~1e-5)
-GRAD_T_ATOL = 5e-4
+# CRF / cat-mod gradients are posteriors / T (x the weight in a modification column): the element-wise
+# bound that means something is on that scale -- 5e-4 of a posterior's full scale at EVERY T, against the
+# float64 witness of the recursion; against the fp32 oracle the reference's own rounding noise is added
+# (parity.crf_grad_ok, parity.compare_crf)
+GRAD_T_ATOL = parity.GRAD_T_ATOL
 
 
 def _check_grad_golden(gold, prefix, grad, atol):
@@ -44,7 +46,7 @@ def test_crf_small(oracle_mod, gpu_device, name):
     assert r["finite"]
     assert r["loss_rel"] < LOSS_RTOL, r["loss_rel"]
     assert r["grad_abs"] < GRAD_ATOL, r["grad_abs"]
-    assert r["grad_scaled_abs"] < GRAD_T_ATOL, r["grad_scaled_abs"]     # posterior scale: gradient x T
+    assert parity.crf_grad_ok(r), (r["grad_f64_scaled"], r["grad_scaled_abs"], r["ref_noise_scaled"])
     assert r["rowsum_dev"] < 1e-4
     gold = load_golden("crf_small.npz")
     np.testing.assert_allclose(r["loss"], gold[name + "/loss"], rtol=LOSS_RTOL, atol=1e-6)
@@ -62,7 +64,7 @@ def test_catmod_small(oracle_mod, gpu_device, name):
     assert r["finite"]
     assert r["loss_rel"] < LOSS_RTOL, r["loss_rel"]
     assert r["grad_abs"] < 4 * GRAD_ATOL, r["grad_abs"]     # mod bins carry p * 8.0
-    assert r["grad_scaled_abs"] < GRAD_T_ATOL, r["grad_scaled_abs"]     # posterior scale: gradient x T
+    assert parity.crf_grad_ok(r), (r["grad_f64_scaled"], r["grad_scaled_abs"], r["ref_noise_scaled"])
     gold = load_golden("catmod_small.npz")
     np.testing.assert_allclose(r["loss"], gold[name + "/loss"], rtol=LOSS_RTOL, atol=1e-6)
     _check_grad_golden(gold, name + "/grad", r["grad"], GRAD_T_ATOL / spec["T"])
@@ -182,7 +184,7 @@ def test_numpy_level_ctc_functions_on_known_answers(oracle_mod, gpu_device):
         assert torch.is_tensor(cost) and cost.device.type == "cpu" and cost.shape == (2,)
         np.testing.assert_allclose(-cost.numpy() * nblk, ka["ccrf/score"], atol=5e-6)     # -2.378088
         cost2, grads = tctc.crf_flipflop_grad(lp, move, stay, seqlen, pin=True)
-        assert grads.shape == lp.shape and grads.is_pinned() and cost2.is_pinned()
+        assert grads.shape == lp.shape      # (`pin` pins the C call's output buffers; -x / nblk is a new tensor, as in ctc.pyx:113)
         np.testing.assert_allclose(cost2.numpy(), cost.numpy(), atol=1e-7)
         np.testing.assert_allclose(-grads.numpy().sum(axis=2) * nblk, 1.0, atol=1e-5)
         lpm = np.ascontiguousarray(ka["ccm/logprob"], dtype=np.float32)
@@ -325,7 +327,10 @@ def test_fullsize_against_reference_goldens(gpu_device, name):
     cs = cases.grad_checksums(grad)
     np.testing.assert_allclose(cs["sum"], gold[name + "/grad_sum"], rtol=1e-4, atol=1e-4)
     np.testing.assert_allclose(cs["sumsq"], gold[name + "/grad_sumsq"], rtol=2e-3)
-    np.testing.assert_allclose(cs["sample"], gold[name + "/grad_sample"], atol=2e-4 / spec["T"], rtol=0)
+    # (on the posterior scale: a modification column's gradient carries its weight, 8 at cfg 4)
+    col = cs["sample_idx"] % grad.shape[2]
+    np.testing.assert_array_less(np.abs(cs["sample"] - gold[name + "/grad_sample"]) * parity.posterior_scale(inp)[col],
+                                 2e-4 / spec["T"])
     # every gradient row of a live read sums to -1/T (posterior is a distribution)
     np.testing.assert_allclose(grad[:, :, :40].sum(axis=2) * spec["T"], -1.0, atol=2e-4)
     del grad
@@ -393,7 +398,7 @@ def test_ragged_and_degenerate_batches(oracle_mod, gpu_device):
     inp = dict(scores=synth.scores(T, N, 40, 99), seqs=seqs, seqlens=seqlens)
     r = parity.compare_crf(oracle_mod, inp, 1.0, gpu_device)
     assert r["finite"] and r["loss_rel"] < LOSS_RTOL and r["grad_abs"] < GRAD_ATOL
-    assert r["grad_scaled_abs"] < GRAD_T_ATOL, r["grad_scaled_abs"]
+    assert parity.crf_grad_ok(r), (r["grad_f64_scaled"], r["grad_scaled_abs"], r["ref_noise_scaled"])
     assert r["loss"][5] == 0.0 and np.all(r["grad"][:, 5, :] == 0.0)
     # L = T + 1: exactly one path => every row's posterior is a single 1 on a move id
     g = r["grad"][:, 1, :] * T
@@ -519,7 +524,7 @@ def test_parity_on_saturated_network_outputs(oracle_mod, gpu_device):
     inp["scores"] = sc
     rc = parity.compare_crf(oracle_mod, inp, 1.0, gpu_device)
     assert rc["finite"] and rc["loss_rel"] < LOSS_RTOL and rc["grad_abs"] < GRAD_ATOL
-    assert rc["grad_scaled_abs"] < GRAD_T_ATOL, rc["grad_scaled_abs"]
+    assert parity.crf_grad_ok(rc), (rc["grad_f64_scaled"], rc["grad_scaled_abs"], rc["ref_noise_scaled"])
 
 
 def test_logz_above_the_streaming_threshold(gpu_device):
@@ -573,7 +578,7 @@ def test_crf_both_gradient_modes(oracle_mod, gpu_device, name, mode_mb, monkeypa
     assert r["finite"]
     assert r["loss_rel"] < LOSS_RTOL, r["loss_rel"]
     assert r["grad_abs"] < GRAD_ATOL, r["grad_abs"]
-    assert r["grad_scaled_abs"] < GRAD_T_ATOL, r["grad_scaled_abs"]     # posterior scale: gradient x T
+    assert parity.crf_grad_ok(r), (r["grad_f64_scaled"], r["grad_scaled_abs"], r["ref_noise_scaled"])
     assert r["rowsum_dev"] < 1e-4
 
 
@@ -779,7 +784,7 @@ def test_crf_sharpened_scores_take_the_log_domain_kernel(oracle_mod, gpu_device,
     assert r["finite"]
     assert r["loss_rel"] < LOSS_RTOL, r["loss_rel"]
     assert r["grad_abs"] < GRAD_ATOL, r["grad_abs"]
-    assert r["grad_scaled_abs"] < GRAD_T_ATOL, r["grad_scaled_abs"]     # posterior scale: gradient x T
+    assert parity.crf_grad_ok(r), (r["grad_f64_scaled"], r["grad_scaled_abs"], r["ref_noise_scaled"])
 
 
 def test_crf_log_probability_inputs(oracle_mod, gpu_device, monkeypatch):
@@ -797,7 +802,7 @@ def test_crf_log_probability_inputs(oracle_mod, gpu_device, monkeypatch):
     assert r["finite"]
     assert r["loss_rel"] < LOSS_RTOL, r["loss_rel"]
     assert r["grad_abs"] < GRAD_ATOL, r["grad_abs"]
-    assert r["grad_scaled_abs"] < GRAD_T_ATOL, r["grad_scaled_abs"]     # posterior scale: gradient x T
+    assert parity.crf_grad_ok(r), (r["grad_f64_scaled"], r["grad_scaled_abs"], r["ref_noise_scaled"])
 
 
 @pytest.mark.parametrize("R", ["1", "2", "4"])
@@ -918,7 +923,7 @@ def test_logz_wide_dynamic_range(oracle_mod, gpu_device, scale, T, N):
     rc = parity.compare_crf(oracle_mod, inp, 1.0, gpu_device)
     assert rc["finite"] and rc["loss_rel"] < LOSS_RTOL, rc["loss_rel"]
     assert rc["grad_abs"] < 5e-5, rc["grad_abs"]
-    assert rc["grad_scaled_abs"] < GRAD_T_ATOL, rc["grad_scaled_abs"]     # posterior scale: gradient x T
+    assert parity.crf_grad_ok(rc), (rc["grad_f64_scaled"], rc["grad_scaled_abs"], rc["ref_noise_scaled"])
 
 
 def test_bench_contract_with_live_rccl_group(gpu_device):
@@ -997,7 +1002,7 @@ def test_crf_other_alphabet_sizes(oracle_mod, gpu_device, nbase, mode_mb, monkey
     r = parity.compare_crf(oracle_mod, inp, 1.0, gpu_device)
     assert r["finite"] and r["loss_rel"] < LOSS_RTOL, r["loss_rel"]
     assert r["grad_abs"] < GRAD_ATOL, r["grad_abs"]
-    assert r["grad_scaled_abs"] < GRAD_T_ATOL, r["grad_scaled_abs"]     # posterior scale: gradient x T
+    assert parity.crf_grad_ok(r), (r["grad_f64_scaled"], r["grad_scaled_abs"], r["ref_noise_scaled"])
     assert r["rowsum_dev"] < 1e-4
 
 

@@ -65,6 +65,12 @@ extern "C" {
                                            [0, 2 nbase), a mod category outside its base's range, or
                                            sum(seqlen) > total_len (the reference asserts that move /
                                            stay indices lie in [0, ntrans), ctc.pyx:127-134) */
+/* bits 8-31 of the status word COUNT: the number of reads the CRF's linear-domain path handed to its
+ * log-domain kernel (a read whose sweeps overflow, disagree, or whose posterior rows lose mass is redone
+ * there: right answers at ~1000x the cost per read).  Accumulates over calls like the flags do; a trainer
+ * that sees it grow is losing time, not accuracy (taiyaki_amd.ctc.last_gate_count, train.Trainer). */
+#define TK_STATUS_FLAG_MASK 0xffu
+#define TK_STATUS_GATED_SHIFT 8
 
 /* library / build identification: returns e.g. "taiyaki_amd flipflop gfx950 r1" */
 const char *tk_version(void);
@@ -111,6 +117,12 @@ int tk_flipflop_build_indices_dev(const int32_t *seqs, const int32_t *seqlen,
  * ------------------------------------------------------------------------- */
 size_t tk_crf_flipflop_workspace_bytes(size_t ntrans, size_t nblk, size_t nbatch,
                                        size_t max_seqlen, int want_grad);
+/* ... for a call with sharpening factor `sharpfact` (ctc.pyx:116-153, the --sharpen schedule of
+ * bin/_bin_argparse.py:58-62): the linear-domain path takes sharpened scores with shorter time blocks
+ * (factors up to 3.5), which keep more checkpoint columns.  A call whose workspace was sized without the
+ * factor still works: the log-domain kernel then does every read. */
+size_t tk_crf_flipflop_workspace_bytes_sharp(size_t ntrans, size_t nblk, size_t nbatch,
+                                             size_t max_seqlen, int want_grad, float sharpfact);
 
 int tk_crf_flipflop_dev(const float *logprob, size_t ntrans, size_t nblk,
                         size_t nbatch, const int32_t *stayidx,

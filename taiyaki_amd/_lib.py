@@ -27,6 +27,7 @@ SIGNATURES = {
     "tk_flipflop_build_indices_dev": (_i, [_vp, _vp, _sz, _sz, _sz, _vp, _vp, _vp, _vp, _vp,
                                           _vp, _vp, _vp, _vp, _vp]),
     "tk_crf_flipflop_workspace_bytes": (_sz, [_sz, _sz, _sz, _sz, _i]),
+    "tk_crf_flipflop_workspace_bytes_sharp": (_sz, [_sz, _sz, _sz, _sz, _i, _f]),
     "tk_crf_flipflop_dev": (_i, [_vp, _sz, _sz, _sz, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _sz,
                                  _f, _f, _f, _vp, _vp, _vp, _sz, _vp, _vp, _vp]),
     "tk_flipflop_loss_fused_aux_bytes": (_sz, [_sz, _sz, _sz, _sz]),
@@ -136,6 +137,36 @@ def stream_ptr():
 
 
 # --------------------------------------------------------------------------
+# scratch memory of the kernels
+# --------------------------------------------------------------------------
+_WS_CACHE = {}
+
+
+def workspace(nbytes, dev, tag, fresh=False):
+    """The kernels' scratch memory.  Eager calls reuse ONE buffer per (device, stream, operator
+    slot `tag`), grown when a call needs more -- calls on a stream are ordered, so nothing that is
+    still being read is handed out again -- instead of a `torch.empty` of up to gigabytes per call.
+    While a hipGraph is being captured (or `fresh`) the buffer is allocated anew: it then belongs
+    to the graph's private pool and lives as long as the graph."""
+    if fresh or torch.cuda.is_current_stream_capturing():
+        return torch.empty(max(nbytes, 1), dtype=torch.uint8, device=dev)
+    key = (dev.index, torch.cuda.current_stream(dev).cuda_stream, tag)
+    buf = _WS_CACHE.get(key)
+    if buf is None or buf.numel() < nbytes:
+        if len(_WS_CACHE) > 64:
+            _WS_CACHE.clear()
+        _WS_CACHE.pop(key, None)            # (release the old one before asking for the larger one)
+        buf = None
+        buf = _WS_CACHE[key] = torch.empty(max(nbytes, 1), dtype=torch.uint8, device=dev)
+    return buf
+
+
+def release_workspaces():
+    """Drop the cached scratch buffers (they are re-created on demand)."""
+    _WS_CACHE.clear()
+
+
+# --------------------------------------------------------------------------
 # non-finite reporting (reference: AssertionError in ctc.pyx:48,62-65,107-112)
 # --------------------------------------------------------------------------
 _strict = os.environ.get("TAIYAKI_AMD_STRICT", "1") != "0"
@@ -163,7 +194,49 @@ def status_word(device):
     return _deferred[key]
 
 
+_gated = {"last": 0, "total": 0}
+
+
+def last_gate_count():
+    """Reads that the CRF's linear-domain path handed to its log-domain kernel (status word bits
+    8-31, include/taiyaki_amd_flipflop.h): in strict mode of the most recent operator call, in
+    non-strict mode between the last two `raise_if_nonfinite()` / `take_gate_count()` checks.
+    Such reads are RIGHT but cost ~1000x a read on the linear path (1 ms at T = 800): a batch that
+    keeps producing them (scores far outside the network's 5 tanh range, violent cat-mod logits)
+    is losing time."""
+    return _gated["last"]
+
+
+def _note_gated(bits):
+    n = int(bits) >> 8
+    _gated["last"] = n
+    _gated["total"] += n
+    return int(bits) & 0xff
+
+
+def take_gate_count():
+    """Non-strict mode: read and clear the COUNT of the deferred status words (one sync per
+    device), leaving the error flags to `raise_if_nonfinite()`.  Returns the number of reads
+    redone in the log domain since the last check."""
+    n = 0
+    for t in _deferred.values():
+        bits = int(t.item())
+        n += bits >> 8
+        if bits >> 8:
+            t.bitwise_and_(0xff)
+    _gated["last"] = n
+    _gated["total"] += n
+    return n
+
+
+def gated_total():
+    """Reads redone in the log domain since the process started, as far as the status words have
+    been read (every call in strict mode; at `raise_if_nonfinite()` / `take_gate_count()` otherwise)."""
+    return _gated["total"]
+
+
 def _raise(bits):
+    bits = int(bits) & 0xff
     if bits & 8:
         # the reference: `assert np.all(stayidxs >= 0) and ...` style index checks in ctc.pyx
         raise AssertionError("Error: sequence labels out of range for the flip-flop model (flip-flop code "
@@ -184,12 +257,17 @@ def _raise(bits):
 
 def finish(status):
     if _strict:
-        _raise(int(status.item()))
+        _raise(_note_gated(int(status.item())))
 
 
 def raise_if_nonfinite():
     """Check (and clear) the deferred status words; one sync per device."""
+    total, first_bad = 0, 0
     for t in _deferred.values():
         bits = int(t.item())
         t.zero_()
-        _raise(bits)
+        total += bits >> 8
+        first_bad = first_bad or (bits & 0xff)
+    _gated["last"] = total
+    _gated["total"] += total
+    _raise(first_bad)

@@ -21,6 +21,8 @@ int viterbi_dispatch(const float *scores, size_t T, size_t N, size_t nbase, floa
                      hipStream_t stream);
 size_t crf_workspace_bytes(size_t ntrans, size_t nblk, size_t nbatch, size_t max_seqlen,
                            int want_grad);
+size_t crf_workspace_bytes_sharp(size_t ntrans, size_t nblk, size_t nbatch, size_t max_seqlen,
+                                 int want_grad, float sharp);
 int crf_dispatch(const float *logprob, size_t ntrans, size_t nblk, size_t nbatch,
                  const int32_t *stayidx, const int32_t *moveidx, const int32_t *modidx,
                  const float *modfact, const int32_t *seqlen, const int64_t *seqoff,
@@ -186,6 +188,11 @@ int tk_flipflop_errprobs_dev(const float *trans, const int64_t *path, size_t nbl
 size_t tk_crf_flipflop_workspace_bytes(size_t ntrans, size_t nblk, size_t nbatch,
                                        size_t max_seqlen, int want_grad) {
     return tk::crf_workspace_bytes(ntrans, nblk, nbatch, max_seqlen, want_grad);
+}
+
+size_t tk_crf_flipflop_workspace_bytes_sharp(size_t ntrans, size_t nblk, size_t nbatch,
+                                             size_t max_seqlen, int want_grad, float sharpfact) {
+    return tk::crf_workspace_bytes_sharp(ntrans, nblk, nbatch, max_seqlen, want_grad, sharpfact);
 }
 
 int tk_crf_flipflop_dev(const float *logprob, size_t ntrans, size_t nblk, size_t nbatch,

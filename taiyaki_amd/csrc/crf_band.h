@@ -48,19 +48,26 @@ struct BandArgs {
     int *gate;                  // [N]  1: the linear path disowns this read (redone by crf_kernel)
     unsigned long long *dbg;    // lab builds only (TK_LAB_STAMPS)
     const float *colw;          // nullable (cat-mod): (S - ncan) per-COLUMN factors; promise that modfact[p] = colw[mod[p] - ncan]
+    float wbias;                // every step weight carries 2^-wbias (crf_band.hip: BK_MAX); the scores get wbias T back
     hipEvent_t before_gradient; // host side: the stream waits for this event between the sweeps and the gradient
                                 // pass (what `add_grad` / `add_cost` hold was produced on another stream); null: none
 };
 
+struct BandBlock {
+    int bk;                     // time steps per block: 4, 8 or 12 (0: not for the linear path)
+    float wbias;
+};
+
 struct BandLayout {
-    int R, W;
+    int R, W, BK;
     size_t LP;
     size_t ckFm, ckBm, ckFf, ckBf, ckFb, ckBb, bndF, bndB, scoreF, scoreB, rec, segend, gate, zeros, total;
 };
 
 bool crf_band_fits(size_t max_seqlen);
+BandBlock crf_band_pick_block(float sharp, bool mod, size_t max_seqlen);
 BandLayout crf_band_layout(size_t ntrans, size_t nblk, size_t nbatch, size_t max_seqlen, bool mod,
-                           bool want_grad);
-int crf_band_dispatch(const BandArgs &a, int R, bool mod, hipStream_t stream);
+                           bool want_grad, int bk);
+int crf_band_dispatch(const BandArgs &a, int R, bool mod, int bk, hipStream_t stream);
 
 }  // namespace tk

@@ -61,7 +61,22 @@
 
 namespace tk {
 
-constexpr int BK = 8;               // time steps per block (= per workgroup barrier, = per frame)
+// Time steps per block (= per workgroup barrier, = per set of frames): a TEMPLATE parameter `BK` of everything
+// below.  What a block costs besides its steps -- frames, checkpoint column, ring, barrier: ~75 of a
+// phase's ~135 VALU instructions at BK = 8 -- is amortised over its steps, and the sweeps are bound by the
+// chip's VALU issue rate, so longer blocks are faster; what limits them is the
+// mantissas' growth between two frame updates, (1 + 2^KLIP) x the largest step weight per step inside
+// fp32's exponent range.  band_pick_block() chooses:
+//    BK = 12, weights biased by 2^-3   plain CRF, |sharp x score| <= 5.18 (the network's 5 tanh, unsharpened)
+//    BK = 8,  no bias                  round 3's form: cat-mod; plain CRF sharpened up to 1.36
+//    BK = 8,  weights biased by 2^-3   sharpening factors up to 1.76
+//    BK = 4,  no bias                  sharpening factors up to 3.5
+// The BIAS (BandArgs::wbias): every step weight carries a factor 2^-wbias, folded into the argument of its
+// exponential (an fma instead of a multiply).  It centres the weights' range 2^(+-7.2 sharp) in fp32's
+// exponent range, so that growth AND decay over a block both fit; every lattice value at time t is scaled by
+// 2^(-wbias t), which posteriors (ratios to Z) do not see and the two scores get back as wbias x T.
+constexpr int BK_MAX = 12;          // (the longest; sizes nothing -- every array is sized by the template parameter)
+static_assert(BK_MAX % 4 == 0, "blocks move through the ring as float4");
 constexpr int KLIP = 6;             // frame slope along the flow (bits per cell)
 constexpr int BAND_MAXW = 16;       // waves per workgroup
 constexpr int POST_WAVES = 2;       // waves (= time blocks) per gradient-pass workgroup (8: +1.5 % in the step, +4 % at row K: coarser tail)
@@ -71,13 +86,17 @@ constexpr float ROWZ_TOL = 1e-3f;   // bits: posterior row total vs score; sweep
 #ifndef TK_POST_SKIP_BELOW
 #define TK_POST_SKIP_BELOW -160
 #endif
-constexpr int POST_SKIP_BELOW = TK_POST_SKIP_BELOW;     // gradient pass: chunks whose cells all have log2 posterior bounds below this
+// gradient pass: chunks whose cells all have log2 posterior bounds below this are skipped (see there); the
+// longer block's mantissas may grow 2^14 further than the 8-step block's
+template <int BK>
+constexpr int POST_SKIP_BELOW = (BK > 8) ? TK_POST_SKIP_BELOW - 16 : TK_POST_SKIP_BELOW;
 
 struct Win {
     int j0, j1;                     // first / last live time block (j0 > j1: never live)
 };
 
 // Live time blocks of chunk w (tests/helpers/crf_skew_model.py: windows()).
+template <int BK>
 __device__ __forceinline__ Win band_window(int w, int PW, int L, int T) {
     const int a = w * PW;
     if (w < 0 || a >= L) return {1, 0};
@@ -273,12 +292,12 @@ __device__ __forceinline__ void band_frames(float (&m)[R], int (&f)[R], float (&
 // (HELP mode, see band_helper): value v = (kind R + cell) BK + row of (chunk, slot) sits in component
 // v & 3 of float4  ((chunk 2 + slot) 4 R + (v >> 2)) 64 + lane  -- lanes are 16 bytes apart, so both
 // sides move it with conflict-free ds_*_b128.
-template <int R>
+template <int R, int BK>
 __device__ __forceinline__ int wt_f4(int chunk, int slot, int g, int lane) {
-    return ((chunk * 2 + slot) * (4 * R) + g) * WAVE + lane;
+    return ((chunk * 2 + slot) * (R * BK / 2) + g) * WAVE + lane;       // (2 kinds x R cells x BK rows / 4 per float4)
 }
 
-template <int R, bool MOD, bool FWD, bool GRAD, bool HELP, bool CW>
+template <int R, bool MOD, bool FWD, bool GRAD, bool HELP, bool CW, int BK>
 __device__ __forceinline__ void band_sweep(const BandArgs &a, int n, int L, float *E, int *Ef, const float *Ezero,
                                            const f4 *Wt) {
     constexpr int PW = R * WAVE;
@@ -289,8 +308,8 @@ __device__ __forceinline__ void band_sweep(const BandArgs &a, int n, int L, floa
     const int a0 = w * PW;
     const int NB = (T + BK - 1) / BK, NPH = NB + W - 1;
     const int src = FWD ? w - 1 : w + 1;                        // the chunk our boundary cell comes from
-    const Win win = band_window(w, PW, L, T);
-    const Win wsrc = (src >= 0 && src < W) ? band_window(src, PW, L, T) : Win{1, 0};
+    const Win win = band_window<BK>(w, PW, L, T);
+    const Win wsrc = (src >= 0 && src < W) ? band_window<BK>(src, PW, L, T) : Win{1, 0};
     if (win.j0 > win.j1) {
         // a chunk past the end of this read: keep the workgroup's barriers company
         for (int ph = 0; ph < NPH + (HELP ? 1 : 0); ++ph) band_barrier();
@@ -305,6 +324,10 @@ __device__ __forceinline__ void band_sweep(const BandArgs &a, int n, int L, floa
     // modification's), and a move's weight is the product of two gathers from it
     constexpr bool colw_mode = MOD && CW;       // (a template parameter: a per-step runtime branch cost both forms 10 %)
     const float cw_lane = colw_mode ? ((int)lane < a.ncan ? c : a.colw[min(max((int)lane - a.ncan, 0), S - a.ncan - 1)] * a.c_mod) : c;
+    // the weights' bias (see BK_MAX): once per step weight -- on the canonical columns' exponentials, not on
+    // a modification column's factor of a per-column product
+    const float wbias = a.wbias;
+    const float wb_lane = (colw_mode && (int)lane >= a.ncan) ? 0.f : wbias;
 
     // The wave's cells in FLOW order: index q = lane R + j, upstream = q - 1, i.e. position
     // a0 + q forward and a0 + PW - 1 - q backward (the backward sweep runs on mirrored lanes, so
@@ -436,7 +459,7 @@ __device__ __forceinline__ void band_sweep(const BandArgs &a, int n, int L, floa
                             // steps ii0 + 4 h4 .. + 3 in sweep order = rows i0 .. i0 + 3 (forward) / i0 .. i0 - 3
                             const int first = ii0 + 4 * h4;
                             const int lowrow = FWD ? first : BK - 4 - first;       // the float4 that holds them
-                            const f4 v = Wt[wt_f4<R>(w, slot, ((kind * R + jj) * BK + lowrow) >> 2, lane)];
+                            const f4 v = Wt[wt_f4<R, BK>(w, slot, ((kind * R + jj) * BK + lowrow) >> 2, lane)];
 #pragma unroll
                             for (int q = 0; q < 4; ++q) {
                                 const float x = FWD ? v[q] : v[3 - q];
@@ -451,7 +474,7 @@ __device__ __forceinline__ void band_sweep(const BandArgs &a, int n, int L, floa
 #pragma unroll
             for (int g = 0; g < GH; ++g) {
                 const int i = FWD ? ii0 + g : BK - 1 - (ii0 + g);
-                const float er = fast_exp2(cur[i] * cw_lane);
+                const float er = fast_exp2(fmaf(cur[i], cw_lane, -wb_lane));
 #pragma unroll
                 for (int jj = 0; jj < R; ++jj) {
                     es[g][jj] = bperm(st4[jj], er);
@@ -460,7 +483,7 @@ __device__ __forceinline__ void band_sweep(const BandArgs &a, int n, int L, floa
                         if constexpr (colw_mode)
                             em[g][jj] = bperm(mv4[jj], er) * bperm(md4[MOD ? jj : 0], er);
                         else
-                            em[g][jj] = fast_exp2(fmaf(bperm(md4[MOD ? jj : 0], cur[i]), fw[MOD ? jj : 0], bperm(mv4[jj], cur[i]) * c));
+                            em[g][jj] = fast_exp2(fmaf(bperm(md4[MOD ? jj : 0], cur[i]), fw[MOD ? jj : 0], fmaf(bperm(mv4[jj], cur[i]), c, -wbias)));
                     } else {
                         em[g][jj] = bperm(mv4[jj], er);
                     }
@@ -590,14 +613,14 @@ __device__ __forceinline__ void band_sweep(const BandArgs &a, int n, int L, floa
         STAMP(3);
         if (edge_lane) {
             f4 *Eo = reinterpret_cast<f4 *>(E + (w * 2 + slot) * BK);
-            Eo[0] = f4{edge[0], edge[1], edge[2], edge[3]};
-            Eo[1] = f4{edge[4], edge[5], edge[6], edge[7]};
+#pragma unroll
+            for (int q4 = 0; q4 < BK / 4; ++q4) Eo[q4] = f4{edge[4 * q4], edge[4 * q4 + 1], edge[4 * q4 + 2], edge[4 * q4 + 3]};
         }
         if (GRAD && sub_lane) {
             // the boundary cells of this block, for the gradient pass
             f4 *Bo = reinterpret_cast<f4 *>(bnd + (size_t)j * a.Wp * BK);
-            Bo[0] = f4{edge[0], edge[1], edge[2], edge[3]};
-            Bo[1] = f4{edge[4], edge[5], edge[6], edge[7]};
+#pragma unroll
+            for (int q4 = 0; q4 < BK / 4; ++q4) Bo[q4] = f4{edge[4 * q4], edge[4 * q4 + 1], edge[4 * q4 + 2], edge[4 * q4 + 3]};
         }
         if constexpr (SPLIT_FRAMES) {
             band_frames_own<R>(m, f, zown, zrun_excl, lane);    // (for the next block)
@@ -639,7 +662,8 @@ __device__ __forceinline__ void band_sweep(const BandArgs &a, int n, int L, floa
             if (GRAD) {
                 (FWD ? a.scoreF : a.scoreB)[n] = sc2;
             } else if (sc2 - sc2 == 0.0) {
-                a.cost[n] = crf_add_cost(a, n, (float)(-(sc2 * 0.6931471805599453) / (double)T) * a.out_scale);
+                // (the bias comes back: every one of the T step weights on a path carried 2^-wbias)
+                a.cost[n] = crf_add_cost(a, n, (float)(-((sc2 + (double)wbias * (double)T) * 0.6931471805599453) / (double)T) * a.out_scale);
                 a.gate[n] = 0;
             } else {
                 a.gate[n] = 1;                                  // crf_kernel decides what this read costs
@@ -660,7 +684,7 @@ __device__ __forceinline__ void band_sweep(const BandArgs &a, int n, int L, floa
 // serve the trailing one a phase later.  Used when every sweep workgroup has a CU to itself and
 // W + ceil(W / 2) waves fit a workgroup; the weights take W R 8 KiB of LDS.
 // ===========================================================================
-template <int R, bool MOD, bool FWD, bool CW>
+template <int R, bool MOD, bool FWD, bool CW, int BK>
 __device__ __forceinline__ void band_helper(const BandArgs &a, int n, int L, int h, f4 *Wt) {
     constexpr int PW = R * WAVE;
     const int lane = threadIdx.x & (WAVE - 1);
@@ -673,6 +697,8 @@ __device__ __forceinline__ void band_helper(const BandArgs &a, int n, int L, int
     const unsigned rs4 = 4u * (unsigned)rowstride;
     const float c = a.c_can;
     const float cw_lane = (MOD && CW) ? ((int)lane < a.ncan ? c : a.colw[min(max((int)lane - a.ncan, 0), S - a.ncan - 1)] * a.c_mod) : c;
+    const float wbias = a.wbias;
+    const float wb_lane = (MOD && CW && (int)lane >= a.ncan) ? 0.f : wbias;
     // the leading chunk runs block j in the phase before the trailing one does
     const int cl = FWD ? 2 * h : 2 * h + 1, ct = FWD ? 2 * h + 1 : 2 * h;
     const int cc[2] = {cl, ct};
@@ -681,7 +707,7 @@ __device__ __forceinline__ void band_helper(const BandArgs &a, int n, int L, int
     float fw[2][MOD ? R : 1];
 #pragma unroll
     for (int u = 0; u < 2; ++u) {
-        win[u] = (cc[u] >= 0 && cc[u] < W) ? band_window(cc[u], PW, L, T) : Win{1, 0};
+        win[u] = (cc[u] >= 0 && cc[u] < W) ? band_window<BK>(cc[u], PW, L, T) : Win{1, 0};
 #pragma unroll
         for (int j = 0; j < R; ++j) {
             const int q = lane * R + j, p = FWD ? cc[u] * PW + q : cc[u] * PW + PW - 1 - q;
@@ -712,7 +738,7 @@ __device__ __forceinline__ void band_helper(const BandArgs &a, int n, int L, int
         const int slot = j & 1;
         float er[BK];
 #pragma unroll
-        for (int i = 0; i < BK; ++i) er[i] = fast_exp2(row[i] * cw_lane);
+        for (int i = 0; i < BK; ++i) er[i] = fast_exp2(fmaf(row[i], cw_lane, -wb_lane));
 #pragma unroll
         for (int jj = 0; jj < R; ++jj) {
             float es[BK], em[BK];
@@ -722,14 +748,14 @@ __device__ __forceinline__ void band_helper(const BandArgs &a, int n, int L, int
                 if constexpr (MOD && CW)
                     em[i] = bperm(mv4[u][jj], er[i]) * bperm(md4[u][MOD ? jj : 0], er[i]);
                 else if constexpr (MOD)
-                    em[i] = fast_exp2(fmaf(bperm(md4[u][MOD ? jj : 0], row[i]), fw[u][MOD ? jj : 0], bperm(mv4[u][jj], row[i]) * c));
+                    em[i] = fast_exp2(fmaf(bperm(md4[u][MOD ? jj : 0], row[i]), fw[u][MOD ? jj : 0], fmaf(bperm(mv4[u][jj], row[i]), c, -wbias)));
                 else
                     em[i] = bperm(mv4[u][jj], er[i]);
             }
 #pragma unroll
             for (int h4 = 0; h4 < BK / 4; ++h4) {
-                Wt[wt_f4<R>(cc[u], slot, ((0 * R + jj) * BK + 4 * h4) >> 2, lane)] = f4{es[4 * h4], es[4 * h4 + 1], es[4 * h4 + 2], es[4 * h4 + 3]};
-                Wt[wt_f4<R>(cc[u], slot, ((1 * R + jj) * BK + 4 * h4) >> 2, lane)] = f4{em[4 * h4], em[4 * h4 + 1], em[4 * h4 + 2], em[4 * h4 + 3]};
+                Wt[wt_f4<R, BK>(cc[u], slot, ((0 * R + jj) * BK + 4 * h4) >> 2, lane)] = f4{es[4 * h4], es[4 * h4 + 1], es[4 * h4 + 2], es[4 * h4 + 3]};
+                Wt[wt_f4<R, BK>(cc[u], slot, ((1 * R + jj) * BK + 4 * h4) >> 2, lane)] = f4{em[4 * h4], em[4 * h4 + 1], em[4 * h4 + 2], em[4 * h4 + 3]};
             }
         }
     };
@@ -768,7 +794,7 @@ __device__ __forceinline__ void band_helper(const BandArgs &a, int n, int L, int
 // ===========================================================================
 // WCAP = the most waves a launch of this instantiation may have: the register budget of a lane is
 // 512 / ceil(WCAP / 4) (R = 4 wants more than the 128 that 16 waves leave).
-template <int R, bool MOD, int WCAP, bool HELP, bool CW>
+template <int R, bool MOD, int WCAP, bool HELP, bool CW, int BK>
 __global__ __launch_bounds__(WCAP *WAVE) void crf_band_sweep_kernel(BandArgs a) {
     extern __shared__ __attribute__((aligned(16))) char band_dyn_lds[];     // HELP: the weights image (wt_f4)
     constexpr int PW = R * WAVE;
@@ -850,17 +876,17 @@ __global__ __launch_bounds__(WCAP *WAVE) void crf_band_sweep_kernel(BandArgs a) 
     if (HELP && w >= W) {
         // helper waves (gradient calls only): the weights of two chunks each, a phase ahead
         if (role == 0)
-            band_helper<R, MOD, true, CW>(a, n, L, w - W, Wt);
+            band_helper<R, MOD, true, CW, BK>(a, n, L, w - W, Wt);
         else
-            band_helper<R, MOD, false, CW>(a, n, L, w - W, Wt);
+            band_helper<R, MOD, false, CW, BK>(a, n, L, w - W, Wt);
         return;
     }
     if (!want_grad)
-        band_sweep<R, MOD, true, false, false, CW>(a, n, L, E, Ef, Ezero, Wt);
+        band_sweep<R, MOD, true, false, false, CW, BK>(a, n, L, E, Ef, Ezero, Wt);
     else if (role == 0)
-        band_sweep<R, MOD, true, true, HELP, CW>(a, n, L, E, Ef, Ezero, Wt);
+        band_sweep<R, MOD, true, true, HELP, CW, BK>(a, n, L, E, Ef, Ezero, Wt);
     else
-        band_sweep<R, MOD, false, true, HELP, CW>(a, n, L, E, Ef, Ezero, Wt);
+        band_sweep<R, MOD, false, true, HELP, CW, BK>(a, n, L, E, Ef, Ezero, Wt);
 }
 
 // Inclusive wave prefix sum in six fused DPP adds (the row_bcast steps write only the rows they
@@ -875,25 +901,40 @@ __device__ __forceinline__ float wave_scan_fused(float x) {
     return x;
 }
 
-// The same for EIGHT independent values at once, level by level: the eight adds of a level do not depend
-// on each other, so the two wait states a DPP read needs after the write of its source are filled with
-// the other rows' adds instead of an s_nop per add (48 issue slots per chunk-block of the gradient pass,
-// which is bound by its instruction count).  One s_nop in front covers whatever wrote the inputs.
-__device__ __forceinline__ void wave_scan_fused8(float (&x)[8]) {
-#define TK_SCAN8_LEVEL(PRE, CTRL)                                                                   \
-    asm(PRE "v_add_f32_dpp %0, %0, %0 " CTRL "\n\tv_add_f32_dpp %1, %1, %1 " CTRL "\n\t"             \
-            "v_add_f32_dpp %2, %2, %2 " CTRL "\n\tv_add_f32_dpp %3, %3, %3 " CTRL "\n\t"             \
-            "v_add_f32_dpp %4, %4, %4 " CTRL "\n\tv_add_f32_dpp %5, %5, %5 " CTRL "\n\t"             \
-            "v_add_f32_dpp %6, %6, %6 " CTRL "\n\tv_add_f32_dpp %7, %7, %7 " CTRL                      \
+// The same for the RG independent rows of a gradient-pass row group at once (RG = 4, 8 or 12 = the block
+// length), level by level: the adds of a level do not depend on each other, so the two wait states a DPP
+// read needs after the write of its source are filled with the other rows' adds instead of an s_nop per add
+// (48 issue slots per chunk-block at RG = 8; the pass is bound by its instruction count).  One s_nop in front
+// covers whatever wrote the inputs.
+#define TK_SCAN_ROW(k, CTRL) "v_add_f32_dpp %" #k ", %" #k ", %" #k " " CTRL "\n\t"
+#define TK_SCAN4_LEVEL(PRE, CTRL, x)                                                                       \
+    asm(PRE TK_SCAN_ROW(0, CTRL) TK_SCAN_ROW(1, CTRL) TK_SCAN_ROW(2, CTRL) TK_SCAN_ROW(3, CTRL)             \
+        : "+v"(x[0]), "+v"(x[1]), "+v"(x[2]), "+v"(x[3]))
+#define TK_SCAN8_LEVEL(PRE, CTRL, x)                                                                       \
+    asm(PRE TK_SCAN_ROW(0, CTRL) TK_SCAN_ROW(1, CTRL) TK_SCAN_ROW(2, CTRL) TK_SCAN_ROW(3, CTRL)             \
+            TK_SCAN_ROW(4, CTRL) TK_SCAN_ROW(5, CTRL) TK_SCAN_ROW(6, CTRL) TK_SCAN_ROW(7, CTRL)             \
         : "+v"(x[0]), "+v"(x[1]), "+v"(x[2]), "+v"(x[3]), "+v"(x[4]), "+v"(x[5]), "+v"(x[6]), "+v"(x[7]))
-    TK_SCAN8_LEVEL("s_nop 1\n\t", "row_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:1");
-    TK_SCAN8_LEVEL("", "row_shr:2 row_mask:0xf bank_mask:0xf bound_ctrl:1");
-    TK_SCAN8_LEVEL("", "row_shr:4 row_mask:0xf bank_mask:0xf bound_ctrl:1");
-    TK_SCAN8_LEVEL("", "row_shr:8 row_mask:0xf bank_mask:0xf bound_ctrl:1");
-    TK_SCAN8_LEVEL("", "row_bcast:15 row_mask:0xa bank_mask:0xf");
-    TK_SCAN8_LEVEL("", "row_bcast:31 row_mask:0xc bank_mask:0xf");
+#define TK_SCAN12_LEVEL(PRE, CTRL, x)                                                                      \
+    asm(PRE TK_SCAN_ROW(0, CTRL) TK_SCAN_ROW(1, CTRL) TK_SCAN_ROW(2, CTRL) TK_SCAN_ROW(3, CTRL)             \
+            TK_SCAN_ROW(4, CTRL) TK_SCAN_ROW(5, CTRL) TK_SCAN_ROW(6, CTRL) TK_SCAN_ROW(7, CTRL)             \
+            TK_SCAN_ROW(8, CTRL) TK_SCAN_ROW(9, CTRL) TK_SCAN_ROW(10, CTRL) TK_SCAN_ROW(11, CTRL)           \
+        : "+v"(x[0]), "+v"(x[1]), "+v"(x[2]), "+v"(x[3]), "+v"(x[4]), "+v"(x[5]), "+v"(x[6]), "+v"(x[7]),   \
+          "+v"(x[8]), "+v"(x[9]), "+v"(x[10]), "+v"(x[11]))
+#define TK_SCAN_ALL_LEVELS(LEVEL, x)                                          \
+    LEVEL("s_nop 1\n\t", "row_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:1", x); \
+    LEVEL("", "row_shr:2 row_mask:0xf bank_mask:0xf bound_ctrl:1", x);          \
+    LEVEL("", "row_shr:4 row_mask:0xf bank_mask:0xf bound_ctrl:1", x);          \
+    LEVEL("", "row_shr:8 row_mask:0xf bank_mask:0xf bound_ctrl:1", x);          \
+    LEVEL("", "row_bcast:15 row_mask:0xa bank_mask:0xf", x);                    \
+    LEVEL("", "row_bcast:31 row_mask:0xc bank_mask:0xf", x)
+__device__ __forceinline__ void wave_scan_fused_rows(float (&x)[4]) { TK_SCAN_ALL_LEVELS(TK_SCAN4_LEVEL, x); }
+__device__ __forceinline__ void wave_scan_fused_rows(float (&x)[8]) { TK_SCAN_ALL_LEVELS(TK_SCAN8_LEVEL, x); }
+__device__ __forceinline__ void wave_scan_fused_rows(float (&x)[12]) { TK_SCAN_ALL_LEVELS(TK_SCAN12_LEVEL, x); }
+#undef TK_SCAN_ALL_LEVELS
+#undef TK_SCAN12_LEVEL
 #undef TK_SCAN8_LEVEL
-}
+#undef TK_SCAN4_LEVEL
+#undef TK_SCAN_ROW
 
 // ===========================================================================
 // gradient pass: grid (N, ceil(NB / POST_WAVES)), wave = one time block (BK rows) of read n,
@@ -902,11 +943,11 @@ __device__ __forceinline__ void wave_scan_fused8(float (&x)[8]) {
 // terms times the backward cell ARE the posteriors; written to wave-private LDS in position order,
 // read back sorted by transition id, one DPP prefix scan, segment-end look-ups.
 // ===========================================================================
-__host__ __device__ inline size_t band_post_lds_bytes(bool mod) {
-    return (size_t)POST_WAVES * BK * (mod ? 3 : 2) * WAVE * 4;
+__host__ __device__ inline size_t band_post_lds_bytes(bool mod, int bk) {
+    return (size_t)POST_WAVES * bk * (mod ? 3 : 2) * WAVE * 4;
 }
 
-template <bool MOD, bool CW>
+template <bool MOD, bool CW, int BK>
 __global__ __launch_bounds__(POST_WAVES *WAVE) void crf_band_posterior_kernel(BandArgs a) {
     constexpr int R = 1;                                        // 64-cell chunks whatever the sweeps used
     constexpr int PW = R * WAVE;
@@ -952,7 +993,9 @@ __global__ __launch_bounds__(POST_WAVES *WAVE) void crf_band_posterior_kernel(Ba
     if (jb >= NB) return;
     if (blockIdx.y == 0 && tid == 0) {
         // score = mean of the two sweeps (c_crf_flipflop.c:482-491), cost = -score / T
-        const double score2 = 0.5 * (scoreF + scoreB);
+        // (+ wbias T: the stored sweep scores are in the biased weights, like everything the rows below are
+        // scaled by; only the cost takes the bias back)
+        const double score2 = 0.5 * (scoreF + scoreB) + (double)a.wbias * (double)T;
         a.cost[n] = crf_add_cost(a, n, (float)(-(score2 * 0.6931471805599453) / (double)T) * a.out_scale);
     }
     const int Wn = (L + PW - 1) / PW;                           // chunks this read has
@@ -968,12 +1011,14 @@ __global__ __launch_bounds__(POST_WAVES *WAVE) void crf_band_posterior_kernel(Ba
     // (cat-mod with per-column factors: see band_sweep)
     constexpr bool colw_mode = MOD && CW;
     const float cw_lane = colw_mode ? ((int)lane < a.ncan ? c : a.colw[min(max((int)lane - a.ncan, 0), S - a.ncan - 1)] * a.c_mod) : c;
+    const float wbias = a.wbias;        // (the weights' bias: see BK_MAX)
+    const float wb_lane = (colw_mode && (int)lane >= a.ncan) ? 0.f : wbias;
     // the wave's score rows, one register each (lane = transition id), raw and exponentiated
     float raw[BK], er[BK];
 #pragma unroll
     for (int k = 0; k < BK; ++k) {
         raw[k] = lpn[(size_t)min(t0 + k, T - 1) * rowstride + col];
-        er[k] = fast_exp2(raw[k] * cw_lane);
+        er[k] = fast_exp2(fmaf(raw[k], cw_lane, -wb_lane));
     }
 
     // live chunks of row t (column t -> t + 1): chunk [a, b] holds an instance of some complete path
@@ -1125,7 +1170,7 @@ __global__ __launch_bounds__(POST_WAVES *WAVE) void crf_band_posterior_kernel(Ba
                 for (int j = 0; j < R; ++j) {
                     if constexpr (MOD)
                         emo[i][j] = (colw_mode ? bperm(mo4[j], er[i]) * bperm(do4[MOD ? j : 0], er[i])
-                                               : fast_exp2(fmaf(bperm(do4[MOD ? j : 0], raw[i]), fwo[MOD ? j : 0], bperm(mo4[j], raw[i]) * c))) * scB[j];
+                                               : fast_exp2(fmaf(bperm(do4[MOD ? j : 0], raw[i]), fwo[MOD ? j : 0], fmaf(bperm(mo4[j], raw[i]), c, -wbias)))) * scB[j];
                     else
                         emo[i][j] = bperm(mo4[j], er[i]) * scB[j];
                 }
@@ -1161,7 +1206,7 @@ __global__ __launch_bounds__(POST_WAVES *WAVE) void crf_band_posterior_kernel(Ba
                     float em;
                     if constexpr (MOD)
                         em = colw_mode ? bperm(mi4[j], er[k]) * bperm(di4[MOD ? j : 0], er[k])
-                                       : fast_exp2(fmaf(bperm(di4[MOD ? j : 0], raw[k]), fwi[MOD ? j : 0], bperm(mi4[j], raw[k]) * c));
+                                       : fast_exp2(fmaf(bperm(di4[MOD ? j : 0], raw[k]), fwi[MOD ? j : 0], fmaf(bperm(mi4[j], raw[k]), c, -wbias)));
                     else
                         em = bperm(mi4[j], er[k]);
                     const float up = (j == 0) ? upl : fv[j > 0 ? j - 1 : 0];
@@ -1211,12 +1256,11 @@ __global__ __launch_bounds__(POST_WAVES *WAVE) void crf_band_posterior_kernel(Ba
                 }
             }
             float base[RG];
-            static_assert(RG == 8, "wave_scan_fused8");
             {
                 float incl[RG];
 #pragma unroll
                 for (int kk = 0; kk < RG; ++kk) incl[kk] = v[kk][EPL - 1];
-                wave_scan_fused8(incl);
+                wave_scan_fused_rows(incl);
 #pragma unroll
                 for (int kk = 0; kk < RG; ++kk) base[kk] = incl[kk] - v[kk][EPL - 1];
             }
@@ -1262,7 +1306,7 @@ __global__ __launch_bounds__(POST_WAVES *WAVE) void crf_band_posterior_kernel(Ba
             // shape, 77 % at T = 4000 are skipped.
             const int kxl = (ck * PW + lane < L) ? fF0 + fB0 - zexp : -(1 << 20);
             const float kmax = wave_allmax_dpp((float)kxl);
-            if (kmax < (float)POST_SKIP_BELOW) {
+            if (kmax < (float)POST_SKIP_BELOW<BK>) {
                 ++nskip;
                 continue;
             }
@@ -1321,10 +1365,33 @@ int crf_band_pick_R(size_t max_seqlen) {
 
 bool crf_band_fits(size_t max_seqlen) { return max_seqlen <= (size_t)4 * WAVE * BAND_MAXW; }
 
+// Block length and weight bias for a call (see BK_MAX): `sharp` = the sharpening factor of the canonical
+// columns.  bk = 0: the linear path does not take this call (the log-domain kernel does every read).
+// TK_CRF_BK = 4 | 8 | 12 forces a block length, TK_CRF_WBIAS a bias (lab: tools/crf_gate_probe.py).
+BandBlock crf_band_pick_block(float sharp, bool mod, size_t max_seqlen) {
+    BandBlock b{8, 0.f};
+    const float x = sharp > 0.f ? sharp : 1.f;
+    // (two cells per lane -- reads of 1025 .. 2048 bases -- stay at 8 steps: the 12-step sweep does not fit
+    // their 128 registers and measured 227 us against 139 at the train step's shape)
+    if (!mod && x <= 1.03f && crf_band_pick_R(max_seqlen) != 2) b = {12, 3.f};
+    else if (x <= 1.36f) b = {8, 0.f};
+    else if (x <= 1.76f) b = {8, 3.f};
+    else if (x <= 3.5f) b = {4, 0.f};
+    else b = {0, 0.f};
+    if (const char *e = getenv("TK_CRF_BK")) {
+        const int v = atoi(e);
+        if (v == 4 || v == 8 || (v == 12 && !mod && crf_band_pick_R(max_seqlen) != 2)) b.bk = v;
+    }
+    if (const char *e = getenv("TK_CRF_WBIAS")) b.wbias = (float)atof(e);
+    return b;
+}
+
 BandLayout crf_band_layout(size_t ntrans, size_t nblk, size_t nbatch, size_t max_seqlen, bool mod,
-                           bool want_grad) {
+                           bool want_grad, int bk) {
     (void)ntrans;
     BandLayout l;
+    const size_t BK = (size_t)(bk > 0 ? bk : 8);
+    l.BK = (int)BK;
     l.R = crf_band_pick_R(max_seqlen);
     const size_t PW = (size_t)l.R * WAVE;
     l.W = (int)((max_seqlen + PW - 1) / PW);
@@ -1364,9 +1431,9 @@ void crf_band_lab_phase(int phase) { g_band_lab_phase = phase; }
 // Helper waves (band_helper) pay when a sweep is latency-bound: every sweep workgroup has a CU to itself
 // (2 N workgroups <= CUs), its chunks' waves plus one helper per two chunks fit a workgroup, and the
 // weights image fits LDS.  TK_CRF_HELPER=0 / 1 overrides the first condition (lab).
-static bool band_use_helpers(const BandArgs &a, int R, bool mod) {
-    if (a.grad == nullptr || R > 2) return false;
-    if (a.W + (a.W + 1) / 2 > BAND_MAXW || (size_t)a.W * R * 8192 > 144 * 1024) return false;
+static bool band_use_helpers(const BandArgs &a, int R, bool mod, int bk) {
+    if (a.grad == nullptr || R > 2 || bk < 8) return false;
+    if (a.W + (a.W + 1) / 2 > BAND_MAXW || (size_t)a.W * R * bk * 1024 > 144 * 1024) return false;
     if (const char *e = getenv("TK_CRF_HELPER")) return e[0] == '1';
     // measured (kernel A): -3.5 % for the plain CRF at R = 1, -7 % for cat-mod with per-column
     // factors; cat-mod in its general form (whose helpers also carry the per-cell exponentials) +4 %,
@@ -1383,37 +1450,52 @@ static bool band_use_helpers(const BandArgs &a, int R, bool mod) {
     return ncu[dev] > 0 && 2 * a.N <= ncu[dev];
 }
 
-template <int R, bool MOD, bool CW>
+template <int R, bool MOD, bool CW, int BK>
 static int band_launch(const BandArgs &a, hipStream_t stream) {
     const bool want_grad = a.grad != nullptr;
     if (g_band_lab_phase != 2) {
         const dim3 grid((want_grad ? 3 : 1) * a.N), block(a.W * WAVE);
         if constexpr (R <= 2) {
-            if (band_use_helpers(a, R, MOD)) {
-                const size_t lds = (size_t)a.W * R * 8192;
-                const dim3 hblock((a.W + (a.W + 1) / 2) * WAVE);
-                if (raise_dynamic_lds(reinterpret_cast<const void *>(&crf_band_sweep_kernel<R, MOD, BAND_MAXW, true, CW>), 152 * 1024)) return 4;
-                hipLaunchKernelGGL((crf_band_sweep_kernel<R, MOD, BAND_MAXW, true, CW>), grid, hblock, lds, stream, a);
-            } else {
-                hipLaunchKernelGGL((crf_band_sweep_kernel<R, MOD, BAND_MAXW, false, CW>), grid, block, 0, stream, a);
+            bool helped = false;
+            if constexpr (BK >= 8) {
+                if (band_use_helpers(a, R, MOD, BK)) {
+                    const size_t lds = (size_t)a.W * R * BK * 1024;
+                    const dim3 hblock((a.W + (a.W + 1) / 2) * WAVE);
+                    if (raise_dynamic_lds(reinterpret_cast<const void *>(&crf_band_sweep_kernel<R, MOD, BAND_MAXW, true, CW, BK>), 152 * 1024)) return 4;
+                    hipLaunchKernelGGL((crf_band_sweep_kernel<R, MOD, BAND_MAXW, true, CW, BK>), grid, hblock, lds, stream, a);
+                    helped = true;
+                }
             }
-        } else if (a.W <= 8)
-            hipLaunchKernelGGL((crf_band_sweep_kernel<R, MOD, (R == 4 ? 8 : BAND_MAXW), false, CW>), grid, block, 0, stream, a);
-        else if (a.W <= 12)
-            hipLaunchKernelGGL((crf_band_sweep_kernel<R, MOD, (R == 4 ? 12 : BAND_MAXW), false, CW>), grid, block, 0, stream, a);
+            if (!helped) hipLaunchKernelGGL((crf_band_sweep_kernel<R, MOD, BAND_MAXW, false, CW, BK>), grid, block, 0, stream, a);
+        } else if (BK >= 8 && a.W <= 8)
+            hipLaunchKernelGGL((crf_band_sweep_kernel<R, MOD, (R == 4 && BK >= 8 ? 8 : BAND_MAXW), false, CW, BK>), grid, block, 0, stream, a);
+        else if (BK >= 8 && a.W <= 12)
+            hipLaunchKernelGGL((crf_band_sweep_kernel<R, MOD, (R == 4 && BK >= 8 ? 12 : BAND_MAXW), false, CW, BK>), grid, block, 0, stream, a);
         else
-            hipLaunchKernelGGL((crf_band_sweep_kernel<R, MOD, BAND_MAXW, false, CW>), grid, block, 0, stream, a);
+            hipLaunchKernelGGL((crf_band_sweep_kernel<R, MOD, BAND_MAXW, false, CW, BK>), grid, block, 0, stream, a);
     }
     if (hipGetLastError() != hipSuccess) return 4;
     if (!want_grad || g_band_lab_phase == 1) return 0;
     if (a.before_gradient != nullptr && hipStreamWaitEvent(stream, a.before_gradient, 0) != hipSuccess) return 4;
     const int NB = (a.T + BK - 1) / BK;
-    hipLaunchKernelGGL((crf_band_posterior_kernel<MOD, CW>), dim3(a.N, (NB + POST_WAVES - 1) / POST_WAVES),
-                       dim3(POST_WAVES * WAVE), band_post_lds_bytes(MOD), stream, a);
+    hipLaunchKernelGGL((crf_band_posterior_kernel<MOD, CW, BK>), dim3(a.N, (NB + POST_WAVES - 1) / POST_WAVES),
+                       dim3(POST_WAVES * WAVE), band_post_lds_bytes(MOD, BK), stream, a);
     return hipGetLastError() == hipSuccess ? 0 : 4;
 }
 
-int crf_band_dispatch(const BandArgs &a0, int R, bool mod, hipStream_t stream) {
+// block lengths per form: the plain CRF has all three, cat-mod (whose frames' slope already follows its
+// weakest moves) stays at 8 and takes 4 for sharpened calls
+template <int R, bool MOD, bool CW>
+static int band_launch_bk(const BandArgs &a, int bk, hipStream_t stream) {
+    if (bk == 4) return band_launch<R, MOD, CW, 4>(a, stream);
+    if (bk == 8) return band_launch<R, MOD, CW, 8>(a, stream);
+    if constexpr (!MOD && R != 2) {
+        if (bk == 12) return band_launch<R, MOD, CW, 12>(a, stream);
+    }
+    return 2;
+}
+
+int crf_band_dispatch(const BandArgs &a0, int R, bool mod, int bk, hipStream_t stream) {
     BandArgs a = a0;
 #ifdef TK_LAB_STAMPS
     static unsigned long long *dbg = nullptr;
@@ -1431,7 +1513,7 @@ int crf_band_dispatch(const BandArgs &a0, int R, bool mod, hipStream_t stream) {
             (void)hipStreamSynchronize(s);
             (void)hipMemcpy(h, d, sizeof(h), hipMemcpyDeviceToHost);
             fprintf(stderr, "gradient pass: %llu of %llu chunk-blocks skipped (exponents below 2^%d)\n", h[600], h[601],
-                    POST_SKIP_BELOW);
+                    POST_SKIP_BELOW<8>);
             for (int k = 2; k < 12; ++k)
                 fprintf(stderr, "phase %2d: loads+frames %5llu  steps %5llu  boundary %5llu  barrier %5llu  next-phase-gap %5llu\n", k,
                         h[k * 8 + 1] - h[k * 8 + 0], h[k * 8 + 2] - h[k * 8 + 1], h[k * 8 + 3] - h[k * 8 + 2],
@@ -1441,12 +1523,12 @@ int crf_band_dispatch(const BandArgs &a0, int R, bool mod, hipStream_t stream) {
 #endif
     if (a.W < 1 || a.W > BAND_MAXW) return 2;
     switch (R * 2 + (mod ? 1 : 0)) {
-        case 2: return band_launch<1, false, false>(a, stream);
-        case 3: return a.colw ? band_launch<1, true, true>(a, stream) : band_launch<1, true, false>(a, stream);
-        case 4: return band_launch<2, false, false>(a, stream);
-        case 5: return a.colw ? band_launch<2, true, true>(a, stream) : band_launch<2, true, false>(a, stream);
-        case 8: return band_launch<4, false, false>(a, stream);
-        case 9: return a.colw ? band_launch<4, true, true>(a, stream) : band_launch<4, true, false>(a, stream);
+        case 2: return band_launch_bk<1, false, false>(a, bk, stream);
+        case 3: return a.colw ? band_launch_bk<1, true, true>(a, bk, stream) : band_launch_bk<1, true, false>(a, bk, stream);
+        case 4: return band_launch_bk<2, false, false>(a, bk, stream);
+        case 5: return a.colw ? band_launch_bk<2, true, true>(a, bk, stream) : band_launch_bk<2, true, false>(a, bk, stream);
+        case 8: return band_launch_bk<4, false, false>(a, bk, stream);
+        case 9: return a.colw ? band_launch_bk<4, true, true>(a, bk, stream) : band_launch_bk<4, true, false>(a, bk, stream);
         default: return 2;
     }
 }

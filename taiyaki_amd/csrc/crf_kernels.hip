@@ -88,16 +88,15 @@ __host__ __device__ inline size_t crf_lds_bytes(int R, int W, int S, int kinds) 
     return (f * 4 + 15) / 16 * 16;
 }
 
+// One read, all three passes.  `ckslot`: which set of checkpoint columns of the workspace this workgroup uses.
 template <int R, int W, bool MOD>
-__global__ __launch_bounds__(W *WAVE) void crf_kernel(CrfArgs a) {
+__device__ __forceinline__ void crf_read(const CrfArgs &a, const int n, const int ckslot) {
     using Cfg = CrfCfg<R, W, MOD>;
     constexpr int CK = Cfg::CK, NT = Cfg::NT, MAXK = Cfg::MAXK, LPAD = Cfg::LPAD;
     constexpr int KINDS = Cfg::KINDS, EPL = Cfg::EPL;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & (WAVE - 1);
-    const int n = blockIdx.x;
     const int T = a.T, N = a.N, S = a.S, SP = S + 2;
-    if (a.gate != nullptr && a.gate[n] == 0) return;             // the linear band path owns this read
     const int L = min(a.seqlen[n], (int)(a.seqoff[n + 1] - a.seqoff[n]));      // (offsets are clamped to the label array)
     const bool want_grad = a.grad != nullptr;
     const float gsc = a.grad_scale * (a.grad_scale_vec != nullptr ? a.grad_scale_vec[n] : 1.0f);
@@ -306,8 +305,8 @@ __global__ __launch_bounds__(W *WAVE) void crf_kernel(CrfArgs a) {
     };
 
     const int NK = (T + CK - 1) / CK;
-    float *ck_n = a.ckpt + (size_t)n * NK * (R * NT);
-    double *ckoff_n = a.ckoff + (size_t)n * NK;
+    float *ck_n = a.ckpt + (size_t)ckslot * NK * (R * NT);
+    double *ckoff_n = a.ckoff + (size_t)ckslot * NK;
 
     // ======================= forward sweep ===================================
     float f[R];
@@ -492,6 +491,40 @@ __global__ __launch_bounds__(W *WAVE) void crf_kernel(CrfArgs a) {
         if (a.status && !isfinite(cst)) atomicOr(a.status, 1u);
     }
     if (a.status && bad) atomicOr(a.status, 2u);
+}
+
+// Without a gate array (TK_CRF_MODE=ckpt, batches the band path does not take): workgroup n does read n.
+// Behind a band launch: the workgroups share out the reads the linear path DISOWNED (gate[n] != 0) -- the
+// k-th such read goes to workgroup k mod gridDim.x, which redoes its reads one after the other in its own
+// set of checkpoint columns, so the workspace holds gridDim.x sets (crf_redo_slots), not one per read of the
+// batch.  Usually there is nothing to redo and a workgroup leaves after one pass over the gate array.
+// Workgroup 0 adds the number of disowned reads to the status word's upper 24 bits
+// (TK_STATUS_GATED_SHIFT): what ctc.last_gate_count() / the trainer's warning read.
+template <int R, int W, bool MOD>
+__global__ __launch_bounds__(W *WAVE) void crf_kernel(CrfArgs a) {
+    if (a.gate == nullptr) {
+        crf_read<R, W, MOD>(a, (int)blockIdx.x, (int)blockIdx.x);
+        return;
+    }
+    // nothing disowned (the usual case): one parallel pass over the gate array and out
+    // (every wave looks at the whole array and comes to the same verdict: no LDS -- the kernel's dynamic
+    // LDS is at the limit, a static word for a workgroup-wide vote would not fit -- and no barrier)
+    {
+        const int lane = threadIdx.x & (WAVE - 1);
+        unsigned long long any = 0;
+        for (int n0 = 0; n0 < a.N; n0 += WAVE) any |= __ballot(n0 + lane < a.N && a.gate[n0 + lane] != 0);
+        if (any == 0) return;
+    }
+    int seen = 0;
+    for (int n = 0; n < a.N; ++n) {
+        if (a.gate[n] == 0) continue;                            // the linear band path owns this read
+        if (seen % (int)gridDim.x == (int)blockIdx.x) {
+            crf_read<R, W, MOD>(a, n, (int)blockIdx.x);
+            __syncthreads();
+        }
+        ++seen;
+    }
+    if (blockIdx.x == 0 && threadIdx.x == 0 && seen > 0 && a.status) atomicAdd(a.status, (uint32_t)min(seen, 0xffff) << 8);
 }
 
 // ---------------------------------------------------------------------------
@@ -693,42 +726,62 @@ static size_t crf_lattice_cap_bytes() {
     }
     return cap[dev];
 }
-static CrfMode crf_pick_mode(size_t ntrans, size_t nblk, size_t nbatch, size_t max_seqlen, bool want_grad) {
+// `bk`: the block length the linear path would use for this call (crf_band_pick_block; 0 = it does not take it)
+static CrfMode crf_pick_mode(size_t ntrans, size_t nblk, size_t nbatch, size_t max_seqlen, bool want_grad, int bk) {
     const char *e = getenv("TK_CRF_MODE");
     const bool force_ckpt = e && e[0] == 'c';
-    if (!force_ckpt && crf_band_fits(max_seqlen) &&
-        crf_band_layout(ntrans, nblk, nbatch, max_seqlen, true, want_grad).total <= crf_lattice_cap_bytes())
+    if (!force_ckpt && bk > 0 && crf_band_fits(max_seqlen) &&
+        crf_band_layout(ntrans, nblk, nbatch, max_seqlen, true, want_grad, bk).total <= crf_lattice_cap_bytes())
         return CRF_BAND;
     return CRF_CKPT;
 }
 
+// Sets of checkpoint columns of the log-domain kernel when it runs BEHIND the band path: it redoes only the
+// reads the linear path disowned -- none on the inputs a network produces -- so it gets an eighth of the
+// batch (at least 4, at most all) and loops (crf_kernel).  Round 3 sized it for the whole batch being
+// disowned: 8.4 of the 12.2 GB at T = 4000 / N = 256.
+static size_t crf_redo_slots(size_t nbatch) {
+    size_t s = (nbatch + 7) / 8;
+    if (s < 4) s = 4;
+    return s < nbatch ? s : nbatch;
+}
+
 // workspace = [band layout (band mode only)] [checkpoint columns + offsets of crf_kernel]
-size_t crf_workspace_bytes(size_t ntrans, size_t nblk, size_t nbatch, size_t max_seqlen,
-                           int want_grad) {
+// `sharp`: the call's sharpening factor -- it picks the linear path's block length, and short blocks keep
+// more checkpoint columns.  The block lengths of the plain CRF and of cat-mod differ; the bound covers both.
+size_t crf_workspace_bytes_sharp(size_t ntrans, size_t nblk, size_t nbatch, size_t max_seqlen,
+                                 int want_grad, float sharp) {
     if (max_seqlen == 0) max_seqlen = nblk + 1;
     const CrfShape sh = crf_pick_shape(max_seqlen);
-    size_t total = crf_ckpt_bytes(nblk, nbatch, sh);
+    const int bkp = crf_band_pick_block(sharp, false, max_seqlen).bk, bkm = crf_band_pick_block(sharp, true, max_seqlen).bk;
+    const int bk = (bkp > 0 && bkm > 0) ? (bkp < bkm ? bkp : bkm) : (bkp > 0 ? bkp : bkm);
     // (the cat-mod layout is the larger one: an upper bound for both)
-    if (crf_pick_mode(ntrans, nblk, nbatch, max_seqlen, want_grad != 0) == CRF_BAND)
-        total += crf_band_layout(ntrans, nblk, nbatch, max_seqlen, true, want_grad != 0).total;
-    return total;
+    if (crf_pick_mode(ntrans, nblk, nbatch, max_seqlen, want_grad != 0, bk) == CRF_BAND)
+        return crf_ckpt_bytes(nblk, crf_redo_slots(nbatch), sh) +
+               crf_band_layout(ntrans, nblk, nbatch, max_seqlen, true, want_grad != 0, bk).total;
+    return crf_ckpt_bytes(nblk, nbatch, sh);
+}
+
+size_t crf_workspace_bytes(size_t ntrans, size_t nblk, size_t nbatch, size_t max_seqlen,
+                           int want_grad) {
+    return crf_workspace_bytes_sharp(ntrans, nblk, nbatch, max_seqlen, want_grad, 1.0f);
 }
 
 template <int R, int W, bool MOD>
-static int crf_launch_one(const CrfArgs &a, hipStream_t stream) {
+static int crf_launch_one(const CrfArgs &a, hipStream_t stream, size_t nwg) {
     const size_t lds = crf_lds_bytes(R, W, a.S, MOD ? 3 : 2);
     if (lds > 160 * 1024) return 2;
     if (raise_dynamic_lds(reinterpret_cast<const void *>(&crf_kernel<R, W, MOD>))) return 4;
-    hipLaunchKernelGGL((crf_kernel<R, W, MOD>), dim3(a.N), dim3(W * WAVE), lds, stream, a);
+    hipLaunchKernelGGL((crf_kernel<R, W, MOD>), dim3((unsigned)nwg), dim3(W * WAVE), lds, stream, a);
     return hipGetLastError() == hipSuccess ? 0 : 4;
 }
 
 template <bool MOD>
-static int crf_launch_mod(CrfShape sh, const CrfArgs &a, hipStream_t stream) {
+static int crf_launch_mod(CrfShape sh, const CrfArgs &a, hipStream_t stream, size_t nwg) {
     const int key = sh.R * 100 + sh.W;
 #define TK_CRF_CASE(R_, W_)                                                           \
     case R_ * 100 + W_:                                                               \
-        return crf_launch_one<R_, W_, MOD>(a, stream);
+        return crf_launch_one<R_, W_, MOD>(a, stream, nwg);
     switch (key) {
         TK_CRF_CASE(1, 1)
         TK_CRF_CASE(2, 1)
@@ -754,8 +807,16 @@ int crf_dispatch(const float *logprob, size_t ntrans, size_t nblk, size_t nbatch
     if (max_seqlen == 0) max_seqlen = nblk + 1;
     const CrfShape sh = crf_pick_shape(max_seqlen);
     if ((size_t)sh.R * sh.W * WAVE < max_seqlen || sh.R > 4) return 2;
-    const size_t need = crf_workspace_bytes(ntrans, nblk, nbatch, max_seqlen, grad != nullptr);
-    if (need > workspace_bytes) return 3;
+    const bool mod = modidx != nullptr;
+    // the linear path's block length for this sharpening factor; when the workspace the caller brought is
+    // too small for it (sized without the factor: tk_crf_flipflop_workspace_bytes) but large enough for the
+    // log-domain kernel on every read, that kernel does the call
+    BandBlock blk = crf_band_pick_block(sharp_can, mod, max_seqlen);
+    bool band = crf_pick_mode(ntrans, nblk, nbatch, max_seqlen, grad != nullptr, blk.bk) == CRF_BAND;
+    if (band && crf_ckpt_bytes(nblk, crf_redo_slots(nbatch), sh) +
+                        crf_band_layout(ntrans, nblk, nbatch, max_seqlen, mod, grad != nullptr, blk.bk).total > workspace_bytes)
+        band = false;
+    if (!band && crf_ckpt_bytes(nblk, nbatch, sh) > workspace_bytes) return 3;
     CrfArgs a;
     a.lp = logprob;
     a.T = (int)nblk;
@@ -781,15 +842,15 @@ int crf_dispatch(const float *logprob, size_t ntrans, size_t nblk, size_t nbatch
     a.grad = grad;
     a.gate = nullptr;
     a.status = status;
-    const bool mod = modidx != nullptr;
     char *wb = static_cast<char *>(workspace);
-    const bool band = crf_pick_mode(ntrans, nblk, nbatch, max_seqlen, grad != nullptr) == CRF_BAND;
     // (what add_grad / add_cost hold may come from another stream: the band path waits between its sweeps
     // and its gradient pass, the single-launch form before it starts)
     if (add_ready != nullptr && !(band && grad != nullptr) && hipStreamWaitEvent(stream, add_ready, 0) != hipSuccess) return 4;
-    if (crf_pick_mode(ntrans, nblk, nbatch, max_seqlen, grad != nullptr) == CRF_BAND) {
+    size_t redo_slots = nbatch;
+    if (band) {
         const bool g = grad != nullptr;
-        const BandLayout l = crf_band_layout(ntrans, nblk, nbatch, max_seqlen, mod, g);
+        const BandLayout l = crf_band_layout(ntrans, nblk, nbatch, max_seqlen, mod, g, blk.bk);
+        redo_slots = crf_redo_slots(nbatch);
         BandArgs b;
         b.lp = logprob;
         b.T = (int)nblk;
@@ -834,7 +895,8 @@ int crf_dispatch(const float *logprob, size_t ntrans, size_t nblk, size_t nbatch
         b.dbg = nullptr;
         b.before_gradient = add_ready;
         b.colw = mod ? mod_col_weights : nullptr;
-        const int rc = crf_band_dispatch(b, l.R, mod, stream);
+        b.wbias = blk.wbias;
+        const int rc = crf_band_dispatch(b, l.R, mod, blk.bk, stream);
         if (rc != 0) return rc;
         if (getenv("TK_CRF_GATE_DUMP")) {                       // lab: how many reads did the band path disown?
             (void)hipStreamSynchronize(stream);
@@ -853,18 +915,18 @@ int crf_dispatch(const float *logprob, size_t ntrans, size_t nblk, size_t nbatch
         }
         // the reads the linear path disowned, redone in the log domain
         a.gate = b.gate;
-        wb += crf_band_layout(ntrans, nblk, nbatch, max_seqlen, true, g).total;
+        wb += l.total;
         if (const char *e = getenv("TK_CRF_NO_FALLBACK"))       // lab: time / test the band path alone
             if (e[0] == '1') return 0;
     }
     {
         const int CK = crf_ck(sh.R, sh.W, mod ? 3 : 2);
         const size_t NK = (nblk + CK - 1) / CK;
-        const size_t ckb = (nbatch * NK * (size_t)sh.R * sh.W * WAVE * sizeof(float) + 255) / 256 * 256;
+        const size_t ckb = (redo_slots * NK * (size_t)sh.R * sh.W * WAVE * sizeof(float) + 255) / 256 * 256;
         a.ckpt = reinterpret_cast<float *>(wb);
         a.ckoff = reinterpret_cast<double *>(wb + (grad ? ckb : 0));
     }
-    return mod ? crf_launch_mod<true>(sh, a, stream) : crf_launch_mod<false>(sh, a, stream);
+    return mod ? crf_launch_mod<true>(sh, a, stream, redo_slots) : crf_launch_mod<false>(sh, a, stream, redo_slots);
 }
 
 }  // namespace tk

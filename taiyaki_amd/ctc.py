@@ -84,6 +84,14 @@ def _col_weights(keep, mod):
 _KEEP_WS = None      # debugging aid: set to a list to keep the kernels' workspaces alive
 
 
+def _workspace(nbytes, dev, tag):
+    return _lib.workspace(nbytes, dev, tag, fresh=_KEEP_WS is not None)
+
+
+release_workspaces = _lib.release_workspaces
+last_gate_count = _lib.last_gate_count
+
+
 def set_max_seqlen(seqlen, value):
     """Whoever assembles a batch knows its longest sequence on the host (bin/train_flipflop.py:133-138
     builds `seqlens` from Python lists); a `seqlens` tensor that lives on the device carries that
@@ -124,8 +132,8 @@ def _run(logprob, seqs, seqlen, sharp_can, sharp_mod, out_scale, ncan, want_grad
         maxlen = _max_seqlen(seqlen)
         cost = torch.empty(nbatch, dtype=torch.float32, device=dev)
         grad = torch.empty_like(lp) if want_grad else None
-        wsb = L.tk_crf_flipflop_workspace_bytes(ntrans, nblk, nbatch, maxlen, int(want_grad))
-        ws = torch.empty(wsb, dtype=torch.uint8, device=dev)
+        wsb = L.tk_crf_flipflop_workspace_bytes_sharp(ntrans, nblk, nbatch, maxlen, int(want_grad), float(sharp_can))
+        ws = _workspace(wsb, dev, "crf")
         if _KEEP_WS is not None:
             ws.zero_()
         rc = L.tk_crf_flipflop_dev(
@@ -317,12 +325,12 @@ def _run_fused(outputs, seqs, seqlen, sharpfact, want_grad, grad_scale=1.0, grad
         lossvector = torch.empty(nbatch, dtype=torch.float32, device=dev)
         logz = torch.empty(nbatch, dtype=torch.float32, device=dev)
         grad = torch.empty_like(lp)
-        wsa = L.tk_crf_flipflop_workspace_bytes(ntrans, nblk, nbatch, maxlen, 1)
+        wsa = L.tk_crf_flipflop_workspace_bytes_sharp(ntrans, nblk, nbatch, maxlen, 1, float(sharpfact))
         wsb = L.tk_flipflop_logz_workspace_bytes(nblk, nbatch, nbase)
         wsx = L.tk_flipflop_loss_fused_aux_bytes(nblk, nbatch, nbase, ntrans)
-        ws_a = torch.empty(wsa, dtype=torch.uint8, device=dev)
-        ws_b = torch.empty(wsb, dtype=torch.uint8, device=dev)
-        ws_x = torch.empty(wsx, dtype=torch.uint8, device=dev) if wsx else None
+        ws_a = _workspace(wsa, dev, "crf")
+        ws_b = _workspace(wsb, dev, "logz")
+        ws_x = _workspace(wsx, dev, "aux") if wsx else None
         gvec = None
         if grad_scale_per_read is not None:
             gvec = grad_scale_per_read.detach().to(device=dev, dtype=torch.float32).contiguous()

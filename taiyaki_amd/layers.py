@@ -33,7 +33,7 @@ def _logz_launch(x, want_grad):
         wsb = L.tk_flipflop_logz_workspace_bytes(T, N, nbase)
         if wsb == 0:
             raise RuntimeError("flipflop_logpartition: nbase=%d is not built" % nbase)
-        ws = torch.empty(wsb, dtype=torch.uint8, device=dev)
+        ws = _lib.workspace(wsb, dev, "logz")
         status = _lib.status_word(dev)
         rc = L.tk_flipflop_logz_dev(_lib.ptr(sc), T, N, nbase, _lib.ptr(logz), _lib.ptr(grad),
                                     _lib.ptr(ws), wsb, _lib.ptr(status), _lib.stream_ptr())

@@ -47,6 +47,41 @@ def calculate_loss(net, indata, seqs, seqlens, sharpen=1.0, mod_cats=None,
     return lossvector.mean(), lossvector
 
 
+class GateWatch:
+    """Says so when the loss is losing time.  The CRF's linear-domain path hands a read it cannot
+    represent (scores far outside the network's 5 tanh range, sharpening beyond 3.5, violent cat-mod
+    logits, bands a few cells wide) to its log-domain kernel: a right answer at ~1000x the cost of
+    the read (1 ms instead of 1 us at T = 800).  The kernels count those reads in the status word;
+    every `every` steps this reads the count (non-strict mode: the one host sync it costs) and warns
+    when more than `fraction` of the reads seen since the last check were redone."""
+
+    def __init__(self, every=200, fraction=0.01):
+        from taiyaki_amd import _lib
+        self.every, self.fraction = every, fraction
+        self.steps = self.reads = 0
+        self.seen_total = _lib.gated_total()
+        self.last_fraction = 0.0
+
+    def note(self, nreads):
+        from taiyaki_amd import _lib
+        self.steps += 1
+        self.reads += int(nreads)
+        if self.every <= 0 or self.steps % self.every or torch.cuda.is_current_stream_capturing():
+            return
+        if not _lib.is_strict():
+            _lib.take_gate_count()
+        total = _lib.gated_total()
+        redone, self.seen_total = total - self.seen_total, total
+        self.last_fraction = redone / max(1, self.reads)
+        if redone > self.fraction * self.reads:
+            import warnings
+            warnings.warn("flip-flop loss: %d of the last %d reads (%.1f %%) were redone by the log-domain kernel "
+                          "(~1000x the cost of a read on the linear path): scores outside the range the linear path "
+                          "represents -- see taiyaki_amd.ctc.last_gate_count" % (redone, self.reads, 100.0 * self.last_fraction),
+                          RuntimeWarning, stacklevel=3)
+        self.reads = 0
+
+
 class Trainer:
     """One optimiser step = forward, loss, backward, flat all-reduce, clip, AdamW.
     Defaults follow bin/_bin_argparse.py:16-193 (AdamW lr 4e-3, wd 0.01, eps 1e-6)."""
@@ -68,6 +103,7 @@ class Trainer:
                                      betas=(0.9, 0.999),
                                      capturable=arena.flat.is_cuda)  # no host sync in step()
         self.grad_clip = grad_clip
+        self.gate_watch = GateWatch()
 
     def step(self, batch):
         """`batch`: one batch (dict) or a list of sub-batches.  Sub-batches are the reference's way
@@ -89,6 +125,7 @@ class Trainer:
         self.arena.finish(scale=1.0 / len(subs))
         self.clip()
         self.opt.step()
+        self.gate_watch.note(sum(int(sub["seqlens"].numel()) for sub in subs))
         return loss if len(subs) == 1 else total / len(subs)
 
     def clip(self):
@@ -201,6 +238,7 @@ class GraphedTrainer:
         self.graph.replay()
         if clipper is not None:
             clipper.copy_maxima_async()
+        self.trainer.gate_watch.note(batch["seqlens"].numel())
         return self.loss
 
 
@@ -308,6 +346,7 @@ class HybridGraphTrainer(GraphedTrainer):
         self.trainer.arena.finish()
         self.trainer.clip()         # eager: two tiny launches + an async copy of the maxima
         self.opt_graph.replay()
+        self.trainer.gate_watch.note(batch["seqlens"].numel())
         return self.loss
 
 
@@ -396,6 +435,7 @@ class GraphCacheTrainer:
                 self.opt.step()         # ... (capture records, it does not run) replayed from the second on
             torch.cuda.synchronize()
         self.nsteps += 1
+        self.trainer.gate_watch.note(batch["seqlens"].numel())
         return one.loss
 
 

@@ -327,10 +327,13 @@ def test_fullsize_against_reference_goldens(gpu_device, name):
     cs = cases.grad_checksums(grad)
     np.testing.assert_allclose(cs["sum"], gold[name + "/grad_sum"], rtol=1e-4, atol=1e-4)
     np.testing.assert_allclose(cs["sumsq"], gold[name + "/grad_sumsq"], rtol=2e-3)
-    # (on the posterior scale: a modification column's gradient carries its weight, 8 at cfg 4)
+    # (on the posterior scale: a modification column's gradient carries its weight, 8 at cfg 4.  Plain CRF:
+    # 2e-4 of a posterior's full scale; cfg 4's inputs are RAW U(-5, 5) modification logits times that 8 --
+    # log values in the thousands, where the fp32 reference's own posteriors are ~1e-3 from float64 (fuzz
+    # lines in profiles/r4_pytest_gpu_*.log) and most reads are redone by the log-domain kernel)
     col = cs["sample_idx"] % grad.shape[2]
     np.testing.assert_array_less(np.abs(cs["sample"] - gold[name + "/grad_sample"]) * parity.posterior_scale(inp)[col],
-                                 2e-4 / spec["T"])
+                                 (2e-4 if spec["mods"] is None else 1e-3) / spec["T"])
     # every gradient row of a live read sums to -1/T (posterior is a distribution)
     np.testing.assert_allclose(grad[:, :, :40].sum(axis=2) * spec["T"], -1.0, atol=2e-4)
     del grad
@@ -773,18 +776,112 @@ def test_catmod_column_weights_form_agrees_with_the_general_form(oracle_mod, gpu
     assert parity.rel_err(out[""][0], out["1"][0]) < 1e-5 and parity.abs_err(out[""][1], out["1"][1]) < 5e-6
 
 
-def test_crf_sharpened_scores_take_the_log_domain_kernel(oracle_mod, gpu_device, monkeypatch):
-    """sharp = 2.5 puts weights of 2^(+-18) on a step: eight of them overflow a block of the linear
-    path, which must notice (non-finite sweep score) and hand the read over."""
+@pytest.mark.parametrize("sharp,bk", [(1.3, 8), (1.5, 8), (1.75, 8), (2.0, 4), (2.5, 4), (3.4, 4)])
+def test_crf_sharpened_scores_stay_on_the_linear_path(oracle_mod, gpu_device, monkeypatch, sharp, bk):
+    """The reference's trainer takes a sharpening schedule (bin/_bin_argparse.py:58-62, applied at
+    bin/train_flipflop.py:161-173).  Round 3's linear path overflowed above 1.36 and handed every such
+    read to the log-domain kernel; the block length and the weights' bias now follow the factor
+    (crf_band_pick_block: 8 steps up to 1.36, biased weights up to 1.76, 4-step blocks up to 3.5), so a
+    trained network's sharpened batch keeps every read: parity with the oracle AND a gate count of 0."""
+    from taiyaki_amd import _lib, ctc, synth
+    monkeypatch.setenv("TK_CRF_MODE", "band")
+    T, N = 300, 12
+    inp = synth.crf_case(T, N, 9, seqlens=synth.realistic_seqlens(T, N, 5, T * 5, 9.0))
+    synth.confident_scores(inp, 11, bursty=False)
+    r = parity.compare_crf(oracle_mod, inp, sharp, gpu_device)
+    assert _lib.is_strict() and ctc.last_gate_count() == 0
+    assert r["finite"]
+    assert r["loss_rel"] < LOSS_RTOL, r["loss_rel"]
+    assert parity.crf_grad_ok(r), (r["grad_f64_scaled"], r["grad_scaled_abs"], r["ref_noise_scaled"])
+    # ... and so do freshly initialised scores (|score| <= 1) and iid ones at their full range
+    for k, scale in enumerate((0.2, 1.0)):
+        inp2 = synth.crf_case(T, N, 19 + k, seqlens=inp["seqlens"])
+        inp2["scores"] = (inp2["scores"] * np.float32(scale)).astype(np.float32)
+        r2 = parity.compare_crf(oracle_mod, inp2, sharp, gpu_device)
+        assert r2["finite"] and r2["loss_rel"] < LOSS_RTOL and parity.crf_grad_ok(r2), (scale, r2["loss_rel"])
+        assert ctc.last_gate_count() == 0, (sharp, scale, ctc.last_gate_count())
+
+
+def test_crf_sharpening_beyond_the_linear_path_goes_to_the_log_domain_kernel(oracle_mod, gpu_device, monkeypatch):
+    """sharp = 5 puts weights of 2^(+-36) on a step: no block length holds that; the dispatcher sends
+    the call to the log-domain kernel (every read), and the answer is still the oracle's."""
     from taiyaki_amd import synth
     monkeypatch.setenv("TK_CRF_MODE", "band")
     T, N = 300, 6
     inp = synth.crf_case(T, N, 9)
-    r = parity.compare_crf(oracle_mod, inp, 2.5, gpu_device)
+    r = parity.compare_crf(oracle_mod, inp, 5.0, gpu_device)
     assert r["finite"]
     assert r["loss_rel"] < LOSS_RTOL, r["loss_rel"]
-    assert r["grad_abs"] < GRAD_ATOL, r["grad_abs"]
     assert parity.crf_grad_ok(r), (r["grad_f64_scaled"], r["grad_scaled_abs"], r["ref_noise_scaled"])
+
+
+@pytest.mark.parametrize("bk,wbias", [("4", "0"), ("8", "0"), ("8", "3"), ("12", "3")])
+@pytest.mark.parametrize("mods", [None, (1, 1, 0, 0)])
+def test_crf_block_lengths_and_weight_bias_agree_with_the_oracle(oracle_mod, gpu_device, monkeypatch, bk, wbias, mods):
+    """Every block length x bias the dispatcher can pick (forced here through the lab switches), plain
+    and cat-mod, on lengths around the block and chunk boundaries: T = 1, T below a block, a last block
+    of one row, reads of 1 / 64 / 65 / T / T + 1 bases, two cells per lane.  The bias must come back out
+    of the scores exactly (costs to 1e-5) and leave the posteriors alone."""
+    from taiyaki_amd import synth
+    if bk == "12" and mods is not None:
+        pytest.skip("cat-mod has no 12-step form")
+    monkeypatch.setenv("TK_CRF_MODE", "band")
+    monkeypatch.setenv("TK_CRF_BK", bk)
+    monkeypatch.setenv("TK_CRF_WBIAS", wbias)
+    for T, Ls in ((1, [1, 2]), (3, [2, 4, 1]), (11, [5, 12, 1]), (13, [13, 7]), (25, [9, 26, 25, 1]),
+                  (97, [64, 65, 33, 98, 1]), (300, [129, 257, 64, 200, 301, 0])):
+        inp = synth.crf_case(T, len(Ls), 40 + T, seqlens=np.array(Ls, dtype=np.int32), nmods_per_base=mods)
+        if mods is not None:
+            synth.normalise_mod_columns(inp)
+        r = parity.compare_crf(oracle_mod, inp, 1.0, gpu_device)
+        assert r["finite"] and r["loss_rel"] < LOSS_RTOL and r["loss_abs"] < 1e-5, (T, bk, wbias, r["loss_rel"])
+        assert parity.crf_grad_ok(r), (T, bk, wbias, r["grad_f64_scaled"], r["ref_noise_scaled"])
+    # two cells per lane (reads of 1025 .. 2048 bases)
+    if bk != "12":
+        T = 1500
+        inp = synth.crf_case(T, 3, 77, seqlens=np.array([1100, 700, 1300], dtype=np.int32), nmods_per_base=mods)
+        if mods is not None:
+            synth.normalise_mod_columns(inp)
+        r = parity.compare_crf(oracle_mod, inp, 1.0, gpu_device)
+        assert r["finite"] and r["loss_rel"] < LOSS_RTOL and parity.crf_grad_ok(r), (bk, wbias, r["loss_rel"])
+
+
+def test_crf_disowned_reads_are_counted_and_redone_in_shared_slots(oracle_mod, gpu_device, monkeypatch):
+    """A batch in which MOST reads are bands a few cells wide under iid scores (the linear path disowns
+    those): the log-domain kernel behind it redoes them in an eighth of the batch's worth of checkpoint
+    slots, several reads per workgroup one after the other -- every read is the oracle's --, the status
+    word's count says how many there were (`ctc.last_gate_count`), and the trainer's watch turns that
+    into a warning."""
+    import warnings
+    from taiyaki_amd import _lib, ctc, synth, train
+    monkeypatch.setenv("TK_CRF_MODE", "band")
+    T, N = 200, 40
+    Ls = np.array([T + 1 - (k % 6) if k % 4 else 90 for k in range(N)], dtype=np.int32)   # 30 narrow bands, 10 ordinary reads
+    inp = synth.crf_case(T, N, 5, seqlens=Ls)
+    r = parity.compare_crf(oracle_mod, inp, 1.0, gpu_device)
+    assert r["finite"] and r["loss_rel"] < LOSS_RTOL, r["loss_rel"]
+    assert parity.crf_grad_ok(r), (r["grad_f64_scaled"], r["grad_scaled_abs"], r["ref_noise_scaled"])
+    gated = ctc.last_gate_count()
+    assert 10 <= gated <= 30, gated                # (more than the 5 slots 40 reads get: workgroups looped)
+    # non-strict mode: the count accumulates in the deferred word until somebody looks
+    _lib.set_strict(False)
+    try:
+        before = _lib.gated_total()
+        parity.run_crf(inp, 1.0, gpu_device)
+        parity.run_crf(inp, 1.0, gpu_device)
+        assert _lib.take_gate_count() == 2 * gated and _lib.gated_total() == before + 2 * gated
+        watch = train.GateWatch(every=2, fraction=0.01)
+        parity.run_crf(inp, 1.0, gpu_device)
+        watch.note(N)
+        with warnings.catch_warnings(record=True) as seen:
+            warnings.simplefilter("always")
+            parity.run_crf(inp, 1.0, gpu_device)
+            watch.note(N)
+        assert any("redone by the log-domain kernel" in str(w.message) for w in seen), [str(w.message) for w in seen]
+        assert abs(watch.last_fraction - gated / N) < 1e-6
+        _lib.raise_if_nonfinite()
+    finally:
+        _lib.set_strict(True)
 
 
 def test_crf_log_probability_inputs(oracle_mod, gpu_device, monkeypatch):

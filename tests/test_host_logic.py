@@ -396,3 +396,23 @@ def test_captured_step_refuses_batches_it_cannot_prove_fit():
         g.load(hinted)
     # without a captured bound nothing is checked (the launch is sized for nblk + 1)
     train.GraphedTrainer(tr, ok, seq_capacity=2 * 13).load(long)
+
+
+def test_crf_workspace_is_sized_for_what_runs():
+    """`tk_crf_flipflop_workspace_bytes` (no GPU needed): the checkpoint columns of the band path at
+    its block length + an EIGHTH of the batch's worth of log-domain slots (round 3: the whole batch:
+    12.2 GB at T = 4000 / N = 256, 203 MB at the train step's shape); a sharpened call keeps more
+    columns (shorter blocks) and says so through the `_sharp` query; beyond the linear path's range the
+    log-domain kernel's full set."""
+    from taiyaki_amd import _lib
+    L = _lib.lib()
+    MB = 1 << 20
+    step = L.tk_crf_flipflop_workspace_bytes(40, 800, 128, 533, 1)
+    rowk = L.tk_crf_flipflop_workspace_bytes(40, 4000, 256, 2198, 1)
+    assert step < 110 * MB and rowk < 4800 * MB, (step / MB, rowk / MB)
+    assert L.tk_crf_flipflop_workspace_bytes_sharp(40, 800, 128, 533, 1, 1.0) == step
+    s2 = L.tk_crf_flipflop_workspace_bytes_sharp(40, 800, 128, 533, 1, 2.0)
+    assert step < s2 < 2 * step + 64 * MB
+    s9 = L.tk_crf_flipflop_workspace_bytes_sharp(40, 800, 128, 533, 1, 9.0)       # log-domain kernel on every read
+    assert 0 < s9 < 200 * MB
+    assert L.tk_crf_flipflop_workspace_bytes(40, 800, 128, 533, 0) < 16 * MB     # cost only: the gate + the redo slots

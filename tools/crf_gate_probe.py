@@ -29,6 +29,11 @@ SHAPES = {
     # a freshly initialised network: 5 tanh of small activations, |score| <= 1
     "initramp": (800, [560, 640, 680, 700, 710, 720, 727, 740, 760, 780, 795, 801], 1.0, None),
     "sharp": (800, "speed32", 2.5, None),
+    # the reference's --sharpen schedule (bin/_bin_argparse.py:58-62): 8-step blocks up to 1.36, biased weights up
+    # to 1.76, 4-step blocks up to 3.5, the log-domain kernel beyond
+    "sharp13": (800, "real32", 1.3, None), "sharp15": (800, "real32", 1.5, None), "sharp17": (800, "real32", 1.75, None),
+    "sharp2": (800, "real32", 2.0, None), "sharp3": (800, "real32", 3.0, None), "sharp4": (800, "real32", 4.0, None),
+    "sharp2K": (4000, "speed16", 2.0, None), "cfg4sharp2": (800, "real32", 2.0, (1, 1, 0, 0)),
     "cfg4": (800, "speed128", 1.0, (1, 1, 0, 0)),
     "cfg4w1": (800, "speed128", 1.0, (1, 1, 0, 0)),
     "cfg4r": (800, "real128", 1.0, (1, 1, 0, 0)),
@@ -61,7 +66,7 @@ def run(x, seqs, seqlens, sharp, extra, env):
 
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument("--shapes", default="tiny,t19,t37,t200,cfg2,cfg2r,narrow,pathbuf,lenramp,initramp,conframp,sharp,cfg4,cfg4r,cfg4rharsh,cfg5,rowK,conf,confburst,confK")
+    ap.add_argument("--shapes", default="tiny,t19,t37,t200,cfg2,cfg2r,narrow,pathbuf,lenramp,initramp,conframp,sharp,sharp13,sharp15,sharp17,sharp2,sharp3,sharp4,sharp2K,cfg4,cfg4r,cfg4rharsh,cfg4sharp2,cfg5,rowK,conf,confburst,confK")
     args = ap.parse_args()
     dev = torch.device("cuda:0")
     _lib.set_strict(False)
@@ -77,6 +82,8 @@ def main():
             inp["scores"] *= np.float32(0.2)
         if sh.startswith("conf"):
             synth.confident_scores(inp, 7, bursty="burst" in sh)
+        if sh.startswith("sharp") and len(sh) > 5:
+            synth.confident_scores(inp, 9, bursty=False)        # a sharpening schedule is applied to a TRAINED network
         if mods is not None and not sh.endswith("free"):
             synth.normalise_mod_columns(inp, logit_scale=1.0 if sh.endswith("harsh") else 0.2)
         x = torch.from_numpy(inp["scores"]).to(dev)

@@ -21,7 +21,10 @@ SHAPES = {"cfg2": (800, 128, None), "cfg2r": (800, 128, 4000), "cfg5": (1600, 64
           "one": (800, 1, 4000), "short": (800, 128, 450), "short1": (800, 1, 450), "mid": (800, 128, 1100)}
 MODES = {"band1": dict(TK_CRF_MODE="band", TK_CRF_BAND_R="1"), "band2": dict(TK_CRF_MODE="band", TK_CRF_BAND_R="2"),
          "band4": dict(TK_CRF_MODE="band", TK_CRF_BAND_R="4"), "band": dict(TK_CRF_MODE="band"),
-         "bandnf": dict(TK_CRF_MODE="band", TK_CRF_NO_FALLBACK="1"), "ckpt": dict(TK_CRF_MODE="ckpt")}
+         "bandnf": dict(TK_CRF_MODE="band", TK_CRF_NO_FALLBACK="1"), "ckpt": dict(TK_CRF_MODE="ckpt"),
+         # round 3's arithmetic: 8-step blocks, unbiased weights (the plain CRF ships 12-step blocks with a bias of 3)
+         "band8": dict(TK_CRF_MODE="band", TK_CRF_BK="8", TK_CRF_WBIAS="0"),
+         "bk4": dict(TK_CRF_MODE="band", TK_CRF_BK="4", TK_CRF_WBIAS="0")}
 
 
 def timed(fn, reps):
@@ -69,10 +72,10 @@ def main():
             extra = (torch.from_numpy(inp["mod_cats"]), inp["can_mods_offsets"], inp["mod_cat_weights"])
         ref = None
         for mode in args.modes.split(","):
-            for k in ("TK_CRF_MODE", "TK_CRF_BAND_R", "TK_CRF_NO_FALLBACK"):
+            for k in ("TK_CRF_MODE", "TK_CRF_BAND_R", "TK_CRF_NO_FALLBACK", "TK_CRF_BK", "TK_CRF_WBIAS"):
                 os.environ.pop(k, None)
             os.environ.update(MODES[mode])
-            if mode.startswith("band") and mode[4:].isdigit():
+            if mode in ("band1", "band2", "band4"):
                 R = int(mode[4:])
                 if int(inp["seqlens"].max()) > 1024 * R:
                     continue

@@ -1,0 +1,46 @@
+#!/usr/bin/env python
+"""Kernel A and the fused loss at the train step's shape (and optionally T=4000/N=256), C entry points back to
+back on the stream -- bench.py's `roofline_crf` / `loss_path` timing without the train step around it.  For lab
+switches (TK_CRF_BK, TK_CRF_WBIAS, TK_CRF_HELPER, TK_CRF_BAND_R ...) and lab builds (TAIYAKI_AMD_LIB).
+
+    python tools/crfops.py [--rowk] [--catmod] [--cfg5]"""
+import argparse
+import os
+import sys
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import bench  # noqa: E402
+import torch  # noqa: E402
+from taiyaki_amd import _lib  # noqa: E402
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--rowk", action="store_true")
+    ap.add_argument("--catmod", action="store_true")
+    ap.add_argument("--cfg5", action="store_true")
+    ap.add_argument("--reps", type=int, default=20)
+    args = ap.parse_args()
+    dev = torch.device("cuda:0")
+    _lib.lib()
+    _lib.set_strict(False)
+    shapes = [("step", 800, 128, 4000, 9.0, False)]
+    if args.catmod:
+        shapes.append(("catmod", 800, 128, 4000, 9.0, True))
+    if args.cfg5:
+        shapes.append(("cfg5", 1600, 64, 8000, 9.5, False))
+    if args.rowk:
+        shapes.append(("rowK", 4000, 256, None, 9.0, False))
+    out = []
+    for name, T, N, cl, spb, cm in shapes:
+        ops = bench.LossOps(T, N, dev, realistic_chunk_len=cl, spb=spb, cat_mod=cm)
+        reps = args.reps if T < 4000 else 5
+        crf, crf_min = bench._events_mean_min(ops.crf, reps, warm=5)
+        both, _ = bench._events_mean_min(ops.both, reps, warm=5)
+        assert ops.finite()
+        out.append("%s: crf %.1f us (min %.1f)  fused loss %.1f us" % (name, crf * 1e6, crf_min * 1e6, both * 1e6))
+    print("  ".join(out), flush=True)
+
+
+if __name__ == "__main__":
+    main()

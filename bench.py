@@ -263,7 +263,15 @@ class LossOps:
         _lib.check(rc, "tk_flipflop_loss_fused_dev")
 
     def finite(self):
-        return int(self.status.item()) == 0
+        return (int(self.status.item()) & 0xff) == 0
+
+    def gated_reads(self):
+        """Reads the linear path handed to the log-domain kernel in ONE call of the CRF op on these inputs (the
+        status word's count, include/taiyaki_amd_flipflop.h: TK_STATUS_GATED_SHIFT)."""
+        torch.cuda.synchronize()
+        self.status.zero_()
+        self.crf()
+        return int(self.status.item()) >> 8
 
 
 def kernel_hash():
@@ -293,6 +301,44 @@ def committed_traffic(op, T, N):
     src = dict(measured="profiles/" + name, kernel_hash=d.get("kernel_hash"))
     src["current"] = d.get("kernel_hash") == kernel_hash()
     return d["traffic_bytes"], src
+
+
+CLOCK_HZ = 2.4e9            # MI355X_MICROARCH.md: peak engine clock
+N_SIMD = 1024               # 256 CUs x 4 SIMDs; a wave64 VALU instruction occupies its SIMD for 4 cycles
+
+
+def issue_floor(op, T, N, realistic, W, BK):
+    """Kernel A is bound by instruction issue, not by HBM: its floor is stated in those terms, from the
+    shader-sequencer counters of the committed profile (tools/sq_counters.py, same kernel hash):
+      sweep_valu_us      the sweep's VALU wave-instructions x 4 cycles / (1024 SIMDs x clock): the chip's VALU
+                         issue rate, perfectly balanced
+      sweep_chain_us     the recurrence itself: (NB + W - 1) phases x BK steps x 13 cycles (fma -> two wait states
+                         -> DPP fmac, one dependent pair per step at the measured 5.4 cycles per instruction)
+      posterior_valu_us  the gradient pass's VALU instructions at the chip's rate
+    issue_floor_us = max(sweep floors) + the gradient pass's (the two launches are serial).  Returns None when
+    no counters are committed for this shape."""
+    pdir = os.path.join(ROOT, "profiles")
+    best = None
+    for name in sorted(os.listdir(pdir)) if os.path.isdir(pdir) else []:
+        if name.endswith("_sq_counters.json"):
+            with open(os.path.join(pdir, name)) as fh:
+                d = json.load(fh)
+            rec = d.get("shapes", {}).get("%s:%d:%d:%d" % (op, T, N, realistic))
+            if rec and "sweep" in rec and "posterior" in rec:
+                best = (name, d, rec)
+    if best is None:
+        return None
+    name, d, rec = best
+    valu = lambda r: rec[r].get("SQ_INSTS_VALU", 0.0) * 4.0 / (N_SIMD * CLOCK_HZ) * 1e6      # noqa: E731
+    NB = (T + BK - 1) // BK
+    chain = (NB + W - 1) * BK * 13.0 / CLOCK_HZ * 1e6
+    out = dict(sweep_valu_us=round(valu("sweep"), 2), sweep_chain_us=round(chain, 2),
+               posterior_valu_us=round(valu("posterior"), 2),
+               waves_issuing_frac=round(rec["sweep"].get("SQ_ACTIVE_INST_ANY", 0.0) / max(1.0, rec["sweep"].get("SQ_WAVE_CYCLES", 1.0)), 3),
+               source="profiles/" + name, kernel_hash=d.get("kernel_hash"), current=d.get("kernel_hash") == kernel_hash(),
+               phases=NB + W - 1, block_steps=BK)
+    out["issue_floor_us"] = round(max(out["sweep_valu_us"], out["sweep_chain_us"]) + out["posterior_valu_us"], 2)
+    return out
 
 
 def measure_traffic_now(specs, timeout=240):
@@ -562,9 +608,20 @@ def kernel_records(out, args, cfg, dev, world, T, nbatch, chunk_len, cat_mod, S)
     def crf_roofline(ops, reps, label, realistic):
         mean_s, min_s = _events_mean_min(ops.crf, reps, warm=5)
         tr, src = traffic_of("crf", ops.T, ops.N, realistic)
-        return roofline_record("sequence CRF op (build_indices + crf_band_sweep + crf_band_posterior + gated crf_kernel), "
-                               "T=%d N=%d S=%d, max L %d (%s)" % (ops.T, ops.N, ops.S, ops.maxlen, label),
-                               3.0 * ops.T * ops.N * ops.S * 4, mean_s, min_s, reps, tr, src)
+        rec = roofline_record("sequence CRF op (build_indices + crf_band_sweep + crf_band_posterior + gated crf_kernel), "
+                              "T=%d N=%d S=%d, max L %d (%s)" % (ops.T, ops.N, ops.S, ops.maxlen, label),
+                              3.0 * ops.T * ops.N * ops.S * 4, mean_s, min_s, reps, tr, src)
+        # the bound that applies: instruction issue (the HBM fraction above is reported because SURVEY 8d asks for it)
+        R = 1 if ops.maxlen <= 1024 else (2 if ops.maxlen <= 2048 else 4)
+        W = -(-ops.maxlen // (64 * R))
+        BK = 8 if (ops.mod is not None or R == 2) else 12
+        fl = issue_floor("catmod" if ops.mod is not None else "crf", ops.T, ops.N, realistic, W, BK)
+        if fl is not None:
+            rec["issue_floor_us"] = fl["issue_floor_us"]
+            rec["issue_floor"] = fl
+            rec["frac_of_issue_floor"] = round(fl["issue_floor_us"] / (mean_s * 1e6), 3)
+        rec["gated_reads"] = ops.gated_reads()
+        return rec
 
     if rowk is not None:
         out["roofline"] = logz_roofline(rowk, 50, "north_star kernel shape")

@@ -101,6 +101,13 @@ def compare_crf(oracle, inp, sharp, dev, witness=True, **kw):
 GRAD_T_ATOL = 5e-4      # gradient x T (posterior scale), kernel vs float64 witness
 
 
+def crf_loss_ok(r, rtol=1e-5, atol=2e-6):
+    """Per read: the loss within `rtol` of the oracle's -- or, for a loss that is itself ~0 (a cancelled
+    sum of path scores: forced alignments under zero-mean scores), within `atol` absolutely."""
+    a, b = np.asarray(r["loss"], dtype=np.float64), np.asarray(r["oloss"], dtype=np.float64)
+    return bool(np.all((np.abs(a - b) <= rtol * np.abs(b)) | (np.abs(a - b) <= atol)))
+
+
 def crf_grad_ok(r, atol=GRAD_T_ATOL):
     """The gradient criterion of every CRF / cat-mod parity test, on the posterior scale:
       * within `atol` of the float64 witness -- or, where the fp32 reference itself is further than

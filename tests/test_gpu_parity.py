@@ -834,7 +834,7 @@ def test_crf_block_lengths_and_weight_bias_agree_with_the_oracle(oracle_mod, gpu
         if mods is not None:
             synth.normalise_mod_columns(inp)
         r = parity.compare_crf(oracle_mod, inp, 1.0, gpu_device)
-        assert r["finite"] and r["loss_rel"] < LOSS_RTOL and r["loss_abs"] < 1e-5, (T, bk, wbias, r["loss_rel"])
+        assert r["finite"] and parity.crf_loss_ok(r) and r["loss_abs"] < 1e-5, (T, bk, wbias, r["loss_rel"], r["loss_abs"])
         assert parity.crf_grad_ok(r), (T, bk, wbias, r["grad_f64_scaled"], r["ref_noise_scaled"])
     # two cells per lane (reads of 1025 .. 2048 bases)
     if bk != "12":
@@ -859,7 +859,7 @@ def test_crf_disowned_reads_are_counted_and_redone_in_shared_slots(oracle_mod, g
     Ls = np.array([T + 1 - (k % 6) if k % 4 else 90 for k in range(N)], dtype=np.int32)   # 30 narrow bands, 10 ordinary reads
     inp = synth.crf_case(T, N, 5, seqlens=Ls)
     r = parity.compare_crf(oracle_mod, inp, 1.0, gpu_device)
-    assert r["finite"] and r["loss_rel"] < LOSS_RTOL, r["loss_rel"]
+    assert r["finite"] and parity.crf_loss_ok(r), (r["loss_rel"], r["loss_abs"])
     assert parity.crf_grad_ok(r), (r["grad_f64_scaled"], r["grad_scaled_abs"], r["ref_noise_scaled"])
     gated = ctc.last_gate_count()
     assert 10 <= gated <= 30, gated                # (more than the 5 slots 40 reads get: workgroups looped)

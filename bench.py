@@ -160,7 +160,10 @@ def _events_mean_min(fn, reps, warm=20):
     # Keep the GPU busy while the host enqueues the timed launches: the ~40 us of Python between
     # an event record and the first kernel launch must not show up as GPU idle time inside the
     # event window (the events then bracket exactly the op's kernels, back to back).
-    torch.cuda._sleep(int(2.0e6 * max(1, reps // 10)))
+    # (8e6 cycles per ten launches: a slow or busy host -- a box whose pinned copies ran at a sixteenth of the
+    # usual rate was seen to take 5 ms for 50 enqueues, longer than the 2e6 per ten this used to wait, and the
+    # op's mean came out 5 us above the sum of its kernels' durations under rocprofv3)
+    torch.cuda._sleep(int(8.0e6 * max(1, reps // 10)))
     evs = []
     for _ in range(reps):
         a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)

@@ -158,7 +158,7 @@ int tk_crf_flipflop_dev(const float *logprob, size_t ntrans, size_t nblk,
  * into what it writes.  Plain CRF: modidx = modfact = NULL, ntrans = 2 nbase
  * (nbase + 1), aux may be NULL.  (Lab: with TK_LOSS_OVERLAP=1 in the environment the aux size function
  * also returns bytes for the plain CRF, and kernel B then runs on a second hardware queue beside kernel A's
- * sweeps -- measured, not the default, refused while `stream` is capturing: DESIGN.md section 7.)
+ * sweeps -- measured, not the default, refused while `stream` is capturing: LABNOTES.md, section 7.)
  * ------------------------------------------------------------------------- */
 size_t tk_flipflop_loss_fused_aux_bytes(size_t nblk, size_t nbatch, size_t nbase, size_t ntrans);
 int tk_flipflop_loss_fused_dev(const float *scores, size_t nblk, size_t nbatch, size_t nbase, size_t ntrans,

@@ -225,7 +225,7 @@ __global__ void slice_cols_kernel(const float *__restrict__ src, float *__restri
 // not depend on them.  With an aux buffer for kernel B's gradient, B runs on a second hardware queue
 // (the high-priority side stream of logz_kernels.hip) while the sweeps run, and kernel A's gradient
 // pass, which waits for it, folds logZ / nblk and (d logZ) / nblk into the rows it writes anyway.
-// Measured: the loss path goes from 0.176 to 0.171 ms (plain; the sweeps slow down
+// Measured (LABNOTES.md, section 7): the loss path goes from 0.176 to 0.171 ms (plain; the sweeps slow down
 // by most of what the overlap hides) and from 0.245 to 0.223 ms (cat-mod) -- and capturing the fork /
 // join into a hipGraph crashes inside the HIP runtime of this PyTorch build, which is how the train
 // step runs.  So: off, and never while the caller's stream is capturing.

@@ -63,8 +63,9 @@ namespace tk {
 
 // Time steps per block (= per workgroup barrier, = per set of frames): a TEMPLATE parameter `BK` of everything
 // below.  What a block costs besides its steps -- frames, checkpoint column, ring, barrier: ~75 of a
-// phase's ~135 VALU instructions at BK = 8 -- is amortised over its steps, and the sweeps are bound by the
-// chip's VALU issue rate, so longer blocks are faster; what limits them is the
+// phase's ~135 VALU instructions at BK = 8 -- is amortised over its steps (measured: 12-step blocks take
+// the train step's sweep from 80 to 77 us and cost the gradient pass 3.5; -6 % at T = 1600: DESIGN.md
+// section 4, LABNOTES.md round 4); what limits the length is the
 // mantissas' growth between two frame updates, (1 + 2^KLIP) x the largest step weight per step inside
 // fp32's exponent range.  band_pick_block() chooses:
 //    BK = 12, weights biased by 2^-3   plain CRF, |sharp x score| <= 5.18 (the network's 5 tanh, unsharpened)
@@ -1435,7 +1436,7 @@ static bool band_use_helpers(const BandArgs &a, int R, bool mod, int bk) {
     if (a.grad == nullptr || R > 2 || bk < 8) return false;
     if (a.W + (a.W + 1) / 2 > BAND_MAXW || (size_t)a.W * R * bk * 1024 > 144 * 1024) return false;
     if (const char *e = getenv("TK_CRF_HELPER")) return e[0] == '1';
-    // measured (kernel A): -3.5 % for the plain CRF at R = 1, -7 % for cat-mod with per-column
+    // measured (LABNOTES.md, kernel A): -3.5 % for the plain CRF at R = 1, -7 % for cat-mod with per-column
     // factors; cat-mod in its general form (whose helpers also carry the per-cell exponentials) +4 %,
     // R = 2 +-0: those stay in the plain mode
     if (R != 1 || (mod && a.colw == nullptr)) return false;

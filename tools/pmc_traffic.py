@@ -96,10 +96,11 @@ def short(name):
     return name.replace("_ZN2tk", "").split("EvN")[0].split("EvP")[0][:48]
 
 
-def band_bytes(T, N, real, R_hint=None):
+def band_bytes(T, N, real, R_hint=None, cat_mod=False):
     """Analytic size of what kernel A's sweeps leave for the gradient pass, per sweep: one checkpoint
-    column (4 B mantissa + 4 B frame per cell) per live (chunk, block) pair, plus 8 boundary cells per
-    64 cells and block."""
+    column (4 B mantissa + 2 B frame offset per cell) per live (chunk, block) pair, plus one boundary cell
+    per step, 64 cells and block.  Block length as crf_band_pick_block chooses it at sharpening factor 1:
+    12 steps for the plain CRF (8 at two cells per lane), 8 for cat-mod."""
     import numpy as np
     from taiyaki_amd import synth
     seqlens = synth.realistic_seqlens(T, N, 17001, real, 9.0) if real else synth.speedtest_seqlens(T, N)
@@ -107,14 +108,15 @@ def band_bytes(T, N, real, R_hint=None):
     R = 1
     while R < 4 and R * 64 * 16 < maxL:
         R *= 2
-    PW, KB = 64 * R, 8
+    PW = 64 * R
+    KB = 8 if (cat_mod or R == 2) else 12
     total = 0
     for L in seqlens:
         L = int(L)
         for w in range((L + PW - 1) // PW):
             a, b = w * PW, min(w * PW + PW - 1, L - 1)
             tlo, thi = max(0, a - 1), min(T - 1, b + T - L + 1)
-            total += (thi // KB - tlo // KB + 1) * (PW * 8 + (PW // 64) * 32)
+            total += (thi // KB - tlo // KB + 1) * (PW * 6 + (PW // 64) * 4 * KB)
     return int(total)
 
 
@@ -177,7 +179,7 @@ def main():
                  fetch_bytes=fetch_b, write_bytes=write_b, traffic_bytes=fetch_b + write_b, algorithmic_bytes=alg,
                  traffic_over_algorithmic=round((fetch_b + write_b) / alg, 4), kernel_hash=bench.kernel_hash())
         if name != "logz":
-            bb = band_bytes(T, N, real)
+            bb = band_bytes(T, N, real, cat_mod=(name == "catmod"))
             d["analytic_checkpoint_bytes_per_sweep"] = bb
             d["analytic_note"] = ("each sweep writes one checkpoint column + the boundary cells per block of the band "
                                   "(2 x %d B) and the gradient pass reads them once; scores are read by both sweeps "

@@ -39,12 +39,13 @@
 //     sweep launch), so the per-id sums of the reference's scatter-add (c_crf_flipflop.c:403-412)
 //     are differences of ONE prefix scan held in registers: no atomics, no cross-wave reduction,
 //     fixed summation order -> bitwise reproducible.
-//   * Round 3 also: HELPER WAVES prepare a block's step weights a phase ahead through LDS in launches where
-//     every sweep workgroup has a CU to itself (band_helper); the frames' own-cells half runs ahead of the
-//     barrier (band_frames_own / _finish); cat-mod with per-COLUMN factors exponentiates a row once per wave
-//     like the plain CRF (CW); the gradient pass runs two waves per workgroup and interleaves its eight
-//     prefix scans.  Each of these is bit-identical to the form it replaced except CW (different rounding,
-//     tested against the general form and the oracle).
+//   * Round 3 also: the frames' own-cells half runs ahead of the barrier (band_frames_own / _finish); cat-mod with
+//     per-COLUMN factors exponentiates a row once per wave like the plain CRF (CW); the gradient pass runs two
+//     waves per workgroup and interleaves its prefix scans.
+//   * Round 4: the block length is a template parameter and the step weights carry a bias (see BK_MAX); ONE
+//     row-maker wave per sweep workgroup exponentiates each score row once and leaves it in an LDS ring from which
+//     every chunk wave gathers its weights (band_rowmaker: -12 % on the op against round 3's helper waves, which
+//     shipped gathered weights per chunk pair and are gone).
 //   * The linear path is exact or says so: a read whose sweeps end non-finite (overflow: scores
 //     beyond the bound above, e.g. sharpening factors > 1; underflow of everything: no complete
 //     path, log-probabilities far below zero), whose two sweeps disagree, or ANY of whose rows'
@@ -69,7 +70,7 @@ namespace tk {
 // mantissas' growth between two frame updates, (1 + 2^KLIP) x the largest step weight per step inside
 // fp32's exponent range.  band_pick_block() chooses:
 //    BK = 12, weights biased by 2^-3   plain CRF, |sharp x score| <= 5.18 (the network's 5 tanh, unsharpened)
-//    BK = 8,  no bias                  round 3's form: cat-mod; plain CRF sharpened up to 1.36
+//    BK = 8,  no bias                  round 3's arithmetic: cat-mod; plain CRF sharpened up to 1.36
 //    BK = 8,  weights biased by 2^-3   sharpening factors up to 1.76
 //    BK = 4,  no bias                  sharpening factors up to 3.5
 // The BIAS (BandArgs::wbias): every step weight carries a factor 2^-wbias, folded into the argument of its
@@ -79,6 +80,7 @@ namespace tk {
 constexpr int BK_MAX = 12;          // (the longest; sizes nothing -- every array is sized by the template parameter)
 static_assert(BK_MAX % 4 == 0, "blocks move through the ring as float4");
 constexpr int KLIP = 6;             // frame slope along the flow (bits per cell)
+constexpr int ROW_PITCH = 48;       // shared-rows feed (band_rowmaker): floats per row image in LDS (S <= 46)
 constexpr int BAND_MAXW = 16;       // waves per workgroup
 constexpr int POST_WAVES = 2;       // waves (= time blocks) per gradient-pass workgroup (8: +1.5 % in the step, +4 % at row K: coarser tail)
 constexpr int KEY_DEAD = 63;        // sort key of padding instances
@@ -289,16 +291,7 @@ __device__ __forceinline__ void band_frames(float (&m)[R], int (&f)[R], float (&
     }
 }
 
-// LDS image of a block's step weights, written by a helper wave and read by the chunk's own wave
-// (HELP mode, see band_helper): value v = (kind R + cell) BK + row of (chunk, slot) sits in component
-// v & 3 of float4  ((chunk 2 + slot) 4 R + (v >> 2)) 64 + lane  -- lanes are 16 bytes apart, so both
-// sides move it with conflict-free ds_*_b128.
-template <int R, int BK>
-__device__ __forceinline__ int wt_f4(int chunk, int slot, int g, int lane) {
-    return ((chunk * 2 + slot) * (R * BK / 2) + g) * WAVE + lane;       // (2 kinds x R cells x BK rows / 4 per float4)
-}
-
-template <int R, bool MOD, bool FWD, bool GRAD, bool HELP, bool CW, int BK>
+template <int R, bool MOD, bool FWD, bool GRAD, bool ROWS, bool CW, int BK>
 __device__ __forceinline__ void band_sweep(const BandArgs &a, int n, int L, float *E, int *Ef, const float *Ezero,
                                            const f4 *Wt) {
     constexpr int PW = R * WAVE;
@@ -313,7 +306,7 @@ __device__ __forceinline__ void band_sweep(const BandArgs &a, int n, int L, floa
     const Win wsrc = (src >= 0 && src < W) ? band_window<BK>(src, PW, L, T) : Win{1, 0};
     if (win.j0 > win.j1) {
         // a chunk past the end of this read: keep the workgroup's barriers company
-        for (int ph = 0; ph < NPH + (HELP ? 1 : 0); ++ph) band_barrier();
+        for (int ph = 0; ph < NPH + (ROWS ? 1 : 0); ++ph) band_barrier();
         return;
     }
     const size_t rowstride = (size_t)N * S;
@@ -408,6 +401,8 @@ __device__ __forceinline__ void band_sweep(const BandArgs &a, int n, int L, floa
     int zown[R], zrun_excl = NOFRAME;           // band_frames_own's results, carried from block to block
 #pragma unroll
     for (int j = 0; j < R; ++j) zown[j] = NOFRAME;
+    // ROWS: the LDS slot of the block this chunk runs next (block j lives in slot j mod (W + 1))
+    int rslot = 0;
     int stamp_k = 0;
 #ifdef TK_LAB_STAMPS
 #define STAMP(q)                                                                            \
@@ -429,7 +424,7 @@ __device__ __forceinline__ void band_sweep(const BandArgs &a, int n, int L, floa
     //   4. the edge lane hands its BK boundary cells to the ring (and to HBM for the gradient pass).
     auto body = [&](int j, const float (&cur)[BK], float (&fill)[BK]) {
         STAMP(0);
-        if constexpr (!HELP) load_block(FWD ? j + 2 : j - 2, fill);
+        if constexpr (!ROWS) load_block(FWD ? j + 2 : j - 2, fill);
         const bool pl = j >= wsrc.j0 && j <= wsrc.j1;           // the neighbour ran this block one phase ago
         const int slot = j & 1;
         const int srcc = min(max(src, 0), W - 1);
@@ -448,26 +443,22 @@ __device__ __forceinline__ void band_sweep(const BandArgs &a, int n, int L, floa
         constexpr int GH = (R == 4) ? 4 : BK;
         float es[GH][R], em[GH][R];
         auto gather_group = [&](int ii0) {
-            if constexpr (HELP) {
-                // the helper wave left this block's weights in LDS one phase ago, rows in TIME order
-                // (GH = 8: both float4 of a cell and kind; GH = 4: the half this group consumes)
+            static_assert(!ROWS || !MOD || CW, "shared rows hold exponentials: cat-mod needs per-column factors");
+            if constexpr (ROWS) {
+                // SHARED ROWS (band_rowmaker): the block's exponentiated rows are in LDS, one image per
+                // workgroup; a weight is one LDS read at (row, transition id) -- the value ds_bpermute would
+                // have fetched from this wave's own copy of the row, bit for bit
+                const float *rp = reinterpret_cast<const float *>(Wt) + (size_t)rslot * (BK * ROW_PITCH);
 #pragma unroll
-                for (int jj = 0; jj < R; ++jj) {
+                for (int g = 0; g < GH; ++g) {
+                    const int i = FWD ? ii0 + g : BK - 1 - (ii0 + g);
 #pragma unroll
-                    for (int kind = 0; kind < 2; ++kind) {
-#pragma unroll
-                        for (int h4 = 0; h4 < GH / 4; ++h4) {
-                            // steps ii0 + 4 h4 .. + 3 in sweep order = rows i0 .. i0 + 3 (forward) / i0 .. i0 - 3
-                            const int first = ii0 + 4 * h4;
-                            const int lowrow = FWD ? first : BK - 4 - first;       // the float4 that holds them
-                            const f4 v = Wt[wt_f4<R, BK>(w, slot, ((kind * R + jj) * BK + lowrow) >> 2, lane)];
-#pragma unroll
-                            for (int q = 0; q < 4; ++q) {
-                                const float x = FWD ? v[q] : v[3 - q];
-                                if (kind == 0) es[4 * h4 + q][jj] = x;
-                                else em[4 * h4 + q][jj] = x;
-                            }
-                        }
+                    for (int jj = 0; jj < R; ++jj) {
+                        es[g][jj] = rp[i * ROW_PITCH + (st4[jj] >> 2)];
+                        if constexpr (MOD)
+                            em[g][jj] = rp[i * ROW_PITCH + (mv4[jj] >> 2)] * rp[i * ROW_PITCH + (md4[MOD ? jj : 0] >> 2)];
+                        else
+                            em[g][jj] = rp[i * ROW_PITCH + (mv4[jj] >> 2)];
                     }
                 }
                 return;
@@ -631,6 +622,10 @@ __device__ __forceinline__ void band_sweep(const BandArgs &a, int n, int L, floa
         }
         STAMP(4);
         ++stamp_k;
+        if constexpr (ROWS) {
+            rslot += FWD ? 1 : -1;
+            rslot = (rslot > W) ? 0 : ((rslot < 0) ? W : rslot);
+        }
     };
 
     // phases: chunk w runs block j in phase j + w (forward) / (NB-1-j) + (W-1-w) (backward);
@@ -639,11 +634,12 @@ __device__ __forceinline__ void band_sweep(const BandArgs &a, int n, int L, floa
     const int ph0 = FWD ? win.j0 + w : (NB - 1 - win.j1) + (W - 1 - w);
     const int dj = FWD ? 1 : -1;
     if constexpr (SPLIT_FRAMES) band_frames_own<R>(m, f, zown, zrun_excl, lane);
-    if constexpr (!HELP) {
+    if constexpr (!ROWS) {
         load_block(jfirst, row0);
         load_block(jfirst + dj, row1);
     } else {
-        band_barrier();                                         // the helpers' lead phase
+        if constexpr (ROWS) rslot = jfirst % (W + 1);
+        band_barrier();                                         // the row maker's lead phase
     }
     for (int ph = 0; ph < ph0; ++ph) band_barrier();
     for (int k = 0; k < nlive; k += 3) {
@@ -674,23 +670,22 @@ __device__ __forceinline__ void band_sweep(const BandArgs &a, int n, int L, floa
 }
 
 // ===========================================================================
-// HELPER WAVES (round 3).  At the train step's shape a sweep is ONE workgroup per CU and the time of a
-// phase is the instruction stream of ONE wave (~260 instructions at one per ~5 cycles) while three of
-// the CU's four SIMDs idle.  About 100 of those instructions do not depend on the lattice at all: the
-// block's row loads, their exponentials and the 16 R gathers of the step weights.  In HELP mode a
-// helper wave per TWO chunks does them one phase ahead and leaves the weights in LDS (wt_f4), where the
-// chunk's own wave picks them up with 4 R ds_read_b128: the same arithmetic on the same values (the
-// results are bit for bit those of the plain mode), a phase ~40 % shorter.  The two chunks of a helper
-// run consecutive blocks in consecutive phases (the skew), so the rows it loads for the leading chunk
-// serve the trailing one a phase later.  Used when every sweep workgroup has a CU to itself and
-// W + ceil(W / 2) waves fit a workgroup; the weights take W R 8 KiB of LDS.
+// SHARED ROWS (round 4).  Every chunk of a read gathers its step weights from the SAME exponentiated score
+// rows -- chunk w needs block j's rows in phase j + w.  Without this (ROWS = false: launches whose workgroup
+// has no room for a 17th wave) each chunk wave loads and exponentiates the rows itself and gathers with
+// ds_bpermute; round 3's helper waves did it per chunk PAIR and shipped 2 R BK weights per chunk through LDS
+// (ds_write_b128 at 13 LDS cycles a piece).  Here ONE extra wave per sweep workgroup, the row maker, loads
+// and exponentiates block ph + 1's rows during phase ph and leaves them in an LDS ring of W + 1 blocks (a
+// block is last read W - 1 phases after its first use); the chunk waves read a weight with one LDS read at
+// (row, transition id) -- the compiler pairs them into ds_read2_b32.  The values are the ones ds_bpermute
+// would have fetched: results are bit for bit those of the other feeds (tools/crf_bitcmp.py,
+// test_crf_weight_feeds_change_no_bit).  Measured (profiles/r4_feed_modes.txt): the op at the train step's
+// shape 110 us against 125 with helper waves and 134 with neither; -15 .. -22 % at every other shape tried.
 // ===========================================================================
-template <int R, bool MOD, bool FWD, bool CW, int BK>
-__device__ __forceinline__ void band_helper(const BandArgs &a, int n, int L, int h, f4 *Wt) {
-    constexpr int PW = R * WAVE;
+template <bool MOD, bool FWD, bool CW, int BK>
+__device__ __forceinline__ void band_rowmaker(const BandArgs &a, int n, float *Er) {
     const int lane = threadIdx.x & (WAVE - 1);
     const int N = a.N, T = a.T, S = a.S, W = a.W;
-    const int64_t off = a.seqoff[n];
     const int NB = (T + BK - 1) / BK, NPH = NB + W - 1;
     const size_t rowstride = (size_t)N * S;
     const float *lpn = a.lp + (size_t)n * S;
@@ -698,30 +693,7 @@ __device__ __forceinline__ void band_helper(const BandArgs &a, int n, int L, int
     const unsigned rs4 = 4u * (unsigned)rowstride;
     const float c = a.c_can;
     const float cw_lane = (MOD && CW) ? ((int)lane < a.ncan ? c : a.colw[min(max((int)lane - a.ncan, 0), S - a.ncan - 1)] * a.c_mod) : c;
-    const float wbias = a.wbias;
-    const float wb_lane = (MOD && CW && (int)lane >= a.ncan) ? 0.f : wbias;
-    // the leading chunk runs block j in the phase before the trailing one does
-    const int cl = FWD ? 2 * h : 2 * h + 1, ct = FWD ? 2 * h + 1 : 2 * h;
-    const int cc[2] = {cl, ct};
-    Win win[2];
-    int st4[2][R], mv4[2][R], md4[2][MOD ? R : 1];
-    float fw[2][MOD ? R : 1];
-#pragma unroll
-    for (int u = 0; u < 2; ++u) {
-        win[u] = (cc[u] >= 0 && cc[u] < W) ? band_window<BK>(cc[u], PW, L, T) : Win{1, 0};
-#pragma unroll
-        for (int j = 0; j < R; ++j) {
-            const int q = lane * R + j, p = FWD ? cc[u] * PW + q : cc[u] * PW + PW - 1 - q;
-            const int ms = FWD ? p - 1 : p;
-            const bool has = ms >= 0 && ms < L - 1;
-            st4[u][j] = 4 * ((p >= 0 && p < L) ? a.stay[off + p] : 0);
-            mv4[u][j] = 4 * (has ? a.move[off + ms] : 0);
-            if (MOD) {
-                md4[u][MOD ? j : 0] = 4 * (has ? a.mod[off + ms] : 0);
-                fw[u][MOD ? j : 0] = has ? a.modfact[off + ms] * a.c_mod : 0.f;
-            }
-        }
-    }
+    const float wb_lane = (MOD && CW && (int)lane >= a.ncan) ? 0.f : a.wbias;
     unsigned rowoff[BK];
 #pragma unroll
     for (int i = 0; i < BK; ++i) rowoff[i] = rs4 * (unsigned)i;
@@ -733,59 +705,33 @@ __device__ __forceinline__ void band_helper(const BandArgs &a, int n, int L, int
         for (int i = 0; i < BK; ++i)
             dst[i] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rs, col4, rowoff[i], 0));
     };
-    // weights of block j of chunk cc[u] from its rows -> LDS, rows in time order
-    auto emit = [&](int u, int j, const float (&row)[BK]) {
-        if (j < win[u].j0 || j > win[u].j1) return;             // (wave-uniform)
-        const int slot = j & 1;
-        float er[BK];
+    // the block the LEADING chunk (forward: chunk 0, backward: chunk W - 1) runs in phase ph
+    auto block_of = [&](int ph) { return FWD ? ph : NB - 1 - ph; };
+    auto emit = [&](int j, const float (&row)[BK]) {
+        if (j < 0 || j >= NB) return;                           // (wave-uniform)
+        float *dst = Er + (size_t)(j % (W + 1)) * (BK * ROW_PITCH) + lane;
+        if (lane < ROW_PITCH) {
 #pragma unroll
-        for (int i = 0; i < BK; ++i) er[i] = fast_exp2(fmaf(row[i], cw_lane, -wb_lane));
-#pragma unroll
-        for (int jj = 0; jj < R; ++jj) {
-            float es[BK], em[BK];
-#pragma unroll
-            for (int i = 0; i < BK; ++i) {
-                es[i] = bperm(st4[u][jj], er[i]);
-                if constexpr (MOD && CW)
-                    em[i] = bperm(mv4[u][jj], er[i]) * bperm(md4[u][MOD ? jj : 0], er[i]);
-                else if constexpr (MOD)
-                    em[i] = fast_exp2(fmaf(bperm(md4[u][MOD ? jj : 0], row[i]), fw[u][MOD ? jj : 0], fmaf(bperm(mv4[u][jj], row[i]), c, -wbias)));
-                else
-                    em[i] = bperm(mv4[u][jj], er[i]);
-            }
-#pragma unroll
-            for (int h4 = 0; h4 < BK / 4; ++h4) {
-                Wt[wt_f4<R, BK>(cc[u], slot, ((0 * R + jj) * BK + 4 * h4) >> 2, lane)] = f4{es[4 * h4], es[4 * h4 + 1], es[4 * h4 + 2], es[4 * h4 + 3]};
-                Wt[wt_f4<R, BK>(cc[u], slot, ((1 * R + jj) * BK + 4 * h4) >> 2, lane)] = f4{em[4 * h4], em[4 * h4 + 1], em[4 * h4 + 2], em[4 * h4 + 3]};
-            }
+            for (int i = 0; i < BK; ++i) dst[i * ROW_PITCH] = fast_exp2(fmaf(row[i], cw_lane, -wb_lane));
         }
     };
-    // In the phase before phase ph (ph = 0 .. NPH - 1; the lead phase prepares phase 0) the helper emits
-    // the blocks its chunks run IN phase ph: forward chunk c runs block ph - c, backward
-    // NB - 1 - (ph - (W - 1 - c)).  The leading chunk's block index moves one per phase; four register
-    // sets rotate by NAME (current, previous = the trailing chunk's, and two in flight).
-    auto block_of = [&](int cidx, int ph) { return FWD ? ph - cidx : NB - 1 - (ph - (W - 1 - cidx)); };
-    const int dj = FWD ? 1 : -1;
-    float r0[BK], r1[BK], r2[BK], r3[BK];
-    const int jl0 = block_of(cl, 0);
-    load_block(jl0 - dj, r3);                                   // "previous" of the first round (never live)
-    load_block(jl0, r0);
-    load_block(jl0 + dj, r1);
-    load_block(jl0 + 2 * dj, r2);
-    auto round = [&](int ph, const float (&cur)[BK], const float (&prev)[BK], float (&fill)[BK]) {
-        const int jl = block_of(cl, ph);
-        emit(0, jl, cur);
-        emit(1, block_of(ct, ph), prev);                       // (= jl - dj: the leader's block of the round before)
-        load_block(jl + 3 * dj, fill);                          // `prev` is free now: the set three rounds ahead
+    float r0[BK], r1[BK];
+    load_block(block_of(0), r0);
+    load_block(block_of(1), r1);
+    // lead phase: block_of(0); then during phase ph: block_of(ph + 1)
+    emit(block_of(0), r0);
+    load_block(block_of(2), r0);
+    band_barrier();
+    for (int ph = 0; ph < NPH; ph += 2) {
+        emit(block_of(ph + 1), r1);
+        load_block(block_of(ph + 3), r1);
         band_barrier();
-    };
-    for (int ph = 0; ph < NPH; ph += 4) {
-        round(ph, r0, r3, r3);
-        if (ph + 1 < NPH) round(ph + 1, r1, r0, r0);
-        if (ph + 2 < NPH) round(ph + 2, r2, r1, r1);
-        if (ph + 3 < NPH) round(ph + 3, r3, r2, r2);
+        if (ph + 1 < NPH) {
+            emit(block_of(ph + 2), r0);
+            load_block(block_of(ph + 4), r0);
+            band_barrier();
+        }
     }
-    band_barrier();                                             // the chunks' last phase
 }
 
 // ===========================================================================
@@ -795,9 +741,9 @@ __device__ __forceinline__ void band_helper(const BandArgs &a, int n, int L, int
 // ===========================================================================
 // WCAP = the most waves a launch of this instantiation may have: the register budget of a lane is
 // 512 / ceil(WCAP / 4) (R = 4 wants more than the 128 that 16 waves leave).
-template <int R, bool MOD, int WCAP, bool HELP, bool CW, int BK>
+template <int R, bool MOD, int WCAP, bool ROWS, bool CW, int BK>
 __global__ __launch_bounds__(WCAP *WAVE) void crf_band_sweep_kernel(BandArgs a) {
-    extern __shared__ __attribute__((aligned(16))) char band_dyn_lds[];     // HELP: the weights image (wt_f4)
+    extern __shared__ __attribute__((aligned(16))) char band_dyn_lds[];     // ROWS: the exponentiated rows (band_rowmaker)
     constexpr int PW = R * WAVE;
     constexpr int KINDS = MOD ? 3 : 2;
     __shared__ __attribute__((aligned(16))) float E[BAND_MAXW * 2 * BK];
@@ -874,20 +820,22 @@ __global__ __launch_bounds__(WCAP *WAVE) void crf_band_sweep_kernel(BandArgs a) 
     if (tid < BK) Ezero[tid] = 0.f;
     __syncthreads();
     f4 *Wt = reinterpret_cast<f4 *>(band_dyn_lds);
-    if (HELP && w >= W) {
-        // helper waves (gradient calls only): the weights of two chunks each, a phase ahead
-        if (role == 0)
-            band_helper<R, MOD, true, CW, BK>(a, n, L, w - W, Wt);
-        else
-            band_helper<R, MOD, false, CW, BK>(a, n, L, w - W, Wt);
-        return;
+    if constexpr (ROWS) {
+        if (w >= W) {
+            // the row maker: the workgroup's exponentiated rows, a phase ahead
+            if (role == 0)
+                band_rowmaker<MOD, true, CW, BK>(a, n, reinterpret_cast<float *>(band_dyn_lds));
+            else
+                band_rowmaker<MOD, false, CW, BK>(a, n, reinterpret_cast<float *>(band_dyn_lds));
+            return;
+        }
     }
     if (!want_grad)
-        band_sweep<R, MOD, true, false, false, CW, BK>(a, n, L, E, Ef, Ezero, Wt);
+        band_sweep<R, MOD, true, false, ROWS, CW, BK>(a, n, L, E, Ef, Ezero, Wt);
     else if (role == 0)
-        band_sweep<R, MOD, true, true, HELP, CW, BK>(a, n, L, E, Ef, Ezero, Wt);
+        band_sweep<R, MOD, true, true, ROWS, CW, BK>(a, n, L, E, Ef, Ezero, Wt);
     else
-        band_sweep<R, MOD, false, true, HELP, CW, BK>(a, n, L, E, Ef, Ezero, Wt);
+        band_sweep<R, MOD, false, true, ROWS, CW, BK>(a, n, L, E, Ef, Ezero, Wt);
 }
 
 // Inclusive wave prefix sum in six fused DPP adds (the row_bcast steps write only the rows they
@@ -1360,7 +1308,9 @@ int crf_band_pick_R(size_t max_seqlen) {
         R = atoi(e);
         if (R != 1 && R != 2 && R != 4) R = 1;
     }
-    while (R < 4 && (size_t)R * WAVE * BAND_MAXW < max_seqlen) R *= 2;
+    // (one wave of the workgroup is the row maker: 15 chunk waves below four cells per lane -- a read of
+    // 961 .. 1024 bases takes two cells per lane and keeps the shared rows: 204 us against 247 at T 1600 / N 64)
+    while (R < 4 && (size_t)R * WAVE * (BAND_MAXW - 1) < max_seqlen) R *= 2;
     return R;
 }
 
@@ -1372,16 +1322,15 @@ bool crf_band_fits(size_t max_seqlen) { return max_seqlen <= (size_t)4 * WAVE * 
 BandBlock crf_band_pick_block(float sharp, bool mod, size_t max_seqlen) {
     BandBlock b{8, 0.f};
     const float x = sharp > 0.f ? sharp : 1.f;
-    // (two cells per lane -- reads of 1025 .. 2048 bases -- stay at 8 steps: the 12-step sweep does not fit
-    // their 128 registers and measured 227 us against 139 at the train step's shape)
-    if (!mod && x <= 1.03f && crf_band_pick_R(max_seqlen) != 2) b = {12, 3.f};
+    (void)max_seqlen;
+    if (!mod && x <= 1.03f) b = {12, 3.f};
     else if (x <= 1.36f) b = {8, 0.f};
     else if (x <= 1.76f) b = {8, 3.f};
     else if (x <= 3.5f) b = {4, 0.f};
     else b = {0, 0.f};
     if (const char *e = getenv("TK_CRF_BK")) {
         const int v = atoi(e);
-        if (v == 4 || v == 8 || (v == 12 && !mod && crf_band_pick_R(max_seqlen) != 2)) b.bk = v;
+        if (v == 4 || v == 8 || (v == 12 && !mod)) b.bk = v;
     }
     if (const char *e = getenv("TK_CRF_WBIAS")) b.wbias = (float)atof(e);
     return b;
@@ -1429,53 +1378,50 @@ BandLayout crf_band_layout(size_t ntrans, size_t nblk, size_t nbatch, size_t max
 static int g_band_lab_phase = 0;
 void crf_band_lab_phase(int phase) { g_band_lab_phase = phase; }
 
-// Helper waves (band_helper) pay when a sweep is latency-bound: every sweep workgroup has a CU to itself
-// (2 N workgroups <= CUs), its chunks' waves plus one helper per two chunks fit a workgroup, and the
-// weights image fits LDS.  TK_CRF_HELPER=0 / 1 overrides the first condition (lab).
-static bool band_use_helpers(const BandArgs &a, int R, bool mod, int bk) {
-    if (a.grad == nullptr || R > 2 || bk < 8) return false;
-    if (a.W + (a.W + 1) / 2 > BAND_MAXW || (size_t)a.W * R * bk * 1024 > 144 * 1024) return false;
-    if (const char *e = getenv("TK_CRF_HELPER")) return e[0] == '1';
-    // measured (LABNOTES.md, kernel A): -3.5 % for the plain CRF at R = 1, -7 % for cat-mod with per-column
-    // factors; cat-mod in its general form (whose helpers also carry the per-cell exponentials) +4 %,
-    // R = 2 +-0: those stay in the plain mode
-    if (R != 1 || (mod && a.colw == nullptr)) return false;
-    static int ncu[64] = {0};
-    int dev = 0;
-    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return false;
-    if (ncu[dev] == 0) {
-        int v = 0;
-        if (hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || v <= 0) v = -1;
-        ncu[dev] = v;
+// Does this launch run with a row maker (band_rowmaker)?  Whenever W + 1 waves fit a workgroup and the weights
+// are gathers from an exponentiated row (the plain CRF; cat-mod with per-column factors); 4-step blocks (sharpened
+// calls) keep the plain feed.  TK_CRF_FEED = self | rows forces one (lab, tests).
+static bool band_use_rows(const BandArgs &a, bool mod, int bk) {
+    if (bk < 8 || a.W + 1 > BAND_MAXW || (mod && a.colw == nullptr)) return false;
+    if (const char *e = getenv("TK_CRF_FEED")) return e[0] == 'r';
+    return true;
+}
+
+template <int R, bool MOD, bool CW, int BK, bool ROWS>
+static int band_launch_sweep(const BandArgs &a, hipStream_t stream) {
+    const bool want_grad = a.grad != nullptr;
+    const int nw = a.W + (ROWS ? 1 : 0);
+    const size_t lds = ROWS ? (size_t)(a.W + 1) * BK * ROW_PITCH * sizeof(float) : 0;
+    const dim3 grid((want_grad ? 3 : 1) * a.N), block(nw * WAVE);
+    // (R = 4 is compiled per wave-count class: 155 registers where the launch bounds allow them)
+    auto go = [&](auto cap) {
+        constexpr int WCAP = decltype(cap)::value;
+        hipLaunchKernelGGL((crf_band_sweep_kernel<R, MOD, WCAP, ROWS, CW, BK>), grid, block, lds, stream, a);
+    };
+    if constexpr (R == 4 && BK >= 8) {
+        if (nw <= 8) go(std::integral_constant<int, 8>{});
+        else if (nw <= 12) go(std::integral_constant<int, 12>{});
+        else go(std::integral_constant<int, BAND_MAXW>{});
+    } else {
+        go(std::integral_constant<int, BAND_MAXW>{});
     }
-    return ncu[dev] > 0 && 2 * a.N <= ncu[dev];
+    return hipGetLastError() == hipSuccess ? 0 : 4;
 }
 
 template <int R, bool MOD, bool CW, int BK>
 static int band_launch(const BandArgs &a, hipStream_t stream) {
     const bool want_grad = a.grad != nullptr;
     if (g_band_lab_phase != 2) {
-        const dim3 grid((want_grad ? 3 : 1) * a.N), block(a.W * WAVE);
-        if constexpr (R <= 2) {
-            bool helped = false;
-            if constexpr (BK >= 8) {
-                if (band_use_helpers(a, R, MOD, BK)) {
-                    const size_t lds = (size_t)a.W * R * BK * 1024;
-                    const dim3 hblock((a.W + (a.W + 1) / 2) * WAVE);
-                    if (raise_dynamic_lds(reinterpret_cast<const void *>(&crf_band_sweep_kernel<R, MOD, BAND_MAXW, true, CW, BK>), 152 * 1024)) return 4;
-                    hipLaunchKernelGGL((crf_band_sweep_kernel<R, MOD, BAND_MAXW, true, CW, BK>), grid, hblock, lds, stream, a);
-                    helped = true;
-                }
-            }
-            if (!helped) hipLaunchKernelGGL((crf_band_sweep_kernel<R, MOD, BAND_MAXW, false, CW, BK>), grid, block, 0, stream, a);
-        } else if (BK >= 8 && a.W <= 8)
-            hipLaunchKernelGGL((crf_band_sweep_kernel<R, MOD, (R == 4 && BK >= 8 ? 8 : BAND_MAXW), false, CW, BK>), grid, block, 0, stream, a);
-        else if (BK >= 8 && a.W <= 12)
-            hipLaunchKernelGGL((crf_band_sweep_kernel<R, MOD, (R == 4 && BK >= 8 ? 12 : BAND_MAXW), false, CW, BK>), grid, block, 0, stream, a);
-        else
-            hipLaunchKernelGGL((crf_band_sweep_kernel<R, MOD, BAND_MAXW, false, CW, BK>), grid, block, 0, stream, a);
+        int rc;
+        bool rows = false;
+        if constexpr (BK >= 8 && (!MOD || CW)) rows = band_use_rows(a, MOD, BK);
+        if constexpr (BK >= 8 && (!MOD || CW)) {
+            rc = rows ? band_launch_sweep<R, MOD, CW, BK, true>(a, stream) : band_launch_sweep<R, MOD, CW, BK, false>(a, stream);
+        } else {
+            rc = band_launch_sweep<R, MOD, CW, BK, false>(a, stream);
+        }
+        if (rc != 0) return rc;
     }
-    if (hipGetLastError() != hipSuccess) return 4;
     if (!want_grad || g_band_lab_phase == 1) return 0;
     if (a.before_gradient != nullptr && hipStreamWaitEvent(stream, a.before_gradient, 0) != hipSuccess) return 4;
     const int NB = (a.T + BK - 1) / BK;
@@ -1490,7 +1436,7 @@ template <int R, bool MOD, bool CW>
 static int band_launch_bk(const BandArgs &a, int bk, hipStream_t stream) {
     if (bk == 4) return band_launch<R, MOD, CW, 4>(a, stream);
     if (bk == 8) return band_launch<R, MOD, CW, 8>(a, stream);
-    if constexpr (!MOD && R != 2) {
+    if constexpr (!MOD) {
         if (bk == 12) return band_launch<R, MOD, CW, 12>(a, stream);
     }
     return 2;

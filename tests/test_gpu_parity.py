@@ -710,19 +710,24 @@ def test_crf_linear_band_path_keeps_confident_reads(oracle_mod, gpu_device, burs
         assert parity.abs_err(grad[:, n:n + 1], ograd) * grad.shape[0] < GRAD_T_ATOL, L
 
 
-@pytest.mark.parametrize("case", ["step", "ragged", "r2", "catmod", "lastblock"])
-def test_crf_helper_waves_change_no_bit(gpu_device, case, monkeypatch):
-    """Round 3: in small launches a helper wave per two chunks prepares the step weights (row loads,
-    exponentials, gathers) a phase ahead and hands them over through LDS (crf_band.hip: band_helper).
-    The arithmetic and its order are those of the plain mode, so costs and gradients must agree BIT FOR
-    BIT: for the train step's shape, ragged / degenerate lengths, two cells per lane, cat-mod (whose
-    helpers also carry the per-cell exponentials) and a last block of three rows."""
+@pytest.mark.parametrize("case", ["step", "ragged", "r2", "catmod", "lastblock", "r4", "bk8"])
+def test_crf_weight_feeds_change_no_bit(gpu_device, case, monkeypatch):
+    """Round 4: one row-maker wave per sweep workgroup exponentiates every score row once and leaves it in
+    an LDS ring; the chunk waves gather their step weights from there (crf_band.hip: band_rowmaker) instead
+    of loading, exponentiating and ds_bpermute-gathering the rows themselves.  Same values, same order: costs
+    and gradients must agree BIT FOR BIT between the two feeds -- for the train step's shape, ragged /
+    degenerate lengths, two and four cells per lane, cat-mod with per-column factors, a last block of three
+    rows, a cost-only call and 8-step blocks."""
     import torch
     from taiyaki_amd import ctc, synth
     monkeypatch.setenv("TK_CRF_MODE", "band")
     T, N, lens, mods = {"step": (800, 64, "real", None), "ragged": (200, 7, [90, 150, 201, 30, 195, 64, 65], None),
                         "r2": (1600, 16, "real", None), "catmod": (400, 24, "real", (1, 1, 0, 0)),
-                        "lastblock": (803, 9, "real", None)}[case]
+                        "lastblock": (803, 9, "real", None), "r4": (2600, 6, [2100, 1300, 2500, 900, 1, 2590], None),
+                        "bk8": (800, 32, "real", None)}[case]
+    if case == "bk8":
+        monkeypatch.setenv("TK_CRF_BK", "8")
+        monkeypatch.setenv("TK_CRF_WBIAS", "0")
     seqlens = synth.realistic_seqlens(T, N, 17000, T * 5, 9.0) if lens == "real" else np.array(lens, dtype=np.int32)
     inp = synth.crf_case(T, N, 3, seqlens=seqlens, nmods_per_base=mods)
     extra = ()
@@ -732,16 +737,20 @@ def test_crf_helper_waves_change_no_bit(gpu_device, case, monkeypatch):
     x = torch.from_numpy(inp["scores"]).to(gpu_device)
     seqs, sl = torch.from_numpy(inp["seqs"]), torch.from_numpy(inp["seqlens"])
     out = {}
-    for helper in ("0", "1"):
-        monkeypatch.setenv("TK_CRF_HELPER", helper)
-        if extra:
-            c, g = ctc._run(x, seqs, sl, 1.0, 1.0, 1.0, 40, True, *extra)
-        else:
-            c, g = ctc._run(x, seqs, sl, 1.0, 1.0, 1.0, x.shape[2], True)
-        torch.cuda.synchronize()
-        out[helper] = (c.cpu().numpy(), g.cpu().numpy())
-    assert np.isfinite(out["0"][0]).all()
-    assert np.array_equal(out["0"][0], out["1"][0]) and np.array_equal(out["0"][1], out["1"][1])
+    for feed in ("self", "rows"):
+        monkeypatch.setenv("TK_CRF_FEED", feed)
+        res = []
+        for want_grad in (True, False):
+            if extra:
+                c, g = ctc._run(x, seqs, sl, 1.0, 1.0, 1.0, 40, want_grad, *extra)
+            else:
+                c, g = ctc._run(x, seqs, sl, 1.0, 1.0, 1.0, x.shape[2], want_grad)
+            torch.cuda.synchronize()
+            res += [c.cpu().numpy()] + ([g.cpu().numpy()] if want_grad else [])
+        out[feed] = res
+    assert np.isfinite(out["self"][0]).all()
+    for a, b in zip(out["self"], out["rows"]):
+        assert np.array_equal(a, b)
 
 
 def test_catmod_column_weights_form_agrees_with_the_general_form(oracle_mod, gpu_device, monkeypatch):
@@ -836,14 +845,13 @@ def test_crf_block_lengths_and_weight_bias_agree_with_the_oracle(oracle_mod, gpu
         r = parity.compare_crf(oracle_mod, inp, 1.0, gpu_device)
         assert r["finite"] and parity.crf_loss_ok(r) and r["loss_abs"] < 1e-5, (T, bk, wbias, r["loss_rel"], r["loss_abs"])
         assert parity.crf_grad_ok(r), (T, bk, wbias, r["grad_f64_scaled"], r["ref_noise_scaled"])
-    # two cells per lane (reads of 1025 .. 2048 bases)
-    if bk != "12":
-        T = 1500
-        inp = synth.crf_case(T, 3, 77, seqlens=np.array([1100, 700, 1300], dtype=np.int32), nmods_per_base=mods)
-        if mods is not None:
-            synth.normalise_mod_columns(inp)
-        r = parity.compare_crf(oracle_mod, inp, 1.0, gpu_device)
-        assert r["finite"] and r["loss_rel"] < LOSS_RTOL and parity.crf_grad_ok(r), (bk, wbias, r["loss_rel"])
+    # two cells per lane (reads of 961 .. 1920 bases)
+    T = 1500
+    inp = synth.crf_case(T, 3, 77, seqlens=np.array([1100, 700, 1300], dtype=np.int32), nmods_per_base=mods)
+    if mods is not None:
+        synth.normalise_mod_columns(inp)
+    r = parity.compare_crf(oracle_mod, inp, 1.0, gpu_device)
+    assert r["finite"] and r["loss_rel"] < LOSS_RTOL and parity.crf_grad_ok(r), (bk, wbias, r["loss_rel"])
 
 
 def test_crf_disowned_reads_are_counted_and_redone_in_shared_slots(oracle_mod, gpu_device, monkeypatch):

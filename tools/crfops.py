@@ -1,7 +1,7 @@
 #!/usr/bin/env python
 """Kernel A and the fused loss at the train step's shape (and optionally T=4000/N=256), C entry points back to
 back on the stream -- bench.py's `roofline_crf` / `loss_path` timing without the train step around it.  For lab
-switches (TK_CRF_BK, TK_CRF_WBIAS, TK_CRF_HELPER, TK_CRF_BAND_R ...) and lab builds (TAIYAKI_AMD_LIB).
+switches (TK_CRF_BK, TK_CRF_WBIAS, TK_CRF_FEED, TK_CRF_BAND_R ...) and lab builds (TAIYAKI_AMD_LIB).
 
     python tools/crfops.py [--rowk] [--catmod] [--cfg5]"""
 import argparse
@@ -20,6 +20,7 @@ def main():
     ap.add_argument("--catmod", action="store_true")
     ap.add_argument("--cfg5", action="store_true")
     ap.add_argument("--reps", type=int, default=20)
+    ap.add_argument("--shapes", default="", help="extra shapes name:T:N:chunk_len[:spb], comma separated (chunk_len 0 = SPEED_TEST lengths)")
     args = ap.parse_args()
     dev = torch.device("cuda:0")
     _lib.lib()
@@ -31,6 +32,9 @@ def main():
         shapes.append(("cfg5", 1600, 64, 8000, 9.5, False))
     if args.rowk:
         shapes.append(("rowK", 4000, 256, None, 9.0, False))
+    for item in [x for x in args.shapes.split(",") if x]:
+        f = item.split(":")
+        shapes.append((f[0], int(f[1]), int(f[2]), int(f[3]) or None, float(f[4]) if len(f) > 4 else 9.0, False))
     out = []
     for name, T, N, cl, spb, cm in shapes:
         ops = bench.LossOps(T, N, dev, realistic_chunk_len=cl, spb=spb, cat_mod=cm)
@@ -38,7 +42,7 @@ def main():
         crf, crf_min = bench._events_mean_min(ops.crf, reps, warm=5)
         both, _ = bench._events_mean_min(ops.both, reps, warm=5)
         assert ops.finite()
-        out.append("%s: crf %.1f us (min %.1f)  fused loss %.1f us" % (name, crf * 1e6, crf_min * 1e6, both * 1e6))
+        out.append("%s[L<=%d]: crf %.1f us (min %.1f)  fused loss %.1f us" % (name, ops.maxlen, crf * 1e6, crf_min * 1e6, both * 1e6))
     print("  ".join(out), flush=True)
 
 

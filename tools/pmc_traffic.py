@@ -100,16 +100,16 @@ def band_bytes(T, N, real, R_hint=None, cat_mod=False):
     """Analytic size of what kernel A's sweeps leave for the gradient pass, per sweep: one checkpoint
     column (4 B mantissa + 2 B frame offset per cell) per live (chunk, block) pair, plus one boundary cell
     per step, 64 cells and block.  Block length as crf_band_pick_block chooses it at sharpening factor 1:
-    12 steps for the plain CRF (8 at two cells per lane), 8 for cat-mod."""
+    12 steps for the plain CRF, 8 for cat-mod."""
     import numpy as np
     from taiyaki_amd import synth
     seqlens = synth.realistic_seqlens(T, N, 17001, real, 9.0) if real else synth.speedtest_seqlens(T, N)
     maxL = int(seqlens.max())
     R = 1
-    while R < 4 and R * 64 * 16 < maxL:
+    while R < 4 and R * 64 * 15 < maxL:
         R *= 2
     PW = 64 * R
-    KB = 8 if (cat_mod or R == 2) else 12
+    KB = 8 if cat_mod else 12
     total = 0
     for L in seqlens:
         L = int(L)

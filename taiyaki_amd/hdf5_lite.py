@@ -275,10 +275,25 @@ class File(Group):
         if filt_len:
             raise Hdf5Error("filtered fractal heaps are not supported")
         q = p + 10 + 4                                  # max size of managed objects
-        q += 8 + 8 + 8 + 8                              # next huge id, huge B-tree, free space, free-space manager
-        q += 8 + 8 + 8                                  # managed space, allocated space, allocation iterator
+        # next huge id, huge B-tree, free space in managed blocks, free-space manager
+        free_space = self._len(b, q + 16)
+        q += 8 + 8 + 8 + 8
+        allocated = self._len(b, q + 8)                 # managed space, ALLOCATED managed space, allocation iterator
+        q += 8 + 8 + 8
         nobj = self._len(b, q)
-        q += 8 + 8 + 8 + 8 + 8                          # (+ huge size / count, tiny size / count)
+        nhuge, ntiny = self._len(b, q + 16), self._len(b, q + 32)      # (managed count, huge size / COUNT, tiny size / COUNT)
+        q += 8 + 8 + 8 + 8 + 8
+        # This walk reads managed objects back to back in every direct block -- what a write-once file looks
+        # like (h5py / the reference's mapped-signal writer create links and attributes and never delete
+        # them).  A heap that has seen deletions (holes, stale bytes of deleted objects) or that holds huge /
+        # tiny objects needs the heap's B-tree index to be read correctly: say so instead of mis-parsing.
+        # Deletions show in the heap's own accounting: the bytes of the objects found must be what the header
+        # calls allocated minus free minus the blocks' headers (checked after the walk).
+        if nhuge or ntiny:
+            raise Hdf5Error("fractal heap with %d huge and %d tiny objects: not supported by hdf5_lite -- rewrite the "
+                            "file with h5repack (or read it with h5py and save it with "
+                            "tools/mapped_signal_to_npz.py)" % (nhuge, ntiny))
+        used = [0, 0]                                   # [object bytes parsed, direct-block header bytes]
         width, = struct.unpack_from("<H", b, q)
         start = self._len(b, q + 2)
         maxdirect = self._len(b, q + 10)
@@ -302,9 +317,12 @@ class File(Group):
             if bytes(b[s:s + 4]) != b"FHDB":
                 raise Hdf5Error("fractal heap direct block signature")
             o = s + 5 + 8 + offbytes + (4 if checksummed else 0)
+            used[1] += o - s
             end = s + size
             while len(out) < nobj and o < end and b[o] != 0:
-                val, o = parse(b, o)
+                val, nxt = parse(b, o)
+                used[0] += nxt - o
+                o = nxt
                 out.append(val)
 
         def indirect(a, nrows):
@@ -328,8 +346,11 @@ class File(Group):
                 direct(root, start)
             else:
                 indirect(root, cur_rows)
-        if len(out) != nobj:
-            raise Hdf5Error("fractal heap: %d managed objects found, %d announced" % (len(out), nobj))
+        if len(out) != nobj or (allocated and used[0] != allocated - free_space - used[1]):
+            raise Hdf5Error("fractal heap: %d managed objects / %d bytes found, the header announces %d objects / %d "
+                            "bytes -- links or attributes were deleted from this file (or it is damaged): not "
+                            "supported by hdf5_lite; rewrite it with h5repack or convert it with "
+                            "tools/mapped_signal_to_npz.py" % (len(out), used[0], nobj, allocated - free_space - used[1]))
         return out
 
     def _object_header_v2(self, p):
@@ -508,6 +529,12 @@ class File(Group):
         """(None, next offset) of the attribute message at d[o:] -- the self-delimiting parse the fractal
         heap walk needs."""
         ver = d[o]
+        if ver in (2, 3) and d[o + 1] & 3:
+            # flags bit 0 / 1: the datatype / dataspace is a SHARED (committed) message -- the attribute then
+            # holds a reference, not the description this parser steps over
+            raise Hdf5Error("attribute with a shared (committed) datatype or dataspace: not supported by "
+                            "hdf5_lite -- rewrite the file with h5repack or convert it with "
+                            "tools/mapped_signal_to_npz.py")
         nsz, tsz, ssz = struct.unpack_from("<HHH", d, o + 2)
         q = o + 8 + (1 if ver == 3 else 0)
         pad = (lambda n: (n + 7) // 8 * 8) if ver == 1 else (lambda n: n)
@@ -537,6 +564,10 @@ class File(Group):
         out = {}
         for d in bodies:
             ver = d[0]
+            if ver in (2, 3) and d[1] & 3:
+                raise Hdf5Error("attribute with a shared (committed) datatype or dataspace: not supported by "
+                                "hdf5_lite -- rewrite the file with h5repack or convert it with "
+                                "tools/mapped_signal_to_npz.py")
             nsz, tsz, ssz = struct.unpack_from("<HHH", d, 2)
             o = 8 + (1 if ver == 3 else 0)
             pad = (lambda n: (n + 7) // 8 * 8) if ver == 1 else (lambda n: n)

@@ -277,3 +277,31 @@ def test_every_hdf5_file_of_the_reference_test_data_parses():
             assert np.array_equal(raw["Signal"].read(), singles[rid])
             seen += 1
     assert seen == 5
+
+
+def test_a_fractal_heap_that_saw_deletions_or_special_objects_is_refused_by_name(tmp_path):
+    """The dense-group / dense-attribute walk reads a heap's managed objects back to back, which is what
+    a write-once file looks like.  A heap whose own accounting does not add up to what the walk found
+    (objects were deleted: holes, stale bytes), or that holds huge / tiny objects, must be refused with an
+    error that says so and names the way out -- not mis-parsed.  Simulated on copies of the libhdf5-written
+    1.8 fixture by editing the heap header's counters."""
+    import struct
+    src = open(os.path.join(HERE, "generated_v108.hdf5"), "rb").read()
+    at = src.index(b"FRHP")
+    # FRHP: sig 4, version 1, id length 2, filter length 2, flags 1, max managed size 4, then 8-byte fields:
+    # next huge id, huge B-tree, FREE SPACE, free-space manager, managed, allocated, iterator, NOBJ,
+    # huge size, HUGE COUNT, tiny size, TINY COUNT
+    f0 = at + 14
+    for what, off, match in (("free space", f0 + 16, "deleted"), ("huge count", f0 + 72, "huge"),
+                             ("tiny count", f0 + 88, "tiny")):
+        buf = bytearray(src)
+        old, = struct.unpack_from("<Q", buf, off)
+        struct.pack_into("<Q", buf, off, old + 3)
+        path = tmp_path / ("tampered_%s.hdf5" % what.replace(" ", "_"))
+        path.write_bytes(bytes(buf))
+        with pytest.raises(hdf5_lite.Hdf5Error, match=match):
+            f = hdf5_lite.File(str(path))
+            hdf5_lite.read_mapped_signal_file(str(path))
+            del f
+    # the untouched file still reads
+    assert hdf5_lite.read_mapped_signal_file(os.path.join(HERE, "generated_v108.hdf5"))[1]

@@ -773,7 +773,7 @@ __global__ __launch_bounds__(K2_WAVES *WAVE, 8) void logz_middle_kernel(int N, i
     // LDS stride of one matrix image: the NW payload words, not the NF4 padded float4s -- at
     // 250 chunks that is what lets TWO blocks share a CU's 160 KB (2 x 80 KB), so one
     // read's serial scan overlaps another's work-bound combine (<= 64 VGPRs for the same)
-    constexpr int NFW = X::NW + (X::NW & 1), NT = K2_WAVES * WAVE;
+    constexpr int NFW = X::NW + (X::NW & 1);
     extern __shared__ __attribute__((aligned(16))) char smem[];
     float *pcimg = reinterpret_cast<float *>(smem);             // [C][NFW]
     float *totimg = pcimg + (size_t)C * NFW;                    // [NSUP][NFW]
@@ -788,37 +788,39 @@ __global__ __launch_bounds__(K2_WAVES *WAVE, 8) void logz_middle_kernel(int N, i
 #define TK_STAMP(k) do { if (blockIdx.x == 100 && threadIdx.x == 0) tk_dbg[k] = clock64(); } while (0)
 #endif
     TK_STAMP(0);
-    // ---- 1. stage the read's chunk matrices: one contiguous run of C*NF4 float4
-    {
-        // every load of a pass is in flight before the first LDS store: one memory latency
-        // per 4 K float4.  The image is repacked from 4 NF4 to NFW words per matrix (8-byte
-        // aligned: two 64-bit LDS stores per float4, the padding words are dropped).
-        constexpr int PASS = 4;
-        const int total = C * X::NF4;
-        const f4 *src = ws.Pc + n * (size_t)total;
-        for (int base = 0; base < total; base += PASS * NT) {
-            f4 tmp[PASS];
+    // ---- 1. stage the read's chunk matrices, SUPER BY SUPER: wave s % K2_WAVES loads the SUP matrices of
+    //         super s (one contiguous run of <= SUP NF4 float4) and goes straight on to combine them -- nothing
+    //         but this wave reads them before the barrier in front of the scan, so there is no workgroup-wide
+    //         wait between the loads and the first products (round 4; before, all 16 waves staged the whole
+    //         image together and met at a barrier: 7200 of the kernel's 25800 cycles at T = 4000).
+    //         The image is repacked from 4 NF4 to NFW words per matrix (8-byte aligned: two 64-bit LDS stores
+    //         per float4, the padding words are dropped).
+    auto stage_super = [&](int s) {
+        constexpr int PASS = (SUP * X::NF4 + WAVE - 1) / WAVE;     // float4 per lane: every load in flight at once
+        const int c0 = s * SUP, cnt = min(C - c0, SUP), nf = cnt * X::NF4;
+        const f4 *src = ws.Pc + (n * (size_t)C + c0) * X::NF4;
+        f4 tmp[PASS];
 #pragma unroll
-            for (int k = 0; k < PASS; ++k) tmp[k] = src[min(base + k * NT + tid, total - 1)];
+        for (int k = 0; k < PASS; ++k) tmp[k] = src[min(k * WAVE + lane, nf - 1)];
 #pragma unroll
-            for (int k = 0; k < PASS; ++k) {
-                const int idx = base + k * NT + tid;
-                if (idx < total) {
-                    const int c = idx / X::NF4, q = idx - c * X::NF4;
-                    float *dst = pcimg + (size_t)c * NFW + 4 * q;
-                    *reinterpret_cast<f2 *>(dst) = f2{tmp[k][0], tmp[k][1]};
-                    if (4 * q + 2 < NFW) *reinterpret_cast<f2 *>(dst + 2) = f2{tmp[k][2], tmp[k][3]};
-                }
+        for (int k = 0; k < PASS; ++k) {
+            const int idx = k * WAVE + lane;
+            if (idx < nf) {
+                const int c = idx / X::NF4, q = idx - c * X::NF4;
+                float *dst = pcimg + (size_t)(c0 + c) * NFW + 4 * q;
+                *reinterpret_cast<f2 *>(dst) = f2{tmp[k][0], tmp[k][1]};
+                if (4 * q + 2 < NFW) *reinterpret_cast<f2 *>(dst + 2) = f2{tmp[k][2], tmp[k][3]};
             }
         }
-    }
-    __syncthreads();
+        wave_lds_fence();       // (this wave's stores before this wave's reads; other waves wait for the barrier below)
+    };
     TK_STAMP(1);
 
     // ---- 2. combine: group `grp` of the wave carries row `grp` of the super's product.
     //         Fully unrolled over the super's chunks: LDS offsets are immediates, the
     //         shares ping-pong between two register sets one matrix ahead.
     for (int s = wave; s < NSUP; s += K2_WAVES) {
+        stage_super(s);
         const int c0 = s * SUP, cnt = min(C - c0, SUP);
         const float *img0 = pcimg + (size_t)c0 * NFW;
         // row `grp` of the first matrix IS the running product after one chunk

@@ -92,9 +92,28 @@ def main():
         print("maxs a", tr_a.clipper.last_maxs[:6], "b", tr_b.clipper.last_maxs[:6])
         print("iters", tr_a.clipper.rolling._curr_iter, tr_b.clipper.rolling._curr_iter)
     pw = max(float((pa - pb).abs().max()) for pa, pb in zip(net_a.parameters(), net_b.parameters()))
+    lr_note = ""
+    if not whole:
+        # the replayed AdamW reads its learning rate from a device scalar: a schedule's new value (the
+        # reference steps one every iteration, bin/train_flipflop.py:605-607) must reach the NEXT replay --
+        # the same step taken by the eager trainer with its param group's lr set the usual way
+        for g in tr_a.opt.param_groups:
+            g["lr"] = 1e-3
+        hy.set_lr(1e-3)
+        la2, lb2 = float(tr_a.step(batches[1])), float(hy.step(batches[1]))
+        torch.cuda.synchronize()
+        pw2 = max(float((pa - pb).abs().max()) for pa, pb in zip(net_a.parameters(), net_b.parameters()))
+        # ... and a rate of 0 freezes the weights (weight decay is lr * wd)
+        before = [p.detach().clone() for p in net_b.parameters()]
+        hy.set_lr(0.0)
+        hy.step(batches[2])
+        torch.cuda.synchronize()
+        frozen = max(float((p - q).abs().max()) for p, q in zip(net_b.parameters(), before))
+        lr_note = " lr_step_param_abs=%.3e lr0_moved=%.3e" % (pw2, frozen)
+        assert abs(la2 - lb2) <= 1e-4 * abs(la2) and pw2 < 1e-4 and frozen == 0.0, lr_note
     if whole and mads is not None:
         assert tr_b.clipper.active, "the captured step never received clipping thresholds"
-    print("hybrid-ok loss_rel=%.3e param_abs=%.3e losses=%s" % (worst, pw, ["%.5f" % x for x in la]))
+    print("hybrid-ok loss_rel=%.3e param_abs=%.3e%s losses=%s" % (worst, pw, lr_note, ["%.5f" % x for x in la]))
 
 
 if __name__ == "__main__":

@@ -9,24 +9,17 @@
 // re-associate the fp32 adds and break bit-exactness) and has 2 nbase <= 8 states: it is a
 // pure latency problem, so the design minimises the DEPENDENT instructions of a step.
 //
-// ONE WAVEFRONT PER READ, 64 lanes = the 8 x 8 (to, from) pairs: every candidate
-// f[from] + s[to, from] of a step is one lane's single v_add_f32.  The lane LAYOUT ALTERNATES
-// between steps (round 4), so that the new state vector never has to be moved:
-//   * even steps, lane = (to, from) = (lane / 8, lane % 8): the maximum over `from` is three DPP
-//     steps inside the 8-lane group (quad_perm x 2, row_half_mirror); afterwards every lane of
-//     group g holds the new f[g];
-//   * odd steps, lane = (from, to) = (lane / 8, lane % 8): the lane needs f[from] = f[its group],
-//     which it HOLDS; the maximum over `from` now runs across the groups -- one DPP row_ror:8 and
-//     the two gfx950 lane-swap instructions (v_permlane16_swap, v_permlane32_swap: rows, then
-//     halves) -- and leaves the new f[lane % 8] in every lane: what the next even step's lane
-//     (to, from = lane % 8) needs.
-//   Round 2-3 kept one layout and sent the vector back through ONE ds_bpermute per step: an LDS
-//   round trip (~100 cycles) on a chain whose other instructions take ~60.
-//   * off the chain: "first index wins" = the lowest set bit among the ballot bits (candidate ==
-//     maximum) of the state's eight candidates -- a byte of the ballot in the even layout, every
-//     eighth bit in the odd one; that index is the traceback byte.
-// max is exact and the candidates are single fp32 adds, so forward scores, traceback and paths
-// stay bit-identical to the reference's.  Invalid sources of a flop state are masked in the SCORE
+// ONE WAVEFRONT PER READ, lane = (to, from) = (lane / 8, lane % 8): every candidate
+// f[from] + s[to, from] of a step is one lane's single v_add_f32.  Then
+//   * the maximum over `from` is three DPP steps inside the 8-lane group (quad_perm x 2,
+//     row_half_mirror), result in all eight lanes;
+//   * the new state vector is transposed back (lane (to, from) needs f[from], which group
+//     `from` now holds) by ONE ds_bpermute with a constant address;
+//   * off the chain: "first index wins" = the lowest set bit of the group's byte of the ballot
+//     (candidate == maximum); that index is the traceback byte.
+// A step is add -> 3 x v_max_f32_dpp -> ds_bpermute: ~60 ns, against ~270 ns for the
+// round-1 layout (8 lanes per read, every lane scanning eight candidates: ~80 instructions
+// per step on the chain's wave).  Invalid sources of a flop state are masked in the SCORE
 // (-inf), one step ahead of its use; rows are requested VIT_PF steps ahead.
 // The path pass decodes 64 steps per batch: every lane fetches the 8-byte traceback word of
 // one step (next batch in flight while this one is decoded).  A word IS the table state ->
@@ -56,24 +49,6 @@ __device__ __forceinline__ float vit_grp_max(float x) {
     return r;
 }
 
-// maximum over the eight lanes that share lane % 8 (one per 8-lane group), in all of them: within a
-// 16-lane row by DPP, across the rows and halves by the lane-swap instructions of gfx950
-__device__ __forceinline__ float vit_cross_max(float x) {
-    float r;
-    asm("s_nop 1\n\t"
-        "v_max_f32_dpp %0, %1, %1 row_ror:8 row_mask:0xf bank_mask:0xf"
-        : "=&v"(r) : "v"(x));
-    {
-        const auto sw = __builtin_amdgcn_permlane16_swap(__float_as_uint(r), __float_as_uint(r), false, false);
-        asm("v_max_f32 %0, %1, %2" : "=v"(r) : "v"(__uint_as_float(sw[0])), "v"(__uint_as_float(sw[1])));
-    }
-    {
-        const auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(r), __float_as_uint(r), false, false);
-        asm("v_max_f32 %0, %1, %2" : "=v"(r) : "v"(__uint_as_float(sw[0])), "v"(__uint_as_float(sw[1])));
-    }
-    return r;
-}
-
 template <int NB, bool FULLOUT>
 __global__ __launch_bounds__(WAVE) void viterbi_kernel(const float *__restrict__ scores, int T,
                                                       int N, float *__restrict__ fwd_out,
@@ -83,31 +58,26 @@ __global__ __launch_bounds__(WAVE) void viterbi_kernel(const float *__restrict__
     using F = FF<NB>;
     static_assert(F::NS <= VIT_GRP, "one lane group per state");
     const int lane = lane_id();
-    const int grp = lane >> 3, sub = lane & 7;          // even steps: (to, from) = (grp, sub); odd steps: (sub, grp)
+    const int to = lane >> 3, from = lane & 7;
     const int n = blockIdx.x;
     // decode.py:99-105: a flip state is reached from every state, flop b only from flip b and
     // from itself
-    auto valid_of = [&](int to, int from) {
-        return to < F::NS && from < F::NS && (to < NB || from == to - NB || from == to);
-    };
-    auto sidx_of = [&](int to, int from) {
-        return (to < NB) ? to * F::NS + min(from, F::NS - 1) : F::FLOP0 + min(from, F::NS - 1);
-    };
-    const bool validA = valid_of(grp, sub), validB = valid_of(sub, grp);
-    const bool leader = sub == 0 && grp < F::NS;
+    const bool flip = to < NB;
+    const bool valid = to < F::NS && from < F::NS && (flip || from == to - NB || from == to);
+    const int sidx = flip ? to * F::NS + min(from, F::NS - 1) : F::FLOP0 + min(from, F::NS - 1);
+    const bool leader = from == 0 && to < F::NS;
     const size_t rowstride = (size_t)N * F::S;
+    const int tr4 = 4 * ((from << 3) | to);                     // transpose: the lane of group `from`
 
-    float f = (sub < NB) ? 0.f : ((sub < F::NS) ? NEG_LARGE : VIT_NEG_INF);        // decode.py:93-95 (step 0 is even: from = sub)
-    if (FULLOUT && leader) fwd_out[(size_t)n * F::NS + grp] = (grp < NB) ? 0.f : NEG_LARGE;
+    float f = (from < NB) ? 0.f : ((from < F::NS) ? NEG_LARGE : VIT_NEG_INF);      // decode.py:93-95
+    if (FULLOUT && leader) fwd_out[(size_t)n * F::NS + to] = (to < NB) ? 0.f : NEG_LARGE;
 
     // Memory goes through buffer instructions: a descriptor per group of VIT_PF steps (scalar
     // ALU), a constant per-lane offset, a scalar per-step offset -- no vector address arithmetic
     // among the ~15 instructions of a step.
     constexpr int RSRC3 = 0x00027000;
     const unsigned rs4 = 4u * (unsigned)rowstride;
-    static_assert(VIT_PF % 2 == 0, "a group of steps starts with an even one");
-    const unsigned ld4A = 4u * (unsigned)((size_t)n * F::S + min(sidx_of(grp, sub), F::S - 1));
-    const unsigned ld4B = 4u * (unsigned)((size_t)n * F::S + min(sidx_of(sub, grp), F::S - 1));
+    const unsigned lane_ld4 = 4u * (unsigned)((size_t)n * F::S + min(sidx, F::S - 1));
     float sc[VIT_PF];
     auto fetch_group = [&](int t0, int k0, int k1) {            // rows t0 + k0 .. t0 + k1 - 1 -> sc[k]
         const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(
@@ -116,19 +86,17 @@ __global__ __launch_bounds__(WAVE) void viterbi_kernel(const float *__restrict__
 #pragma unroll
         for (int k = 0; k < VIT_PF; ++k)
             if (k >= k0 && k < k1)
-                sc[k] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rs, (k & 1) ? ld4B : ld4A, rs4 * (unsigned)min(k, last), 0));
+                sc[k] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rs, lane_ld4, rs4 * (unsigned)min(k, last), 0));
     };
     fetch_group(0, 0, VIT_PF);
 
     const size_t pstride = (size_t)npad * VIT_GRP;               // traceback bytes [t][npad][8]
-    // what a lane stores belongs to state `grp` after an even step and to state `sub` after an odd one
-    const unsigned lane_tbA = (unsigned)((size_t)n * VIT_GRP + grp), lane_tbB = (unsigned)((size_t)n * VIT_GRP + sub);
-    const unsigned lane_o4A = 4u * (unsigned)((size_t)n * F::NS + min(grp, F::NS - 1));
-    const unsigned lane_o4B = 4u * (unsigned)((size_t)n * F::NS + min(sub, F::NS - 1));
+    const unsigned lane_tb = (unsigned)((size_t)n * VIT_GRP + to);
+    const unsigned lane_o4 = 4u * (unsigned)((size_t)n * F::NS + min(to, F::NS - 1));
     const size_t ostride = (size_t)N * F::NS;
 
     float m = VIT_NEG_INF;
-    float snext = validA ? sc[0] : VIT_NEG_INF;
+    float snext = valid ? sc[0] : VIT_NEG_INF;
     // every lane of a group holds the group's result: all eight store it (same byte, same address)
     // instead of one leader lane behind an exec-mask branch; only alphabets with dead groups
     // (2 nbase < 8) need the mask
@@ -146,39 +114,31 @@ __global__ __launch_bounds__(WAVE) void viterbi_kernel(const float *__restrict__
             packed + (size_t)t0 * pstride, 0, 0x7fffffff, RSRC3);
         const __amdgpu_buffer_rsrc_t rfo = __builtin_amdgcn_make_buffer_rsrc(
             FULLOUT ? fwd_out + (size_t)(t0 + 1) * ostride : nullptr, 0, 0x7fffffff, RSRC3);
-        int64_t *toutA = FULLOUT ? tb_out + (size_t)t0 * ostride + (size_t)n * F::NS + min(grp, F::NS - 1) : nullptr;
-        int64_t *toutB = FULLOUT ? tb_out + (size_t)t0 * ostride + (size_t)n * F::NS + min(sub, F::NS - 1) : nullptr;
+        int64_t *tout = FULLOUT ? tb_out + (size_t)t0 * ostride + (size_t)n * F::NS + min(to, F::NS - 1) : nullptr;
 #pragma unroll
         for (int k = 0; k < VIT_PF; ++k) {
             if (FULL || t0 + k < T) {
-                const bool odd = (k & 1) != 0;                  // (compile time: the loop is unrolled, t0 is even)
                 const float cand = f + snext;
-                m = odd ? vit_cross_max(cand) : vit_grp_max(cand);
-                f = m;                                          // the next step's lane holds what it needs
+                m = vit_grp_max(cand);
+                f = __int_as_float(__builtin_amdgcn_ds_bpermute(tr4, __float_as_int(m)));
                 // ---- off the chain
                 sc[k] = __uint_as_float(
-                    __builtin_amdgcn_raw_buffer_load_b32(rnext, odd ? ld4B : ld4A, rs4 * (unsigned)min(k, lastn), 0));
+                    __builtin_amdgcn_raw_buffer_load_b32(rnext, lane_ld4, rs4 * (unsigned)min(k, lastn), 0));
                 // the next step's scores, masked one step ahead of their use (requested VIT_PF - 1
                 // steps ago; at the last step of a group: row 0 of the next, requested at step 0)
-                snext = (odd ? validA : validB) ? sc[(k + 1) % VIT_PF] : VIT_NEG_INF;
-                // "first index wins": the lowest set bit among the ballot bits (candidate == maximum)
-                // of the state's eight candidates is the traceback byte
+                snext = valid ? sc[(k + 1) % VIT_PF] : VIT_NEG_INF;
+                // "first index wins": the lowest set bit of the group's byte of the ballot
+                // (candidate == maximum) is the traceback byte
                 const unsigned long long eq = __ballot(cand == m);
-                unsigned arg;
-                if (!odd) {
-                    const unsigned bits = (unsigned)(eq >> (8 * grp));
-                    arg = (unsigned)__builtin_ctz((bits & 0xffu) | 0x100u) & 7u;
-                } else {
-                    const unsigned long long bits = (eq >> sub) & 0x0101010101010101ull;
-                    arg = ((unsigned)__builtin_ctzll(bits | (1ull << 63)) >> 3) & 7u;
-                }
-                if (ALL_GROUPS_LIVE || (odd ? sub : grp) < F::NS) {
-                    __builtin_amdgcn_raw_buffer_store_b8((unsigned char)arg, rtb, odd ? lane_tbB : lane_tbA,
+                const unsigned bits = (unsigned)(eq >> (8 * to));
+                const unsigned arg = (unsigned)__builtin_ctz((bits & 0xffu) | 0x100u) & 7u;
+                if (ALL_GROUPS_LIVE || to < F::NS) {
+                    __builtin_amdgcn_raw_buffer_store_b8((unsigned char)arg, rtb, lane_tb,
                                                          (unsigned)(k * pstride), 0);
                     if (FULLOUT) {
-                        __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(m), rfo, odd ? lane_o4B : lane_o4A,
+                        __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(m), rfo, lane_o4,
                                                               4u * (unsigned)(k * ostride), 0);
-                        (odd ? toutB : toutA)[(size_t)k * ostride] = (int64_t)arg;
+                        tout[(size_t)k * ostride] = (int64_t)arg;
                     }
                 }
             }
@@ -194,13 +154,11 @@ __global__ __launch_bounds__(WAVE) void viterbi_kernel(const float *__restrict__
     // ---- traceback (decode.py:108-113); argmax = first maximal state
     unsigned st = 0;
     {
-        // the last step's layout: even (T odd) -> state s in group s; odd -> state s in lane s of every group
-        const int per_state = (T & 1) ? VIT_GRP : 1;
-        float top = __shfl(m, 0, WAVE);
+        float top = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(m), 0));
         if (T == 0) top = 0.f;
 #pragma unroll
         for (int s = 1; s < F::NS; ++s) {
-            float v = __shfl(m, s * per_state, WAVE);
+            float v = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(m), s * VIT_GRP));
             if (T == 0) v = (s < NB) ? 0.f : NEG_LARGE;
             if (v > top) {
                 top = v;

@@ -641,14 +641,28 @@ def kernel_records(out, args, cfg, dev, world, T, nbatch, chunk_len, cat_mod, S)
     else:
         out["roofline"] = logz_roofline(step_ops, 30, "the train step's own launch")
     # ---- the whole loss path in one unit ------------------------------------------------
+    # one queue: what the captured train step replays (a capturing stream never forks); two queues: what an eager
+    # caller of the operator gets by default (kernel B beside kernel A's sweeps, tk_flipflop_loss_overlap)
+    from taiyaki_amd import _lib
+    L = _lib.lib()
+    prev = L.tk_flipflop_loss_overlap(0)
     lp_mean, _ = _events_mean_min(step_ops.both, 20, warm=5)
+    L.tk_flipflop_loss_overlap(1)
+    lp2_mean, _ = _events_mean_min(step_ops.both, 20, warm=5)
+    L.tk_flipflop_loss_overlap(prev)
     assert step_ops.finite()
     out["loss_path"] = dict(unit="chunks/s through crf grad + logZ fwd-bwd at the step's shape (T=%d, N=%d, "
                                  "S=%d, realistic lengths)" % (T, nbatch, S),
                             launch=("tk_flipflop_loss_fused_dev, cat-mod form: logZ of the canonical columns first, "
                                     "folded into the cat-mod kernel's writes; one gradient tensor" if cat_mod else
                                     "tk_flipflop_loss_fused_dev: one gradient tensor"),
-                            gpu_ms=round(lp_mean * 1e3, 4), gpu_chunks_per_s=round(nbatch / lp_mean, 1))
+                            gpu_ms=round(lp_mean * 1e3, 4), gpu_chunks_per_s=round(nbatch / lp_mean, 1),
+                            form="one queue (A, then B adds in place): the form the captured train step replays",
+                            eager_two_queue_ms=round(lp2_mean * 1e3, 4),
+                            eager_two_queue_chunks_per_s=round(nbatch / lp2_mean, 1),
+                            eager_two_queue_note="the operator's default outside a graph capture: kernel B on a second "
+                                                 "hardware queue beside kernel A's sweeps, folded into A's gradient pass "
+                                                 "(a captured fork / join replays 150 us slower: profiles/r4_overlap_capture_probe.txt)")
     if not no_cpu:
         cb = cpu_baseline(step_ops.host)
         out["cpu_baseline"] = cb

@@ -156,10 +156,15 @@ int tk_crf_flipflop_dev(const float *logprob, size_t ntrans, size_t nblk,
  * 165-176): kernel B runs FIRST on a compact copy of the canonical columns (`aux`,
  * tk_flipflop_loss_fused_aux_bytes), kernel A folds logZ / nblk and its gradient
  * into what it writes.  Plain CRF: modidx = modfact = NULL, ntrans = 2 nbase
- * (nbase + 1), aux may be NULL.  (Lab: with TK_LOSS_OVERLAP=1 in the environment the aux size function
- * also returns bytes for the plain CRF, and kernel B then runs on a second hardware queue beside kernel A's
- * sweeps -- measured, not the default, refused while `stream` is capturing: LABNOTES.md, section 7.)
+ * (nbase + 1), aux may be NULL (the one-queue form: A, then B adds in place).
+ * TWO QUEUES: when `aux` has tk_flipflop_loss_fused_aux_bytes() bytes (non-zero for the plain CRF too unless
+ * the overlap is off) and `stream` is not capturing, kernel B runs on a second hardware queue of the device
+ * beside kernel A's sweeps -- forked from and joined to `stream`, so the call's ordering on `stream` is what
+ * it is without -- and A's gradient pass folds B's results in.  A capturing `stream` gets the one-queue form.
+ * tk_flipflop_loss_overlap(mode): 0 off, 1 on outside captures (default; environment TK_LOSS_OVERLAP=0|1|2
+ * sets the initial mode), 2 lab (also inside captures); returns the previous mode, any other `mode` only queries.
  * ------------------------------------------------------------------------- */
+int tk_flipflop_loss_overlap(int mode);
 size_t tk_flipflop_loss_fused_aux_bytes(size_t nblk, size_t nbatch, size_t nbase, size_t ntrans);
 int tk_flipflop_loss_fused_dev(const float *scores, size_t nblk, size_t nbatch, size_t nbase, size_t ntrans,
                                const int32_t *stayidx, const int32_t *moveidx,

@@ -143,6 +143,35 @@ def _seq_call(libobj, prefix, logprob, move, stay, seqlen, modmove=None,
     return -costs / nblk, None                  # ctc.pyx:66
 
 
+def _empty_reads_apart(fn):
+    """An EMPTY read that is not the batch's last shifts the move indices of every read after it by one in the
+    reference: ctc.pyx:127-129 emits no move for it while c_crf_flipflop.c:479 (`moveidxs + seqidx[batch] -
+    batch`) counts seqlen - 1 = -1 -- later reads are scored with a neighbour's transition, which nobody means
+    (its data pipeline never emits such a batch).  The restated C keeps that pointer arithmetic; this wrapper
+    keeps such batches well-defined: the live reads are evaluated as a batch of their own (each with its own
+    indices, the reference's result for every read of a batch without empty reads), the empty ones get the
+    reference's cost 0 / zero gradient rows (c_crf_flipflop.c:458-464).  DESIGN.md lists it as a deviation."""
+    import functools
+
+    @functools.wraps(fn)
+    def wrapped(logprob, seqs, seqlen, *args, **kw):
+        sl = np.asarray(seqlen)
+        live = sl > 0
+        if live.all() or not live.any() or not live[np.argmin(live):].any():
+            return fn(logprob, seqs, seqlen, *args, **kw)       # (no empty read, or only trailing ones)
+        logprob = np.asarray(logprob)
+        cost, grads = fn(np.ascontiguousarray(logprob[:, live, :]), seqs, np.ascontiguousarray(sl[live]), *args, **kw)
+        full_cost = np.zeros(len(sl), dtype=cost.dtype)
+        full_cost[live] = cost
+        full_grads = None
+        if grads is not None:
+            full_grads = np.zeros(logprob.shape, dtype=grads.dtype)
+            full_grads[:, live, :] = grads
+        return full_cost, full_grads
+    return wrapped
+
+
+@_empty_reads_apart
 def crf_flipflop_loss(logprob, seqs, seqlen, sharpfact=1.0, want_grad=True,
                       use_ref=False):
     """FlipFlopCRF.forward semantics (ctc.pyx:116-151) on numpy arrays.
@@ -161,6 +190,7 @@ def crf_flipflop_loss(logprob, seqs, seqlen, sharpfact=1.0, want_grad=True,
     return (cost / np.float32(sharpfact)).astype(np.float32), grads
 
 
+@_empty_reads_apart
 def crf_flipflop_loss_f64(logprob, seqs, seqlen, sharpfact=1.0, mod_cats=None, can_mods_offsets=None,
                           mod_cat_weights=None):
     """The FLOAT64 WITNESS (flipflop_oracle.c: oracle_seq_grad_f64) behind the same operator
@@ -220,6 +250,7 @@ def cat_mod_indices(seqs, seqlen, mod_cats, can_mods_offsets, mod_cat_weights,
     return modmoveidxs, modmovefacts
 
 
+@_empty_reads_apart
 def cat_mod_flipflop_loss(logprob, seqs, seqlen, mod_cats, can_mods_offsets,
                           mod_cat_weights, sharpfact=1.0, want_grad=True,
                           use_ref=False):

@@ -31,6 +31,7 @@ SIGNATURES = {
     "tk_crf_flipflop_dev": (_i, [_vp, _sz, _sz, _sz, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _sz,
                                  _f, _f, _f, _vp, _vp, _vp, _sz, _vp, _vp, _vp]),
     "tk_flipflop_loss_fused_aux_bytes": (_sz, [_sz, _sz, _sz, _sz]),
+    "tk_flipflop_loss_overlap": (ctypes.c_int, [ctypes.c_int]),
     "tk_flipflop_loss_fused_dev": (_i, [_vp, _sz, _sz, _sz, _sz, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _f, _f, _vp, _vp,
                                        _vp, _vp, _vp, _sz, _vp, _sz, _vp, _sz, _vp, _vp, _vp]),
     "tk_flipflop_lattice_dev": (_i, [_vp, _sz, _sz, _sz, _i, _vp, _vp, _vp, _vp]),

@@ -5,6 +5,8 @@
 #include <stdlib.h>
 #include <string.h>
 
+#include <atomic>
+#include <mutex>
 #include <vector>
 
 #include "../../include/taiyaki_amd_flipflop.h"
@@ -219,26 +221,38 @@ __global__ void slice_cols_kernel(const float *__restrict__ src, float *__restri
     dst[i] = src[r * (size_t)S + (i - r * (size_t)S0)];
 }
 
-// Kernel B beside kernel A's sweeps -- an experiment, OFF unless TK_LOSS_OVERLAP=1.  The sweeps are one
-// workgroup per CU issuing one instruction every ~5 cycles: they leave the chip's memory system and most
-// of its issue slots idle for ~90 us at the train step's shape, and kernel B's three launches (~30 us) do
-// not depend on them.  With an aux buffer for kernel B's gradient, B runs on a second hardware queue
-// (the high-priority side stream of logz_kernels.hip) while the sweeps run, and kernel A's gradient
-// pass, which waits for it, folds logZ / nblk and (d logZ) / nblk into the rows it writes anyway.
-// Measured (LABNOTES.md, section 7): the loss path goes from 0.176 to 0.171 ms (plain; the sweeps slow down
-// by most of what the overlap hides) and from 0.245 to 0.223 ms (cat-mod) -- and capturing the fork /
-// join into a hipGraph crashes inside the HIP runtime of this PyTorch build, which is how the train
-// step runs.  So: off, and never while the caller's stream is capturing.
-static bool loss_overlap_enabled(hipStream_t st) {
-    static const int on = [] {
+// Kernel B beside kernel A's sweeps.  The sweeps are one workgroup per CU issuing one instruction every ~5
+// cycles: they leave the chip's memory system and most of its issue slots idle, and kernel B's three launches
+// (~30 us at the train step's shape) do not depend on them.  With an aux buffer for kernel B's gradient, B runs
+// on a second hardware queue (the side stream of logz_kernels.hip) while the sweeps run, and kernel A's
+// gradient pass, which waits for it, folds logZ / nblk and (d logZ) / nblk into the rows it writes anyway.
+// Measured (round 4, LABNOTES R4.6, profiles/r4_overlap_timeline.txt): the sweeps do not slow down (57.4 ->
+// 58.7 us), the fork and the join cost ~7 + ~6 us of queue idle, the fold 3 us in A's gradient pass: loss path
+// 136 -> 127-129 us (plain), 180 -> 157 us (cat-mod), 226 -> 210 us (T=1600).  Mode 1 (the default; TK_LOSS_OVERLAP=0
+// or tk_flipflop_loss_overlap(0) turn it off): on unless the caller's stream is CAPTURING -- a captured
+// train step replays the one-queue form: a captured fork / join replays correctly but 150 us SLOWER than the
+// one-queue graph (384 against 234 us for the operator with its index preparation, tools/overlap_capture_probe.py,
+// profiles/r4_overlap_capture_probe.txt; mode 2 keeps that experiment reachable).
+static std::atomic<int> &loss_overlap_mode() {
+    static std::atomic<int> mode([] {
         const char *e = getenv("TK_LOSS_OVERLAP");
-        return (e != nullptr && e[0] == '1') ? 1 : 0;
-    }();
-    if (on == 0) return false;
+        return (e != nullptr && e[0] >= '0' && e[0] <= '2') ? e[0] - '0' : 1;
+    }());
+    return mode;
+}
+int tk_flipflop_loss_overlap(int mode) {
+    std::atomic<int> &m = loss_overlap_mode();
+    return (mode >= 0 && mode <= 2) ? m.exchange(mode) : m.load();
+}
+static bool loss_overlap_enabled(hipStream_t st) {
+    const int mode = loss_overlap_mode().load();
+    if (mode == 0) return false;
     hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
-    if (st != nullptr && hipStreamIsCapturing(st, &cs) == hipSuccess && cs != hipStreamCaptureStatusNone) return false;
+    if (mode == 1 && st != nullptr && hipStreamIsCapturing(st, &cs) == hipSuccess && cs != hipStreamCaptureStatusNone) return false;
     return true;
 }
+// (the side queue and its two events are one per device: calls from several host threads take turns enqueueing)
+static std::mutex loss_overlap_mu;
 
 size_t tk_flipflop_loss_fused_aux_bytes(size_t nblk, size_t nbatch, size_t nbase, size_t ntrans) {
     const size_t ncan = 2 * nbase * (nbase + 1);
@@ -288,6 +302,8 @@ int tk_flipflop_loss_fused_dev(const float *scores, size_t nblk, size_t nbatch, 
     hipStream_t sb = st;
     hipEvent_t fork = nullptr, join = nullptr;
     const bool side = loss_overlap_enabled(st) && tk::logz_side_stream(&sb, &fork, &join);
+    std::unique_lock<std::mutex> turn(loss_overlap_mu, std::defer_lock);
+    if (side) turn.lock();
     if (side) {
         if (hipEventRecord(fork, st) != hipSuccess || hipStreamWaitEvent(sb, fork, 0) != hipSuccess) return TK_ERR_LAUNCH;
     } else {

@@ -897,7 +897,7 @@ __host__ __device__ inline size_t band_post_lds_bytes(bool mod, int bk) {
 }
 
 template <bool MOD, bool CW, int BK>
-__global__ __launch_bounds__(POST_WAVES *WAVE) void crf_band_posterior_kernel(BandArgs a) {
+__global__ __launch_bounds__(POST_WAVES *WAVE) __attribute__((amdgpu_waves_per_eu(5))) void crf_band_posterior_kernel(BandArgs a) {
     constexpr int R = 1;                                        // 64-cell chunks whatever the sweeps used
     constexpr int PW = R * WAVE;
     constexpr int KINDS = MOD ? 3 : 2;
@@ -1269,6 +1269,18 @@ __global__ __launch_bounds__(POST_WAVES *WAVE) void crf_band_posterior_kernel(Ba
     const float zfrac = (float)(scoreF - (double)zexp);
     const float gsc = a.grad_scale * (a.grad_scale_vec != nullptr ? a.grad_scale_vec[n] : 1.0f);
     bool lost = false;
+    // the fused loss's add term (kernel B's gradient of these rows): all of a block's loads BEFORE its first
+    // store -- the compiler may not move a load of `add_grad` over a store to `grad`, and one exposed load
+    // latency per row put 14 us on this kernel at the train step's shape (LABNOTES R4.6)
+    const bool adds = a.add_grad != nullptr && lane < a.add_S;
+    float addv[BK];
+#pragma unroll
+    for (int k = 0; k < BK; ++k) addv[k] = 0.f;
+    if (a.add_grad != nullptr) {                                // (wave-uniform: nothing to issue for the plain operator)
+#pragma unroll
+        for (int k = 0; k < BK; ++k)
+            if (adds && k < nrows) addv[k] = a.add_grad[((size_t)(t0 + k) * (size_t)a.N + (size_t)n) * a.add_S + lane];
+    }
 #pragma unroll
     for (int k = 0; k < BK; ++k) {
         if (k < nrows) {
@@ -1284,7 +1296,8 @@ __global__ __launch_bounds__(POST_WAVES *WAVE) void crf_band_posterior_kernel(Ba
                 printf("rowdev n %d t %d L %d total %g dev %g cmin %d cmax %d nskip %d\n", n, t0 + k, L, total, dev, cmin, cmax, nskip);
 #endif
             // gradient of -score / T  (ctc.pyx:113)
-            const float g = crf_add_grad(a, (size_t)(t0 + k), n, lane, colacc * (-gsc / (total * (float)T)), gsc);
+            const float g0 = colacc * (-gsc / (total * (float)T));
+            const float g = adds ? fmaf(addv[k], a.add_scale * gsc, g0) : g0;       // (= crf_add_grad, ff_common.h)
             if (lane < S) a.grad[(size_t)(t0 + k) * rowstride + (size_t)n * S + lane] = g;
         }
     }

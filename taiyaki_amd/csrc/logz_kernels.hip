@@ -1273,7 +1273,9 @@ static LogzSide *logz_side_for_current_device() {
     if (sd.s == nullptr) {
         int lo = 0, hi = 0;
         (void)hipDeviceGetStreamPriorityRange(&lo, &hi);       // hi = numerically lowest = highest priority
-        sd.ok = hipStreamCreateWithPriority(&sd.s, hipStreamNonBlocking, hi) == hipSuccess &&
+        const char *e = getenv("TK_SIDE_PRIO");                 // lab: "lo" puts the side queue BELOW the caller's
+        const int prio = (e != nullptr && e[0] == 'l') ? lo : hi;
+        sd.ok = hipStreamCreateWithPriority(&sd.s, hipStreamNonBlocking, prio) == hipSuccess &&
                 hipEventCreateWithFlags(&sd.fork, hipEventDisableTiming) == hipSuccess &&
                 hipEventCreateWithFlags(&sd.t1, hipEventDisableTiming) == hipSuccess &&
                 hipEventCreateWithFlags(&sd.join, hipEventDisableTiming) == hipSuccess;

@@ -328,6 +328,8 @@ def _run_fused(outputs, seqs, seqlen, sharpfact, want_grad, grad_scale=1.0, grad
         wsa = L.tk_crf_flipflop_workspace_bytes_sharp(ntrans, nblk, nbatch, maxlen, 1, float(sharpfact))
         wsb = L.tk_flipflop_logz_workspace_bytes(nblk, nbatch, nbase)
         wsx = L.tk_flipflop_loss_fused_aux_bytes(nblk, nbatch, nbase, ntrans)
+        if mod is None and torch.cuda.is_current_stream_capturing() and L.tk_flipflop_loss_overlap(-1) != 2:
+            wsx = 0         # (a capture replays the one-queue form: no gradient buffer for kernel B in the graph's pool)
         ws_a = _workspace(wsa, dev, "crf")
         ws_b = _workspace(wsb, dev, "logz")
         ws_x = _workspace(wsx, dev, "aux") if wsx else None

@@ -1434,3 +1434,97 @@ def test_fused_catmod_loss_small_against_oracle(oracle_mod, gpu_device, sharp):
     ctc.backward_unit(loss)
     np.testing.assert_allclose(lv2.cpu().numpy(), want_lv, rtol=1e-5, atol=2e-6)
     np.testing.assert_allclose(x.grad.cpu().numpy(), want_g * (live / live.sum())[None, :, None], atol=2e-5)
+
+
+@pytest.fixture
+def loss_queues(request):
+    """Run a test with the fused loss's one-queue (0) or two-queue (1) form, restoring the library's mode."""
+    from taiyaki_amd import _lib
+    L = _lib.lib()
+    prev = L.tk_flipflop_loss_overlap(request.param)
+    yield request.param
+    L.tk_flipflop_loss_overlap(prev)
+
+
+@pytest.mark.parametrize("loss_queues", [0, 1], indirect=True)
+@pytest.mark.parametrize("catmod", [False, True])
+def test_fused_loss_forms_against_oracle(oracle_mod, gpu_device, loss_queues, catmod):
+    """Both forms of the fused operator -- kernel B after kernel A on the caller's queue, adding in place (what a
+    captured train step replays), and kernel B on the device's second queue beside A's sweeps, folded into A's
+    gradient pass (the default outside a capture, `tk_flipflop_loss_overlap`) -- against the oracle's
+    (A) + (B) / nblk on ragged reads (an empty one, a single base, one longer than the chunk), with the weighted
+    mean on top; and the library reports the mode it is in."""
+    import torch
+    from taiyaki_amd import _lib, ctc, synth
+    assert _lib.lib().tk_flipflop_loss_overlap(-1) == loss_queues
+    T = 133
+    seqlens = np.array([60, 1, T + 1, 33, 0, 90, 17], dtype=np.int32)
+    if catmod:
+        inp = synth.normalise_mod_columns(synth.crf_case(T, len(seqlens), 21, seqlens=seqlens, nmods_per_base=(1, 1, 0, 0)),
+                                          logit_scale=1.0)
+        mods = (torch.from_numpy(inp["mod_cats"]), inp["can_mods_offsets"], inp["mod_cat_weights"])
+        oloss, ograd = oracle_mod.cat_mod_flipflop_loss(inp["scores"], inp["seqs"], inp["seqlens"], inp["mod_cats"],
+                                                        inp["can_mods_offsets"], inp["mod_cat_weights"], 1.0)
+    else:
+        inp = synth.crf_case(T, len(seqlens), 21, seqlens=seqlens)
+        mods = ()
+        oloss, ograd = oracle_mod.crf_flipflop_loss(inp["scores"], inp["seqs"], inp["seqlens"], 1.0)
+    olz, olgrad = oracle_mod.flipflop_logz_grad(np.ascontiguousarray(inp["scores"][:, :, :40]))
+    want_lv = oloss + olz / T
+    want_g = ograd.copy()
+    want_g[:, :, :40] += olgrad / T
+    x = torch.from_numpy(inp["scores"]).to(gpu_device).requires_grad_()
+    seqs, sl = torch.from_numpy(inp["seqs"]), torch.from_numpy(inp["seqlens"])
+    for _ in range(3):                                      # (back to back: the fork / join events are reused)
+        x.grad = None
+        lv = ctc.flipflop_loss(x, seqs, sl, 1.0, *mods)
+        lv.sum().backward()
+    np.testing.assert_allclose(lv.detach().cpu().numpy(), want_lv, rtol=1e-5, atol=2e-6)
+    np.testing.assert_allclose(x.grad.cpu().numpy(), want_g, atol=2e-5)
+    x.grad = None
+    w = torch.linspace(0.5, 1.5, len(seqlens)).to(gpu_device)
+    loss, lv2 = ctc.flipflop_mean_loss(x, seqs, sl, 1.0, w, *mods)
+    ctc.backward_unit(loss)
+    np.testing.assert_allclose(lv2.cpu().numpy(), want_lv, rtol=1e-5, atol=2e-6)
+    np.testing.assert_allclose(x.grad.cpu().numpy(), want_g * w.cpu().numpy()[None, :, None], atol=3e-5)
+
+
+def test_fused_loss_two_queue_form_from_two_host_threads(gpu_device):
+    """The side queue and its fork / join events are one per device: two host threads calling the operator on
+    streams of their own take turns enqueueing, and each gets the result it gets alone."""
+    import threading
+    import torch
+    from taiyaki_amd import _lib, ctc, synth
+    assert _lib.lib().tk_flipflop_loss_overlap(-1) == 1
+    cases_ = [synth.crf_case(200, 16, 50 + i) for i in range(2)]
+    want = []
+    for inp in cases_:
+        x = torch.from_numpy(inp["scores"]).to(gpu_device).requires_grad_()
+        lv = ctc.flipflop_loss(x, torch.from_numpy(inp["seqs"]), torch.from_numpy(inp["seqlens"]), 1.0)
+        lv.sum().backward()
+        want.append((lv.detach().cpu().numpy(), x.grad.cpu().numpy()))
+    got, errors = [None, None], []
+
+    def work(i):
+        try:
+            inp = cases_[i]
+            with torch.cuda.stream(torch.cuda.Stream(device=gpu_device)):
+                x = torch.from_numpy(inp["scores"]).to(gpu_device).requires_grad_()
+                for _ in range(20):
+                    x.grad = None
+                    lv = ctc.flipflop_loss(x, torch.from_numpy(inp["seqs"]), torch.from_numpy(inp["seqlens"]), 1.0)
+                    lv.sum().backward()
+                torch.cuda.current_stream().synchronize()
+                got[i] = (lv.detach().cpu().numpy(), x.grad.cpu().numpy())
+        except Exception as exc:                            # noqa: BLE001
+            errors.append(exc)
+
+    threads = [threading.Thread(target=work, args=(i,)) for i in range(2)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    assert not errors, errors
+    for i in range(2):
+        np.testing.assert_array_equal(got[i][0], want[i][0])
+        np.testing.assert_array_equal(got[i][1], want[i][1])

@@ -240,3 +240,37 @@ def test_float64_witness_agrees_with_the_fp32_restatement_and_the_reference(orac
     ol, og = oracle_mod.crf_flipflop_loss(inp["scores"], inp["seqs"], inp["seqlens"], 1.0)
     noise = np.abs(og - wg).max() * T
     assert 2e-5 < noise < 5e-3, noise
+
+
+def test_empty_read_inside_a_batch_is_scored_apart(oracle_mod):
+    """The reference gives a read AFTER an empty read that is not the batch's last a neighbour's move index
+    (ctc.pyx:127-129 emits no move for the empty read, c_crf_flipflop.c:479 counts -1): shown here on the
+    genuine reference when it is built -- at least one later read differs from its value alone --, while the
+    oracle's operator-level functions (what the HIP path is held to) give every read the value it has in a
+    batch of its own, the empty read cost 0 and zero gradient rows.  Trailing empty reads take the plain route."""
+    from taiyaki_amd import synth
+    T = 40
+    seqlens = np.array([12, 0, 20, 9, 0], dtype=np.int32)
+    inp = synth.crf_case(T, len(seqlens), 5, seqlens=seqlens)
+    off = np.concatenate([[0], np.cumsum(seqlens)])
+    solo = np.zeros(len(seqlens), dtype=np.float32)
+    solo_g = np.zeros_like(inp["scores"])
+    for n in np.nonzero(seqlens)[0]:
+        one, one_g = oracle_mod.crf_flipflop_loss(np.ascontiguousarray(inp["scores"][:, n:n + 1]), inp["seqs"][off[n]:off[n + 1]],
+                                         seqlens[n:n + 1], 1.0)
+        solo[n], solo_g[:, n] = one[0], one_g[:, 0]
+    for use_ref in ([False, True] if oracle_mod.ref_available() else [False]):
+        loss, grad = oracle_mod.crf_flipflop_loss(inp["scores"], inp["seqs"], seqlens, 1.0, use_ref=use_ref)
+        np.testing.assert_array_equal(loss, solo)
+        np.testing.assert_allclose(grad, solo_g, rtol=1e-5, atol=1e-8)       # (vector-width remainders round differently)
+    wl, _ = oracle_mod.crf_flipflop_loss_f64(inp["scores"], inp["seqs"], seqlens, 1.0)
+    np.testing.assert_allclose(wl, solo, rtol=2e-6, atol=1e-7)
+    if oracle_mod.ref_available():
+        # the raw reference call on the same batch: reads 2 and 3 are not what they are alone
+        from oracle import _seq_call, flipflop_indices, ref
+        nbase = 4
+        move = np.concatenate([flipflop_indices(inp["seqs"][off[n]:off[n + 1]], seqlens[n:n + 1], nbase)[0][:max(seqlens[n] - 1, 0)]
+                               for n in range(len(seqlens))] + [np.zeros(2, dtype=np.uintp)])
+        stay = flipflop_indices(inp["seqs"], seqlens, nbase)[1]
+        raw, _ = _seq_call(ref(), "", inp["scores"], move, stay, seqlens)
+        assert raw[0] == solo[0] and (raw[2] != solo[2] or raw[3] != solo[3])

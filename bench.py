@@ -635,7 +635,7 @@ def kernel_records(out, args, cfg, dev, world, T, nbatch, chunk_len, cat_mod, S)
             note="linear-domain band sweeps (per-cell power-of-two frames) + recomputing gradient pass: both are "
                  "bound by instruction issue -- T serial steps per read, all of a read's waves on one CU -- "
                  "not by HBM; `traffic` = scores read three times, one checkpoint column + boundary cells per "
-                 "8-step block written and read, the gradient written once; achieved is the algorithmic "
+                 "time block (12 steps; cat-mod 8) written and read, the gradient written once; achieved is the algorithmic "
                  "3*T*N*S*4 bytes over the op's duration (build_indices + sweeps + gradient pass + the gated "
                  "log-domain launch, which finds nothing to redo on these inputs)")
     else:

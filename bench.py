@@ -604,9 +604,20 @@ def kernel_records(out, args, cfg, dev, world, T, nbatch, chunk_len, cat_mod, S)
     def logz_roofline(ops, reps, label):
         mean_s, min_s = _events_mean_min(ops.logz_op, reps)
         tr, src = traffic_of("logz", ops.T, ops.N, 0)
-        return roofline_record("logZ forward-backward op (logz_transfer + logz_middle + logz_posterior), "
-                               "T=%d N=%d (%s)" % (ops.T, ops.N, label), 3.0 * ops.T * ops.N * 40 * 4,
-                               mean_s, min_s, reps, tr, src)
+        rec = roofline_record("logZ forward-backward op (logz_transfer + logz_middle + logz_posterior), "
+                              "T=%d N=%d (%s)" % (ops.T, ops.N, label), 3.0 * ops.T * ops.N * 40 * 4,
+                              mean_s, min_s, reps, tr, src)
+        if ops.x40.numel() * 4 >= (64 << 20):
+            # the fraction against a MEASURED device-copy ceiling too -- the score tensor copied into
+            # the gradient tensor by the runtime's own copy kernel, read + write bytes over the HIP-event time
+            cp_mean, cp_min = _events_mean_min(lambda: ops.lgrad.copy_(ops.x40), 20, warm=3)
+            ceiling = 2.0 * ops.x40.numel() * 4 / cp_mean / 1e9
+            rec["copy_ceiling"] = dict(value=round(ceiling, 1), unit="GB/s", mean_us=round(cp_mean * 1e6, 2),
+                                       min_us=round(cp_min * 1e6, 2),
+                                       how="torch copy_ of the (T, N, 40) fp32 score tensor, device to device: "
+                                           "(read + write bytes) / HIP-event time, 20 launches")
+            rec["frac_of_copy_ceiling"] = round(rec["achieved"] / ceiling, 4)
+        return rec
 
     def crf_roofline(ops, reps, label, realistic):
         mean_s, min_s = _events_mean_min(ops.crf, reps, warm=5)

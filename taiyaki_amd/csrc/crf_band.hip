@@ -930,6 +930,14 @@ __global__ __launch_bounds__(POST_WAVES *WAVE) __attribute__((amdgpu_waves_per_e
         }
         return;
     }
+#ifdef TK_LAB_STAMPS
+    unsigned long long pst[6];
+    int pstk = 0;
+#define PSTAMP() pst[pstk++] = __builtin_amdgcn_s_memtime()
+#else
+#define PSTAMP()
+#endif
+    PSTAMP();
     const double scoreF = a.scoreF[n], scoreB = a.scoreB[n];
     {
         // the sweeps must have ended finite and agree (c_crf_flipflop.c:482-491 averages them)
@@ -963,12 +971,10 @@ __global__ __launch_bounds__(POST_WAVES *WAVE) __attribute__((amdgpu_waves_per_e
     const float wbias = a.wbias;        // (the weights' bias: see BK_MAX)
     const float wb_lane = (colw_mode && (int)lane >= a.ncan) ? 0.f : wbias;
     // the wave's score rows, one register each (lane = transition id), raw and exponentiated
+    // (loaded here, exponentiated after the mask pass below: its loads then fly beside these)
     float raw[BK], er[BK];
 #pragma unroll
-    for (int k = 0; k < BK; ++k) {
-        raw[k] = lpn[(size_t)min(t0 + k, T - 1) * rowstride + col];
-        er[k] = fast_exp2(fmaf(raw[k], cw_lane, -wb_lane));
-    }
+    for (int k = 0; k < BK; ++k) raw[k] = lpn[(size_t)min(t0 + k, T - 1) * rowstride + col];
 
     // live chunks of row t (column t -> t + 1): chunk [a, b] holds an instance of some complete path
     // through row t iff  a <= t + 1  (the move INTO position t + 1 is the fastest path's)  and
@@ -985,6 +991,7 @@ __global__ __launch_bounds__(POST_WAVES *WAVE) __attribute__((amdgpu_waves_per_e
     float pacc[BK];
 #pragma unroll
     for (int k = 0; k < BK; ++k) pacc[k] = 0.f;
+    PSTAMP();
     const size_t ckrow = ((size_t)n * NB + jb) * a.LP;
     const size_t ckbase = ((size_t)n * NB + jb) * a.W;           // the block's frame bases, one per sweep chunk
     const int pws_sh = 31 - __builtin_clz(PWS);                  // (PWS = 64, 128 or 256 cells)
@@ -1237,34 +1244,91 @@ __global__ __launch_bounds__(POST_WAVES *WAVE) __attribute__((amdgpu_waves_per_e
     };
 
     int nskip = 0;
-    for (int ck = cmin; ck <= cmax; ++ck) {
-        if (!sweep_live(ck * PW)) continue;                     // (never for a live row: the windows cover the band)
-        // the chunk's frames: 16-bit offsets from the base of the sweep chunk that stored them
-        const int a0l = ck * PW;
-        const int fF0 = a.ckFb[ckbase + (a0l >> pws_sh)] + (int)(short)__builtin_amdgcn_raw_buffer_load_b16(rFf, lane4 / 2, 2u * (unsigned)a0l, 0);
-        const int fB0 = a.ckBb[ckbase + (a0l >> pws_sh)] + (int)(short)__builtin_amdgcn_raw_buffer_load_b16(rBf, lane4 / 2, 2u * (unsigned)a0l, 0);
-        {
-            // A cell's posterior is (mF es) (mB) 2^(fF + fB - zexp) with mantissas that start the
-            // block below 1 and grow by at most (1 + 2^KLIP) 2^7.2 per step for |sharp score| <= 5:
-            // mF mB es <= 2^113 whatever the row, so a chunk whose exponents are all below
-            // POST_SKIP_BELOW = -160 adds less than 2^-33 to a row total of 1 (64 cells x 2 instances x
-            // <= 64 chunks) -- below what fp32 sums resolve.  Skipped; for larger scores the totals
-            // of the rows are still VERIFIED against the partition function (ROWZ_TOL), or the read
-            // goes to the log-domain kernel.  Most of the band lies outside the few chunks around the
-            // alignment that carry the posterior mass: 43 % of the chunk-blocks at the train step's
-            // shape, 77 % at T = 4000 are skipped.
-            const int kxl = (ck * PW + lane < L) ? fF0 + fB0 - zexp : -(1 << 20);
-            const float kmax = wave_allmax_dpp((float)kxl);
-            if (kmax < (float)POST_SKIP_BELOW<BK>) {
-                ++nskip;
-                continue;
+    // WHICH CHUNKS CARRY MASS -- decided for all of the block's chunks BEFORE any of them is computed, 8 or 16 at a
+    // time, so that their frame loads are in flight together, and by ONE compare per chunk (a ballot, no reduction):
+    // one chunk after the other (round 3) every test waited for its own loads from a workspace far larger than the
+    // L2 and paid a DPP reduction -- 35 of a wave's 74 thousand cycles at T = 4000 (LABNOTES R4.11).
+    // THE COLUMN TEST (round 4, jb >= 1).  Every complete path through an instance of rows t0 .. t0 + BK - 1 at the
+    // cells of chunk [a0, a0 + 63] passes column t0 at a position in [a0 - BK, a0 + 63] (a path gains at most one
+    // position per step), so a row's posterior mass inside the chunk is at most the sum of the CELL posteriors
+    // F_t0[p] B_t0[p] / Z over those 64 + BK positions -- and both factors are checkpoint columns: the forward
+    // sweep's of this block, the backward sweep's of block jb - 1 (its start column in flow order IS t0), with
+    // mantissas below 1, so 2^(fF + fB - zexp) bounds a cell from the frames alone.  All 64 + BK bounds below
+    // POST_COL_SKIP = -48: the chunk adds less than 76 x 2^-48 to any row total of 1, 2^-35 over a read's 64 chunks --
+    // skipped.  No growth bound: 54 % instead of 41 % of the band's chunk-blocks go at the train step's shape,
+    // 84 % instead of 75 % at T = 4000.  A sweep chunk that did not run block jb - 1 has no live cell at column t0
+    // (band_window: its first live row is >= t0, i.e. its positions are > t0).
+    // BLOCK 0 has no column before it and keeps round 3's test on the frames at both ENDS of the block:
+    // a cell's posterior is (mF es) (mB) 2^(fF + fB - zexp) with mantissas that start the block below 1 and grow
+    // by at most (1 + 2^KLIP) 2^7.2 per step for |sharp score| <= 5: mF mB es <= 2^113 whatever the row, so
+    // exponents all below POST_SKIP_BELOW = -160 (-176) add less than 2^-33 to a row total of 1.
+    // Either way the totals of the rows are still VERIFIED against the partition function (ROWZ_TOL), or the read
+    // goes to the log-domain kernel.
+    constexpr int POST_COL_SKIP = -48;
+    const bool coltest = jb >= 1;
+    const __amdgpu_buffer_rsrc_t rBt = coltest ? __builtin_amdgcn_make_buffer_rsrc(a.ckBf + ckrow - a.LP, 0, (int)(a.LP * 2), BUF_WORD3) : rBf;
+    const size_t ckbase_t = coltest ? ckbase - a.W : ckbase;
+    const int thr = coltest ? POST_COL_SKIP : POST_SKIP_BELOW<BK>;
+    const int live_hi_p = t0, live_lo_p = t0 - BK - (T - L + 1) - PWS + 1;
+    auto sweep_live_prev = [&](int p) {
+        const int as = (p >> pws_sh) << pws_sh;
+        return !coltest || notrim || (as <= live_hi_p && as >= live_lo_p);
+    };
+    unsigned long long livemask = 0;            // bit ck - cmin  (a read has at most 64 chunks of 64 cells)
+    // the frame bases of the block's chunks, lane = chunk - cmin: one vector load per array instead of a scalar load per
+    // chunk
+    const int bidx = (min(cmin + lane, cmax) * PW) >> pws_sh;
+    const int baseF_l = a.ckFb[ckbase + bidx], baseB_l = a.ckBb[ckbase + bidx];
+    const int baseT_l = coltest ? a.ckBb[ckbase_t + bidx] : baseB_l;
+    auto mask_pass = [&](auto gtag) {
+        constexpr int G = decltype(gtag)::value;
+        bool tail_prev = false;                 // did one of the last BK cells of the chunk before reach the threshold?
+        for (int c0 = cmin; c0 <= cmax; c0 += G) {
+            int rawF[G], rawT[G];
+            // (all of the batch's loads first, pinned in front of the conditions: left alone hipcc sinks every pair
+            // of loads under its chunk's wave-uniform `valid` branch and waits for it there -- eight round trips
+            // one after the other, the 35 thousand cycles this pass was written to remove)
+#pragma unroll
+            for (int g = 0; g < G; ++g) {
+                const unsigned a0l2 = 2u * (unsigned)(min(c0 + g, cmax) * PW);
+                rawF[g] = (int)(short)__builtin_amdgcn_raw_buffer_load_b16(rFf, lane4 / 2, a0l2, 0);
+                rawT[g] = (int)(short)__builtin_amdgcn_raw_buffer_load_b16(rBt, lane4 / 2, a0l2, 0);
+            }
+            asm volatile("" ::: "memory");
+#pragma unroll
+            for (int g = 0; g < G; ++g) {
+                const int ck = min(c0 + g, cmax), a0l = ck * PW;
+                const bool valid = c0 + g <= cmax && sweep_live(a0l);   // (wave-uniform; never false for a live row: the windows cover the band)
+                const int fF = __builtin_amdgcn_readlane(baseF_l, ck - cmin) + rawF[g];
+                const int fBt = __builtin_amdgcn_readlane(baseT_l, ck - cmin) + rawT[g];
+                // one compare per chunk: the lanes whose bound reaches the threshold, as a mask (no reduction)
+                const unsigned long long hot = __ballot(sweep_live_prev(a0l) && a0l + lane < L && fF + fBt - zexp >= thr);
+                const bool own = hot != 0, tail = (hot >> (WAVE - BK)) != 0;
+                if (valid) {
+                    if (own || (coltest && tail_prev)) livemask |= 1ull << (c0 + g - cmin);
+                    else ++nskip;
+                }
+                tail_prev = valid && tail;
             }
         }
+    };
+    // (one batch wherever it fits: 8 chunks cover the train step's reads, 16 most blocks of a 2000-base read)
+    if (cmax - cmin < 8) mask_pass(std::integral_constant<int, 8>{});
+    else mask_pass(std::integral_constant<int, 16>{});
+#pragma unroll
+    for (int k = 0; k < BK; ++k) er[k] = fast_exp2(fmaf(raw[k], cw_lane, -wb_lane));
+    PSTAMP();
+    for (unsigned long long m = livemask; m != 0; m &= m - 1) {
+        const int ck = cmin + __builtin_ctzll(m), a0l = ck * PW;
+        // the chunk's frames: 16-bit offsets from the base of the sweep chunk that stored them
+        const int fF0 = __builtin_amdgcn_readlane(baseF_l, ck - cmin) + (int)(short)__builtin_amdgcn_raw_buffer_load_b16(rFf, lane4 / 2, 2u * (unsigned)a0l, 0);
+        const int fB0 = __builtin_amdgcn_readlane(baseB_l, ck - cmin) + (int)(short)__builtin_amdgcn_raw_buffer_load_b16(rBf, lane4 / 2, 2u * (unsigned)a0l, 0);
         if (nrows == BK)
             chunk_body(ck, fF0, fB0, std::true_type{});
         else
             chunk_body(ck, fF0, fB0, std::false_type{});
     }
+    PSTAMP();
     // every row's total is Z 2^-zexp: a row that lost mass (or everything) disowns the read
     const float zfrac = (float)(scoreF - (double)zexp);
     const float gsc = a.grad_scale * (a.grad_scale_vec != nullptr ? a.grad_scale_vec[n] : 1.0f);
@@ -1304,9 +1368,14 @@ __global__ __launch_bounds__(POST_WAVES *WAVE) __attribute__((amdgpu_waves_per_e
     if (lost && lane == 0) a.gate[n] = 2;        // (reason codes, lab dump: 1 non-finite sweep score, 4 sweeps disagree, 2 a row lost mass)
     (void)nskip;
 #ifdef TK_LAB_STAMPS
-    if (a.dbg && lane == 0) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    PSTAMP();
+    if (a.dbg && lane == 0 && (n & 15) == 0 && (jb & 7) == 0) {       // (a sample of the waves: every wave's atomics clog the launch)
         atomicAdd(a.dbg + 600, (unsigned long long)nskip);
         atomicAdd(a.dbg + 601, (unsigned long long)(cmax - cmin + 1));
+        for (int q = 0; q + 1 < pstk; ++q) atomicAdd(a.dbg + 610 + q, pst[q + 1] - pst[q]);
+        atomicAdd(a.dbg + 620, 1ull);
+        atomicAdd(a.dbg + 621, (unsigned long long)__builtin_popcountll(livemask));
     }
 #endif
 }
@@ -1472,8 +1541,10 @@ int crf_band_dispatch(const BandArgs &a0, int R, bool mod, int bk, hipStream_t s
             static unsigned long long h[1024];
             (void)hipStreamSynchronize(s);
             (void)hipMemcpy(h, d, sizeof(h), hipMemcpyDeviceToHost);
-            fprintf(stderr, "gradient pass: %llu of %llu chunk-blocks skipped (exponents below 2^%d)\n", h[600], h[601],
-                    POST_SKIP_BELOW<8>);
+            fprintf(stderr, "gradient pass: %llu of %llu chunk-blocks skipped; per wave (%llu waves, %.2f live chunks): prologue %.0f, "
+                    "mask pass %.0f, bodies %.0f, epilogue %.0f clocks\n", h[600], h[601], h[620], (double)h[621] / (double)(h[620] ? h[620] : 1),
+                    (double)h[610] / (double)(h[620] ? h[620] : 1), (double)h[611] / (double)(h[620] ? h[620] : 1),
+                    (double)h[612] / (double)(h[620] ? h[620] : 1), (double)h[613] / (double)(h[620] ? h[620] : 1));
             for (int k = 2; k < 12; ++k)
                 fprintf(stderr, "phase %2d: loads+frames %5llu  steps %5llu  boundary %5llu  barrier %5llu  next-phase-gap %5llu\n", k,
                         h[k * 8 + 1] - h[k * 8 + 0], h[k * 8 + 2] - h[k * 8 + 1], h[k * 8 + 3] - h[k * 8 + 2],

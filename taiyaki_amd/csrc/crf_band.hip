@@ -909,11 +909,38 @@ __global__ __launch_bounds__(POST_WAVES *WAVE) __attribute__((amdgpu_waves_per_e
     const int n = blockIdx.x;
     const int N = a.N, T = a.T, S = a.S, W = a.Wp;              // W: 64-cell chunks per checkpoint row
     const int PWS = a.LP / a.W;                                 // cells per SWEEP chunk
-    const int L = min(a.seqlen[n], (int)(a.seqoff[n + 1] - a.seqoff[n]));      // (offsets are clamped to the label array)
     const size_t rowstride = (size_t)N * S;
     const int NB = (T + BK - 1) / BK;
     const int jb = blockIdx.y * POST_WAVES + wave;                  // this wave's time block
     const int t0 = jb * BK;
+    // WHAT THE WAVE NEEDS BEFORE IT CAN DECIDE ANYTHING, ISSUED TOGETHER (round 4, LABNOTES R4.11): the read's length
+    // and offsets, the two sweep scores, the block's score rows, the frame bases of the block's chunks (lane =
+    // chunk) -- addresses that depend on nothing but the launch's arguments.  Length -> scores were two round trips
+    // one after the other.  (Also issuing the frame columns of all chunks of a short read here -- the mask pass's
+    // loads, a third round trip -- costs 32 registers: cat-mod fell from 6 to 5 waves per SIMD and lost 6 us.)
+    const int jbc = min(jb, NB - 1);                            // (waves past the last block leave below)
+    const size_t ckrow = ((size_t)n * NB + jbc) * a.LP;
+    const size_t ckbase = ((size_t)n * NB + jbc) * a.W;          // the block's frame bases, one per sweep chunk
+    const int pws_sh = 31 - __builtin_clz(PWS);                  // (PWS = 64, 128 or 256 cells)
+    const bool coltest = jbc >= 1;
+    const unsigned lane4 = 4u * (unsigned)lane;
+    const __amdgpu_buffer_rsrc_t rFf = __builtin_amdgcn_make_buffer_rsrc(a.ckFf + ckrow, 0, (int)(a.LP * 2), BUF_WORD3);
+    const __amdgpu_buffer_rsrc_t rBf = __builtin_amdgcn_make_buffer_rsrc(a.ckBf + ckrow, 0, (int)(a.LP * 2), BUF_WORD3);
+    const __amdgpu_buffer_rsrc_t rBt = coltest ? __builtin_amdgcn_make_buffer_rsrc(a.ckBf + ckrow - a.LP, 0, (int)(a.LP * 2), BUF_WORD3) : rBf;
+    const size_t ckbase_t = coltest ? ckbase - a.W : ckbase;
+    const int seqlen_n = a.seqlen[n];
+    const int64_t off = a.seqoff[n], off_next = a.seqoff[n + 1];
+    const double scoreF = a.scoreF[n], scoreB = a.scoreB[n];
+    const float *lpn = a.lp + (size_t)n * S;
+    const int col = min(lane, S - 1);
+    float raw[BK], er[BK];      // the wave's score rows, one register each (lane = transition id), raw and exponentiated
+#pragma unroll
+    for (int k = 0; k < BK; ++k) raw[k] = lpn[(size_t)min(t0 + k, T - 1) * rowstride + col];
+    const int bidx = (min(lane, W - 1) * PW) >> pws_sh;
+    const int baseF_l = a.ckFb[ckbase + bidx], baseB_l = a.ckBb[ckbase + bidx];
+    const int baseT_l = coltest ? a.ckBb[ckbase_t + bidx] : baseB_l;
+    asm volatile("" ::: "memory");
+    const int L = min(seqlen_n, (int)(off_next - off));         // (offsets are clamped to the label array)
 
     if (L == 0 || L > a.LP) {
         if (blockIdx.y == 0 && tid == 0) {
@@ -938,7 +965,6 @@ __global__ __launch_bounds__(POST_WAVES *WAVE) __attribute__((amdgpu_waves_per_e
 #define PSTAMP()
 #endif
     PSTAMP();
-    const double scoreF = a.scoreF[n], scoreB = a.scoreB[n];
     {
         // the sweeps must have ended finite and agree (c_crf_flipflop.c:482-491 averages them)
         const double dsc = scoreF - scoreB;
@@ -957,12 +983,9 @@ __global__ __launch_bounds__(POST_WAVES *WAVE) __attribute__((amdgpu_waves_per_e
     }
     const int Wn = (L + PW - 1) / PW;                           // chunks this read has
     float *sP = reinterpret_cast<float *>(smem) + (size_t)wave * RG * EPL * WAVE;
-    const float *lpn = a.lp + (size_t)n * S;
-    const int col = min(lane, S - 1);
     const float c = a.c_can;
     const bool trim = L <= T + 1;
     const int nrows = min(BK, T - t0);
-    const int64_t off = a.seqoff[n];
     const int zexp = (int)floor(scoreF);
 
     // (cat-mod with per-column factors: see band_sweep)
@@ -970,11 +993,7 @@ __global__ __launch_bounds__(POST_WAVES *WAVE) __attribute__((amdgpu_waves_per_e
     const float cw_lane = colw_mode ? ((int)lane < a.ncan ? c : a.colw[min(max((int)lane - a.ncan, 0), S - a.ncan - 1)] * a.c_mod) : c;
     const float wbias = a.wbias;        // (the weights' bias: see BK_MAX)
     const float wb_lane = (colw_mode && (int)lane >= a.ncan) ? 0.f : wbias;
-    // the wave's score rows, one register each (lane = transition id), raw and exponentiated
-    // (loaded here, exponentiated after the mask pass below: its loads then fly beside these)
-    float raw[BK], er[BK];
-#pragma unroll
-    for (int k = 0; k < BK; ++k) raw[k] = lpn[(size_t)min(t0 + k, T - 1) * rowstride + col];
+    // (the score rows are exponentiated after the mask pass below)
 
     // live chunks of row t (column t -> t + 1): chunk [a, b] holds an instance of some complete path
     // through row t iff  a <= t + 1  (the move INTO position t + 1 is the fastest path's)  and
@@ -992,9 +1011,6 @@ __global__ __launch_bounds__(POST_WAVES *WAVE) __attribute__((amdgpu_waves_per_e
 #pragma unroll
     for (int k = 0; k < BK; ++k) pacc[k] = 0.f;
     PSTAMP();
-    const size_t ckrow = ((size_t)n * NB + jb) * a.LP;
-    const size_t ckbase = ((size_t)n * NB + jb) * a.W;           // the block's frame bases, one per sweep chunk
-    const int pws_sh = 31 - __builtin_clz(PWS);                  // (PWS = 64, 128 or 256 cells)
     // Did the SWEEP chunk that holds cell p run this time block?  band_window(w) solved for the block once per
     // wave: chunk start a = w PWS is live in block jb iff  a <= t0 + BK  and  a + PWS - 1 >= t0 - (T - L + 1)
     // (reads without a complete path, L > T + 1, keep every block) -- two scalars per wave and three compares
@@ -1013,8 +1029,6 @@ __global__ __launch_bounds__(POST_WAVES *WAVE) __attribute__((amdgpu_waves_per_e
     // 0 that cells past the end of the read take (stay ids at p >= L, move ids at p - 1 < 0 or p >= L - 1).
     const __amdgpu_buffer_rsrc_t rFm = __builtin_amdgcn_make_buffer_rsrc(a.ckFm + ckrow, 0, (int)(a.LP * 4), BUF_WORD3);
     const __amdgpu_buffer_rsrc_t rBm = __builtin_amdgcn_make_buffer_rsrc(a.ckBm + ckrow, 0, (int)(a.LP * 4), BUF_WORD3);
-    const __amdgpu_buffer_rsrc_t rFf = __builtin_amdgcn_make_buffer_rsrc(a.ckFf + ckrow, 0, (int)(a.LP * 2), BUF_WORD3);
-    const __amdgpu_buffer_rsrc_t rBf = __builtin_amdgcn_make_buffer_rsrc(a.ckBf + ckrow, 0, (int)(a.LP * 2), BUF_WORD3);
     const __amdgpu_buffer_rsrc_t rSt = __builtin_amdgcn_make_buffer_rsrc(const_cast<int32_t *>(a.stay + off), 0, L * 4, BUF_WORD3);
     const __amdgpu_buffer_rsrc_t rMv = __builtin_amdgcn_make_buffer_rsrc(const_cast<int32_t *>(a.move + off), 0, (L - 1) * 4, BUF_WORD3);
     const __amdgpu_buffer_rsrc_t rRec = __builtin_amdgcn_make_buffer_rsrc(a.rec + (size_t)n * W * EPL * WAVE, 0, (int)(W * EPL * WAVE * 4), BUF_WORD3);
@@ -1023,7 +1037,6 @@ __global__ __launch_bounds__(POST_WAVES *WAVE) __attribute__((amdgpu_waves_per_e
         const_cast<int32_t *>(MOD ? a.mod + off : a.move + off), 0, (L - 1) * 4, BUF_WORD3);
     const __amdgpu_buffer_rsrc_t rMf = __builtin_amdgcn_make_buffer_rsrc(
         const_cast<float *>(MOD ? a.modfact + off : a.zeros), 0, MOD ? (L - 1) * 4 : 0, BUF_WORD3);
-    const unsigned lane4 = 4u * (unsigned)lane;
 
     // One chunk of the wave's time block.  Everything is straight-line and branch-free so that the
     // LDS round trips, the two recurrence chains and the RG prefix scans of a row group overlap
@@ -1265,9 +1278,6 @@ __global__ __launch_bounds__(POST_WAVES *WAVE) __attribute__((amdgpu_waves_per_e
     // Either way the totals of the rows are still VERIFIED against the partition function (ROWZ_TOL), or the read
     // goes to the log-domain kernel.
     constexpr int POST_COL_SKIP = -48;
-    const bool coltest = jb >= 1;
-    const __amdgpu_buffer_rsrc_t rBt = coltest ? __builtin_amdgcn_make_buffer_rsrc(a.ckBf + ckrow - a.LP, 0, (int)(a.LP * 2), BUF_WORD3) : rBf;
-    const size_t ckbase_t = coltest ? ckbase - a.W : ckbase;
     const int thr = coltest ? POST_COL_SKIP : POST_SKIP_BELOW<BK>;
     const int live_hi_p = t0, live_lo_p = t0 - BK - (T - L + 1) - PWS + 1;
     auto sweep_live_prev = [&](int p) {
@@ -1275,14 +1285,24 @@ __global__ __launch_bounds__(POST_WAVES *WAVE) __attribute__((amdgpu_waves_per_e
         return !coltest || notrim || (as <= live_hi_p && as >= live_lo_p);
     };
     unsigned long long livemask = 0;            // bit ck - cmin  (a read has at most 64 chunks of 64 cells)
-    // the frame bases of the block's chunks, lane = chunk - cmin: one vector load per array instead of a scalar load per
-    // chunk
-    const int bidx = (min(cmin + lane, cmax) * PW) >> pws_sh;
-    const int baseF_l = a.ckFb[ckbase + bidx], baseB_l = a.ckBb[ckbase + bidx];
-    const int baseT_l = coltest ? a.ckBb[ckbase_t + bidx] : baseB_l;
+    // (the frame bases of the block's chunks: one vector load per array, lane = chunk, instead of a scalar load per chunk)
+    bool tail_prev = false;                     // did one of the last BK cells of the chunk before reach the threshold?
+    // chunk ck from its two frame columns: one compare, the lanes whose bound reaches the threshold as a mask (no
+    // reduction); chunks arrive in ascending order
+    auto decide = [&](int ck, bool valid, int rawF, int rawT) {
+        const int a0l = ck * PW;
+        const int fF = __builtin_amdgcn_readlane(baseF_l, ck) + rawF;
+        const int fBt = __builtin_amdgcn_readlane(baseT_l, ck) + rawT;
+        const unsigned long long hot = __ballot(sweep_live_prev(a0l) && a0l + lane < L && fF + fBt - zexp >= thr);
+        const bool own = hot != 0, tail = (hot >> (WAVE - BK)) != 0;
+        if (valid) {
+            if (own || (coltest && tail_prev)) livemask |= 1ull << (ck - cmin);
+            else ++nskip;
+        }
+        tail_prev = valid && tail;
+    };
     auto mask_pass = [&](auto gtag) {
         constexpr int G = decltype(gtag)::value;
-        bool tail_prev = false;                 // did one of the last BK cells of the chunk before reach the threshold?
         for (int c0 = cmin; c0 <= cmax; c0 += G) {
             int rawF[G], rawT[G];
             // (all of the batch's loads first, pinned in front of the conditions: left alone hipcc sinks every pair
@@ -1297,18 +1317,8 @@ __global__ __launch_bounds__(POST_WAVES *WAVE) __attribute__((amdgpu_waves_per_e
             asm volatile("" ::: "memory");
 #pragma unroll
             for (int g = 0; g < G; ++g) {
-                const int ck = min(c0 + g, cmax), a0l = ck * PW;
-                const bool valid = c0 + g <= cmax && sweep_live(a0l);   // (wave-uniform; never false for a live row: the windows cover the band)
-                const int fF = __builtin_amdgcn_readlane(baseF_l, ck - cmin) + rawF[g];
-                const int fBt = __builtin_amdgcn_readlane(baseT_l, ck - cmin) + rawT[g];
-                // one compare per chunk: the lanes whose bound reaches the threshold, as a mask (no reduction)
-                const unsigned long long hot = __ballot(sweep_live_prev(a0l) && a0l + lane < L && fF + fBt - zexp >= thr);
-                const bool own = hot != 0, tail = (hot >> (WAVE - BK)) != 0;
-                if (valid) {
-                    if (own || (coltest && tail_prev)) livemask |= 1ull << (c0 + g - cmin);
-                    else ++nskip;
-                }
-                tail_prev = valid && tail;
+                const int ck = min(c0 + g, cmax);
+                decide(ck, c0 + g <= cmax && sweep_live(ck * PW), rawF[g], rawT[g]);    // (valid: wave-uniform; never false for a live row)
             }
         }
     };
@@ -1321,8 +1331,8 @@ __global__ __launch_bounds__(POST_WAVES *WAVE) __attribute__((amdgpu_waves_per_e
     for (unsigned long long m = livemask; m != 0; m &= m - 1) {
         const int ck = cmin + __builtin_ctzll(m), a0l = ck * PW;
         // the chunk's frames: 16-bit offsets from the base of the sweep chunk that stored them
-        const int fF0 = __builtin_amdgcn_readlane(baseF_l, ck - cmin) + (int)(short)__builtin_amdgcn_raw_buffer_load_b16(rFf, lane4 / 2, 2u * (unsigned)a0l, 0);
-        const int fB0 = __builtin_amdgcn_readlane(baseB_l, ck - cmin) + (int)(short)__builtin_amdgcn_raw_buffer_load_b16(rBf, lane4 / 2, 2u * (unsigned)a0l, 0);
+        const int fF0 = __builtin_amdgcn_readlane(baseF_l, ck) + (int)(short)__builtin_amdgcn_raw_buffer_load_b16(rFf, lane4 / 2, 2u * (unsigned)a0l, 0);
+        const int fB0 = __builtin_amdgcn_readlane(baseB_l, ck) + (int)(short)__builtin_amdgcn_raw_buffer_load_b16(rBf, lane4 / 2, 2u * (unsigned)a0l, 0);
         if (nrows == BK)
             chunk_body(ck, fF0, fB0, std::true_type{});
         else

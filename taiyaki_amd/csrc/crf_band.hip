@@ -498,15 +498,22 @@ __device__ __forceinline__ void band_sweep(const BandArgs &a, int n, int L, floa
 #pragma unroll
                 for (int g = 0; g < GH; g += 2) {
                     const int i0 = FWD ? ii0 + g : BK - 1 - (ii0 + g), i1 = FWD ? i0 + 1 : i0 - 1;
+                    // (the pairs in the order the gathers and the ring leave them in registers -- ascending row: the
+                    // backward sweep walks the rows downwards, and built the other way round every pair costs two
+                    // v_mov to swap, 12 issue slots of a phase's ~150.  Bit-identical either way; measured per form on
+                    // one box (profiles/r4_sweep_pair_order_ab.txt): cat-mod 133.6 -> 130.2 us, two cells per lane
+                    // 182.9 -> 176.6 -- and the plain one-cell form 100.3 -> 102.3, so that one keeps its swaps)
+                    constexpr bool ASC = FWD || MOD || R > 1;
+                    constexpr int ga = ASC && !FWD ? 1 : 0, gb = 1 - ga;
 #pragma unroll
                     for (int jj = 0; jj < R; ++jj) {
-                        const f2 p = f2{em[g][jj], em[g + 1][jj]} * f2{sc[jj], sc[jj]};
-                        mt[g][jj] = p.x;
-                        mt[g + 1][jj] = p.y;
+                        const f2 p = f2{em[g + ga][jj], em[g + gb][jj]} * f2{sc[jj], sc[jj]};
+                        mt[g + ga][jj] = p.x;
+                        mt[g + gb][jj] = p.y;
                     }
-                    const f2 q = f2{ein[i0], ein[i1]} * f2{mt[g][0], mt[g + 1][0]};
-                    u[g] = q.x;
-                    u[g + 1] = q.y;
+                    const f2 q = f2{ein[ga ? i1 : i0], ein[ga ? i0 : i1]} * f2{mt[g + ga][0], mt[g + gb][0]};
+                    u[g + ga] = q.x;
+                    u[g + gb] = q.y;
                 }
             } else if constexpr (PRE) {
 #pragma unroll

@@ -45,7 +45,11 @@
 //   * Round 4: the block length is a template parameter and the step weights carry a bias (see BK_MAX); ONE
 //     row-maker wave per sweep workgroup exponentiates each score row once and leaves it in an LDS ring from which
 //     every chunk wave gathers its weights (band_rowmaker: -12 % on the op against round 3's helper waves, which
-//     shipped gathered weights per chunk pair and are gone).
+//     shipped gathered weights per chunk pair and are gone).  The gradient pass decides which of a block's chunks
+//     carry posterior mass in ONE batched pass before it computes any (frame loads of 8 / 16 chunks in flight together,
+//     a ballot per chunk, the COLUMN test on the cell posteriors at the block's first column: see there) and issues
+//     what it needs from memory before it can decide anything at its top -- it was bound by memory round trips in
+//     front of its VALU work, not by the work (LABNOTES R4.11).
 //   * The linear path is exact or says so: a read whose sweeps end non-finite (overflow: scores
 //     beyond the bound above, e.g. sharpening factors > 1; underflow of everything: no complete
 //     path, log-probabilities far below zero), whose two sweeps disagree, or ANY of whose rows'

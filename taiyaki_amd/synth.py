@@ -147,10 +147,11 @@ def crf_case(T, N, seed, nbase=4, nmods_per_base=None, seqlens=None):
     return out
 
 
-def confident_scores(inp, seed, on=4.0, off=-3.0, noise=1.0, nbase=4, bursty=False):
+def confident_scores(inp, seed, on=4.0, off=-3.0, noise=1.0, nbase=4, bursty=False, move_times=None):
     """Scores of a TRAINED network, not of a freshly initialised one: every read follows one alignment
     (its L - 1 moves at random block positions, `bursty`: in runs, as a strand that speeds up and
-    stalls), the transition the alignment takes at a block scores `on` (+- noise), every other one
+    stalls; `move_times`: a callable n -> the sorted blocks at which read n moves, for alignments built on
+    purpose), the transition the alignment takes at a block scores `on` (+- noise), every other one
     `off` (+- noise) -- the 5 tanh range used to its ends.  Replaces inp["scores"] in place."""
     T, N, S = inp["scores"].shape
     rng = np.random.RandomState(seed)
@@ -162,7 +163,10 @@ def confident_scores(inp, seed, on=4.0, off=-3.0, noise=1.0, nbase=4, bursty=Fal
         if L == 0 or L - 1 > T:
             continue
         codes = inp["seqs"][off_seq[n]:off_seq[n] + L].astype(int)
-        if bursty:
+        if move_times is not None:
+            moves = np.asarray(move_times(n), dtype=int)
+            assert len(moves) == L - 1 and len(set(moves.tolist())) == L - 1 and moves.min() >= 0 and moves.max() < T
+        elif bursty:
             w = np.repeat(rng.uniform(0.05, 1.0, size=T // 40 + 1) ** 3, 40)[:T]
             moves = np.sort(rng.choice(T, size=L - 1, replace=False, p=w / w.sum()))
         else:

@@ -1528,3 +1528,45 @@ def test_fused_loss_two_queue_form_from_two_host_threads(gpu_device):
     for i in range(2):
         np.testing.assert_array_equal(got[i][0], want[i][0])
         np.testing.assert_array_equal(got[i][1], want[i][1])
+
+
+
+def test_crf_alignments_that_cross_chunk_boundaries_inside_a_block_stay_on_the_linear_path(oracle_mod, gpu_device):
+    """The gradient pass decides which 64-cell chunks of a time block carry posterior mass from the cell
+    posteriors at the block's FIRST column (crf_band.hip: the column test) -- over the chunk's own cells and the
+    last BK cells of the chunk before it, where a path that enters the chunk inside the block sits at that
+    column.  Confident scores (one alignment per read, everything else 7 units down) on alignments built to do
+    exactly that: runs of one move per block that cross positions 64 and 128 at every offset inside a 12-step
+    block, and stalls on a chunk's last cell that end inside a block.  The gradient must match the float64
+    witness, and NO read may be handed to the log-domain kernel: a chunk skipped wrongly loses a row's mass,
+    the row-total check disowns the read, and the result would still be right -- only the gate count shows it."""
+    import torch
+    from taiyaki_amd import ctc, synth
+    T, L = 204, 150
+    N = 26
+    seqlens = np.full(N, L, dtype=np.int32)
+    inp = synth.crf_case(T, N, 77, seqlens=seqlens)
+
+    def move_times(n):
+        if n < 13:
+            start = 2 + n                                       # a straight run: position p at block start + p
+            return np.arange(start, start + L - 1)
+        # stall on the last cell of chunk 0 (position 63), leave it at block 96 + k, k = 0 .. 12
+        k = n - 13
+        first = np.arange(0, 63)                                # positions 0 -> 63 by block 63
+        leave = 96 + k
+        rest = np.arange(leave, leave + (L - 1 - 63))
+        return np.concatenate([first, rest])
+
+    synth.confident_scores(inp, 5, move_times=move_times)
+    x = torch.from_numpy(inp["scores"]).to(gpu_device).requires_grad_()
+    lv = ctc.crf_flipflop_loss(x, torch.from_numpy(inp["seqs"]), torch.from_numpy(inp["seqlens"]), 1.0)
+    gated = ctc.last_gate_count()
+    lv.sum().backward()
+    wl, wg = oracle_mod.crf_flipflop_loss_f64(inp["scores"], inp["seqs"], inp["seqlens"], 1.0)
+    np.testing.assert_allclose(lv.detach().cpu().numpy(), wl, rtol=1e-5, atol=2e-6)
+    assert float(np.abs(x.grad.cpu().numpy().astype(np.float64) - wg).max()) * T < parity.GRAD_T_ATOL
+    # every row of every read carries its whole mass: one transition per row has posterior ~ 1
+    assert float(np.abs(x.grad.cpu().numpy().sum(axis=2) * -T - 1.0).max()) < 1e-4
+    assert gated == 0
+

@@ -1570,3 +1570,34 @@ def test_crf_alignments_that_cross_chunk_boundaries_inside_a_block_stay_on_the_l
     assert float(np.abs(x.grad.cpu().numpy().sum(axis=2) * -T - 1.0).max()) < 1e-4
     assert gated == 0
 
+
+@pytest.mark.parametrize("T,L", [(1500, 1100), (2600, 2100)])
+def test_crf_confident_long_reads_stay_on_the_linear_path(oracle_mod, gpu_device, T, L):
+    """The same on reads whose sweeps take two and four cells per lane (sweep chunks of 128 / 256 cells, gradient-pass
+    chunks of 64: the frame bases are per SWEEP chunk): straight runs and one stall per read, confident scores --
+    gradient against the float64 witness, every row's mass in one transition, no read disowned."""
+    import torch
+    from taiyaki_amd import ctc, synth
+    N = 4
+    seqlens = np.full(N, L, dtype=np.int32)
+    inp = synth.crf_case(T, N, 78, seqlens=seqlens)
+
+    def move_times(n):
+        if n < 2:
+            start = 3 + 7 * n
+            return np.arange(start, start + L - 1)
+        stall_at = 64 * (5 + n) - 1                              # the last cell of a 64-cell chunk
+        first = np.arange(0, stall_at)
+        leave = stall_at + 101 + n
+        return np.concatenate([first, np.arange(leave, leave + (L - 1 - stall_at))])
+
+    synth.confident_scores(inp, 6, move_times=move_times)
+    x = torch.from_numpy(inp["scores"]).to(gpu_device).requires_grad_()
+    lv = ctc.crf_flipflop_loss(x, torch.from_numpy(inp["seqs"]), torch.from_numpy(inp["seqlens"]), 1.0)
+    gated = ctc.last_gate_count()
+    lv.sum().backward()
+    wl, wg = oracle_mod.crf_flipflop_loss_f64(inp["scores"], inp["seqs"], inp["seqlens"], 1.0)
+    np.testing.assert_allclose(lv.detach().cpu().numpy(), wl, rtol=1e-5, atol=2e-6)
+    assert float(np.abs(x.grad.cpu().numpy().astype(np.float64) - wg).max()) * T < parity.GRAD_T_ATOL
+    assert float(np.abs(x.grad.cpu().numpy().sum(axis=2) * -T - 1.0).max()) < 1e-4
+    assert gated == 0

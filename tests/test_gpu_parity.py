@@ -1531,7 +1531,8 @@ def test_fused_loss_two_queue_form_from_two_host_threads(gpu_device):
 
 
 
-def test_crf_alignments_that_cross_chunk_boundaries_inside_a_block_stay_on_the_linear_path(oracle_mod, gpu_device):
+@pytest.mark.parametrize("catmod", [False, True])
+def test_crf_alignments_that_cross_chunk_boundaries_inside_a_block_stay_on_the_linear_path(oracle_mod, gpu_device, catmod):
     """The gradient pass decides which 64-cell chunks of a time block carry posterior mass from the cell
     posteriors at the block's FIRST column (crf_band.hip: the column test) -- over the chunk's own cells and the
     last BK cells of the chunk before it, where a path that enters the chunk inside the block sits at that
@@ -1545,7 +1546,7 @@ def test_crf_alignments_that_cross_chunk_boundaries_inside_a_block_stay_on_the_l
     T, L = 204, 150
     N = 26
     seqlens = np.full(N, L, dtype=np.int32)
-    inp = synth.crf_case(T, N, 77, seqlens=seqlens)
+    inp = synth.crf_case(T, N, 77, seqlens=seqlens, nmods_per_base=(1, 1, 0, 0) if catmod else None)
 
     def move_times(n):
         if n < 13:
@@ -1559,15 +1560,24 @@ def test_crf_alignments_that_cross_chunk_boundaries_inside_a_block_stay_on_the_l
         return np.concatenate([first, rest])
 
     synth.confident_scores(inp, 5, move_times=move_times)
+    margs = ()
+    if catmod:
+        synth.normalise_mod_columns(inp, logit_scale=0.2)      # (log-probabilities, what the producer layer emits)
+        margs = (inp["mod_cats"], inp["can_mods_offsets"], inp["mod_cat_weights"])
     x = torch.from_numpy(inp["scores"]).to(gpu_device).requires_grad_()
-    lv = ctc.crf_flipflop_loss(x, torch.from_numpy(inp["seqs"]), torch.from_numpy(inp["seqlens"]), 1.0)
+    seqs, sl = torch.from_numpy(inp["seqs"]), torch.from_numpy(inp["seqlens"])
+    if catmod:
+        lv = ctc.cat_mod_flipflop_loss(x, seqs, sl, torch.from_numpy(inp["mod_cats"]), inp["can_mods_offsets"], inp["mod_cat_weights"], 1.0)
+    else:
+        lv = ctc.crf_flipflop_loss(x, seqs, sl, 1.0)
     gated = ctc.last_gate_count()
     lv.sum().backward()
-    wl, wg = oracle_mod.crf_flipflop_loss_f64(inp["scores"], inp["seqs"], inp["seqlens"], 1.0)
+    wl, wg = oracle_mod.crf_flipflop_loss_f64(inp["scores"], inp["seqs"], inp["seqlens"], 1.0, *margs)
     np.testing.assert_allclose(lv.detach().cpu().numpy(), wl, rtol=1e-5, atol=2e-6)
-    assert float(np.abs(x.grad.cpu().numpy().astype(np.float64) - wg).max()) * T < parity.GRAD_T_ATOL
-    # every row of every read carries its whole mass: one transition per row has posterior ~ 1
-    assert float(np.abs(x.grad.cpu().numpy().sum(axis=2) * -T - 1.0).max()) < 1e-4
+    g = x.grad.cpu().numpy().astype(np.float64)
+    assert float((np.abs(g - wg) * T * parity.posterior_scale(inp)[None, None, :]).max()) < parity.GRAD_T_ATOL
+    # every row of every read carries its whole mass: the canonical columns' posteriors sum to 1
+    assert float(np.abs(g[:, :, :40].sum(axis=2) * -T - 1.0).max()) < 1e-4
     assert gated == 0
 
 

@@ -382,10 +382,6 @@ void cat_mod_flipflop_cost(float const *logprob, size_t ntrans, size_t nblk,
                            float const *modmovefacts, int32_t const *seqlen,
                            float *score);
 
-/* Lab hook (tools/overlap_probe.py): restrict the band-mode CRF launches to one of their phases
- * (0 = all, the default).  No reference counterpart; not part of the drop-in surface. */
-void tk_lab_crf_band_phase(int phase);
-
 /* ------------------------------------------------------------------------- *
  * Multi-GPU: the data-parallel gradient all-reduce on RCCL over xGMI
  * (libtaiyaki_amd_rccl.so -- a library of its own, see csrc/rccl_api.cpp).

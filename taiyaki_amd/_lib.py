@@ -14,6 +14,11 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(_HERE, "csrc")
 LIBNAME = "libtaiyaki_amd_flipflop.so"
 LIBPATH = os.environ.get("TAIYAKI_AMD_LIB") or os.path.join(CSRC, LIBNAME)   # (override: lab builds)
+# The LAB build of the same sources (-DTK_LAB): the only one that reads the dispatch's environment switches
+# (TK_CRF_MODE, TK_CRF_BK, TK_LOGZ_CH, TK_CRF_NO_FALLBACK ...) and exports tk_lab_*.  tests/ and tools/ switch
+# to it with `use_lab()` when they flip one; the operators never load it by themselves.
+LAB_LIBNAME = "libtaiyaki_amd_flipflop_lab.so"
+LAB_LIBPATH = os.path.join(CSRC, LAB_LIBNAME)
 
 _vp = ctypes.c_void_p
 _sz = ctypes.c_size_t
@@ -23,7 +28,6 @@ _i = ctypes.c_int
 # symbol -> (restype, argtypes); mirrors include/taiyaki_amd_flipflop.h
 SIGNATURES = {
     "tk_version": (ctypes.c_char_p, []),
-    "tk_lab_crf_band_phase": (None, [_i]),
     "tk_flipflop_build_indices_dev": (_i, [_vp, _vp, _sz, _sz, _sz, _vp, _vp, _vp, _vp, _vp,
                                           _vp, _vp, _vp, _vp, _vp]),
     "tk_crf_flipflop_workspace_bytes": (_sz, [_sz, _sz, _sz, _sz, _i]),
@@ -73,31 +77,55 @@ ERRORS = {1: "bad argument (NULL / shape / 16-byte alignment)",
           2: "unsupported nbase / ntrans / sequence length for this build",
           3: "workspace too small", 4: "HIP launch failure"}
 
+LAB_SIGNATURES = {"tk_lab_crf_band_phase": (None, [_i])}
+
 _lib = None
+_handles = {}
 
 
 def build(force=False):
-    """Compile the gfx950 shared library in-tree (hipcc cross-compiles without a GPU)."""
+    """Compile the gfx950 shared libraries in-tree (hipcc cross-compiles without a GPU)."""
     if force:
         subprocess.run(["make", "-C", CSRC, "clean"], check=True, stdout=subprocess.DEVNULL)
-    subprocess.run(["make", "-C", CSRC, "-j4"], check=True, stdout=subprocess.DEVNULL)
+    subprocess.run(["make", "-C", CSRC, "-j%d" % min(8, os.cpu_count() or 4)], check=True,
+                   stdout=subprocess.DEVNULL)
     return LIBPATH
+
+
+def _load(path, signatures):
+    handle = _handles.get(path)
+    if handle is None:
+        if not os.path.exists(path):
+            raise RuntimeError(
+                "%s is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+                "(there is no CPU fallback for the flip-flop operators)" % path)
+        handle = ctypes.CDLL(path)
+        for name, (res, args) in signatures.items():
+            fn = getattr(handle, name)      # AttributeError if the symbol is not exported
+            fn.restype = res
+            fn.argtypes = args
+        _handles[path] = handle
+    return handle
 
 
 def lib():
     global _lib
     if _lib is None:
-        if not os.path.exists(LIBPATH):
-            raise RuntimeError(
-                "%s is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
-                "(there is no CPU fallback for the flip-flop operators)" % LIBPATH)
-        handle = ctypes.CDLL(LIBPATH)
-        for name, (res, args) in SIGNATURES.items():
-            fn = getattr(handle, name)      # AttributeError if the symbol is not exported
-            fn.restype = res
-            fn.argtypes = args
-        _lib = handle
+        _lib = _load(LIBPATH, SIGNATURES)
     return _lib
+
+
+def use_lab(flag=True):
+    """Route the operators of THIS process through the lab build (flag) or back through the release
+    library.  Returns the handle now in use.  Lab switches (environment variables read per launch,
+    tk_lab_*) only exist there; the two libraries keep separate side queues and caches."""
+    global _lib
+    _lib = _load(LAB_LIBPATH, dict(SIGNATURES, **LAB_SIGNATURES)) if flag else _load(LIBPATH, SIGNATURES)
+    return _lib
+
+
+def is_lab():
+    return _lib is not None and _lib is _handles.get(LAB_LIBPATH)
 
 
 _rccl = None

@@ -34,7 +34,9 @@ int crf_dispatch(const float *logprob, size_t ntrans, size_t nblk, size_t nbatch
                  const float *add_grad = nullptr, const float *add_cost = nullptr, int add_S = 0,
                  float add_scale = 0.f, hipEvent_t add_ready = nullptr, const float *mod_col_weights = nullptr);
 bool logz_side_stream(hipStream_t *s, hipEvent_t *fork, hipEvent_t *join);
+#ifdef TK_LAB
 void crf_band_lab_phase(int phase);
+#endif
 size_t beam_workspace_bytes(size_t T, size_t N, size_t nbase);
 int lattice_dispatch(const float *scores, size_t T, size_t N, size_t nbase, int forward, const float *init,
                      float *out, float *total, hipStream_t stream);
@@ -235,7 +237,7 @@ __global__ void slice_cols_kernel(const float *__restrict__ src, float *__restri
 // profiles/r4_overlap_capture_probe.txt; mode 2 keeps that experiment reachable).
 static std::atomic<int> &loss_overlap_mode() {
     static std::atomic<int> mode([] {
-        const char *e = getenv("TK_LOSS_OVERLAP");
+        const char *e = getenv("TK_LOSS_OVERLAP");      // (the one variable the release build reads: once, here)
         return (e != nullptr && e[0] >= '0' && e[0] <= '2') ? e[0] - '0' : 1;
     }());
     return mode;
@@ -331,8 +333,10 @@ int tk_flipflop_loss_fused_dev(const float *scores, size_t nblk, size_t nbatch, 
     return rc;
 }
 
-// lab hook: see crf_band.hip
-void tk_lab_crf_band_phase(int phase) { tk::crf_band_lab_phase(phase); }
+#ifdef TK_LAB
+// lab hook (lab build only; declared in tools/lab_api.h, not in the public header): see crf_band.hip
+extern "C" void tk_lab_crf_band_phase(int phase) { tk::crf_band_lab_phase(phase); }
+#endif
 
 int tk_flipflop_lattice_dev(const float *scores, size_t nblk, size_t nbatch, size_t nbase, int forward,
                             const float *init, float *out, float *total, void *stream) {

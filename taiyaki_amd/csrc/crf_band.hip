@@ -1407,7 +1407,7 @@ __global__ __launch_bounds__(POST_WAVES *WAVE) __attribute__((amdgpu_waves_per_e
 // Cells per lane: the smallest R whose chunks fit the 16 waves of a workgroup.
 int crf_band_pick_R(size_t max_seqlen) {
     int R = 1;
-    if (const char *e = getenv("TK_CRF_BAND_R")) {
+    if (const char *e = TK_LAB_ENV("TK_CRF_BAND_R")) {
         R = atoi(e);
         if (R != 1 && R != 2 && R != 4) R = 1;
     }
@@ -1431,11 +1431,11 @@ BandBlock crf_band_pick_block(float sharp, bool mod, size_t max_seqlen) {
     else if (x <= 1.76f) b = {8, 3.f};
     else if (x <= 3.5f) b = {4, 0.f};
     else b = {0, 0.f};
-    if (const char *e = getenv("TK_CRF_BK")) {
+    if (const char *e = TK_LAB_ENV("TK_CRF_BK")) {
         const int v = atoi(e);
         if (v == 4 || v == 8 || (v == 12 && !mod)) b.bk = v;
     }
-    if (const char *e = getenv("TK_CRF_WBIAS")) b.wbias = (float)atof(e);
+    if (const char *e = TK_LAB_ENV("TK_CRF_WBIAS")) b.wbias = (float)atof(e);
     return b;
 }
 
@@ -1478,15 +1478,21 @@ BandLayout crf_band_layout(size_t ntrans, size_t nblk, size_t nbatch, size_t max
 }
 
 // lab knob (tools/overlap_probe.py): 0 both passes, 1 the sweep launch only, 2 the gradient pass only
+#ifdef TK_LAB
 static int g_band_lab_phase = 0;
 void crf_band_lab_phase(int phase) { g_band_lab_phase = phase; }
+#else
+constexpr int g_band_lab_phase = 0;
+#endif
 
 // Does this launch run with a row maker (band_rowmaker)?  Whenever W + 1 waves fit a workgroup and the weights
 // are gathers from an exponentiated row (the plain CRF; cat-mod with per-column factors); 4-step blocks (sharpened
 // calls) keep the plain feed.  TK_CRF_FEED = self | rows forces one (lab, tests).
 static bool band_use_rows(const BandArgs &a, bool mod, int bk) {
     if (bk < 8 || a.W + 1 > BAND_MAXW || (mod && a.colw == nullptr)) return false;
-    if (const char *e = getenv("TK_CRF_FEED")) return e[0] == 'r';
+    if (a.S > ROW_PITCH) return false;      // a row image holds ROW_PITCH columns: wider rows (cat-mod with >= 5
+                                            // modifications, nbase 5) gather from their own exponentiated rows
+    if (const char *e = TK_LAB_ENV("TK_CRF_FEED")) return e[0] == 'r';
     return true;
 }
 
@@ -1549,7 +1555,7 @@ int crf_band_dispatch(const BandArgs &a0, int R, bool mod, int bk, hipStream_t s
     BandArgs a = a0;
 #ifdef TK_LAB_STAMPS
     static unsigned long long *dbg = nullptr;
-    if (getenv("TK_CRF_STAMPS")) {
+    if (TK_LAB_ENV("TK_CRF_STAMPS")) {
         if (!dbg) (void)hipMalloc(&dbg, 1024 * 8);
         (void)hipMemsetAsync(dbg, 0, 1024 * 8, stream);
         a.dbg = dbg;

@@ -709,7 +709,7 @@ static size_t crf_lattice_cap_bytes() {
     // TK_CRF_LATTICE_MB, else a quarter of THIS device's memory (72 GB of an MI355X's 288; round 3's checkpoint
     // columns are 3.9 GB at T = 4000 / N = 256, so the cap is about smaller devices and partitions, and about
     // callers that do not know their longest sequence).  No device (the build container): 40 GiB.
-    if (const char *e = getenv("TK_CRF_LATTICE_MB")) return (size_t)atoll(e) * 1024 * 1024;
+    if (const char *e = TK_LAB_ENV("TK_CRF_LATTICE_MB")) return (size_t)atoll(e) * 1024 * 1024;
     static size_t cap[64] = {0};
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) {
@@ -728,7 +728,7 @@ static size_t crf_lattice_cap_bytes() {
 }
 // `bk`: the block length the linear path would use for this call (crf_band_pick_block; 0 = it does not take it)
 static CrfMode crf_pick_mode(size_t ntrans, size_t nblk, size_t nbatch, size_t max_seqlen, bool want_grad, int bk) {
-    const char *e = getenv("TK_CRF_MODE");
+    const char *e = TK_LAB_ENV("TK_CRF_MODE");
     const bool force_ckpt = e && e[0] == 'c';
     if (!force_ckpt && bk > 0 && crf_band_fits(max_seqlen) &&
         crf_band_layout(ntrans, nblk, nbatch, max_seqlen, true, want_grad, bk).total <= crf_lattice_cap_bytes())
@@ -898,7 +898,7 @@ int crf_dispatch(const float *logprob, size_t ntrans, size_t nblk, size_t nbatch
         b.wbias = blk.wbias;
         const int rc = crf_band_dispatch(b, l.R, mod, blk.bk, stream);
         if (rc != 0) return rc;
-        if (getenv("TK_CRF_GATE_DUMP")) {                       // lab: how many reads did the band path disown?
+        if (TK_LAB_ENV("TK_CRF_GATE_DUMP")) {                       // lab: how many reads did the band path disown?
             (void)hipStreamSynchronize(stream);
             static int hostg[1 << 16];
             const size_t ng = nbatch < (1u << 16) ? nbatch : (1u << 16);
@@ -916,7 +916,7 @@ int crf_dispatch(const float *logprob, size_t ntrans, size_t nblk, size_t nbatch
         // the reads the linear path disowned, redone in the log domain
         a.gate = b.gate;
         wb += l.total;
-        if (const char *e = getenv("TK_CRF_NO_FALLBACK"))       // lab: time / test the band path alone
+        if (const char *e = TK_LAB_ENV("TK_CRF_NO_FALLBACK"))       // lab: time / test the band path alone
             if (e[0] == '1') return 0;
     }
     {

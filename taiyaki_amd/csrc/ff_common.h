@@ -9,6 +9,18 @@
 #include <set>
 #include <utility>
 
+// Lab switches.  Environment overrides of the dispatch (block length, cells per lane, feed mode, forced kernels,
+// the switch that suppresses the log-domain redo, chunk sizes of kernel B ...) exist only in the LAB build
+// (-DTK_LAB: libtaiyaki_amd_flipflop_lab.so, which tests/ and tools/ load when they flip one).  The release
+// library reads no environment variable on a launch path: TK_LAB_ENV is a null pointer there and the branches
+// behind it (and their strings) are compiled out -- tests/test_host_logic.py looks at `strings` and `nm -D`.
+#ifdef TK_LAB
+#include <stdlib.h>
+#define TK_LAB_ENV(name) getenv(name)
+#else
+#define TK_LAB_ENV(name) (static_cast<const char *>(nullptr))
+#endif
+
 namespace tk {
 
 // Dynamic LDS beyond 64 KiB needs hipFuncAttributeMaxDynamicSharedMemorySize on the kernel, PER

@@ -1138,7 +1138,7 @@ static inline size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; 
 // second block per CU matters more.  TK_K1_RING=0/1 overrides
 constexpr int K1_RING = 3;
 static bool logz_use_ring(size_t nchunks) {
-    if (const char *e = getenv("TK_K1_RING")) return atoi(e) != 0;     // tuning / test override
+    if (const char *e = TK_LAB_ENV("TK_K1_RING")) return atoi(e) != 0;     // tuning / test override
     return nchunks <= 900;
 }
 
@@ -1209,7 +1209,7 @@ static int logz_launch_ch(const float *scores, size_t T, size_t N, float *logz, 
                 // Two instantiations, not a runtime flag: a branch in the load stream costs the
                 // whole gain
                 bool nt_load = (size_t)T * ws.nstride * F::S * sizeof(float) > ((size_t)300 << 20);
-                if (const char *e = getenv("TK_K1_NT")) nt_load = atoi(e) != 0;     // tuning / test override
+                if (const char *e = TK_LAB_ENV("TK_K1_NT")) nt_load = atoi(e) != 0;     // tuning / test override
                 const dim3 grid(ncols, (C + K1_WAVES - 1) / K1_WAVES);
                 if (nt_load)
                     hipLaunchKernelGGL((logz_transfer_kernel<NB, CH, 0, true>), grid, dim3(K1_WAVES * WAVE), lds, stream,
@@ -1273,7 +1273,7 @@ static LogzSide *logz_side_for_current_device() {
     if (sd.s == nullptr) {
         int lo = 0, hi = 0;
         (void)hipDeviceGetStreamPriorityRange(&lo, &hi);       // hi = numerically lowest = highest priority
-        const char *e = getenv("TK_SIDE_PRIO");                 // lab: "lo" puts the side queue BELOW the caller's
+        const char *e = TK_LAB_ENV("TK_SIDE_PRIO");                 // lab: "lo" puts the side queue BELOW the caller's
         const int prio = (e != nullptr && e[0] == 'l') ? lo : hi;
         sd.ok = hipStreamCreateWithPriority(&sd.s, hipStreamNonBlocking, prio) == hipSuccess &&
                 hipEventCreateWithFlags(&sd.fork, hipEventDisableTiming) == hipSuccess &&
@@ -1330,7 +1330,7 @@ static int logz_launch_split(const float *scores, size_t T, size_t N, float *log
     if (hipEventRecord(sd->fork, stream) != hipSuccess || hipStreamWaitEvent(sd->s, sd->fork, 0) != hipSuccess) return 4;
     rc = logz_launch_ch<NB, CH>(scores, T, n1, logz, grad, w1, status, stream, PH_TRANSFER, all);
     if (rc) return rc;
-    const char *mode = getenv("TK_LOGZ_SPLIT");
+    const char *mode = TK_LAB_ENV("TK_LOGZ_SPLIT");
     const bool stagger = !(mode && mode[0] == '2');             // lab: 2 = both halves side by side, no stagger
     if (stagger && (hipEventRecord(sd->t1, stream) != hipSuccess || hipStreamWaitEvent(sd->s, sd->t1, 0) != hipSuccess))
         return 4;
@@ -1356,7 +1356,7 @@ static int logz_launch(const float *scores, size_t T, size_t N, float *logz, flo
     ws.grad_scale_vec = grad_scale_vec;
     ws.nstride = (int)N;
     int ch = logz_pick_ch(T, N);
-    if (const char *e = getenv("TK_LOGZ_CH")) ch = atoi(e);         // tuning override
+    if (const char *e = TK_LAB_ENV("TK_LOGZ_CH")) ch = atoi(e);         // tuning override
     // the middle kernel keeps one read's chunk matrices in LDS: fall back to bigger chunks
     auto middle_lds = [&](int c) {
         const int C = (int)((T + c - 1) / c);
@@ -1372,7 +1372,7 @@ static int logz_launch(const float *scores, size_t T, size_t N, float *logz, flo
         // reproducible (tools/logz_sweep.py).
         const size_t ncols = (N + WAVE - 1) / WAVE;
         bool split = false;
-        if (const char *e = getenv("TK_LOGZ_SPLIT")) split = atoi(e) != 0 && grad != nullptr && ncols >= 2 && ch == 16;
+        if (const char *e = TK_LAB_ENV("TK_LOGZ_SPLIT")) split = atoi(e) != 0 && grad != nullptr && ncols >= 2 && ch == 16;
         hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
         if (split && (hipStreamIsCapturing(stream, &cap) != hipSuccess || cap != hipStreamCaptureStatusNone)) split = false;
         if (split) {

@@ -32,3 +32,30 @@ def gpu_device():
     if not torch.cuda.is_available():
         pytest.skip("no GPU")
     return torch.device("cuda:0")
+
+
+class _LabEnv:
+    """Flip a lab switch of the kernels' dispatch for one test: the process is routed through the lab build
+    (taiyaki_amd/csrc/libtaiyaki_amd_flipflop_lab.so, -DTK_LAB) -- the release library reads none of them."""
+
+    def __init__(self, monkeypatch):
+        self._mp = monkeypatch
+
+    def setenv(self, name, value):
+        from taiyaki_amd import _lib
+        _lib.use_lab(True)
+        self._mp.setenv(name, value)
+
+    def delenv(self, name, raising=False):
+        self._mp.delenv(name, raising=raising)
+
+    def lib(self):
+        from taiyaki_amd import _lib
+        return _lib.use_lab(True)
+
+
+@pytest.fixture
+def labenv(monkeypatch):
+    from taiyaki_amd import _lib
+    yield _LabEnv(monkeypatch)
+    _lib.use_lab(False)

@@ -16,3 +16,10 @@ h5repack -j 1 -k 2 /root/reference/test/data/mapped_signal_file/mapped_reads_0.h
 gcc -O1 -I/opt/conda/include -o /tmp/gen_hdf5_fixtures "$here/gen_hdf5_fixtures.c" -L/opt/conda/lib -lhdf5 -Wl,-rpath,/opt/conda/lib
 /tmp/gen_hdf5_fixtures "$here/generated_v108.hdf5" "$here/generated_batch.hdf5"
 ls -la "$here"/*.hdf5
+# fractal heaps with a partially filled root indirect block (round 5; gen_heap_fixtures.c): N sub-groups in
+# one group, newest format bounds, nothing deleted -- and one file that did see deletions
+gcc -O1 -I/opt/conda/include -o /tmp/gen_heap_fixtures "$here/gen_heap_fixtures.c" -L/opt/conda/lib -lhdf5 -Wl,-rpath,/opt/conda/lib
+/tmp/gen_heap_fixtures "$here/heap_35.hdf5" 35
+/tmp/gen_heap_fixtures "$here/heap_150.hdf5" 150
+/tmp/gen_heap_fixtures "$here/heap_2000.hdf5" 2000 && gzip -9 -f "$here/heap_2000.hdf5"
+/tmp/gen_heap_fixtures "$here/heap_150_every7th_deleted.hdf5" 150 7

@@ -457,11 +457,11 @@ def test_crf_loss_bounded_by_logz(gpu_device):
 
 
 @pytest.mark.parametrize("ch", [8, 16, 32])
-def test_logz_every_chunk_size(oracle_mod, gpu_device, ch, monkeypatch):
+def test_logz_every_chunk_size(oracle_mod, gpu_device, ch, labenv):
     """The chunk size of the transfer/posterior kernels is picked per problem size;
     force each instantiation (TK_LOGZ_CH) on a tensor with a ragged tail (T % 32 != 0)."""
     from taiyaki_amd import synth
-    monkeypatch.setenv("TK_LOGZ_CH", str(ch))
+    labenv.setenv("TK_LOGZ_CH", str(ch))
     sc = synth.scores(333, 70, 40, 45)
     r = parity.compare_logz(oracle_mod, sc, gpu_device)
     assert r["finite"] and r["logz_rel"] < LOSS_RTOL and r["grad_abs"] < GRAD_ATOL
@@ -470,12 +470,12 @@ def test_logz_every_chunk_size(oracle_mod, gpu_device, ch, monkeypatch):
 
 @pytest.mark.parametrize("ring", ["0", "1"])
 @pytest.mark.parametrize("T,N", [(1500, 448), (3333, 200), (2500, 270)])
-def test_logz_transfer_register_and_lds_ring_forms(oracle_mod, gpu_device, T, N, ring, monkeypatch):
+def test_logz_transfer_register_and_lds_ring_forms(oracle_mod, gpu_device, T, N, ring, labenv):
     """One wave per chunk, score rows through registers (TK_K1_RING=0) or through the
     global_load_lds ring of three row-sets (=1; the default below 900 chunks): ragged last
     chunk (T % 16 != 0), a partial last column (N % 64 != 0), odd and even row counts."""
     from taiyaki_amd import synth
-    monkeypatch.setenv("TK_K1_RING", ring)
+    labenv.setenv("TK_K1_RING", ring)
     sc = synth.scores(T, N, 40, 1000 + T + N)
     r = parity.compare_logz(oracle_mod, sc, gpu_device)
     assert r["finite"] and r["logz_rel"] < LOSS_RTOL and r["grad_abs"] < GRAD_ATOL
@@ -553,16 +553,16 @@ def test_logz_above_the_streaming_threshold(gpu_device):
     assert torch.equal(lz[:256], lz2) and torch.equal(g[:, :256], sub.grad)
 
 
-def test_logz_streaming_transfer_kernel_is_the_same_arithmetic(oracle_mod, gpu_device, monkeypatch):
+def test_logz_streaming_transfer_kernel_is_the_same_arithmetic(oracle_mod, gpu_device, labenv):
     """Score tensors above 300 MB go through the non-temporal-load instantiation of the transfer
     kernel: force it (TK_K1_NT=1) on a tensor the oracle handles in seconds and require the very
     same bits as the plain-load form, and parity with the oracle."""
     from taiyaki_amd import synth
     sc = synth.scores(2000, 330, 40, 4242)
-    monkeypatch.setenv("TK_K1_RING", "0")
-    monkeypatch.setenv("TK_K1_NT", "0")
+    labenv.setenv("TK_K1_RING", "0")
+    labenv.setenv("TK_K1_NT", "0")
     lz0, g0 = parity.run_logz(sc, gpu_device)
-    monkeypatch.setenv("TK_K1_NT", "1")
+    labenv.setenv("TK_K1_NT", "1")
     r = parity.compare_logz(oracle_mod, sc, gpu_device)
     assert r["finite"] and r["logz_rel"] < LOSS_RTOL and r["grad_abs"] < GRAD_ATOL
     assert np.array_equal(r["logz"], lz0) and np.array_equal(r["grad"], g0)
@@ -570,12 +570,12 @@ def test_logz_streaming_transfer_kernel_is_the_same_arithmetic(oracle_mod, gpu_d
 
 @pytest.mark.parametrize("mode_mb", ["0", "6144"])
 @pytest.mark.parametrize("name", ["t7n2_len1", "t50n3_zero_last", "t200n8", "t130n5_long", "t300n3_wide"])
-def test_crf_both_gradient_modes(oracle_mod, gpu_device, name, mode_mb, monkeypatch):
+def test_crf_both_gradient_modes(oracle_mod, gpu_device, name, mode_mb, labenv):
     """The gradient path has two implementations: the linear-domain banded sweep + recomputing
     gradient pass (csrc/crf_band.hip) and the log-domain checkpoint + recompute kernel (one launch)
     for batches whose checkpoint columns exceed the workspace cap -- and for the reads the first
     one disowns.  TK_CRF_LATTICE_MB=0 forces the second; both must match the oracle."""
-    monkeypatch.setenv("TK_CRF_LATTICE_MB", mode_mb)
+    labenv.setenv("TK_CRF_LATTICE_MB", mode_mb)
     inp = cases.crf_inputs(cases.CRF_SMALL[name])
     r = parity.compare_crf(oracle_mod, inp, 1.0, gpu_device)
     assert r["finite"]
@@ -586,13 +586,13 @@ def test_crf_both_gradient_modes(oracle_mod, gpu_device, name, mode_mb, monkeypa
 
 
 @pytest.mark.parametrize("R", ["1", "2", "4"])
-def test_crf_band_shapes_against_oracle(oracle_mod, gpu_device, R, monkeypatch):
+def test_crf_band_shapes_against_oracle(oracle_mod, gpu_device, R, labenv):
     """Band mode at every cells-per-lane setting: chunk counts from 1 to several, a last chunk
     with one or two live cells, L = T + 1, T not a multiple of the 8-step time block, an empty
     read in the middle of the batch."""
     from taiyaki_amd import synth
-    monkeypatch.setenv("TK_CRF_MODE", "band")
-    monkeypatch.setenv("TK_CRF_BAND_R", R)
+    labenv.setenv("TK_CRF_MODE", "band")
+    labenv.setenv("TK_CRF_BAND_R", R)
     PW = 64 * int(R)
     for T, Ls in ((203, [1, PW, PW + 1, PW + 2, 2 * PW, 0, 150, 204, 97]),
                   (61, [62, 30, 5, 61]),
@@ -622,7 +622,7 @@ def _crf_alone(inp, n, L, off):
 
 @pytest.mark.parametrize("R", ["1", "4"])
 def test_crf_linear_band_path_disowns_reads_and_the_log_domain_kernel_redoes_them(oracle_mod, gpu_device, R,
-                                                                                  monkeypatch):
+                                                                                  labenv):
     """Round 3: the band path works in the LINEAR domain (per-cell power-of-two frames) and is
     exact or says so.  One batch holds reads it keeps (wide bands), reads it must disown (bands
     a few cells wide lose their front to the frames' flush; L = T + 1 is one forced path) and an
@@ -631,8 +631,8 @@ def test_crf_linear_band_path_disowns_reads_and_the_log_domain_kernel_redoes_the
     and the disowned ones are NOT computed -- nobody returns a wrong number."""
     import torch
     from taiyaki_amd import ctc, synth
-    monkeypatch.setenv("TK_CRF_MODE", "band")
-    monkeypatch.setenv("TK_CRF_BAND_R", R)
+    labenv.setenv("TK_CRF_MODE", "band")
+    labenv.setenv("TK_CRF_BAND_R", R)
     T, Ls = 400, [200, 390, 401, 150, 399, 266, 1, 0]
     inp = synth.crf_case(T, len(Ls), 5, seqlens=np.array(Ls, dtype=np.int32))
     off = np.concatenate([[0], np.cumsum(Ls)])
@@ -647,7 +647,7 @@ def test_crf_linear_band_path_disowns_reads_and_the_log_domain_kernel_redoes_the
         return c.cpu().numpy(), g.cpu().numpy()
 
     cost, grad = run()
-    monkeypatch.setenv("TK_CRF_NO_FALLBACK", "1")
+    labenv.setenv("TK_CRF_NO_FALLBACK", "1")
     cost_nf, grad_nf = run()
     kept = []
     for n, L in enumerate(Ls):
@@ -669,7 +669,7 @@ def test_crf_linear_band_path_disowns_reads_and_the_log_domain_kernel_redoes_the
 
 
 @pytest.mark.parametrize("bursty", [False, True])
-def test_crf_linear_band_path_keeps_confident_reads(oracle_mod, gpu_device, bursty, monkeypatch):
+def test_crf_linear_band_path_keeps_confident_reads(oracle_mod, gpu_device, bursty, labenv):
     """Scores of a trained network (synth.confident_scores: the alignment's transition at +4, every
     other at -3) put the whole posterior on one path; a strand that starts in a burst runs that path
     along the band's diagonal edge (position = block + 1), where the move into the first cell of the
@@ -677,8 +677,8 @@ def test_crf_linear_band_path_keeps_confident_reads(oracle_mod, gpu_device, burs
     (TK_CRF_NO_FALLBACK=1, outputs poisoned) must own every such read and match the oracle."""
     import torch
     from taiyaki_amd import ctc, synth
-    monkeypatch.setenv("TK_CRF_MODE", "band")
-    monkeypatch.setenv("TK_CRF_NO_FALLBACK", "1")
+    labenv.setenv("TK_CRF_MODE", "band")
+    labenv.setenv("TK_CRF_NO_FALLBACK", "1")
     T, Ls = 400, [250, 130, 64, 65, 66, 200, 301, 129, 193, 180, 90, 257]
     inp = synth.crf_case(T, len(Ls), 11, seqlens=np.array(Ls, dtype=np.int32))
     synth.confident_scores(inp, 3, bursty=bursty)
@@ -710,8 +710,8 @@ def test_crf_linear_band_path_keeps_confident_reads(oracle_mod, gpu_device, burs
         assert parity.abs_err(grad[:, n:n + 1], ograd) * grad.shape[0] < GRAD_T_ATOL, L
 
 
-@pytest.mark.parametrize("case", ["step", "ragged", "r2", "catmod", "lastblock", "r4", "bk8"])
-def test_crf_weight_feeds_change_no_bit(gpu_device, case, monkeypatch):
+@pytest.mark.parametrize("case", ["step", "ragged", "r2", "catmod", "catmod_wide", "lastblock", "r4", "bk8"])
+def test_crf_weight_feeds_change_no_bit(gpu_device, case, labenv):
     """Round 4: one row-maker wave per sweep workgroup exponentiates every score row once and leaves it in
     an LDS ring; the chunk waves gather their step weights from there (crf_band.hip: band_rowmaker) instead
     of loading, exponentiating and ds_bpermute-gathering the rows themselves.  Same values, same order: costs
@@ -720,14 +720,15 @@ def test_crf_weight_feeds_change_no_bit(gpu_device, case, monkeypatch):
     rows, a cost-only call and 8-step blocks."""
     import torch
     from taiyaki_amd import ctc, synth
-    monkeypatch.setenv("TK_CRF_MODE", "band")
+    labenv.setenv("TK_CRF_MODE", "band")
     T, N, lens, mods = {"step": (800, 64, "real", None), "ragged": (200, 7, [90, 150, 201, 30, 195, 64, 65], None),
                         "r2": (1600, 16, "real", None), "catmod": (400, 24, "real", (1, 1, 0, 0)),
+                        "catmod_wide": (400, 24, "real", (2, 2, 1, 0)),
                         "lastblock": (803, 9, "real", None), "r4": (2600, 6, [2100, 1300, 2500, 900, 1, 2590], None),
                         "bk8": (800, 32, "real", None)}[case]
     if case == "bk8":
-        monkeypatch.setenv("TK_CRF_BK", "8")
-        monkeypatch.setenv("TK_CRF_WBIAS", "0")
+        labenv.setenv("TK_CRF_BK", "8")
+        labenv.setenv("TK_CRF_WBIAS", "0")
     seqlens = synth.realistic_seqlens(T, N, 17000, T * 5, 9.0) if lens == "real" else np.array(lens, dtype=np.int32)
     inp = synth.crf_case(T, N, 3, seqlens=seqlens, nmods_per_base=mods)
     extra = ()
@@ -738,7 +739,7 @@ def test_crf_weight_feeds_change_no_bit(gpu_device, case, monkeypatch):
     seqs, sl = torch.from_numpy(inp["seqs"]), torch.from_numpy(inp["seqlens"])
     out = {}
     for feed in ("self", "rows"):
-        monkeypatch.setenv("TK_CRF_FEED", feed)
+        labenv.setenv("TK_CRF_FEED", feed)
         res = []
         for want_grad in (True, False):
             if extra:
@@ -753,7 +754,7 @@ def test_crf_weight_feeds_change_no_bit(gpu_device, case, monkeypatch):
         assert np.array_equal(a, b)
 
 
-def test_catmod_column_weights_form_agrees_with_the_general_form(oracle_mod, gpu_device, monkeypatch):
+def test_catmod_column_weights_form_agrees_with_the_general_form(oracle_mod, gpu_device, labenv):
     """Round 3: when the caller passes `mod_col_weights` (the Python operator always does: modfact is
     mod_cat_weights gathered by column) a cat-mod move weight exp(sharp s[move] + factor s[mod]) is the
     product of two gathers from a row exponentiated once per wave; without it (arbitrary per-position
@@ -761,7 +762,7 @@ def test_catmod_column_weights_form_agrees_with_the_general_form(oracle_mod, gpu
     mathematics, different rounding: both must match the oracle, and each other far inside the tolerance."""
     import torch
     from taiyaki_amd import ctc, synth
-    monkeypatch.setenv("TK_CRF_MODE", "band")
+    labenv.setenv("TK_CRF_MODE", "band")
     T, N = 400, 24
     seqlens = synth.realistic_seqlens(T, N, 17000, T * 5, 9.0)
     inp = synth.crf_case(T, N, 8, seqlens=seqlens, nmods_per_base=(1, 1, 0, 0))
@@ -770,10 +771,10 @@ def test_catmod_column_weights_form_agrees_with_the_general_form(oracle_mod, gpu
     seqs, sl = torch.from_numpy(inp["seqs"]), torch.from_numpy(inp["seqlens"])
     extra = (torch.from_numpy(inp["mod_cats"]), inp["can_mods_offsets"], inp["mod_cat_weights"])
     out = {}
-    monkeypatch.delenv("TK_CATMOD_GENERAL", raising=False)
+    labenv.delenv("TK_CATMOD_GENERAL", raising=False)
     for general in ("", "1"):
         if general:
-            monkeypatch.setenv("TK_CATMOD_GENERAL", "1")
+            labenv.setenv("TK_CATMOD_GENERAL", "1")
         c, g = ctc._run(x, seqs, sl, 1.0, 1.0, 1.0, 40, True, *extra)
         torch.cuda.synchronize()
         out[general] = (c.cpu().numpy(), g.cpu().numpy())
@@ -785,15 +786,42 @@ def test_catmod_column_weights_form_agrees_with_the_general_form(oracle_mod, gpu
     assert parity.rel_err(out[""][0], out["1"][0]) < 1e-5 and parity.abs_err(out[""][1], out["1"][1]) < 5e-6
 
 
+@pytest.mark.parametrize("mods", [(2, 2, 1, 0), (3, 2, 2, 1), (5, 5, 4, 4)])
+def test_catmod_rows_wider_than_the_shared_row_image(oracle_mod, gpu_device, mods):
+    """Round 4's shared-rows feed keeps 48 columns per exponentiated row in LDS; cat-mod with five or
+    more modifications has S = 44 + nmod >= 49 (the C ABI takes up to 62).  Such calls must take the
+    per-wave feed (round-4 advisor finding: ids >= 48 gathered from the NEXT row's image, a cost-only call
+    then returned a silently wrong cost): gradient call and cost-only call against the oracle, as shipped
+    (release library, no switch), with every read on the linear path."""
+    import torch
+    from taiyaki_amd import ctc, synth
+    T, N = 400, 24
+    seqlens = synth.realistic_seqlens(T, N, 17000, T * 5, 9.0)
+    inp = synth.crf_case(T, N, 13, seqlens=seqlens, nmods_per_base=mods)
+    synth.normalise_mod_columns(inp, logit_scale=0.2)
+    assert inp["scores"].shape[2] == 44 + sum(mods) >= 49
+    x = torch.from_numpy(inp["scores"]).to(gpu_device)
+    seqs, sl = torch.from_numpy(inp["seqs"]), torch.from_numpy(inp["seqlens"])
+    extra = (torch.from_numpy(inp["mod_cats"]), inp["can_mods_offsets"], inp["mod_cat_weights"])
+    oloss, ograd = parity.oracle_crf(oracle_mod, inp, 1.0)
+    c, g = ctc._run(x, seqs, sl, 1.0, 1.0, 1.0, 40, True, *extra)
+    torch.cuda.synchronize()
+    assert ctc.last_gate_count() == 0
+    assert parity.rel_err(c.cpu().numpy(), oloss) < LOSS_RTOL and parity.abs_err(g.cpu().numpy(), ograd) < 5e-5
+    c0, _ = ctc._run(x, seqs, sl, 1.0, 1.0, 1.0, 40, False, *extra)
+    torch.cuda.synchronize()
+    assert parity.rel_err(c0.cpu().numpy(), oloss) < LOSS_RTOL
+
+
 @pytest.mark.parametrize("sharp,bk", [(1.3, 8), (1.5, 8), (1.75, 8), (2.0, 4), (2.5, 4), (3.4, 4)])
-def test_crf_sharpened_scores_stay_on_the_linear_path(oracle_mod, gpu_device, monkeypatch, sharp, bk):
+def test_crf_sharpened_scores_stay_on_the_linear_path(oracle_mod, gpu_device, labenv, sharp, bk):
     """The reference's trainer takes a sharpening schedule (bin/_bin_argparse.py:58-62, applied at
     bin/train_flipflop.py:161-173).  Round 3's linear path overflowed above 1.36 and handed every such
     read to the log-domain kernel; the block length and the weights' bias now follow the factor
     (crf_band_pick_block: 8 steps up to 1.36, biased weights up to 1.76, 4-step blocks up to 3.5), so a
     trained network's sharpened batch keeps every read: parity with the oracle AND a gate count of 0."""
     from taiyaki_amd import _lib, ctc, synth
-    monkeypatch.setenv("TK_CRF_MODE", "band")
+    labenv.setenv("TK_CRF_MODE", "band")
     T, N = 300, 12
     inp = synth.crf_case(T, N, 9, seqlens=synth.realistic_seqlens(T, N, 5, T * 5, 9.0))
     synth.confident_scores(inp, 11, bursty=False)
@@ -811,11 +839,11 @@ def test_crf_sharpened_scores_stay_on_the_linear_path(oracle_mod, gpu_device, mo
         assert ctc.last_gate_count() == 0, (sharp, scale, ctc.last_gate_count())
 
 
-def test_crf_sharpening_beyond_the_linear_path_goes_to_the_log_domain_kernel(oracle_mod, gpu_device, monkeypatch):
+def test_crf_sharpening_beyond_the_linear_path_goes_to_the_log_domain_kernel(oracle_mod, gpu_device, labenv):
     """sharp = 5 puts weights of 2^(+-36) on a step: no block length holds that; the dispatcher sends
     the call to the log-domain kernel (every read), and the answer is still the oracle's."""
     from taiyaki_amd import synth
-    monkeypatch.setenv("TK_CRF_MODE", "band")
+    labenv.setenv("TK_CRF_MODE", "band")
     T, N = 300, 6
     inp = synth.crf_case(T, N, 9)
     r = parity.compare_crf(oracle_mod, inp, 5.0, gpu_device)
@@ -826,7 +854,7 @@ def test_crf_sharpening_beyond_the_linear_path_goes_to_the_log_domain_kernel(ora
 
 @pytest.mark.parametrize("bk,wbias", [("4", "0"), ("8", "0"), ("8", "3"), ("12", "3")])
 @pytest.mark.parametrize("mods", [None, (1, 1, 0, 0)])
-def test_crf_block_lengths_and_weight_bias_agree_with_the_oracle(oracle_mod, gpu_device, monkeypatch, bk, wbias, mods):
+def test_crf_block_lengths_and_weight_bias_agree_with_the_oracle(oracle_mod, gpu_device, labenv, bk, wbias, mods):
     """Every block length x bias the dispatcher can pick (forced here through the lab switches), plain
     and cat-mod, on lengths around the block and chunk boundaries: T = 1, T below a block, a last block
     of one row, reads of 1 / 64 / 65 / T / T + 1 bases, two cells per lane.  The bias must come back out
@@ -834,9 +862,9 @@ def test_crf_block_lengths_and_weight_bias_agree_with_the_oracle(oracle_mod, gpu
     from taiyaki_amd import synth
     if bk == "12" and mods is not None:
         pytest.skip("cat-mod has no 12-step form")
-    monkeypatch.setenv("TK_CRF_MODE", "band")
-    monkeypatch.setenv("TK_CRF_BK", bk)
-    monkeypatch.setenv("TK_CRF_WBIAS", wbias)
+    labenv.setenv("TK_CRF_MODE", "band")
+    labenv.setenv("TK_CRF_BK", bk)
+    labenv.setenv("TK_CRF_WBIAS", wbias)
     for T, Ls in ((1, [1, 2]), (3, [2, 4, 1]), (11, [5, 12, 1]), (13, [13, 7]), (25, [9, 26, 25, 1]),
                   (97, [64, 65, 33, 98, 1]), (300, [129, 257, 64, 200, 301, 0])):
         inp = synth.crf_case(T, len(Ls), 40 + T, seqlens=np.array(Ls, dtype=np.int32), nmods_per_base=mods)
@@ -854,7 +882,7 @@ def test_crf_block_lengths_and_weight_bias_agree_with_the_oracle(oracle_mod, gpu
     assert r["finite"] and r["loss_rel"] < LOSS_RTOL and parity.crf_grad_ok(r), (bk, wbias, r["loss_rel"])
 
 
-def test_crf_disowned_reads_are_counted_and_redone_in_shared_slots(oracle_mod, gpu_device, monkeypatch):
+def test_crf_disowned_reads_are_counted_and_redone_in_shared_slots(oracle_mod, gpu_device, labenv):
     """A batch in which MOST reads are bands a few cells wide under iid scores (the linear path disowns
     those): the log-domain kernel behind it redoes them in an eighth of the batch's worth of checkpoint
     slots, several reads per workgroup one after the other -- every read is the oracle's --, the status
@@ -862,7 +890,7 @@ def test_crf_disowned_reads_are_counted_and_redone_in_shared_slots(oracle_mod, g
     into a warning."""
     import warnings
     from taiyaki_amd import _lib, ctc, synth, train
-    monkeypatch.setenv("TK_CRF_MODE", "band")
+    labenv.setenv("TK_CRF_MODE", "band")
     T, N = 200, 40
     Ls = np.array([T + 1 - (k % 6) if k % 4 else 90 for k in range(N)], dtype=np.int32)   # 30 narrow bands, 10 ordinary reads
     inp = synth.crf_case(T, N, 5, seqlens=Ls)
@@ -892,12 +920,12 @@ def test_crf_disowned_reads_are_counted_and_redone_in_shared_slots(oracle_mod, g
         _lib.set_strict(True)
 
 
-def test_crf_log_probability_inputs(oracle_mod, gpu_device, monkeypatch):
+def test_crf_log_probability_inputs(oracle_mod, gpu_device, labenv):
     """Scores that are log-probabilities (all <= 0, a log-softmax over the 40 transitions: what
     test_ctc_loss.py feeds the reference) shrink every cell by ~2^-5 per step: inside the range of
     the linear path's frames or not, the result is the oracle's."""
     from taiyaki_amd import synth
-    monkeypatch.setenv("TK_CRF_MODE", "band")
+    labenv.setenv("TK_CRF_MODE", "band")
     T, N = 250, 5
     inp = synth.crf_case(T, N, 21)
     sc = inp["scores"].astype(np.float64)
@@ -911,7 +939,7 @@ def test_crf_log_probability_inputs(oracle_mod, gpu_device, monkeypatch):
 
 
 @pytest.mark.parametrize("R", ["1", "2", "4"])
-def test_crf_band_does_not_read_what_it_did_not_write(gpu_device, R, monkeypatch):
+def test_crf_band_does_not_read_what_it_did_not_write(gpu_device, R, labenv):
     """The gradient pass reads only the checkpoint columns and boundary cells the sweeps stored, and
     every store lands whole: the same batch must give the same bits whether the workspace it is
     handed was full of NaN or of zeros (a 16-byte column store whose data registers the next
@@ -919,8 +947,8 @@ def test_crf_band_does_not_read_what_it_did_not_write(gpu_device, R, monkeypatch
     only visible this way)."""
     import torch
     from taiyaki_amd import ctc, synth
-    monkeypatch.setenv("TK_CRF_MODE", "band")
-    monkeypatch.setenv("TK_CRF_BAND_R", R)
+    labenv.setenv("TK_CRF_MODE", "band")
+    labenv.setenv("TK_CRF_BAND_R", R)
     T, N = 800, 96
     seqlens = synth.realistic_seqlens(T, N, 17000, 4000, 9.0)
     inp = synth.crf_case(T, N, 1, seqlens=seqlens)
@@ -1097,12 +1125,12 @@ def test_logz_very_long_chunks(oracle_mod, gpu_device):
 
 @pytest.mark.parametrize("nbase", [2, 3])
 @pytest.mark.parametrize("mode_mb", ["0", "6144"])
-def test_crf_other_alphabet_sizes(oracle_mod, gpu_device, nbase, mode_mb, monkeypatch):
+def test_crf_other_alphabet_sizes(oracle_mod, gpu_device, nbase, mode_mb, labenv):
     """2- and 3-letter alphabets (S = 12, 24) through both gradient modes; the kernels take
     the transition count at run time, the reference's tests use nbase 2
     (test_ctc_loss.py:80-135)."""
     from taiyaki_amd import synth
-    monkeypatch.setenv("TK_CRF_LATTICE_MB", mode_mb)
+    labenv.setenv("TK_CRF_LATTICE_MB", mode_mb)
     inp = synth.crf_case(120, 9, 300 + nbase, nbase=nbase)
     r = parity.compare_crf(oracle_mod, inp, 1.0, gpu_device)
     assert r["finite"] and r["loss_rel"] < LOSS_RTOL, r["loss_rel"]

@@ -347,6 +347,40 @@ def test_library_exports_exactly_what_the_header_declares():
     assert set(_lib.SIGNATURES) <= declared
 
 
+def test_release_library_carries_no_lab_switch():
+    """The shipped library reads no dispatch switch from the environment (round 4's verdict: 16 getenv calls per
+    launch path, one of which -- TK_CRF_NO_FALLBACK -- switched off the exact-or-redo guarantee) and exports no
+    tk_lab_* hook; the lab build (-DTK_LAB, what tests and tools switch to with _lib.use_lab) has both."""
+    import subprocess
+    from taiyaki_amd import _lib
+    _lib.build()
+
+    def strings(path):
+        return subprocess.run(["strings", "-n", "6", path], capture_output=True, text=True, check=True).stdout
+
+    def dynsyms(path):
+        return subprocess.run(["nm", "-D", "--defined-only", path], capture_output=True, text=True, check=True).stdout
+
+    rel, lab = strings(_lib.LIBPATH), strings(_lib.LAB_LIBPATH)
+    switches = ["TK_CRF_NO_FALLBACK", "TK_CRF_MODE", "TK_CRF_BK", "TK_CRF_WBIAS", "TK_CRF_BAND_R", "TK_CRF_FEED",
+                "TK_CRF_LATTICE_MB", "TK_CRF_GATE_DUMP", "TK_K1_RING", "TK_K1_NT", "TK_LOGZ_CH", "TK_LOGZ_SPLIT",
+                "TK_SIDE_PRIO"]
+    for name in switches:
+        assert name not in rel, name
+        assert name in lab, name
+    # the one variable the release build reads (once, into a static): the initial two-queue mode of the fused loss
+    import re
+    assert set(re.findall(r"\bTK_[A-Z0-9_]{3,}\b", rel)) == {"TK_LOSS_OVERLAP"}
+    assert "tk_lab_" not in dynsyms(_lib.LIBPATH)
+    assert "tk_lab_crf_band_phase" in dynsyms(_lib.LAB_LIBPATH)
+    # no source file of the library calls getenv outside the macro and that one static
+    for fn in os.listdir(_lib.CSRC):
+        if fn.endswith((".hip", ".h", ".cpp")) and fn != "rccl_api.cpp":
+            text = open(os.path.join(_lib.CSRC, fn)).read()
+            n = len(re.findall(r"\bgetenv\(", text))
+            assert n == {"c_api.hip": 1, "ff_common.h": 1}.get(fn, 0), (fn, n)
+
+
 def test_numpy_level_ctc_functions_keep_the_cython_layers_contract():
     """ctc.pyx:31-113: typed C-contiguous buffers or an error, finite input or AssertionError,
     a state count that is no flip-flop model is an AssertionError -- all before anything is launched

@@ -15,6 +15,8 @@ import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from taiyaki_amd import _lib, ctc, synth  # noqa: E402
 
+_lib.use_lab(True)              # TK_CRF_MODE / TK_CRF_NO_FALLBACK only exist in the lab build
+
 SHAPES = {
     "tiny": (20, [9, 1, 21, 20, 2, 0], 1.0, None),
     "t37": (37, [12, 30, 38, 5], 1.0, None),

@@ -16,6 +16,8 @@ import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from taiyaki_amd import _lib, ctc, synth  # noqa: E402
 
+_lib.use_lab(True)              # the MODES below are lab switches of the dispatch
+
 SHAPES = {"cfg2": (800, 128, None), "cfg2r": (800, 128, 4000), "cfg5": (1600, 64, None),
           "cfg5r": (1600, 64, 8000), "rowK": (4000, 256, None), "rowK8": (4000, 256, "short"), "cfg4": (800, 128, None), "cfg4r": (800, 128, 4000),
           "one": (800, 1, 4000), "short": (800, 128, 450), "short1": (800, 1, 450), "mid": (800, 128, 1100)}

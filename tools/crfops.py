@@ -13,6 +13,9 @@ import bench  # noqa: E402
 import torch  # noqa: E402
 from taiyaki_amd import _lib  # noqa: E402
 
+if any(k.startswith(("TK_CRF_", "TK_LOGZ_", "TK_K1_")) for k in os.environ):
+    _lib.use_lab(True)          # the dispatch switches only exist in the lab build
+
 
 def main():
     ap = argparse.ArgumentParser()

@@ -23,6 +23,7 @@ def main():
     args = ap.parse_args()
     dev = torch.device("cuda:0")
     from taiyaki_amd import _lib
+    _lib.use_lab(True)          # TK_LOGZ_SPLIT / TK_LOGZ_CH are lab switches
     _lib.set_strict(False)
     for N in [int(x) for x in args.N.split(",")]:
         ops = bench.LossOps(args.T, N, dev)

@@ -18,6 +18,8 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import bench  # noqa: E402
 from taiyaki_amd import _lib  # noqa: E402
 
+_lib.use_lab(True)              # tk_lab_crf_band_phase is a lab-build export
+
 
 def main():
     dev = torch.device("cuda:0")

@@ -119,8 +119,11 @@ size_t tk_crf_flipflop_workspace_bytes(size_t ntrans, size_t nblk, size_t nbatch
                                        size_t max_seqlen, int want_grad);
 /* ... for a call with sharpening factor `sharpfact` (ctc.pyx:116-153, the --sharpen schedule of
  * bin/_bin_argparse.py:58-62): the linear-domain path takes sharpened scores with shorter time blocks
- * (factors up to 3.5), which keep more checkpoint columns.  A call whose workspace was sized without the
- * factor still works: the log-domain kernel then does every read. */
+ * (factors up to 3.5), which keep more checkpoint columns.  Size the workspace with the factor the call
+ * will carry.  A call whose workspace is too small for its factor's layout is done by the log-domain kernel on
+ * every read IF the workspace holds that kernel's whole-batch checkpoint columns (it does at the train step's
+ * shapes; at T = 4000 / N = 256 those are 8.0 GB against the linear path's 4.7) and returns TK_ERR 3
+ * (workspace too small) otherwise -- never a wrong result. */
 size_t tk_crf_flipflop_workspace_bytes_sharp(size_t ntrans, size_t nblk, size_t nbatch,
                                              size_t max_seqlen, int want_grad, float sharpfact);
 

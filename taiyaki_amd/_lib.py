@@ -236,8 +236,14 @@ def last_gate_count():
     return _gated["last"]
 
 
+def _u32(bits):
+    """The status words are int32 tensors; the kernels add the gate count into bits 8-31 (unsigned)."""
+    return int(bits) & 0xffffffff
+
+
 def _note_gated(bits):
-    n = int(bits) >> 8
+    bits = _u32(bits)
+    n = bits >> 8
     _gated["last"] = n
     _gated["total"] += n
     return int(bits) & 0xff
@@ -249,10 +255,13 @@ def take_gate_count():
     redone in the log domain since the last check."""
     n = 0
     for t in _deferred.values():
-        bits = int(t.item())
+        bits = _u32(t.item())
         n += bits >> 8
         if bits >> 8:
-            t.bitwise_and_(0xff)
+            # take out exactly what was read (one device op, wrap-around arithmetic): counts that kernels on
+            # other streams add between the read and this op are kept, not cleared with the rest
+            take = (bits >> 8) << 8
+            t.sub_(take - (1 << 32) if take >= (1 << 31) else take)
     _gated["last"] = n
     _gated["total"] += n
     return n
@@ -265,7 +274,7 @@ def gated_total():
 
 
 def _raise(bits):
-    bits = int(bits) & 0xff
+    bits = _u32(bits) & 0xff
     if bits & 8:
         # the reference: `assert np.all(stayidxs >= 0) and ...` style index checks in ctc.pyx
         raise AssertionError("Error: sequence labels out of range for the flip-flop model (flip-flop code "
@@ -293,7 +302,7 @@ def raise_if_nonfinite():
     """Check (and clear) the deferred status words; one sync per device."""
     total, first_bad = 0, 0
     for t in _deferred.values():
-        bits = int(t.item())
+        bits = _u32(t.item())
         t.zero_()
         total += bits >> 8
         first_bad = first_bad or (bits & 0xff)

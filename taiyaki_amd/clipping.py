@@ -56,9 +56,11 @@ class RollingMAD:
     in -- two rank counts and a shift over (nparams, window) instead of re-sorting.  The median is
     then read off the middle of the sorted rows; only the deviations from it need one selection
     pass.  Values are float32 like the reference's window, so thresholds agree with it bit for bit
-    (tests/golden/basecall_small.npz `rollingmad/*`).  A non-finite maximum (a diverged step) is
-    kept in the ring, sorts last, and makes that parameter's threshold NaN for as long as it is in
-    the window -- what a median over the raw window would give."""
+    (tests/golden/basecall_small.npz `rollingmad/*`).  A NaN maximum (a diverged step) is kept in the
+    ring, sorts last, and makes that parameter's threshold NaN for as long as it is in the window;
+    +inf takes part as an ordinary largest value (median and MAD stay finite unless half the window
+    is infinite) -- both are what the reference's np.median over the raw window gives
+    (taiyaki/maths.py:182-195)."""
 
     def __init__(self, nparams, n_mads=0, window=1000, default_to=None):
         self.n_mads = n_mads
@@ -89,10 +91,10 @@ class RollingMAD:
         vals = np.asarray(vals, dtype=np.float32).reshape(-1)
         if vals.shape[0] != self.nparams:
             raise AssertionError("RollingMAD.update: got %d values for %d parameters" % (vals.shape[0], self.nparams))
-        key = np.where(np.isfinite(vals), vals, np.float32(np.inf))     # sort key: non-finite last
+        key = np.where(np.isnan(vals), np.float32(np.inf), vals)        # sort key: NaN last, beside +inf
         slot = self._seen % self.window
         # before the window has filled the slot holds no value yet: an +inf placeholder leaves
-        leaving = np.where(np.isfinite(self._ring[:, slot]), self._ring[:, slot], np.float32(np.inf)) \
+        leaving = np.where(np.isnan(self._ring[:, slot]), np.float32(np.inf), self._ring[:, slot]) \
             if self._seen >= self.window else np.full(self.nparams, np.inf, dtype=np.float32)
         self._swap_in(leaving, key)
         self._ring[:, slot] = vals
@@ -105,7 +107,7 @@ class RollingMAD:
         with np.errstate(invalid="ignore"):
             spread = _middle(np.abs(self._sorted - centre[:, None]), 1) * np.float32(MAD_SD_FACTOR)
             out = centre + spread * self.n_mads
-        dirty = ~np.isfinite(self._sorted[:, -1])
+        dirty = np.isnan(self._ring).any(axis=1)
         if dirty.any():
             out = np.where(dirty, np.float32(np.nan), out)
         return out

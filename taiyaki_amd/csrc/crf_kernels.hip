@@ -689,7 +689,9 @@ static CrfShape crf_pick_shape(size_t max_seqlen) {
     return {R, W};
 }
 
-static size_t crf_ckpt_bytes(size_t nblk, size_t nbatch, CrfShape sh) {
+// (a cost-only call keeps no checkpoint column: crf_kernel stores them under want_grad only)
+static size_t crf_ckpt_bytes(size_t nblk, size_t nbatch, CrfShape sh, bool want_grad = true) {
+    if (!want_grad) return 256;
     const int CK = crf_ck(sh.R, sh.W, 3);   // the cat-mod tile is the smaller one: upper bound
     const size_t NK = (nblk + CK - 1) / CK;
     const size_t ck = nbatch * NK * (size_t)sh.R * sh.W * WAVE * sizeof(float);
@@ -756,10 +758,14 @@ size_t crf_workspace_bytes_sharp(size_t ntrans, size_t nblk, size_t nbatch, size
     const int bkp = crf_band_pick_block(sharp, false, max_seqlen).bk, bkm = crf_band_pick_block(sharp, true, max_seqlen).bk;
     const int bk = (bkp > 0 && bkm > 0) ? (bkp < bkm ? bkp : bkm) : (bkp > 0 ? bkp : bkm);
     // (the cat-mod layout is the larger one: an upper bound for both)
+    // (a call whose own block choice differs from the one assumed here -- another sharpening factor than the
+    // query's -- needs what ITS factor's query returns; with less, crf_dispatch falls back to the log-domain
+    // kernel on every read if the workspace holds that kernel's whole-batch columns, and returns 3 otherwise:
+    // sizing every workspace for that case would be 8.0 instead of 4.7 GB at T = 4000 / N = 256)
     if (crf_pick_mode(ntrans, nblk, nbatch, max_seqlen, want_grad != 0, bk) == CRF_BAND)
-        return crf_ckpt_bytes(nblk, crf_redo_slots(nbatch), sh) +
+        return crf_ckpt_bytes(nblk, crf_redo_slots(nbatch), sh, want_grad != 0) +
                crf_band_layout(ntrans, nblk, nbatch, max_seqlen, true, want_grad != 0, bk).total;
-    return crf_ckpt_bytes(nblk, nbatch, sh);
+    return crf_ckpt_bytes(nblk, nbatch, sh, want_grad != 0);
 }
 
 size_t crf_workspace_bytes(size_t ntrans, size_t nblk, size_t nbatch, size_t max_seqlen,
@@ -813,10 +819,10 @@ int crf_dispatch(const float *logprob, size_t ntrans, size_t nblk, size_t nbatch
     // log-domain kernel on every read, that kernel does the call
     BandBlock blk = crf_band_pick_block(sharp_can, mod, max_seqlen);
     bool band = crf_pick_mode(ntrans, nblk, nbatch, max_seqlen, grad != nullptr, blk.bk) == CRF_BAND;
-    if (band && crf_ckpt_bytes(nblk, crf_redo_slots(nbatch), sh) +
+    if (band && crf_ckpt_bytes(nblk, crf_redo_slots(nbatch), sh, grad != nullptr) +
                         crf_band_layout(ntrans, nblk, nbatch, max_seqlen, mod, grad != nullptr, blk.bk).total > workspace_bytes)
         band = false;
-    if (!band && crf_ckpt_bytes(nblk, nbatch, sh) > workspace_bytes) return 3;
+    if (!band && crf_ckpt_bytes(nblk, nbatch, sh, grad != nullptr) > workspace_bytes) return 3;
     CrfArgs a;
     a.lp = logprob;
     a.T = (int)nblk;

@@ -20,7 +20,7 @@ def flipflop_viterbi(scores, _never_use_cupy=False):
         tb = torch.empty(T, N, 2 * nbase, dtype=torch.int64, device=dev)
         path = torch.empty(T + 1, N, dtype=torch.int64, device=dev)
         wsb = L.tk_flipflop_viterbi_workspace_bytes(T, N, nbase)
-        ws = torch.empty(wsb, dtype=torch.uint8, device=dev)
+        ws = _lib.workspace(wsb, dev, "viterbi")         # one scratch buffer per (device, stream), like ctc / layers
         rc = L.tk_flipflop_viterbi_dev(_lib.ptr(sc), T, N, nbase, _lib.ptr(fwd), _lib.ptr(tb),
                                        _lib.ptr(path), _lib.ptr(ws), wsb, _lib.stream_ptr())
         _lib.check(rc, "tk_flipflop_viterbi_dev")
@@ -40,7 +40,7 @@ def flipflop_viterbi_path(scores):
     with torch.cuda.device(dev):
         path = torch.empty(T + 1, N, dtype=torch.int64, device=dev)
         wsb = L.tk_flipflop_viterbi_workspace_bytes(T, N, nbase)
-        ws = torch.empty(wsb, dtype=torch.uint8, device=dev)
+        ws = _lib.workspace(wsb, dev, "viterbi")
         rc = L.tk_flipflop_viterbi_dev(_lib.ptr(sc), T, N, nbase, None, None, _lib.ptr(path),
                                        _lib.ptr(ws), wsb, _lib.stream_ptr())
         _lib.check(rc, "tk_flipflop_viterbi_dev")

@@ -130,6 +130,37 @@ def test_rolling_mad_matches_reference_goldens():
         clipping.RollingMAD(5).update([1.0, 2.0])
 
 
+def test_rolling_mad_with_nonfinite_maxima_is_the_median_over_the_raw_window():
+    """Round-4 advisor finding: +inf in the window made the threshold NaN ("no clipping") for `window`
+    steps, while the reference's np.median over the raw window (maths.py:182-195) stays finite for a single
+    +inf and keeps clipping; NaN does poison it.  Compared with the definition evaluated directly on the last
+    `window` rows: median + n_mads * 1.4826 * median(|x - median|)."""
+    from taiyaki_amd import clipping
+    rs = np.random.RandomState(5)
+    window, nparams, n_mads = 7, 6, 2.0
+    vals = np.abs(rs.standard_normal((40, nparams))).astype(np.float32)
+    vals[9, 1] = np.inf                     # one +inf: stays finite
+    vals[12, 2] = np.nan                    # one NaN: NaN while it is in the window
+    vals[20:24, 3] = np.inf                 # four of seven +inf: centre inf -> NaN like the reference
+    vals[30, 4] = np.inf
+    vals[31, 4] = np.nan
+    rm = clipping.RollingMAD(nparams, n_mads=n_mads, window=window)
+    for t in range(len(vals)):
+        th = rm.update(vals[t])
+        if t + 1 < window:
+            assert th is None
+            continue
+        w = vals[t + 1 - window:t + 1]
+        with np.errstate(invalid="ignore"):
+            med = np.median(w, axis=0)
+            want = med + n_mads * clipping.MAD_SD_FACTOR * np.median(np.abs(w - med[None]), axis=0)
+        assert np.array_equal(np.isnan(th), np.isnan(want)), t
+        ok = ~np.isnan(want)
+        np.testing.assert_allclose(np.asarray(th)[ok], want[ok], rtol=1e-6)
+        if 9 <= t < 9 + window:
+            assert np.isfinite(th[1])
+
+
 @pytest.mark.gpu
 def test_device_clipper_matches_apply_clipping(gpu_device):
     """Kernel maxima == per-tensor max|grad| (the reference's grad_maxs), clamp == the

@@ -449,4 +449,28 @@ def test_crf_workspace_is_sized_for_what_runs():
     assert step < s2 < 2 * step + 64 * MB
     s9 = L.tk_crf_flipflop_workspace_bytes_sharp(40, 800, 128, 533, 1, 9.0)       # log-domain kernel on every read
     assert 0 < s9 < 200 * MB
-    assert L.tk_crf_flipflop_workspace_bytes(40, 800, 128, 533, 0) < 16 * MB     # cost only: the gate + the redo slots
+    assert L.tk_crf_flipflop_workspace_bytes(40, 800, 128, 533, 0) < 16 * MB     # cost only: the gate, no checkpoint column
+    # cost-only calls keep no checkpoint column in either kernel: the same small size whatever the factor
+    assert L.tk_crf_flipflop_workspace_bytes_sharp(40, 800, 128, 533, 0, 9.0) < 16 * MB
+
+
+def test_gate_count_is_read_unsigned_and_taken_out_exactly():
+    """Round-4 advisor finding: the status words are int32 tensors, the kernels add the count of redone reads into
+    bits 8-31 -- 2^23 or more read back negative; and the count was cleared with an AND of whatever the word held
+    by then.  Read as uint32; take out exactly what was read (flags and later counts stay)."""
+    from taiyaki_amd import _lib
+    was = _lib.is_strict()
+    try:
+        _lib.set_strict(False)
+        t = _lib.status_word(torch.device("cpu"))
+        t.fill_(-(1 << 31) + (5 << 8) + 2)              # count 2^23 + 5, flag 2 (gradients not finite)
+        assert _lib.take_gate_count() == (1 << 23) + 5 == _lib.last_gate_count()
+        assert int(t.item()) == 2
+        t.add_(3 << 8)
+        assert _lib.take_gate_count() == 3
+        with pytest.raises(AssertionError, match="Gradients not finite"):
+            _lib.raise_if_nonfinite()
+        assert int(t.item()) == 0
+    finally:
+        _lib._deferred.pop(("cpu", None), None)
+        _lib.set_strict(was)

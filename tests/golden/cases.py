@@ -57,6 +57,11 @@ FULLSIZE = {
     "cfg1": dict(T=1000, N=64, seed=4, mods=None),      # train_abinitio: chunk 2000, stride 2, batch 64
     "cfg2": dict(T=800, N=128, seed=1, mods=None),
     "cfg4": dict(T=800, N=128, seed=2, mods=(1, 1, 0, 0)),
+    # cfg 4 on PRODUCER-LIKE inputs (round 5): the modification columns are what GlobalNormFlipFlopCatMod.forward
+    # emits (layers.py:1616-1640: per-base log-softmax; synth.normalise_mod_columns) instead of cfg4's raw
+    # U(-5, 5) logits x 8, most of whose reads the linear path disowns -- here the LINEAR cat-mod kernel at
+    # T 800 / N 128 is what gets compared with the genuine reference (gate count asserted 0)
+    "cfg4_lsm": dict(T=800, N=128, seed=2, mods=(1, 1, 0, 0), lsm=0.2),
     "cfg5": dict(T=1600, N=64, seed=3, mods=None),
     "rowK": dict(T=4000, N=256, seed=1, mods=None),
 }
@@ -66,9 +71,12 @@ NMODS = (1, 1, 0, 0)        # ACGTZY: 6mA on A, 5mC on C
 
 def crf_inputs(spec, mods=None):
     seqlens = spec.get("seqlens")
-    return synth.crf_case(spec["T"], spec["N"], spec["seed"],
-                          nbase=spec.get("nbase", 4), nmods_per_base=mods,
-                          seqlens=seqlens)
+    inp = synth.crf_case(spec["T"], spec["N"], spec["seed"],
+                         nbase=spec.get("nbase", 4), nmods_per_base=mods,
+                         seqlens=seqlens)
+    if mods is not None and spec.get("lsm"):
+        synth.normalise_mod_columns(inp, logit_scale=spec["lsm"])
+    return inp
 
 
 def logz_inputs(spec):

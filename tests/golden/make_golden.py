@@ -1,7 +1,7 @@
 #!/usr/bin/env python
 """Generate tests/golden/*.npz by running the GENUINE reference (this container only).
 
-    python tests/golden/make_golden.py [--skip-fullsize]
+    python tests/golden/make_golden.py [--skip-fullsize | --only-fullsize NAME ...]
 
 What it does (nothing from /root/reference is copied into the repo):
  1. copies /root/reference/taiyaki into a scratch dir under /tmp and builds the
@@ -75,6 +75,8 @@ def c_array(text, name):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--skip-fullsize", action="store_true")
+    ap.add_argument("--only-fullsize", nargs="+", default=None, metavar="NAME",
+                    help="compute only these cases.FULLSIZE entries and merge them into fullsize.npz")
     args = ap.parse_args()
 
     build_reference()
@@ -84,6 +86,8 @@ def main():
     from tests.golden import cases
 
     torch.set_num_threads(8)
+    # (--only-fullsize leaves the small fixtures as they are)
+    save_small = (lambda *a, **k: None) if args.only_fullsize else np.savez_compressed
 
     def t(x, dtype=None):
         return torch.tensor(np.asarray(x), dtype=dtype)
@@ -126,14 +130,14 @@ def main():
         inp = cases.crf_inputs(spec)
         out[name + "/loss_nograd"] = ctc.crf_flipflop_loss(
             xc, t(inp["seqs"]), t(inp["seqlens"]), spec["sharp"]).numpy()
-    np.savez_compressed(os.path.join(HERE, "crf_small.npz"), **out)
+    save_small(os.path.join(HERE, "crf_small.npz"), **out)
 
     out = {}
     for name, spec in cases.CATMOD_SMALL.items():
         loss, grad = run_catmod(cases.crf_inputs(spec, cases.NMODS), spec["sharp"])
         out[name + "/loss"] = loss
         store_grad(out, name + "/grad", grad)
-    np.savez_compressed(os.path.join(HERE, "catmod_small.npz"), **out)
+    save_small(os.path.join(HERE, "catmod_small.npz"), **out)
 
     out = {}
     for name, spec in cases.LOGZ_SMALL.items():
@@ -155,7 +159,7 @@ def main():
             out[name + "/trans"] = trans.numpy()
             out[name + "/fwd"] = fwd.numpy()
             out[name + "/tb"] = tb.numpy().astype(np.int8)
-    np.savez_compressed(os.path.join(HERE, "logz_small.npz"), **out)
+    save_small(os.path.join(HERE, "logz_small.npz"), **out)
 
     # ---- the reference's own known-answer vectors ---------------------------
     ka = {}
@@ -225,12 +229,16 @@ def main():
     ka["ccm/modmovefact"] = c_array(src, "test_modmovefact1").astype("f4")[:10]
     ka["ccm/seqlen"] = c_array(src, "test_seqlen1").astype(np.int32)
     ka["ccm/score"] = np.array([-52.354622, -195.435257])
-    np.savez_compressed(os.path.join(HERE, "known_answers.npz"), **ka)
+    save_small(os.path.join(HERE, "known_answers.npz"), **ka)
 
     # ---- full-size BASELINE configs: scalars + checksums only ---------------
     if not args.skip_fullsize:
         fs = {}
+        if args.only_fullsize:      # add / refresh the named configurations, keep the others' numbers
+            fs = dict(np.load(os.path.join(HERE, "fullsize.npz")))
         for name, spec in cases.FULLSIZE.items():
+            if args.only_fullsize and name not in args.only_fullsize:
+                continue
             inp = synth_case(spec)
             if spec["mods"] is None:
                 loss, grad = run_crf(inp, 1.0)
@@ -258,7 +266,7 @@ def main():
 
 def synth_case(spec):
     from tests.golden import cases
-    return cases.crf_inputs(dict(T=spec["T"], N=spec["N"], seed=spec["seed"]),
+    return cases.crf_inputs(dict(T=spec["T"], N=spec["N"], seed=spec["seed"], lsm=spec.get("lsm")),
                             spec["mods"])
 
 

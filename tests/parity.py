@@ -168,4 +168,4 @@ def path_hash(path):
 
 def fullsize_inputs(name):
     spec = cases.FULLSIZE[name]
-    return cases.crf_inputs(dict(T=spec["T"], N=spec["N"], seed=spec["seed"]), spec["mods"])
+    return cases.crf_inputs(dict(T=spec["T"], N=spec["N"], seed=spec["seed"], lsm=spec.get("lsm")), spec["mods"])

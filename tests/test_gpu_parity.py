@@ -322,6 +322,12 @@ def test_fullsize_against_reference_goldens(gpu_device, name):
     spec = cases.FULLSIZE[name]
     inp = parity.fullsize_inputs(name)
     loss, grad = parity.run_crf(inp, 1.0, gpu_device)
+    # WHICH kernel answered (round-4 verdict): the log-domain redo is also correct, so a regression that
+    # disowned every read would stay green here and cost 7x in the loss.  Every configuration on inputs a
+    # network can produce keeps all its reads on the linear path; cfg4's raw modification logits x 8 do not.
+    from taiyaki_amd import ctc
+    raw_logits = spec["mods"] is not None and not spec.get("lsm")
+    assert raw_logits or ctc.last_gate_count() == 0, ctc.last_gate_count()
     np.testing.assert_allclose(loss, gold[name + "/loss"], rtol=1e-4)
     assert parity.rel_err(loss, gold[name + "/loss"]) < 2e-5
     cs = cases.grad_checksums(grad)
@@ -333,7 +339,7 @@ def test_fullsize_against_reference_goldens(gpu_device, name):
     # lines in profiles/r4_pytest_gpu_*.log) and most reads are redone by the log-domain kernel)
     col = cs["sample_idx"] % grad.shape[2]
     np.testing.assert_array_less(np.abs(cs["sample"] - gold[name + "/grad_sample"]) * parity.posterior_scale(inp)[col],
-                                 (2e-4 if spec["mods"] is None else 1e-3) / spec["T"])
+                                 (1e-3 if raw_logits else 2e-4) / spec["T"])
     # every gradient row of a live read sums to -1/T (posterior is a distribution)
     np.testing.assert_allclose(grad[:, :, :40].sum(axis=2) * spec["T"], -1.0, atol=2e-4)
     del grad
@@ -1333,6 +1339,7 @@ def test_fused_loss_at_full_size_against_reference_goldens(gpu_device, name):
         # cat-mod form (round 3): logZ of the canonical columns folded into the cat-mod kernel's writes
         mods = (torch.from_numpy(inp["mod_cats"]), inp["can_mods_offsets"], inp["mod_cat_weights"])
     lv = ctc.flipflop_loss(x, seqs, seqlens, 1.0, *mods)
+    assert (bool(mods) and not spec.get("lsm")) or ctc.last_gate_count() == 0, ctc.last_gate_count()
     np.testing.assert_allclose(lv.detach().cpu().numpy(), gold[name + "/lossvector"], rtol=1e-4)
     lv.sum().backward()
     g = x.grad.clone()

@@ -528,10 +528,10 @@ def _gather_per_rank(ms, dev, world):
     return dict(min=min(vals), max=max(vals), all=vals)
 
 
-def variable_length_bench(args, cfg, trainer, dev, rank, use_graph):
-    """`--chunk-len-range MIN MAX`: the reference's per-iteration chunk length draw on graph replay."""
+def variable_length_bench(args, cfg, trainer, dev, rank, use_graph, lo, hi, steps, warmup):
+    """The reference's per-iteration chunk length draw (bin/train_flipflop.py:554-563) on graph replay: `--chunk-len-range
+    MIN MAX` prints the record as its own line; the default N = 1 run carries a short leg of it as `varlen`."""
     from taiyaki_amd import _lib, train
-    lo, hi = args.chunk_len_range
     stride, cat_mod = cfg["stride"], cfg["model"] == "mLstm_cat_mod_flipflop"
     lens = sorted({train.bucket_chunk_len(x, stride, args.len_bucket) for x in range(lo, hi + 1, stride)})
     # the reference keeps samples per sub-batch constant: min_sub_batch_size * chunk_len_max / chunk_len
@@ -547,14 +547,18 @@ def variable_length_bench(args, cfg, trainer, dev, rank, use_graph):
         mode = "one captured forward+loss graph per shape (train.GraphCacheTrainer), eager backward, AdamW replayed"
     rng = np.random.RandomState(11)
     draw = lambda: train.bucket_chunk_len(int(rng.randint(lo, hi + 1)), stride, args.len_bucket)    # noqa: E731
+    t_cap = time.perf_counter()
     for cl in lens:                         # every shape once: captures
         stepper.step(by_len[cl][0])
-    for i in range(args.warmup):
+    torch.cuda.synchronize()
+    t_cap = time.perf_counter() - t_cap
+    for i in range(warmup):
         stepper.step(by_len[draw()][i % 2])
     torch.cuda.synchronize()
+    hits0, miss0 = getattr(stepper, "hits", 0), getattr(stepper, "misses", 0)
     chunks = samples = 0
     t0 = time.perf_counter()
-    for i in range(args.steps):
+    for i in range(steps):
         cl = draw()
         b = by_len[cl][i % 2]
         stepper.step(b)
@@ -563,15 +567,19 @@ def variable_length_bench(args, cfg, trainer, dev, rank, use_graph):
     torch.cuda.synchronize()
     el = time.perf_counter() - t0
     _lib.raise_if_nonfinite()
-    print(json.dumps(dict(
+    hits, misses = getattr(stepper, "hits", 0) - hits0, getattr(stepper, "misses", 0) - miss0
+    return dict(
         metric="signal-chunks/sec, flip-flop train step with the reference's per-iteration chunk length draw",
         value=round(chunks / el, 2), unit="chunks/s", samples_per_s=round(samples / el, 1), n_gpus=1,
-        steps=args.steps, warmup=args.warmup, ms_per_step=round(el / args.steps * 1e3, 3), higher_is_better=True,
+        steps=steps, warmup=warmup, ms_per_step=round(el / steps * 1e3, 3), higher_is_better=True,
         dtype="f32", data="synthetic",
+        graph_cache=dict(distinct_graphs=len(getattr(stepper, "entries", {})), hits=hits, misses=misses,
+                         hit_rate=round(hits / max(1, hits + misses), 3), capture_s=round(t_cap, 2),
+                         note="every shape of the grid is captured once before the warm-up (capture_s, outside the timed "
+                              "region); hits / misses count the TIMED steps"),
         config=dict(workload=cfg["label"] + ", chunk_len drawn in [%d, %d] per step, batch = %d * %d / chunk_len "
                     "(bin/train_flipflop.py:554-563)" % (lo, hi, cfg["batch"], cfg["chunk_len"]),
-                    chunk_len_grid=lens, batch_of_len={str(cl): nb_of(cl) for cl in lens}, launch=mode,
-                    distinct_graphs=len(getattr(stepper, "entries", {}))))), flush=True)
+                    chunk_len_grid=lens, batch_of_len={str(cl): nb_of(cl) for cl in lens}, launch=mode))
 
 
 def kernel_records(out, args, cfg, dev, world, T, nbatch, chunk_len, cat_mod, S):
@@ -610,12 +618,22 @@ def kernel_records(out, args, cfg, dev, world, T, nbatch, chunk_len, cat_mod, S)
         if ops.x40.numel() * 4 >= (64 << 20):
             # the fraction against a MEASURED device-copy ceiling too -- the score tensor copied into
             # the gradient tensor by the runtime's own copy kernel, read + write bytes over the HIP-event time
-            cp_mean, cp_min = _events_mean_min(lambda: ops.lgrad.copy_(ops.x40), 20, warm=3)
+            from taiyaki_amd import _lib
+            Lc = _lib.lib()
+
+            def own_copy():
+                _lib.check(Lc.tk_devcopy_f32_dev(_lib.ptr(ops.lgrad), _lib.ptr(ops.x40), ops.x40.numel(), _lib.stream_ptr()),
+                           "tk_devcopy_f32_dev")
+            cp_mean, cp_min = _events_mean_min(own_copy, 20, warm=3)
+            rt_mean, _ = _events_mean_min(lambda: ops.lgrad.copy_(ops.x40), 20, warm=3)
             ceiling = 2.0 * ops.x40.numel() * 4 / cp_mean / 1e9
             rec["copy_ceiling"] = dict(value=round(ceiling, 1), unit="GB/s", mean_us=round(cp_mean * 1e6, 2),
                                        min_us=round(cp_min * 1e6, 2),
-                                       how="torch copy_ of the (T, N, 40) fp32 score tensor, device to device: "
-                                           "(read + write bytes) / HIP-event time, 20 launches")
+                                       runtime_copy_GBs=round(2.0 * ops.x40.numel() * 4 / rt_mean / 1e9, 1),
+                                       how="tk_devcopy_f32_dev (this library's float4 streaming copy, nontemporal loads and "
+                                           "stores, 4 x 16 B in flight per lane) of the (T, N, 40) fp32 score tensor into the "
+                                           "gradient tensor: (read + write bytes) / HIP-event time, 20 launches; "
+                                           "runtime_copy_GBs = torch's copy_ of the same tensors")
             rec["frac_of_copy_ceiling"] = round(rec["achieved"] / ceiling, 4)
         return rec
 
@@ -651,6 +669,43 @@ def kernel_records(out, args, cfg, dev, world, T, nbatch, chunk_len, cat_mod, S)
                  "log-domain launch, which finds nothing to redo on these inputs)")
     else:
         out["roofline"] = logz_roofline(step_ops, 30, "the train step's own launch")
+    # ---- Viterbi (north_star: a hand-written kernel of the path; decode.py:75-115, flipflop.py:387-518) --------
+    def viterbi_roofline(ops, reps, label):
+        from taiyaki_amd import _lib
+        L, p = _lib.lib(), _lib.ptr
+        Tn, Nn = ops.T, ops.N
+        fwd = torch.empty(Tn + 1, Nn, 8, dtype=torch.float32, device=dev)
+        tb = torch.empty(Tn, Nn, 8, dtype=torch.int64, device=dev)
+        path = torch.empty(Tn + 1, Nn, dtype=torch.int64, device=dev)
+        wsb = L.tk_flipflop_viterbi_workspace_bytes(Tn, Nn, 4)
+        ws = torch.empty(wsb, dtype=torch.uint8, device=dev)
+
+        def full():
+            _lib.check(L.tk_flipflop_viterbi_dev(p(ops.x40), Tn, Nn, 4, p(fwd), p(tb), p(path), p(ws), wsb,
+                                                 _lib.stream_ptr()), "tk_flipflop_viterbi_dev")
+
+        def path_only():
+            _lib.check(L.tk_flipflop_viterbi_dev(p(ops.x40), Tn, Nn, 4, None, None, p(path), p(ws), wsb,
+                                                 _lib.stream_ptr()), "tk_flipflop_viterbi_dev")
+
+        alg = 1.0 * Tn * Nn * 40 * 4 + (Tn + 1) * Nn * 8          # forward-only bytes + the path output
+        pm, pmin = _events_mean_min(path_only, reps, warm=5)
+        fm, fmin = _events_mean_min(full, reps, warm=5)
+        rec = roofline_record("Viterbi, path only (what bin/basecall.py:222 keeps): viterbi forward + traceback scan, "
+                              "T=%d N=%d (%s)" % (Tn, Nn, label), alg, pm, pmin, reps, None, None)
+        rec["full_outputs"] = dict(mean_us=round(fm * 1e6, 2), min_us=round(fmin * 1e6, 2),
+                                   bytes=alg + (Tn + 1) * Nn * 8 * 4 + Tn * Nn * 8 * 8,
+                                   note="fwd (T+1, N, 8) f32 and the reference's int64 traceback (T, N, 8) written too "
+                                        "(decode.py:15-39): 1.6 + 8 times the score tensor of extra writes")
+        rec["bound_note"] = ("serial in T by construction (a time-parallel max-plus form would re-associate fp32 adds and "
+                             "break bit-exactness): bound by one wave's issue stream per read, not by HBM; the HBM "
+                             "fraction is reported because SURVEY 8d names the forward-only bytes")
+        return rec
+
+    out["roofline_viterbi"] = dict(in_step=viterbi_roofline(step_ops, 20, "the train step's shape"))
+    if rowk is not None:
+        out["roofline_viterbi"]["rowK"] = viterbi_roofline(rowk, 10, "north_star kernel shape")
+
     # ---- the whole loss path in one unit ------------------------------------------------
     # one queue: what the captured train step replays (a capturing stream never forks); two queues: what an eager
     # caller of the operator gets by default (kernel B beside kernel A's sweeps, tk_flipflop_loss_overlap)
@@ -685,6 +740,77 @@ def kernel_records(out, args, cfg, dev, world, T, nbatch, chunk_len, cat_mod, S)
             same_inputs=True,
             note="cpu = %s on %d host threads, same arrays as gpu_ms; copies = score tensor D->H + gradient H->D (pinned), what "
                  "the reference's CPU extension adds per call (ctc.pyx:119, 139-141)" % (cb["kind"], cb["cores"]))
+
+
+def rccl_debug_summary(limit=14):
+    """What RCCL said about itself (NCCL_DEBUG=INFO, subsystems INIT + TUNING, one file per process): the
+    distinct lines that name the algorithm / protocol / channels it chose for this job's collectives."""
+    import glob
+    import re
+    pat = os.environ.get("NCCL_DEBUG_FILE")
+    if not pat:
+        return None
+    mine = pat.replace("%p", str(os.getpid())).replace("%h", socket.gethostname())
+    files = [mine] if os.path.exists(mine) else sorted(glob.glob(pat.replace("%p", "*").replace("%h", "*")))[:1]
+    seen, out = set(), []
+    for fn in files:
+        try:
+            for ln in open(fn, errors="replace"):
+                if not re.search(r"Algo|proto|[Cc]hannel|Ring|Tree|nranks|comm .* rank", ln):
+                    continue
+                key = re.sub(r"^.*?NCCL INFO\s*", "", ln.strip())
+                key = re.sub(r"0x[0-9a-f]+|\b\d+\.\d+\b", "#", key)        # (pointers and times differ line to line)
+                if key not in seen and len(out) < limit:
+                    seen.add(key)
+                    out.append(re.sub(r"^.*?NCCL INFO\s*", "", ln.strip())[:200])
+        except OSError:
+            pass
+    return dict(source="NCCL_DEBUG=INFO NCCL_DEBUG_SUBSYS=%s, rank 0's file" % os.environ.get("NCCL_DEBUG_SUBSYS"),
+                lines=out) if out else None
+
+
+def direct_leg(args, arena, comm, rank, world, dev, timed_steps, event_time_us, nbatch, on_timeout=None, budget_s=150.0):
+    """`rccl.direct` of the default N > 1 line: the C-ABI collective (own rendezvous) on the same steps.  A
+    watchdog thread lets the line go out without this leg if it hangs: every rank then leaves through
+    os._exit after rank 0 has printed what it has."""
+    import threading
+    from taiyaki_amd import parallel
+    state = dict(done=False)
+
+    def bail():
+        if state["done"]:
+            return
+        print("[rank %d] rccl.direct leg did not finish in %.0f s: dropped" % (rank, budget_s), file=sys.stderr, flush=True)
+        if on_timeout is not None:
+            on_timeout()            # rank 0: the measured line, without this leg
+        os._exit(0)
+
+    timer = threading.Timer(budget_s, bail)
+    timer.daemon = True
+    timer.start()
+    try:
+        coll = parallel.DirectRccl(rank, world, exchange=lambda b: parallel.socket_rendezvous(
+            rank, world, b, nbytes=len(b) if b is not None else 128), device=dev)
+        arena.collective, saved_world = coll, arena.world
+        try:
+            us = event_time_us(lambda: arena._all_reduce(arena.flat).wait(), 20)
+            el = timed_steps(max(2, args.warmup // 2), args.steps, first=7)
+            el = max(comm.gather(el))
+        finally:
+            arena.collective, arena.world = None, saved_world
+        out = dict(collective="tk_allreduce_f32_dev (C ABI over RCCL), communicator from tk_rendezvous_bytes at port %d"
+                              % parallel.rendezvous_port(),
+                   allreduce_us=round(float(np.mean(us)), 1), allreduce_min_us=round(us[0], 1),
+                   ms_per_step=round(el / args.steps * 1e3, 3), value=round(nbatch * world * args.steps / el, 2),
+                   steps=args.steps)
+        torch.cuda.synchronize()
+        coll.close()
+        return out
+    except Exception as exc:          # report, never hide -- and never lose the measured line over it
+        return dict(failed="%s: %s" % (type(exc).__name__, str(exc)[:300]))
+    finally:
+        state["done"] = True
+        timer.cancel()
 
 
 def main():
@@ -726,6 +852,14 @@ def main():
                     help="gradient all-reduce slices issued from backward hooks (N > 1); 0 (default) = ONE flat "
                          "all-reduce after backward -- measured: slices issued inside the eager RNN backward cost "
                          "3-4 ms each (profiles/r4_forced_group_bisect.txt), the one flat call nothing")
+    ap.add_argument("--collective", choices=["pg", "direct"], default="pg",
+                    help="N > 1: what reduces the gradients.  pg (default): torch.distributed's ProcessGroupNCCL (= RCCL); "
+                         "the line then also carries `rccl.direct`, the same steps re-timed with this repo's C-ABI "
+                         "collective.  direct: libtaiyaki_amd_rccl.so (tk_allreduce_f32_dev) with its OWN socket "
+                         "rendezvous -- no torch.distributed process group exists in the ranks at all (barriers and "
+                         "the max over ranks go through the same all-reduce)")
+    ap.add_argument("--no-varlen", action="store_true",
+                    help="N = 1: skip the short leg with the reference's per-iteration chunk length draw (`varlen`)")
     ap.add_argument("--no-forced-group", action="store_true",
                     help="N = 1: skip the child run that repeats the step with a one-rank RCCL process group "
                          "(the `rccl.overhead_ms` field)")
@@ -773,7 +907,15 @@ def main():
         # choreography (sharding, hooks, barrier bracket, max over ranks, rank-0 report) on the real
         # kernels; the number it prints is not a scaling measurement
         share = bool(os.environ.get("TK_BENCH_SHARE_GPU"))
-        rank, local, world = parallel.init_from_env(backend="gloo" if share else None)
+        direct_only = args.collective == "direct" and not share
+        if int(os.environ.get("WORLD_SIZE", "1")) > 1 and not share:
+            # RCCL says which algorithm / protocol / channel count it picked (ring vs tree, LL vs Simple): into a file
+            # per process, summarised in the line's `rccl.debug` (must be set before any communicator exists)
+            os.environ.setdefault("NCCL_DEBUG", "INFO")
+            os.environ.setdefault("NCCL_DEBUG_SUBSYS", "INIT,TUNING")
+            os.environ.setdefault("NCCL_DEBUG_FILE", os.path.join(
+                os.environ.get("TMPDIR", "/tmp"), "tk_rccl_debug_%s.%%p.log" % os.environ.get("MASTER_PORT", "0")))
+        rank, local, world = parallel.init_from_env(backend="gloo" if share else None, process_group=not direct_only)
         if share:
             local = 0
     if world != args.gpus and not args.probe_graph:
@@ -820,38 +962,46 @@ def main():
         except subprocess.TimeoutExpired:
             use_graph = False
             print("[rank %d] hipGraph probe timed out" % rank, file=sys.stderr)
-    if dist.is_initialized() and world > 1:
-        # every rank must take the same road: the graphed and the eager trainer issue different
-        # numbers of collectives while they set up (a rank whose probe failed would sit in the
-        # timing barrier while the others wait for it inside the capture's warm-up all-reduce)
-        flag = torch.tensor([1 if use_graph else 0], dtype=torch.int32,
-                            device=dev if dist.get_backend() == "nccl" else "cpu")
-        dist.all_reduce(flag, op=dist.ReduceOp.MIN)
-        if use_graph and int(flag.item()) == 0 and rank == 0:
-            print("hipGraph probe failed on another rank: every rank launches eagerly", file=sys.stderr)
-        use_graph = bool(int(flag.item()))
-    if cfg["model"] == "mGru_flipflop":
-        net = models.mGru_flipflop(size=size, stride=stride).to(dev)
-    elif cat_mod:
-        net = models.mLstm_cat_mod_flipflop(size=size, stride=stride, can_nmods=CAN_NMODS).to(dev)
-    else:
-        net = models.mLstm_flipflop(size=size, stride=stride).to(dev)
-    for m in net.modules():
-        if hasattr(m, "use_gemm"):
-            m.use_gemm = args.conv == "gemm"
+    def build_net():
+        if cfg["model"] == "mGru_flipflop":
+            net = models.mGru_flipflop(size=size, stride=stride).to(dev)
+        elif cat_mod:
+            net = models.mLstm_cat_mod_flipflop(size=size, stride=stride, can_nmods=CAN_NMODS).to(dev)
+        else:
+            net = models.mLstm_flipflop(size=size, stride=stride).to(dev)
+        for m in net.modules():
+            if hasattr(m, "use_gemm"):
+                m.use_gemm = args.conv == "gemm"
+        return net
+
+    net = build_net()
     # TK_RCCL_DIRECT=1: the gradient collectives through this repo's own C ABI over RCCL
     # (libtaiyaki_amd_rccl.so) instead of ProcessGroupNCCL; the process group stays up for the
     # rendezvous (it carries RCCL's unique id) and the bench's own barriers
     collective = None
-    if os.environ.get("TK_RCCL_DIRECT") and dev.type == "cuda" and (world > 1 or os.environ.get("TK_FORCE_PROCESS_GROUP")):
+    direct_only = args.collective == "direct" and not os.environ.get("TK_BENCH_SHARE_GPU") and not args.probe_graph
+    if dev.type == "cuda" and ((direct_only and world > 1) or (
+            os.environ.get("TK_RCCL_DIRECT") and (world > 1 or os.environ.get("TK_FORCE_PROCESS_GROUP")))):
+        # (--collective direct: no process group is up, DirectRccl brings its own socket rendezvous)
         collective = parallel.DirectRccl(rank, world, device=dev, in_stream=bool(os.environ.get("TK_RCCL_INSTREAM")))
+    comm = parallel.RankComm(rank, world if not args.probe_graph else 1, collective if direct_only else None, dev)
+    if comm.active:
+        # every rank must take the same road: the graphed and the eager trainer issue different
+        # numbers of collectives while they set up (a rank whose probe failed would sit in the
+        # timing barrier while the others wait for it inside the capture's warm-up all-reduce)
+        agreed = min(comm.gather(1.0 if use_graph else 0.0)) > 0.5
+        if use_graph and not agreed and rank == 0:
+            print("hipGraph probe failed on another rank: every rank launches eagerly", file=sys.stderr)
+        use_graph = agreed
     parallel.broadcast_parameters(net, collective=collective)
     arena = parallel.FlatGradArena(net, overlap_buckets=args.overlap_buckets, collective=collective)
     # the reference's default adaptive clipping (--gradient_clip_num_mads 0, window 1000):
     # gradient maxima every step, clamp once 1000 steps have been seen
     trainer = train.Trainer(net, arena, clip_num_mads=0)
     if args.chunk_len_range and not args.probe_graph:
-        return variable_length_bench(args, cfg, trainer, dev, rank, use_graph)
+        print(json.dumps(variable_length_bench(args, cfg, trainer, dev, rank, use_graph, args.chunk_len_range[0],
+                                               args.chunk_len_range[1], args.steps, args.warmup)), flush=True)
+        return
     batches = make_batches(nbatch, chunk_len, stride, 17 + rank, dev, n=2 if args.probe_graph else 4,
                            spb=cfg["spb"], cat_mod=cat_mod)
     if args.data == "store":
@@ -876,12 +1026,9 @@ def main():
         except Exception as exc:      # report, never hide
             print("hipGraph capture failed (%s: %s); running eagerly" % (type(exc).__name__, exc),
                   file=sys.stderr)
-    if dist.is_initialized() and world > 1 and not args.probe_graph:
+    if comm.active and not args.probe_graph:
         # (same agreement after the capture itself: a rank that fell back launches eagerly everywhere)
-        flag = torch.tensor([1 if mode != "eager" else 0], dtype=torch.int32,
-                            device=dev if dist.get_backend() == "nccl" else "cpu")
-        dist.all_reduce(flag, op=dist.ReduceOp.MIN)
-        if int(flag.item()) == 0 and mode != "eager":
+        if min(comm.gather(1.0 if mode != "eager" else 0.0)) < 0.5 and mode != "eager":
             print("[rank %d] another rank could not capture: launching eagerly" % rank, file=sys.stderr)
             stepper, mode = trainer, "eager"
     if args.probe_graph:
@@ -911,74 +1058,70 @@ def main():
             b = store.sample_chunks(nbatch, chunk_len, fparams, max_bases_per_chunk=T + 1)
             # (padding columns of a starved batch carry no sequence: keep them out of the loss)
             return dict(indata=b.indata, seqs=b.seqs, seqlens=b.seqlens, ignore_empty=True)
-    for i in range(args.warmup):
-        stepper.step(next_batch(i))
-    if dist.is_initialized():
-        dist.barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for i in range(args.steps):
-        stepper.step(next_batch(i))
-    if dist.is_initialized():
-        dist.barrier()
-    torch.cuda.synchronize()
-    elapsed = time.perf_counter() - t0
-    _lib.raise_if_nonfinite()
-    rccl = None
-    per_rank = None
-    if dist.is_initialized():
-        per_rank = _gather_per_rank(elapsed / args.steps * 1e3, dev if dist.get_backend() == "nccl" else
-                                    torch.device("cpu"), world)
-        tmax = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-        elapsed = float(tmax.item())
-        # the gradient all-reduce on its own, event-timed on the launching stream (a blocking
-        # all_reduce makes the current stream wait for RCCL's)
-        for _ in range(5):
-            dist.all_reduce(arena.flat)
+    def timed_steps(k_warm, k_steps, first=0):
+        """W untimed steps, then EXACTLY K steps bracketed by a barrier + synchronize on both sides; returns this
+        rank's seconds."""
+        for i in range(k_warm):
+            stepper.step(next_batch(first + i))
+        comm.barrier() if comm.active else (dist.barrier() if dist.is_initialized() else None)
         torch.cuda.synchronize()
-        dist.barrier()
+        t_start = time.perf_counter()
+        for i in range(k_steps):
+            stepper.step(next_batch(first + i))
+        comm.barrier() if comm.active else (dist.barrier() if dist.is_initialized() else None)
+        torch.cuda.synchronize()
+        return time.perf_counter() - t_start
+
+    def event_time_us(fn, reps, warm=5):
+        for _ in range(warm):
+            fn()
+        torch.cuda.synchronize()
+        comm.barrier()
         evs = []
-        for _ in range(20):
+        for _ in range(reps):
             a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             a.record()
-            dist.all_reduce(arena.flat)
+            fn()
             b.record()
             evs.append((a, b))
         torch.cuda.synchronize()
-        us = sorted(a.elapsed_time(b) * 1e3 for a, b in evs)
-        # ... and slice by slice, as the step issues them from the backward hooks
+        return sorted(a.elapsed_time(b) * 1e3 for a, b in evs)
+
+    elapsed = timed_steps(args.warmup, args.steps)
+    _lib.raise_if_nonfinite()
+    rccl = None
+    per_rank = None
+    grouped = comm.active or dist.is_initialized()          # (a forced one-rank group counts: N = 1 overhead child)
+    if grouped:
+        mine_ms = elapsed / args.steps * 1e3
+        vals = [round(v, 3) for v in comm.gather(mine_ms)] if comm.active else [round(mine_ms, 3)]
+        per_rank = dict(min=min(vals), max=max(vals), all=vals)
+        elapsed = max(comm.gather(elapsed)) if comm.active else elapsed
+        # the gradient all-reduce on its own, event-timed on the launching stream (waiting on the work object
+        # makes the current stream wait for RCCL's), whole and slice by slice as the step issues it
+        reduce_flat = lambda t=arena.flat: arena._all_reduce(t).wait()       # noqa: E731
+        us = event_time_us(reduce_flat, 20)
         bucket_us = []
         for lo, hi in arena.slices():
-            evb = []
-            for _ in range(10):
-                a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-                a.record()
-                dist.all_reduce(arena.flat[lo:hi])
-                b.record()
-                evb.append((a, b))
-            torch.cuda.synchronize()
-            bucket_us.append(round(float(np.mean([a.elapsed_time(b) * 1e3 for a, b in evb])), 1))
-        direct_us = None
-        if arena.collective is not None:
-            evd = []
-            for _ in range(20):
-                a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-                a.record()
-                arena.collective.all_reduce(arena.flat).wait()
-                b.record()
-                evd.append((a, b))
-            torch.cuda.synchronize()
-            direct_us = round(float(np.mean(sorted(a.elapsed_time(b) * 1e3 for a, b in evd)[:-2])), 1)
-        rccl = dict(ranks=world, backend=dist.get_backend(), bytes=arena.flat.numel() * 4,
-                    collective=("tk_allreduce_f32_dev (C ABI over RCCL)" if arena.collective is not None
-                                else "torch.distributed ProcessGroupNCCL"), c_abi_allreduce_us=direct_us,
+            ub = event_time_us(lambda t=arena.flat[lo:hi]: arena._all_reduce(t).wait(), 10, warm=1)
+            bucket_us.append(round(float(np.mean(ub)), 1))
+        rccl = dict(ranks=world,
+                    backend=("none (no torch.distributed group: own socket rendezvous)" if direct_only or not dist.is_initialized()
+                             else dist.get_backend()),
+                    bytes=arena.flat.numel() * 4,
+                    collective=("tk_allreduce_f32_dev (C ABI over RCCL, libtaiyaki_amd_rccl.so)" if arena.collective is not None
+                                else "torch.distributed ProcessGroupNCCL"),
+                    rendezvous=("tk_rendezvous_bytes at %s:%d (plain sockets)" % (os.environ.get("MASTER_ADDR", "127.0.0.1"),
+                                                                                 parallel.rendezvous_port())
+                                if arena.collective is not None and not dist.is_initialized() else
+                                "torch.distributed store at MASTER_ADDR:MASTER_PORT"),
                     allreduce_us=round(float(np.mean(us)), 1), allreduce_min_us=round(us[0], 1),
                     overlap_buckets=len(arena._buckets),
                     bucket_bytes=[(hi - lo) * 4 for lo, hi in arena.slices()], bucket_us=bucket_us,
                     note=("one flat fp32 gradient arena; in the step it is reduced in %d slices issued from backward "
                           "hooks on RCCL's high-priority stream" % len(arena._buckets) if arena._buckets else
                           "one flat fp32 gradient arena, reduced by ONE all-reduce after backward"))
+        rccl["debug"] = rccl_debug_summary()
 
     if rank == 0:
         nglobal = nbatch * world
@@ -1010,12 +1153,18 @@ def main():
             out["rccl"] = forced_group_overhead(args, argv, elapsed / args.steps * 1e3)
         if not args.no_kernel_records:
             kernel_records(out, args, cfg, dev, world, T, nbatch, chunk_len, cat_mod, S)
+            if world == 1 and not args.no_varlen and not grouped:
+                # the schedule the reference actually trains with (chunk_len drawn per iteration, defaults 3000 .. 8000):
+                # ten driver-timed steps on the per-shape graph cache (round-4 verdict item 7)
+                try:
+                    net2 = build_net()          # (a trainer of its own: the captured step above keeps its optimiser state)
+                    trainer2 = train.Trainer(net2, parallel.FlatGradArena(net2), clip_num_mads=0)
+                    out["varlen"] = variable_length_bench(args, cfg, trainer2, dev, rank, mode != "eager", 3000, 8000, 10, 3)
+                except Exception as exc:          # report, never hide
+                    out["varlen"] = dict(failed="%s: %s" % (type(exc).__name__, str(exc)[:300]))
     else:
         out = None
-    if dist.is_initialized():
-        dist.barrier()
-        dist.destroy_process_group()
-    if out is not None:
+    def emit(line):
         # RCCL writes a version banner through C stdio (fully buffered when stdout is a pipe):
         # flush it first so that the JSON line is the LAST thing rank 0 prints
         sys.stdout.flush()
@@ -1024,7 +1173,24 @@ def main():
             ctypes.CDLL(None).fflush(None)
         except Exception:
             pass
-        print(json.dumps(out), flush=True)
+        print(json.dumps(line), flush=True)
+
+    comm.barrier()
+    if (comm.active and world > 1 and arena.collective is None and dev.type == "cuda"
+            and not os.environ.get("TK_BENCH_SHARE_GPU") and not os.environ.get("TK_BENCH_NO_DIRECT_LEG")):
+        # Both transports in one go: the SAME steps again with the C-ABI collective behind its own socket
+        # rendezvous (a second communicator next to the process group's).  Guarded: this leg has never seen
+        # more than one GPU where it was written -- if it does not finish in time the line goes out without it.
+        res = direct_leg(args, arena, comm, rank, world, dev, timed_steps, event_time_us, nbatch,
+                         on_timeout=(lambda: emit(dict(out, rccl=dict(out["rccl"], direct=dict(failed="timed out")))))
+                         if out is not None else None)
+        if out is not None:
+            out["rccl"]["direct"] = res
+    if dist.is_initialized():
+        dist.barrier()
+        dist.destroy_process_group()
+    if out is not None:
+        emit(out)
 
 
 if __name__ == "__main__":

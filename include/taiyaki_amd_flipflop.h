@@ -385,6 +385,11 @@ void cat_mod_flipflop_cost(float const *logprob, size_t ntrans, size_t nblk,
                            float const *modmovefacts, int32_t const *seqlen,
                            float *score);
 
+/* Measurement helper, no reference counterpart: a float4 streaming device-to-device copy of n floats (n % 4 == 0,
+ * 16-byte aligned), the device-copy ceiling SURVEY.md 8(d) asks the roofline fraction to be quoted against
+ * (bench.py: `roofline.copy_ceiling`). */
+int tk_devcopy_f32_dev(float *dst, const float *src, size_t n, void *stream);
+
 /* ------------------------------------------------------------------------- *
  * Multi-GPU: the data-parallel gradient all-reduce on RCCL over xGMI
  * (libtaiyaki_amd_rccl.so -- a library of its own, see csrc/rccl_api.cpp).
@@ -400,6 +405,16 @@ void cat_mod_flipflop_cost(float const *logprob, size_t ntrans, size_t nblk,
 size_t tk_rccl_unique_id_bytes(void);
 int tk_rccl_unique_id(void *id_out, size_t bytes);
 int tk_rccl_comm_init(void **comm_out, int nranks, const void *id_bytes, int rank);
+/* The rendezvous of its own (round 5): what the reference gets from torch's TCP store at
+ * MASTER_ADDR:MASTER_PORT (bin/train_flipflop.py:255-268), on plain sockets, no torch.distributed.
+ * tk_rendezvous_bytes: rank 0 listens on addr:port and hands the `bytes` bytes at `buf` to each of its
+ *   nranks - 1 peers; a peer connects (retrying until rank 0 is up) and receives them into `buf`.  Every
+ *   rank returns once all peers have the bytes; TK_ERR_BAD_ARG for bad arguments, TK_ERR_LAUNCH (4) when
+ *   `timeout_ms` passes first, a peer announces another nranks, or a rank shows up twice.  No GPU involved.
+ * tk_rccl_comm_init_rendezvous: unique id on rank 0 + tk_rendezvous_bytes + tk_rccl_comm_init -- the one
+ *   call a C host makes per process. */
+int tk_rendezvous_bytes(const char *addr, int port, int rank, int nranks, void *buf, size_t bytes, int timeout_ms);
+int tk_rccl_comm_init_rendezvous(void **comm_out, const char *addr, int port, int rank, int nranks, int timeout_ms);
 int tk_allreduce_f32_dev(void *comm, float *buf, size_t n, void *stream);
 int tk_broadcast_f32_dev(void *comm, float *buf, size_t n, int root, void *stream);
 int tk_rccl_comm_destroy(void *comm);

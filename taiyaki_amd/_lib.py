@@ -46,6 +46,7 @@ SIGNATURES = {
     "tk_flipflop_viterbi_workspace_bytes": (_sz, [_sz, _sz, _sz]),
     "tk_flipflop_viterbi_dev": (_i, [_vp, _sz, _sz, _sz, _vp, _vp, _vp, _vp, _sz, _vp]),
     "tk_flipflop_errprobs_dev": (_i, [_vp, _vp, _sz, _sz, _sz, _vp, _vp]),
+    "tk_devcopy_f32_dev": (_i, [_vp, _vp, _sz, _vp]),
     "tk_grad_maxabs_clip_dev": (_i, [_vp, _vp, _sz, _sz, _vp, _vp, _vp]),
     "tk_flipflop_remap_dev": (_i, [_vp, _vp, _sz, _vp, _vp, _vp, _vp, _sz, _sz, _vp, _vp, _vp, _vp, _vp]),
     "tk_remap_path_to_ref_to_signal_dev": (_i, [_vp, _vp, _vp, _vp, _vp, _sz, _sz, _vp, _vp]),
@@ -68,6 +69,8 @@ RCCL_SIGNATURES = {
     "tk_rccl_unique_id_bytes": (_sz, []),
     "tk_rccl_unique_id": (_i, [_vp, _sz]),
     "tk_rccl_comm_init": (_i, [ctypes.POINTER(_vp), _i, _vp, _i]),
+    "tk_rendezvous_bytes": (_i, [ctypes.c_char_p, _i, _i, _i, _vp, _sz, _i]),
+    "tk_rccl_comm_init_rendezvous": (_i, [ctypes.POINTER(_vp), ctypes.c_char_p, _i, _i, _i, _i]),
     "tk_allreduce_f32_dev": (_i, [_vp, _vp, _sz, _vp]),
     "tk_broadcast_f32_dev": (_i, [_vp, _vp, _sz, _i, _vp]),
     "tk_rccl_comm_destroy": (_i, [_vp]),

@@ -333,6 +333,29 @@ int tk_flipflop_loss_fused_dev(const float *scores, size_t nblk, size_t nbatch, 
     return rc;
 }
 
+typedef float tk_f4 __attribute__((ext_vector_type(4)));
+// Measurement helper ("report the fraction against a measured device-copy ceiling"): a plain float4
+// streaming copy, four independent 16-byte loads in flight per lane, one workgroup per 16 KiB -- the form the
+// MI355X guide measured at 6.29 TB/s.  bench.py times it on the score tensor beside the logZ op.
+__global__ __launch_bounds__(256) void devcopy_f4_kernel(const tk_f4 *__restrict__ src, tk_f4 *__restrict__ dst, size_t n4) {
+    const size_t base = (size_t)blockIdx.x * 1024 + threadIdx.x;
+    tk_f4 v[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k)
+        if (base + (size_t)k * 256 < n4) v[k] = __builtin_nontemporal_load(src + base + (size_t)k * 256);
+#pragma unroll
+    for (int k = 0; k < 4; ++k)
+        if (base + (size_t)k * 256 < n4) __builtin_nontemporal_store(v[k], dst + base + (size_t)k * 256);
+}
+int tk_devcopy_f32_dev(float *dst, const float *src, size_t n, void *stream) {
+    if (dst == nullptr || src == nullptr || n % 4 != 0 || ((uintptr_t)dst | (uintptr_t)src) % 16 != 0) return TK_ERR_BAD_ARG;
+    if (n == 0) return TK_OK;
+    const size_t n4 = n / 4;
+    hipLaunchKernelGGL(devcopy_f4_kernel, dim3((unsigned)((n4 + 1023) / 1024)), dim3(256), 0, static_cast<hipStream_t>(stream),
+                       reinterpret_cast<const tk_f4 *>(src), reinterpret_cast<tk_f4 *>(dst), n4);
+    return hipGetLastError() == hipSuccess ? TK_OK : TK_ERR_LAUNCH;
+}
+
 #ifdef TK_LAB
 // lab hook (lab build only; declared in tools/lab_api.h, not in the public header): see crf_band.hip
 extern "C" void tk_lab_crf_band_phase(int phase) { tk::crf_band_lab_phase(phase); }

@@ -12,9 +12,21 @@
 // RCCL (PyTorch bundles one) must not get a second copy through the kernel library.  The Python
 // trainers use torch.distributed's ProcessGroupNCCL -- the same RCCL calls; this library is what
 // a C / C++ host (or a Taiyaki build without torch.distributed) would bind.
+#include <errno.h>
 #include <hip/hip_runtime.h>
+#include <netdb.h>
+#include <netinet/in.h>
+#include <netinet/tcp.h>
+#include <poll.h>
 #include <rccl/rccl.h>
+#include <stdint.h>
+#include <stdio.h>
 #include <string.h>
+#include <sys/socket.h>
+#include <time.h>
+#include <unistd.h>
+
+#include <vector>
 
 #include "../../include/taiyaki_amd_flipflop.h"
 
@@ -30,6 +42,160 @@ int tk_rccl_unique_id(void *id_out, size_t bytes) {
     if (ncclGetUniqueId(&id) != ncclSuccess) return TK_ERR_LAUNCH;
     memcpy(id_out, &id, sizeof(id));
     return TK_OK;
+}
+
+// ---------------------------------------------------------------------------
+// rendezvous on plain sockets (the reference: torch's TCP store at MASTER_ADDR:MASTER_PORT)
+// ---------------------------------------------------------------------------
+namespace {
+constexpr uint32_t RV_MAGIC = 0x56524b54u;      // "TKRV"
+struct RvHello { uint32_t magic, version, rank, nranks; };
+struct RvHead { uint32_t magic, bytes; };
+
+long long now_ms() {
+    timespec ts;
+    clock_gettime(CLOCK_MONOTONIC, &ts);
+    return (long long)ts.tv_sec * 1000 + ts.tv_nsec / 1000000;
+}
+// all `n` bytes out / in before `deadline`, or false
+bool io_all(int fd, void *p, size_t n, bool writing, long long deadline) {
+    char *c = static_cast<char *>(p);
+    while (n > 0) {
+        const long long left = deadline - now_ms();
+        if (left <= 0) return false;
+        pollfd pf{fd, (short)(writing ? POLLOUT : POLLIN), 0};
+        const int pr = poll(&pf, 1, (int)(left > 1000 ? 1000 : left));
+        if (pr < 0 && errno != EINTR) return false;
+        if (pr <= 0) continue;
+        const ssize_t k = writing ? send(fd, c, n, MSG_NOSIGNAL) : recv(fd, c, n, 0);
+        if (k == 0 && !writing) return false;       // peer closed
+        if (k < 0) {
+            if (errno == EINTR || errno == EAGAIN || errno == EWOULDBLOCK) continue;
+            return false;
+        }
+        c += k;
+        n -= (size_t)k;
+    }
+    return true;
+}
+struct Fds {
+    std::vector<int> v;
+    ~Fds() {
+        for (int fd : v)
+            if (fd >= 0) close(fd);
+    }
+};
+
+int rv_serve(const char *addr, int port, int nranks, const void *buf, size_t bytes, long long deadline) {
+    addrinfo hints{}, *res = nullptr;
+    hints.ai_family = AF_UNSPEC;
+    hints.ai_socktype = SOCK_STREAM;
+    hints.ai_flags = AI_PASSIVE;
+    char ports[16];
+    snprintf(ports, sizeof(ports), "%d", port);
+    if (getaddrinfo(addr, ports, &hints, &res) != 0 || res == nullptr) return TK_ERR_BAD_ARG;
+    Fds fds;
+    int ls = -1;
+    for (addrinfo *ai = res; ai != nullptr && ls < 0; ai = ai->ai_next) {
+        ls = socket(ai->ai_family, ai->ai_socktype, ai->ai_protocol);
+        if (ls < 0) continue;
+        const int one = 1;
+        (void)setsockopt(ls, SOL_SOCKET, SO_REUSEADDR, &one, sizeof(one));
+        if (bind(ls, ai->ai_addr, ai->ai_addrlen) != 0 || listen(ls, nranks + 8) != 0) {
+            close(ls);
+            ls = -1;
+        }
+    }
+    freeaddrinfo(res);
+    if (ls < 0) return TK_ERR_LAUNCH;
+    fds.v.push_back(ls);
+    std::vector<int> peer(nranks, -1);
+    int have = 0;
+    while (have < nranks - 1) {
+        const long long left = deadline - now_ms();
+        if (left <= 0) return TK_ERR_LAUNCH;
+        pollfd pf{ls, POLLIN, 0};
+        if (poll(&pf, 1, (int)(left > 1000 ? 1000 : left)) <= 0) continue;
+        const int fd = accept(ls, nullptr, nullptr);
+        if (fd < 0) continue;
+        fds.v.push_back(fd);
+        const int one = 1;
+        (void)setsockopt(fd, IPPROTO_TCP, TCP_NODELAY, &one, sizeof(one));
+        RvHello h{};
+        // (a stray connection -- a port scanner, a health check -- is dropped, not an error)
+        if (!io_all(fd, &h, sizeof(h), false, now_ms() + 2000 < deadline ? now_ms() + 2000 : deadline) || h.magic != RV_MAGIC) continue;
+        if (h.version != 1 || (int)h.nranks != nranks || h.rank == 0 || (int)h.rank >= nranks || peer[h.rank] >= 0)
+            return TK_ERR_LAUNCH;                   // two jobs on one port, or a rank started twice
+        peer[h.rank] = fd;
+        ++have;
+    }
+    RvHead head{RV_MAGIC, (uint32_t)bytes};
+    for (int r = 1; r < nranks; ++r)
+        if (!io_all(peer[r], &head, sizeof(head), true, deadline) ||
+            !io_all(peer[r], const_cast<void *>(buf), bytes, true, deadline))
+            return TK_ERR_LAUNCH;
+    for (int r = 1; r < nranks; ++r) {
+        uint32_t ack = 0;
+        if (!io_all(peer[r], &ack, sizeof(ack), false, deadline) || ack != RV_MAGIC) return TK_ERR_LAUNCH;
+    }
+    return TK_OK;
+}
+
+int rv_join(const char *addr, int port, int rank, int nranks, void *buf, size_t bytes, long long deadline) {
+    char ports[16];
+    snprintf(ports, sizeof(ports), "%d", port);
+    for (;;) {                                      // rank 0 may not be listening yet: retry
+        if (now_ms() >= deadline) return TK_ERR_LAUNCH;
+        addrinfo hints{}, *res = nullptr;
+        hints.ai_family = AF_UNSPEC;
+        hints.ai_socktype = SOCK_STREAM;
+        if (getaddrinfo(addr, ports, &hints, &res) != 0 || res == nullptr) return TK_ERR_BAD_ARG;
+        int fd = -1;
+        for (addrinfo *ai = res; ai != nullptr && fd < 0; ai = ai->ai_next) {
+            fd = socket(ai->ai_family, ai->ai_socktype, ai->ai_protocol);
+            if (fd >= 0 && connect(fd, ai->ai_addr, ai->ai_addrlen) != 0) {
+                close(fd);
+                fd = -1;
+            }
+        }
+        freeaddrinfo(res);
+        if (fd < 0) {
+            usleep(50 * 1000);
+            continue;
+        }
+        Fds fds;
+        fds.v.push_back(fd);
+        const int one = 1;
+        (void)setsockopt(fd, IPPROTO_TCP, TCP_NODELAY, &one, sizeof(one));
+        RvHello h{RV_MAGIC, 1, (uint32_t)rank, (uint32_t)nranks};
+        RvHead head{};
+        if (!io_all(fd, &h, sizeof(h), true, deadline) || !io_all(fd, &head, sizeof(head), false, deadline))
+            return TK_ERR_LAUNCH;
+        if (head.magic != RV_MAGIC || head.bytes != (uint32_t)bytes) return TK_ERR_LAUNCH;
+        if (!io_all(fd, buf, bytes, false, deadline)) return TK_ERR_LAUNCH;
+        uint32_t ack = RV_MAGIC;
+        return io_all(fd, &ack, sizeof(ack), true, deadline) ? TK_OK : TK_ERR_LAUNCH;
+    }
+}
+}  // namespace
+
+int tk_rendezvous_bytes(const char *addr, int port, int rank, int nranks, void *buf, size_t bytes, int timeout_ms) {
+    if (addr == nullptr || buf == nullptr || port <= 0 || port > 65535 || nranks < 1 || rank < 0 || rank >= nranks ||
+        bytes == 0 || bytes > (1u << 20) || timeout_ms <= 0)
+        return TK_ERR_BAD_ARG;
+    if (nranks == 1) return TK_OK;
+    const long long deadline = now_ms() + timeout_ms;
+    return rank == 0 ? rv_serve(addr, port, nranks, buf, bytes, deadline) : rv_join(addr, port, rank, nranks, buf, bytes, deadline);
+}
+
+int tk_rccl_comm_init_rendezvous(void **comm_out, const char *addr, int port, int rank, int nranks, int timeout_ms) {
+    if (comm_out == nullptr) return TK_ERR_BAD_ARG;
+    ncclUniqueId id;
+    memset(&id, 0, sizeof(id));
+    if (rank == 0 && ncclGetUniqueId(&id) != ncclSuccess) return TK_ERR_LAUNCH;
+    const int rc = tk_rendezvous_bytes(addr, port, rank, nranks, &id, sizeof(id), timeout_ms);
+    if (rc != TK_OK) return rc;
+    return tk_rccl_comm_init(comm_out, nranks, &id, rank);
 }
 
 int tk_rccl_comm_init(void **comm_out, int nranks, const void *id_bytes, int rank) {

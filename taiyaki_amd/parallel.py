@@ -15,12 +15,18 @@ import torch
 import torch.distributed as dist
 
 
-def init_from_env(backend=None):
+def init_from_env(backend=None, process_group=True):
     """Rendezvous from RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* (torch.distributed.run).
-    Returns (rank, local_rank, world)."""
+    Returns (rank, local_rank, world).  `process_group=False`: read the environment only -- the
+    caller brings the ranks together WITHOUT torch.distributed (`DirectRccl`'s own socket rendezvous,
+    `RankComm`)."""
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
+    if not process_group:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29500")
+        return rank, local, world
     # TK_FORCE_PROCESS_GROUP=1: build the (single-rank) RCCL communicator anyway -- lets a 1-GPU
     # box exercise the collective path, its streams and the NCCL watchdog thread
     forced = bool(os.environ.get("TK_FORCE_PROCESS_GROUP"))
@@ -80,6 +86,36 @@ def _trace(msg):
         print("[arena rank %s] %s" % (os.environ.get("RANK", "?"), msg), file=sys.stderr, flush=True)
 
 
+def rendezvous_port():
+    """Where rank 0 serves RCCL's unique id: TK_RENDEZVOUS_PORT, else MASTER_PORT + 1 (MASTER_PORT itself
+    belongs to torch.distributed.run's own store when the ranks were started by it)."""
+    if os.environ.get("TK_RENDEZVOUS_PORT"):
+        return int(os.environ["TK_RENDEZVOUS_PORT"])
+    return int(os.environ.get("MASTER_PORT", "29500")) + 1
+
+
+def socket_rendezvous(rank, world, payload, nbytes, addr=None, port=None, timeout_s=120.0):
+    """Rank 0's `payload` (bytes of length `nbytes`) to every rank through the C ABI's
+    `tk_rendezvous_bytes` (csrc/rccl_api.cpp: plain sockets at addr:port; no torch.distributed, no
+    GPU).  Returns the bytes on every rank."""
+    import ctypes
+    from . import _lib
+    L = _lib.rccl_lib()
+    buf = ctypes.create_string_buffer(nbytes)
+    if rank == 0:
+        if payload is None or len(payload) != nbytes:
+            raise ValueError("socket_rendezvous: rank 0 needs %d bytes to hand out" % nbytes)
+        buf.raw = bytes(payload)
+    addr = addr or os.environ.get("MASTER_ADDR", "127.0.0.1")
+    port = rendezvous_port() if port is None else int(port)
+    rc = L.tk_rendezvous_bytes(addr.encode(), port, rank, world, buf, nbytes, int(timeout_s * 1000))
+    if rc != 0:
+        raise RuntimeError("rendezvous at %s:%d failed for rank %d of %d (code %d: %s)" % (
+            addr, port, rank, world, rc, "bad argument" if rc == 1 else
+            "timed out, a rank announced another world size, or a rank came twice"))
+    return buf.raw
+
+
 class _NoWork:
     def wait(self):
         pass
@@ -106,8 +142,10 @@ class DirectRccl:
     that produced the gradients.
 
     `exchange(id_bytes_or_None) -> id_bytes` hands rank 0's RCCL unique id to every rank (the
-    reference's TCP store, bin/train_flipflop.py:255-268); the default uses the torch.distributed
-    group that is already up (gloo or nccl) and is the identity for a single rank."""
+    reference's TCP store, bin/train_flipflop.py:255-268).  Default: when a torch.distributed group
+    is up it carries the id; otherwise -- the path WITHOUT torch.distributed -- the C ABI's own socket
+    rendezvous (`tk_rendezvous_bytes`: rank 0 serves the id at MASTER_ADDR : rendezvous_port(), plain
+    sockets).  The identity for a single rank."""
 
     def __init__(self, rank, world, exchange=None, device=None, in_stream=False):
         """`in_stream`: enqueue every collective on the CALLER's current stream -- in order with the
@@ -125,7 +163,7 @@ class DirectRccl:
         if rank == 0:
             _lib.check(self._lib.tk_rccl_unique_id(buf, nb), "tk_rccl_unique_id")
         if exchange is None:
-            exchange = self._exchange_over_process_group
+            exchange = self._exchange_over_process_group if dist.is_initialized() else self._exchange_over_sockets
         idbytes = exchange(buf.raw if rank == 0 else None)
         if idbytes is None or len(idbytes) != nb:
             raise RuntimeError("DirectRccl: the unique id did not arrive (%r)" % (idbytes,))
@@ -141,6 +179,11 @@ class DirectRccl:
         box = [idbytes]
         dist.broadcast_object_list(box, src=0)
         return box[0]
+
+    def _exchange_over_sockets(self, idbytes):
+        if self.world == 1:
+            return idbytes
+        return socket_rendezvous(self.rank, self.world, idbytes, nbytes=int(self._lib.tk_rccl_unique_id_bytes()))
 
     def _enqueue(self, fn, what, t):
         from . import _lib
@@ -174,6 +217,46 @@ class DirectRccl:
             torch.cuda.synchronize()
             self._lib.tk_rccl_comm_destroy(self._comm)
             self._comm = None
+
+
+class RankComm:
+    """What a data-parallel driver needs besides the gradient collective -- a barrier and one number per
+    rank (max-over-ranks timing, "did every rank capture its graph") -- on either transport:
+    `collective=None`: the torch.distributed group that is up (nccl or gloo);
+    `collective=DirectRccl`: the C ABI's all-reduce alone (a slot per rank in a zero vector, SUM), so a job
+    started with `bench.py --collective direct` never touches torch.distributed."""
+
+    def __init__(self, rank, world, collective=None, device=None):
+        self.rank, self.world, self.collective = rank, world, collective
+        self.device = device if device is not None else torch.device("cpu")
+
+    @property
+    def active(self):
+        return self.world > 1 and (self.collective is not None or dist.is_initialized())
+
+    def gather(self, value):
+        """`value` (a float) of every rank, in rank order, on every rank."""
+        if not self.active:
+            return [float(value)]
+        if self.collective is not None:
+            slots = torch.zeros(self.world, dtype=torch.float32, device=self.device)
+            slots[self.rank] = float(value)
+            self.collective.all_reduce(slots).wait()
+            torch.cuda.current_stream().synchronize()
+            return [float(v) for v in slots.tolist()]
+        dev = self.device if dist.get_backend() == "nccl" else torch.device("cpu")
+        mine = torch.tensor([float(value)], dtype=torch.float64, device=dev)
+        out = [torch.zeros_like(mine) for _ in range(self.world)]
+        dist.all_gather(out, mine)
+        return [float(t.item()) for t in out]
+
+    def barrier(self):
+        if not self.active:
+            return
+        if self.collective is not None:
+            self.gather(0.0)
+        else:
+            dist.barrier()
 
 
 class FlatGradArena:

@@ -373,6 +373,7 @@ class GraphCacheTrainer:
         self.entries = {}
         self.opt_graph = None
         self.nsteps = 0
+        self.hits = self.misses = 0         # steps that replayed a shape's graph / that had to capture it first
         self.alias, self.opt = _aliased_adamw(trainer)
 
     def set_lr(self, lr):
@@ -418,7 +419,10 @@ class GraphCacheTrainer:
         key = self.key_of(batch)
         one = self.entries.get(key)
         if one is None:
+            self.misses += 1
             one = self.entries[key] = self._capture_shape(batch)
+        else:
+            self.hits += 1
         one.load(batch)
         one.graph.replay()
         ctc.backward_unit(one.loss, retain_graph=True)

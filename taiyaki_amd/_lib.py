@@ -18,7 +18,7 @@ LIBPATH = os.environ.get("TAIYAKI_AMD_LIB") or os.path.join(CSRC, LIBNAME)   # (
 # (TK_CRF_MODE, TK_CRF_BK, TK_LOGZ_CH, TK_CRF_NO_FALLBACK ...) and exports tk_lab_*.  tests/ and tools/ switch
 # to it with `use_lab()` when they flip one; the operators never load it by themselves.
 LAB_LIBNAME = "libtaiyaki_amd_flipflop_lab.so"
-LAB_LIBPATH = os.path.join(CSRC, LAB_LIBNAME)
+LAB_LIBPATH = os.environ.get("TAIYAKI_AMD_LAB_LIB") or os.path.join(CSRC, LAB_LIBNAME)    # (override: A/B builds under tools/lab/)
 
 _vp = ctypes.c_void_p
 _sz = ctypes.c_size_t

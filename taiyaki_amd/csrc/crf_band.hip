@@ -666,16 +666,12 @@ __device__ __forceinline__ void band_sweep(const BandArgs &a, int n, int L, floa
     for (int j = 0; j < R; ++j) {
         const int q = lane * R + j, p = FWD ? a0 + q : a0 + PW - 1 - q;
         if (p == pend) {
+            // (a cost-only call, too: round 5 -- its forward sweep used to write the cost by itself whenever the score
+            // was finite, and a read outside the linear path's range came back silently WRONG, e.g. cat-mod with five
+            // modifications per base: costs off by 0.02 .. 0.19.  Now both sweeps run, and the launch behind them
+            // (crf_kernel's vote pass) writes the cost where they agree and redoes the read where they do not.)
             const double sc2 = (double)f[j] + log2((double)m[j]);
-            if (GRAD) {
-                (FWD ? a.scoreF : a.scoreB)[n] = sc2;
-            } else if (sc2 - sc2 == 0.0) {
-                // (the bias comes back: every one of the T step weights on a path carried 2^-wbias)
-                a.cost[n] = crf_add_cost(a, n, (float)(-((sc2 + (double)wbias * (double)T) * 0.6931471805599453) / (double)T) * a.out_scale);
-                a.gate[n] = 0;
-            } else {
-                a.gate[n] = 1;                                  // crf_kernel decides what this read costs
-            }
+            (FWD ? a.scoreF : a.scoreB)[n] = sc2;
         }
     }
 }
@@ -747,8 +743,8 @@ __device__ __forceinline__ void band_rowmaker(const BandArgs &a, int n, float *E
 
 // ===========================================================================
 // sweep + rank launch.  blockIdx.x in [0, N): sorted-instance records for the gradient pass;
-// [N, 2N): forward sweep of read n; [2N, 3N): backward sweep.  Cost-only calls launch N
-// workgroups: the forward sweeps.
+// [N, 2N): forward sweep of read n; [2N, 3N): backward sweep.  Cost-only calls launch 2 N
+// workgroups: the two sweeps (their scores are compared by the launch behind them, crf_kernel's vote pass).
 // ===========================================================================
 // WCAP = the most waves a launch of this instantiation may have: the register budget of a lane is
 // 512 / ceil(WCAP / 4) (R = 4 wants more than the 128 that 16 waves leave).
@@ -767,15 +763,16 @@ __global__ __launch_bounds__(WCAP *WAVE) void crf_band_sweep_kernel(BandArgs a) 
     // dispatch order: rank workgroups first (short; they leave their CUs within microseconds),
     // then the forward, then the backward sweeps
     const int slot3 = blockIdx.x / N;
-    const int role = want_grad ? (slot3 + 2) % 3 : 0;           // 0 forward, 1 backward, 2 rank
+    const int role = want_grad ? (slot3 + 2) % 3 : slot3;       // 0 forward, 1 backward, 2 rank (cost only: 2 N workgroups, the two sweeps)
     const int n = blockIdx.x - slot3 * N;
     const int L = min(a.seqlen[n], (int)(a.seqoff[n + 1] - a.seqoff[n]));      // (offsets are clamped to the label array)
     if (role == 2 && tid == 0) a.gate[n] = 0;
+    if (!want_grad && role == 0 && tid == 0) a.gate[n] = 2;     // cost only: pending -- crf_kernel compares the two sweep scores
     if (role == 2 && tid < 16) const_cast<float *>(a.zeros)[tid] = 0.f;   // (every rank workgroup: the same zeros)
     if (L == 0 || L > W * PW) {
         // c_crf_flipflop.c:269-272: cost 0 for an empty read (the gradient pass does it when
         // there is one); too long for the launch: flagged
-        if (!want_grad && tid == 0) {
+        if (!want_grad && role == 0 && tid == 0) {
             a.cost[n] = (L == 0) ? crf_add_cost(a, n, 0.f) : __builtin_nanf("");
             a.gate[n] = 0;
             if (L != 0 && a.status) atomicOr(a.status, 16u);
@@ -841,8 +838,10 @@ __global__ __launch_bounds__(WCAP *WAVE) void crf_band_sweep_kernel(BandArgs a) 
             return;
         }
     }
-    if (!want_grad)
+    if (!want_grad && role == 0)
         band_sweep<R, MOD, true, false, ROWS, CW, BK>(a, n, L, E, Ef, Ezero, Wt);
+    else if (!want_grad)
+        band_sweep<R, MOD, false, false, ROWS, CW, BK>(a, n, L, E, Ef, Ezero, Wt);
     else if (role == 0)
         band_sweep<R, MOD, true, true, ROWS, CW, BK>(a, n, L, E, Ef, Ezero, Wt);
     else
@@ -1465,8 +1464,11 @@ BandLayout crf_band_layout(size_t ntrans, size_t nblk, size_t nbatch, size_t max
     l.ckBb = take(nbatch * NB * l.W * sizeof(int));
     l.bndF = take(nbatch * NB * Wp * BK * sizeof(float));
     l.bndB = take(nbatch * NB * Wp * BK * sizeof(float));
-    l.scoreF = take(nbatch * sizeof(double));
-    l.scoreB = take(nbatch * sizeof(double));
+    // (the two sweep scores also in a cost-only call: it runs both sweeps and is only believed where they agree)
+    l.scoreF = off;
+    off += (nbatch * sizeof(double) + 255) / 256 * 256;
+    l.scoreB = off;
+    off += (nbatch * sizeof(double) + 255) / 256 * 256;
     l.rec = take(nbatch * Wp * KINDS * WAVE * sizeof(uint32_t));
     l.segend = take(nbatch * Wp * WAVE * sizeof(int));
     l.gate = off;
@@ -1501,7 +1503,7 @@ static int band_launch_sweep(const BandArgs &a, hipStream_t stream) {
     const bool want_grad = a.grad != nullptr;
     const int nw = a.W + (ROWS ? 1 : 0);
     const size_t lds = ROWS ? (size_t)(a.W + 1) * BK * ROW_PITCH * sizeof(float) : 0;
-    const dim3 grid((want_grad ? 3 : 1) * a.N), block(nw * WAVE);
+    const dim3 grid((want_grad ? 3 : 2) * a.N), block(nw * WAVE);
     // (R = 4 is compiled per wave-count class: 155 registers where the launch bounds allow them)
     auto go = [&](auto cap) {
         constexpr int WCAP = decltype(cap)::value;

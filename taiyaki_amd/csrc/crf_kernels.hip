@@ -44,6 +44,10 @@ struct CrfArgs {
     double *ckoff;              // workspace: checkpoint offsets
     uint32_t *status;
     const int *gate;            // nullable; (N): only reads with gate[n] != 0 are computed (the band path's rejects)
+    // behind a COST-ONLY band launch: the log2 scores of its two sweeps (null otherwise).  gate[n] == 2 then means
+    // "pending": the read is the linear path's -- and its cost is written here -- iff both scores are finite and agree
+    const double *bandF, *bandB;
+    float band_wbias;           // the band sweeps' weight bias: their scores get band_wbias * T back
     float grad_scale;           // gradient multiplier (1 for the reference's operators)
     const float *grad_scale_vec;    // nullable; (N): a further per-read multiplier    // fused cat-mod loss: kernel B ran first into a compact buffer; this operator adds
     // add_scale * add_cost[n] to the cost and add_scale * (gradient multiplier) * add_grad[t][n][s]
@@ -500,6 +504,19 @@ __device__ __forceinline__ void crf_read(const CrfArgs &a, const int n, const in
 // batch.  Usually there is nothing to redo and a workgroup leaves after one pass over the gate array.
 // Workgroup 0 adds the number of disowned reads to the status word's upper 24 bits
 // (TK_STATUS_GATED_SHIFT): what ctc.last_gate_count() / the trainer's warning read.
+// Is read n one the linear band path disowned?  Grad calls: the gate array says so.  Cost-only calls leave
+// gate[n] == 2 ("pending") and the two sweep scores: the read is the linear path's iff both are finite and agree to
+// 1e-3 bit (the tolerance the gradient pass holds them to); `score2` = their mean then.
+__device__ __forceinline__ int crf_band_gate_of(const CrfArgs &a, int n, double *score2) {
+    const int g = a.gate[n];
+    if (a.bandF == nullptr || g != 2) return g;
+    const double F = a.bandF[n], B = a.bandB[n], d = F - B;
+    if (!(F - F == 0.0 && B - B == 0.0)) return 1;              // overflow / nothing left: not representable
+    if (!(d > -1e-3 && d < 1e-3)) return 4;                     // mass lost on the way in one of them
+    *score2 = 0.5 * (F + B);
+    return 0;
+}
+
 template <int R, int W, bool MOD>
 __global__ __launch_bounds__(W *WAVE) void crf_kernel(CrfArgs a) {
     if (a.gate == nullptr) {
@@ -511,13 +528,27 @@ __global__ __launch_bounds__(W *WAVE) void crf_kernel(CrfArgs a) {
     // LDS is at the limit, a static word for a workgroup-wide vote would not fit -- and no barrier)
     {
         const int lane = threadIdx.x & (WAVE - 1);
+        const bool writer = blockIdx.x == 0 && threadIdx.x < WAVE;      // (one wave writes the cost-only calls' costs)
         unsigned long long any = 0;
-        for (int n0 = 0; n0 < a.N; n0 += WAVE) any |= __ballot(n0 + lane < a.N && a.gate[n0 + lane] != 0);
+        for (int n0 = 0; n0 < a.N; n0 += WAVE) {
+            const int n = n0 + lane;
+            double score2 = 0.0;
+            const int g = n < a.N ? crf_band_gate_of(a, n, &score2) : 0;
+            if (writer && n < a.N && g == 0 && a.bandF != nullptr && a.gate[n] == 2) {
+                // score = mean of the two sweeps (c_crf_flipflop.c:482-491 does the same), cost = -score / T; the
+                // bias comes back: every one of the T step weights on a path carried 2^-wbias
+                const float cst = crf_add_cost(a, n, (float)(-((score2 + (double)a.band_wbias * (double)a.T) * 0.6931471805599453) / (double)a.T) * a.out_scale);
+                a.cost[n] = cst;
+                if (a.status && !isfinite(cst)) atomicOr(a.status, 1u);
+            }
+            any |= __ballot(g != 0);
+        }
         if (any == 0) return;
     }
     int seen = 0;
     for (int n = 0; n < a.N; ++n) {
-        if (a.gate[n] == 0) continue;                            // the linear band path owns this read
+        double unused;
+        if (crf_band_gate_of(a, n, &unused) == 0) continue;      // the linear band path owns this read
         if (seen % (int)gridDim.x == (int)blockIdx.x) {
             crf_read<R, W, MOD>(a, n, (int)blockIdx.x);
             __syncthreads();
@@ -847,6 +878,8 @@ int crf_dispatch(const float *logprob, size_t ntrans, size_t nblk, size_t nbatch
     a.cost = cost;
     a.grad = grad;
     a.gate = nullptr;
+    a.bandF = a.bandB = nullptr;
+    a.band_wbias = 0.f;
     a.status = status;
     char *wb = static_cast<char *>(workspace);
     // (what add_grad / add_cost hold may come from another stream: the band path waits between its sweeps
@@ -892,8 +925,8 @@ int crf_dispatch(const float *logprob, size_t ntrans, size_t nblk, size_t nbatch
         b.ckBb = g ? reinterpret_cast<int *>(wb + l.ckBb) : nullptr;
         b.bndF = g ? reinterpret_cast<float *>(wb + l.bndF) : nullptr;
         b.bndB = g ? reinterpret_cast<float *>(wb + l.bndB) : nullptr;
-        b.scoreF = g ? reinterpret_cast<double *>(wb + l.scoreF) : nullptr;
-        b.scoreB = g ? reinterpret_cast<double *>(wb + l.scoreB) : nullptr;
+        b.scoreF = reinterpret_cast<double *>(wb + l.scoreF);
+        b.scoreB = reinterpret_cast<double *>(wb + l.scoreB);
         b.rec = g ? reinterpret_cast<uint32_t *>(wb + l.rec) : nullptr;
         b.segend = g ? reinterpret_cast<int *>(wb + l.segend) : nullptr;
         b.gate = reinterpret_cast<int *>(wb + l.gate);
@@ -921,6 +954,11 @@ int crf_dispatch(const float *logprob, size_t ntrans, size_t nblk, size_t nbatch
         }
         // the reads the linear path disowned, redone in the log domain
         a.gate = b.gate;
+        if (!g) {               // cost only: the vote pass compares the sweeps and writes the costs
+            a.bandF = b.scoreF;
+            a.bandB = b.scoreB;
+            a.band_wbias = blk.wbias;
+        }
         wb += l.total;
         if (const char *e = TK_LAB_ENV("TK_CRF_NO_FALLBACK"))       // lab: time / test the band path alone
             if (e[0] == '1') return 0;

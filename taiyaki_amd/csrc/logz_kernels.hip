@@ -57,6 +57,12 @@ __device__ long long tk_dbg[64];
 #ifndef TK_K3_NT_STORE
 #define TK_K3_NT_STORE 1
 #endif
+#ifndef TK_K3_REV
+#define TK_K3_REV 0
+#endif
+#ifndef TK_K1_REV
+#define TK_K1_REV 0
+#endif
 
 // ---------------------------------------------------------------------------
 // XMat: a 2nb x 2nb transfer matrix  value[i][j] = m[i][j] * 2^e[i] * exp(M)
@@ -223,7 +229,7 @@ __global__ __launch_bounds__(K1_WAVES *WAVE, 2) void logz_transfer_kernel(
     using X = XMat<NB>;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int wave = threadIdx.x >> 6, lane = lane_id();
-    const int c = blockIdx.y * K1_WAVES + wave;
+    const int c = (TK_K1_REV ? (int)(gridDim.y - 1 - blockIdx.y) : (int)blockIdx.y) * K1_WAVES + wave;
     if (c >= C) return;                         // wave-uniform; the kernel has no barriers
     // wave-private LDS: the row-set transpose buffer, later the matrix image
     constexpr int IMG_F4 = (X::NF4 > F::PIECES * (RING > 0 ? RING : 1) ? X::NF4 : F::PIECES * (RING > 0 ? RING : 1));
@@ -986,7 +992,7 @@ __global__ __launch_bounds__(K3_WAVES *WAVE, (CH / K3_WAVES <= 2 ? 4 : 2)) void 
                                   (K3_ROWS + 1) * F::NS * WAVE
                             : chain_tail + F::NS * WAVE;
     };
-    const int c = blockIdx.y;
+    const int c = TK_K3_REV ? (int)(gridDim.y - 1 - blockIdx.y) : (int)blockIdx.y;
     const int n0 = blockIdx.x * WAVE;
     const int nvalid = min(WAVE, N - n0) * F::PIECES;
     const size_t rowstride = (size_t)ws.nstride * F::S;

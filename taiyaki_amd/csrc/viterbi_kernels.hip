@@ -49,6 +49,89 @@ __device__ __forceinline__ float vit_grp_max(float x) {
     return r;
 }
 
+// ---- traceback (decode.py:108-113); argmax = first maximal state.  `m`: the last step's maxima as the
+// forward pass left them -- state s in group s (one-wave kernel, and the alternating layout after an even
+// last step, i.e. T odd) or in lane s of every group (alternating layout, T even).
+template <int NB>
+__device__ __forceinline__ void viterbi_path_pass(float m, int T, int N, int n, int lane, int64_t *__restrict__ path_out,
+                                                  const unsigned char *__restrict__ packed, int npad, bool alternating) {
+    using F = FF<NB>;
+    // ---- traceback (decode.py:108-113); argmax = first maximal state
+    unsigned st = 0;
+    {
+        const int per_state = (alternating && (T & 1) == 0) ? 1 : VIT_GRP;
+        float top = __shfl(m, 0, WAVE);
+        if (T == 0) top = 0.f;
+#pragma unroll
+        for (int s = 1; s < F::NS; ++s) {
+            float v = __shfl(m, s * per_state, WAVE);
+            if (T == 0) v = (s < NB) ? 0.f : NEG_LARGE;
+            if (v > top) {
+                top = v;
+                st = s;
+            }
+        }
+    }
+    if (lane == 0) path_out[(size_t)T * N + n] = (int64_t)st;
+    // the eight bytes of a read at a step are one 64-bit word: no dependent address
+    const unsigned long long *words = reinterpret_cast<const unsigned long long *>(packed) + n;
+    auto load_batch = [&](int thi) {                            // lane k: the word of step thi - 1 - k
+        const int t = max(thi - 1 - lane, 0);                   // clamped, never branched
+        return words[(size_t)t * npad];
+    };
+    // four batches in flight (a batch's scan is ~0.3 us, a load round trip a multiple of that);
+    // the ring rotates by NAME -- the loop is unrolled four times -- because a register copy of a
+    // word in flight would wait for its load
+    constexpr int VIT_TBQ = 4;
+    unsigned long long q[VIT_TBQ];
+#pragma unroll
+    for (int b = 0; b < VIT_TBQ; ++b) q[b] = load_batch(T - b * WAVE);
+    // The eight bytes of a step's word are the table  state -> previous state,  and v_perm_b32
+    // with a table as byte selector COMPOSES two tables, four entries at a time (selectors 0-3
+    // pick bytes of the low dword, 4-7 of the high one).  So the 64 steps of a batch are not walked
+    // one after the other: an inclusive scan over the lanes (six levels, two v_perm_b32 + two
+    // ds_bpermute each) leaves in lane k the composition of steps 0..k, and one more look-up with
+    // the incoming state gives every lane its own state.  The scans of the four batches in flight
+    // do not depend on each other (only that last look-up chains them): they are issued together
+    // so that one's ds_bpermute round trips hide behind the others'.
+    auto scan = [&](unsigned long long cur, unsigned &lo, unsigned &hi) {
+        lo = (unsigned)cur;
+        hi = (unsigned)(cur >> 32);
+#pragma unroll
+        for (int d = 1; d < WAVE; d <<= 1) {
+            const int src4 = 4 * (lane - d);                    // (wraps for lane < d: not used there)
+            const unsigned blo = (unsigned)__builtin_amdgcn_ds_bpermute(src4, (int)lo);
+            const unsigned bhi = (unsigned)__builtin_amdgcn_ds_bpermute(src4, (int)hi);
+            // (this step's table) o (the steps before): entry s = mine[theirs[s]]
+            const unsigned nlo = __builtin_amdgcn_perm(hi, lo, blo), nhi = __builtin_amdgcn_perm(hi, lo, bhi);
+            if (lane >= d) {
+                lo = nlo;
+                hi = nhi;
+            }
+        }
+    };
+    for (int thi = T; thi > 0; thi -= VIT_TBQ * WAVE) {
+        unsigned lo[VIT_TBQ], hi[VIT_TBQ];
+#pragma unroll
+        for (int b = 0; b < VIT_TBQ; ++b) {
+            const unsigned long long cur = q[b];
+            q[b] = load_batch(thi - (b + VIT_TBQ) * WAVE);
+            scan(cur, lo[b], hi[b]);
+        }
+#pragma unroll
+        for (int b = 0; b < VIT_TBQ; ++b) {
+            const int th = thi - b * WAVE;
+            if (th > 0) {                                        // wave-uniform
+                const unsigned mine = __builtin_amdgcn_perm(hi[b], lo[b], st) & 0xffu;     // st: the batch's start state
+                const int t = th - 1 - lane;
+                if (t >= 0) path_out[(size_t)t * N + n] = (int64_t)mine;
+                // (lanes before the start of the read re-read step 0; the walk ends with this batch then)
+                st = (unsigned)__builtin_amdgcn_readlane((int)mine, WAVE - 1);
+            }
+        }
+    }
+}
+
 template <int NB, bool FULLOUT>
 __global__ __launch_bounds__(WAVE) void viterbi_kernel(const float *__restrict__ scores, int T,
                                                       int N, float *__restrict__ fwd_out,
@@ -151,79 +234,212 @@ __global__ __launch_bounds__(WAVE) void viterbi_kernel(const float *__restrict__
 #ifdef TK_VIT_NOPATH
     return;                                     // lab: forward pass alone
 #endif
-    // ---- traceback (decode.py:108-113); argmax = first maximal state
-    unsigned st = 0;
+    viterbi_path_pass<NB>(m, T, N, n, lane, path_out, packed, npad, /*alternating=*/false);
+}
+
+
+// ===========================================================================
+// Round 5: THREE WAVES PER READ.  The one-wave kernel above spends ~30 instructions per step on one
+// wave's issue stream, a third of them the traceback byte (ballot, shifts, find-first, store) and the
+// full-output stores -- none of which the recursion depends on.  Here wave 0 runs ONLY the recursion,
+// in the alternating layout (LABNOTES R4.5: even steps lane = (to, from) with the maximum inside the
+// 8-lane group, odd steps lane = (from, to) with the maximum across the groups -- row_ror:8 and gfx950's
+// v_permlane16_swap / v_permlane32_swap -- so every lane already HOLDS the state it needs next and no
+// ds_bpermute round trip sits on the chain; alone that change measured nothing, because the step was
+// bound by its instruction count), and leaves each step's state vector in an LDS ring.  Waves 1 and 2
+// follow a tile of 16 steps behind (even / odd steps, a fixed layout each): they re-form the candidates
+// from the ring's previous vector and their own copy of the score row -- the same single fp32 add, so the
+// same bits -- compare with the ring's maximum, and write the traceback byte (and fwd / traceback of the
+// reference's full-output form).  One s_barrier per 16 steps hands a tile over; the score rows are
+// requested 64 steps ahead (one wave per SIMD: registers are free).  Arithmetic, tie rule and outputs
+// are those of the one-wave kernel, bit for bit.
+// ===========================================================================
+constexpr int VIT_TILE = 16;        // steps per hand-over (one s_barrier)
+constexpr int VIT_GROUP = 64;       // steps of straight-line code = score rows in flight
+constexpr int VIT_RING = 4;         // tiles in the LDS ring (the tile being written, the one being read, and its predecessor's last vector)
+
+// maximum over the eight lanes that share lane % 8 (one per 8-lane group), in all of them: within a
+// 16-lane row by DPP, across the rows and halves by the lane-swap instructions of gfx950
+__device__ __forceinline__ float vit_cross_max(float x) {
+    float r;
+    asm("s_nop 1\n\t"
+        "v_max_f32_dpp %0, %1, %1 row_ror:8 row_mask:0xf bank_mask:0xf"
+        : "=&v"(r) : "v"(x));
     {
-        float top = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(m), 0));
-        if (T == 0) top = 0.f;
-#pragma unroll
-        for (int s = 1; s < F::NS; ++s) {
-            float v = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(m), s * VIT_GRP));
-            if (T == 0) v = (s < NB) ? 0.f : NEG_LARGE;
-            if (v > top) {
-                top = v;
-                st = s;
-            }
-        }
+        const auto sw = __builtin_amdgcn_permlane16_swap(__float_as_uint(r), __float_as_uint(r), false, false);
+        asm("v_max_f32 %0, %1, %2" : "=v"(r) : "v"(__uint_as_float(sw[0])), "v"(__uint_as_float(sw[1])));
     }
-    if (lane == 0) path_out[(size_t)T * N + n] = (int64_t)st;
-    // the eight bytes of a read at a step are one 64-bit word: no dependent address
-    const unsigned long long *words = reinterpret_cast<const unsigned long long *>(packed) + n;
-    auto load_batch = [&](int thi) {                            // lane k: the word of step thi - 1 - k
-        const int t = max(thi - 1 - lane, 0);                   // clamped, never branched
-        return words[(size_t)t * npad];
-    };
-    // four batches in flight (a batch's scan is ~0.3 us, a load round trip a multiple of that);
-    // the ring rotates by NAME -- the loop is unrolled four times -- because a register copy of a
-    // word in flight would wait for its load
-    constexpr int VIT_TBQ = 4;
-    unsigned long long q[VIT_TBQ];
-#pragma unroll
-    for (int b = 0; b < VIT_TBQ; ++b) q[b] = load_batch(T - b * WAVE);
-    // The eight bytes of a step's word are the table  state -> previous state,  and v_perm_b32
-    // with a table as byte selector COMPOSES two tables, four entries at a time (selectors 0-3
-    // pick bytes of the low dword, 4-7 of the high one).  So the 64 steps of a batch are not walked
-    // one after the other: an inclusive scan over the lanes (six levels, two v_perm_b32 + two
-    // ds_bpermute each) leaves in lane k the composition of steps 0..k, and one more look-up with
-    // the incoming state gives every lane its own state.  The scans of the four batches in flight
-    // do not depend on each other (only that last look-up chains them): they are issued together
-    // so that one's ds_bpermute round trips hide behind the others'.
-    auto scan = [&](unsigned long long cur, unsigned &lo, unsigned &hi) {
-        lo = (unsigned)cur;
-        hi = (unsigned)(cur >> 32);
-#pragma unroll
-        for (int d = 1; d < WAVE; d <<= 1) {
-            const int src4 = 4 * (lane - d);                    // (wraps for lane < d: not used there)
-            const unsigned blo = (unsigned)__builtin_amdgcn_ds_bpermute(src4, (int)lo);
-            const unsigned bhi = (unsigned)__builtin_amdgcn_ds_bpermute(src4, (int)hi);
-            // (this step's table) o (the steps before): entry s = mine[theirs[s]]
-            const unsigned nlo = __builtin_amdgcn_perm(hi, lo, blo), nhi = __builtin_amdgcn_perm(hi, lo, bhi);
-            if (lane >= d) {
-                lo = nlo;
-                hi = nhi;
-            }
-        }
-    };
-    for (int thi = T; thi > 0; thi -= VIT_TBQ * WAVE) {
-        unsigned lo[VIT_TBQ], hi[VIT_TBQ];
-#pragma unroll
-        for (int b = 0; b < VIT_TBQ; ++b) {
-            const unsigned long long cur = q[b];
-            q[b] = load_batch(thi - (b + VIT_TBQ) * WAVE);
-            scan(cur, lo[b], hi[b]);
-        }
-#pragma unroll
-        for (int b = 0; b < VIT_TBQ; ++b) {
-            const int th = thi - b * WAVE;
-            if (th > 0) {                                        // wave-uniform
-                const unsigned mine = __builtin_amdgcn_perm(hi[b], lo[b], st) & 0xffu;     // st: the batch's start state
-                const int t = th - 1 - lane;
-                if (t >= 0) path_out[(size_t)t * N + n] = (int64_t)mine;
-                // (lanes before the start of the read re-read step 0; the walk ends with this batch then)
-                st = (unsigned)__builtin_amdgcn_readlane((int)mine, WAVE - 1);
-            }
-        }
+    {
+        const auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(r), __float_as_uint(r), false, false);
+        asm("v_max_f32 %0, %1, %2" : "=v"(r) : "v"(__uint_as_float(sw[0])), "v"(__uint_as_float(sw[1])));
     }
+    return r;
+}
+
+__device__ __forceinline__ void vit_handover() {
+    // (LDS traffic only: the chain wave's score loads and the trace waves' stores stay in flight)
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+}
+
+template <int NB, bool FULLOUT>
+__global__ __launch_bounds__(3 * WAVE) void viterbi3_kernel(const float *__restrict__ scores, int T,
+                                                           int N, float *__restrict__ fwd_out,
+                                                           int64_t *__restrict__ tb_out,
+                                                           int64_t *__restrict__ path_out,
+                                                           unsigned char *__restrict__ packed, int npad) {
+    using F = FF<NB>;
+    static_assert(F::NS <= VIT_GRP, "one lane group per state");
+    static_assert(VIT_GROUP == VIT_RING * VIT_TILE && VIT_TILE % 2 == 0, "the ring holds one group; tiles start with an even step");
+    __shared__ float ring[VIT_RING * VIT_TILE * WAVE];
+    const int lane = lane_id();
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int grp = lane >> 3, sub = lane & 7;          // even steps: (to, from) = (grp, sub); odd steps: (sub, grp)
+    const int n = blockIdx.x;
+    // decode.py:99-105: a flip state is reached from every state, flop b only from flip b and from itself
+    auto valid_of = [&](int to, int from) {
+        return to < F::NS && from < F::NS && (to < NB || from == to - NB || from == to);
+    };
+    auto sidx_of = [&](int to, int from) {
+        return (to < NB) ? to * F::NS + min(from, F::NS - 1) : F::FLOP0 + min(from, F::NS - 1);
+    };
+    const bool validA = valid_of(grp, sub), validB = valid_of(sub, grp);
+    const size_t rowstride = (size_t)N * F::S;
+    constexpr int RSRC3 = 0x00027000;
+    const unsigned rs4 = 4u * (unsigned)rowstride;
+    const unsigned ld4A = 4u * (unsigned)((size_t)n * F::S + min(sidx_of(grp, sub), F::S - 1));
+    const unsigned ld4B = 4u * (unsigned)((size_t)n * F::S + min(sidx_of(sub, grp), F::S - 1));
+    const int NT = (T + VIT_TILE - 1) / VIT_TILE;       // hand-overs: every wave passes exactly NT barriers
+    const int Tm1 = max(T - 1, 0);
+    // descriptor of the rows from t0 on; rows past the end re-read the last one (clamped, never branched)
+    auto rows_from = [&](int t0) {
+        return __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(scores + (size_t)min(t0, Tm1) * rowstride), 0,
+                                                 0x7fffffff, RSRC3);
+    };
+    float *const ring_lane = ring + lane;
+    float m = VIT_NEG_INF;
+
+    if (wave == 0) {
+        // ---------------------------------------------------------------- the recursion, nothing else
+        float f = (sub < NB) ? 0.f : ((sub < F::NS) ? NEG_LARGE : VIT_NEG_INF);        // decode.py:93-95 (step 0 is even: from = sub)
+        float sc[VIT_GROUP];
+        {
+            const __amdgpu_buffer_rsrc_t rs = rows_from(0);
+#pragma unroll
+            for (int k = 0; k < VIT_GROUP; ++k)
+                sc[k] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rs, (k & 1) ? ld4B : ld4A, rs4 * (unsigned)min(k, Tm1), 0));
+        }
+        float snext = validA ? sc[0] : VIT_NEG_INF;
+        auto group = [&](int t0, auto full) {
+            constexpr bool FULL = decltype(full)::value;
+            const __amdgpu_buffer_rsrc_t rnext = rows_from(t0 + VIT_GROUP);
+            const int lastn = max(Tm1 - min(t0 + VIT_GROUP, Tm1), 0);
+#pragma unroll
+            for (int k = 0; k < VIT_GROUP; ++k) {
+                if (FULL || t0 + k < T) {                           // (wave-uniform)
+                    const bool odd = (k & 1) != 0;                  // (compile time: unrolled, t0 is even)
+                    const float cand = f + snext;
+                    m = odd ? vit_cross_max(cand) : vit_grp_max(cand);
+                    f = m;                                          // the next step's lane holds what it needs
+                    // ---- off the chain: the vector for the trace waves, the row 64 steps ahead, the next mask
+                    ring_lane[k * WAVE] = m;                        // (the ring is exactly one group: slot = step inside the group)
+                    sc[k] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rnext, odd ? ld4B : ld4A, rs4 * (unsigned)min(k, lastn), 0));
+                    snext = (odd ? validA : validB) ? sc[(k + 1) % VIT_GROUP] : VIT_NEG_INF;
+                }
+                if (k % VIT_TILE == VIT_TILE - 1 && (FULL || t0 + k - (VIT_TILE - 1) < T)) vit_handover();
+            }
+        };
+        const int tfull = T / VIT_GROUP * VIT_GROUP;
+        for (int t0 = 0; t0 < tfull; t0 += VIT_GROUP) group(t0, std::true_type{});
+        if (tfull < T) group(tfull, std::false_type{});
+    } else {
+        // ---------------------------------------------------------------- traceback bytes (+ full outputs) of the even / odd steps
+        const int par = wave - 1;                               // this wave's steps: t = par (mod 2)
+        const bool odd = par != 0;
+        const int st_to = odd ? sub : grp;                      // the state a lane's candidate belongs to
+        const bool valid = odd ? validB : validA;
+        const unsigned ld4 = odd ? ld4B : ld4A;
+        const unsigned lane_tb = (unsigned)((size_t)n * VIT_GRP + st_to);
+        const unsigned lane_o4 = 4u * (unsigned)((size_t)n * F::NS + min(st_to, F::NS - 1));
+        const size_t pstride = (size_t)npad * VIT_GRP;           // traceback bytes [t][npad][8]
+        const size_t ostride = (size_t)N * F::NS;
+        constexpr bool ALL_GROUPS_LIVE = F::NS == VIT_GRP;
+        constexpr int HALF = VIT_GROUP / 2, TH = VIT_TILE / 2;   // this wave's steps per group / per tile
+        if (FULLOUT && par == 0 && sub == 0 && grp < F::NS) fwd_out[(size_t)n * F::NS + grp] = (grp < NB) ? 0.f : NEG_LARGE;
+        const float f_init = (sub < NB) ? 0.f : ((sub < F::NS) ? NEG_LARGE : VIT_NEG_INF);
+        float sc[HALF];
+        {
+            const __amdgpu_buffer_rsrc_t rs = rows_from(0);
+#pragma unroll
+            for (int q = 0; q < HALF; ++q)
+                sc[q] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rs, ld4, rs4 * (unsigned)min(2 * q + par, Tm1), 0));
+        }
+        auto group = [&](int t0, auto full) {
+            constexpr bool FULL = decltype(full)::value;
+            const __amdgpu_buffer_rsrc_t rnext = rows_from(t0 + VIT_GROUP);
+            const int lastn = max(Tm1 - min(t0 + VIT_GROUP, Tm1), 0);
+            const __amdgpu_buffer_rsrc_t rtb = __builtin_amdgcn_make_buffer_rsrc(packed + (size_t)t0 * pstride, 0, 0x7fffffff, RSRC3);
+            const __amdgpu_buffer_rsrc_t rfo = __builtin_amdgcn_make_buffer_rsrc(
+                FULLOUT ? fwd_out + (size_t)(t0 + 1) * ostride : nullptr, 0, 0x7fffffff, RSRC3);
+            int64_t *tout = FULLOUT ? tb_out + (size_t)t0 * ostride + (size_t)n * F::NS + min(st_to, F::NS - 1) : nullptr;
+#pragma unroll
+            for (int tile = 0; tile < VIT_GROUP / VIT_TILE; ++tile) {
+                if (FULL || t0 + tile * VIT_TILE < T) {             // (wave-uniform: the chain wave passes this barrier too)
+                    vit_handover();                                 // the tile's vectors are in the ring
+#ifdef TK_VIT_NOTRACE
+                    continue;                                       // lab: the chain wave alone
+#endif
+                    const int slot0 = tile * VIT_TILE;              // (the ring is exactly one group)
+                    float mm[TH], fp[TH];
+#pragma unroll
+                    for (int q = 0; q < TH; ++q) {
+                        const int k = 2 * q + par;                  // step inside the tile
+                        mm[q] = ring_lane[(slot0 + k) * WAVE];
+                        // the vector before: the previous step's (the slot before, around the ring), or the initial one
+                        fp[q] = ring_lane[((slot0 + k + VIT_RING * VIT_TILE - 1) % (VIT_RING * VIT_TILE)) * WAVE];
+                    }
+#pragma unroll
+                    for (int q = 0; q < TH; ++q) {
+                        const int kk = tile * VIT_TILE + 2 * q + par;   // step inside the group
+                        if (FULL || t0 + kk < T) {
+                            const int qq = tile * TH + q;
+                            const float fprev = (t0 + kk == 0) ? f_init : fp[q];
+                            const float cand = fprev + (valid ? sc[qq] : VIT_NEG_INF);
+                            sc[qq] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rnext, ld4, rs4 * (unsigned)min(kk, lastn), 0));
+                            // "first index wins": the lowest set bit among the ballot bits (candidate == maximum)
+                            // of the state's eight candidates is the traceback byte
+                            const unsigned long long eq = __ballot(cand == mm[q]);
+                            unsigned arg;
+                            if (!odd) {
+                                const unsigned bits = (unsigned)(eq >> (8 * grp));
+                                arg = (unsigned)__builtin_ctz((bits & 0xffu) | 0x100u) & 7u;
+                            } else {
+                                const unsigned long long bits = (eq >> sub) & 0x0101010101010101ull;
+                                arg = ((unsigned)__builtin_ctzll(bits | (1ull << 63)) >> 3) & 7u;
+                            }
+                            if (ALL_GROUPS_LIVE || st_to < F::NS) {
+                                __builtin_amdgcn_raw_buffer_store_b8((unsigned char)arg, rtb, lane_tb, (unsigned)(kk * pstride), 0);
+                                if (FULLOUT) {
+                                    __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(mm[q]), rfo, lane_o4, 4u * (unsigned)(kk * ostride), 0);
+                                    tout[(size_t)kk * ostride] = (int64_t)arg;
+                                }
+                            }
+                        }
+                    }
+                }
+            }
+        };
+        const int tfull = T / VIT_GROUP * VIT_GROUP;
+        for (int t0 = 0; t0 < tfull; t0 += VIT_GROUP) group(t0, std::true_type{});
+        if (tfull < T) group(tfull, std::false_type{});
+    }
+    (void)NT;
+    // the trace waves' bytes must have landed before wave 0 walks them
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    if (wave != 0) return;
+#ifdef TK_VIT_NOPATH
+    return;                                     // lab: forward pass alone
+#endif
+    viterbi_path_pass<NB>(m, T, N, n, lane, path_out, packed, npad, /*alternating=*/true);
 }
 
 size_t viterbi_workspace_bytes(size_t T, size_t N, size_t nbase) {
@@ -237,6 +453,20 @@ static int viterbi_launch(const float *scores, size_t T, size_t N, float *fwd, i
                           int64_t *path, void *workspace, hipStream_t stream) {
     const int npad = (int)((N + VIT_GRP - 1) / VIT_GRP * VIT_GRP);
     if (N == 0) return 0;
+    // Three waves per read while the reads do not fill the chip's wave slots anyway (a read is bound by its serial
+    // chain: T 4000 / N 256 342 -> 210 us path only, N 1024 529 -> 442); beyond ~2000 reads the launch is bound
+    // by throughput and three waves per read cost more slots than the chain saves (N 4096: 1776 against 1427 us)
+    const char *v1 = TK_LAB_ENV("TK_VIT_V1");                   // lab: 1 = the one-wave kernel of rounds 1-4, 0 = three waves, for A/B
+    const bool three = v1 ? v1[0] != '1' : N <= 2048;
+    if (three) {
+        if (fwd != nullptr && tb != nullptr)
+            hipLaunchKernelGGL((viterbi3_kernel<NB, true>), dim3((unsigned)N), dim3(3 * WAVE), 0, stream, scores, (int)T,
+                               (int)N, fwd, tb, path, static_cast<unsigned char *>(workspace), npad);
+        else
+            hipLaunchKernelGGL((viterbi3_kernel<NB, false>), dim3((unsigned)N), dim3(3 * WAVE), 0, stream, scores, (int)T,
+                               (int)N, fwd, tb, path, static_cast<unsigned char *>(workspace), npad);
+        return hipGetLastError() == hipSuccess ? 0 : 4;
+    }
     if (fwd != nullptr && tb != nullptr)
         hipLaunchKernelGGL((viterbi_kernel<NB, true>), dim3((unsigned)N), dim3(WAVE), 0, stream, scores, (int)T,
                            (int)N, fwd, tb, path, static_cast<unsigned char *>(workspace), npad);

@@ -798,7 +798,7 @@ def test_catmod_rows_wider_than_the_shared_row_image(oracle_mod, gpu_device, mod
     more modifications has S = 44 + nmod >= 49 (the C ABI takes up to 62).  Such calls must take the
     per-wave feed (round-4 advisor finding: ids >= 48 gathered from the NEXT row's image, a cost-only call
     then returned a silently wrong cost): gradient call and cost-only call against the oracle, as shipped
-    (release library, no switch), with every read on the linear path."""
+    (release library, no switch)."""
     import torch
     from taiyaki_amd import ctc, synth
     T, N = 400, 24
@@ -809,14 +809,20 @@ def test_catmod_rows_wider_than_the_shared_row_image(oracle_mod, gpu_device, mod
     x = torch.from_numpy(inp["scores"]).to(gpu_device)
     seqs, sl = torch.from_numpy(inp["seqs"]), torch.from_numpy(inp["seqlens"])
     extra = (torch.from_numpy(inp["mod_cats"]), inp["can_mods_offsets"], inp["mod_cat_weights"])
-    oloss, ograd = parity.oracle_crf(oracle_mod, inp, 1.0)
-    c, g = ctc._run(x, seqs, sl, 1.0, 1.0, 1.0, 40, True, *extra)
-    torch.cuda.synchronize()
-    assert ctc.last_gate_count() == 0
-    assert parity.rel_err(c.cpu().numpy(), oloss) < LOSS_RTOL and parity.abs_err(g.cpu().numpy(), ograd) < 5e-5
+    r = parity.compare_crf(oracle_mod, inp, 1.0, gpu_device)
+    # (more modifications per base = smaller log-softmax values x the weight of 8: reads leave the linear path's
+    # range -- 5 of 24 at two modifications per base, 19 and all 24 for the wider alphabets -- and are redone)
+    if sum(mods) == 5:
+        assert ctc.last_gate_count() <= N // 2, ctc.last_gate_count()
+    assert r["finite"] and parity.crf_loss_ok(r), r["loss_rel"]
+    assert parity.crf_grad_ok(r), (r["grad_f64_scaled"], r["grad_scaled_abs"], r["ref_noise_scaled"])
+    # COST-ONLY call (round 5): its forward sweep used to write the cost by itself whenever its score was finite -- the
+    # reads above that the gradient call disowns came back silently wrong (costs off by up to 0.19 at (5, 5, 4, 4)).
+    # Now both sweeps run and crf_kernel's vote pass believes them only where they agree; the rest is redone.
     c0, _ = ctc._run(x, seqs, sl, 1.0, 1.0, 1.0, 40, False, *extra)
     torch.cuda.synchronize()
-    assert parity.rel_err(c0.cpu().numpy(), oloss) < LOSS_RTOL
+    c0 = c0.cpu().numpy()
+    assert np.all((np.abs(c0 - r["oloss"]) <= 1e-5 * np.abs(r["oloss"])) | (np.abs(c0 - r["oloss"]) <= 1e-5)), np.abs(c0 - r["oloss"]).max()
 
 
 @pytest.mark.parametrize("sharp,bk", [(1.3, 8), (1.5, 8), (1.75, 8), (2.0, 4), (2.5, 4), (3.4, 4)])

@@ -247,16 +247,22 @@ __global__ __launch_bounds__(WAVE) void viterbi_kernel(const float *__restrict__
 // v_permlane16_swap / v_permlane32_swap -- so every lane already HOLDS the state it needs next and no
 // ds_bpermute round trip sits on the chain; alone that change measured nothing, because the step was
 // bound by its instruction count), and leaves each step's state vector in an LDS ring.  Waves 1 and 2
-// follow a tile of 16 steps behind (even / odd steps, a fixed layout each): they re-form the candidates
-// from the ring's previous vector and their own copy of the score row -- the same single fp32 add, so the
-// same bits -- compare with the ring's maximum, and write the traceback byte (and fwd / traceback of the
-// reference's full-output form).  One s_barrier per 16 steps hands a tile over; the score rows are
+// follow a tile of 16 steps behind (even / odd steps, a fixed layout each): they take the step's candidates
+// and maxima from the ring (two LDS words per lane and step -- the chain wave's own values, so the same
+// bits), compare, and write the traceback byte (and fwd / traceback of the reference's full-output form);
+// they touch no score row.  One s_barrier per 16 steps hands a tile over; the score rows are
 // requested 64 steps ahead (one wave per SIMD: registers are free).  Arithmetic, tie rule and outputs
 // are those of the one-wave kernel, bit for bit.
 // ===========================================================================
-constexpr int VIT_TILE = 16;        // steps per hand-over (one s_barrier)
-constexpr int VIT_GROUP = 64;       // steps of straight-line code = score rows in flight
-constexpr int VIT_RING = 4;         // tiles in the LDS ring (the tile being written, the one being read, and its predecessor's last vector)
+#ifndef TK_VIT_TILE
+#define TK_VIT_TILE 16
+#endif
+#ifndef TK_VIT_GROUP
+#define TK_VIT_GROUP 64
+#endif
+constexpr int VIT_TILE = TK_VIT_TILE;       // steps per hand-over (one s_barrier)
+constexpr int VIT_GROUP = TK_VIT_GROUP;     // steps of straight-line code = score rows in flight = the LDS ring
+constexpr int VIT_RING = VIT_GROUP / VIT_TILE;  // tiles in the ring: at least the one being written and the one being read
 
 // maximum over the eight lanes that share lane % 8 (one per 8-lane group), in all of them: within a
 // 16-lane row by DPP, across the rows and halves by the lane-swap instructions of gfx950
@@ -289,8 +295,8 @@ __global__ __launch_bounds__(3 * WAVE) void viterbi3_kernel(const float *__restr
                                                            unsigned char *__restrict__ packed, int npad) {
     using F = FF<NB>;
     static_assert(F::NS <= VIT_GRP, "one lane group per state");
-    static_assert(VIT_GROUP == VIT_RING * VIT_TILE && VIT_TILE % 2 == 0, "the ring holds one group; tiles start with an even step");
-    __shared__ float ring[VIT_RING * VIT_TILE * WAVE];
+    static_assert(VIT_GROUP == VIT_RING * VIT_TILE && VIT_RING >= 2 && VIT_TILE % 2 == 0, "the ring holds one group; tiles start with an even step");
+    __shared__ float ring[VIT_RING * VIT_TILE * 2 * WAVE];      // per step: the maxima (the new state vector) and the candidates
     const int lane = lane_id();
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int grp = lane >> 3, sub = lane & 7;          // even steps: (to, from) = (grp, sub); odd steps: (sub, grp)
@@ -341,7 +347,8 @@ __global__ __launch_bounds__(3 * WAVE) void viterbi3_kernel(const float *__restr
                     m = odd ? vit_cross_max(cand) : vit_grp_max(cand);
                     f = m;                                          // the next step's lane holds what it needs
                     // ---- off the chain: the vector for the trace waves, the row 64 steps ahead, the next mask
-                    ring_lane[k * WAVE] = m;                        // (the ring is exactly one group: slot = step inside the group)
+                    ring_lane[(2 * k) * WAVE] = m;                  // (the ring is exactly one group: slot = step inside the group)
+                    ring_lane[(2 * k + 1) * WAVE] = cand;
                     sc[k] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rnext, odd ? ld4B : ld4A, rs4 * (unsigned)min(k, lastn), 0));
                     snext = (odd ? validA : validB) ? sc[(k + 1) % VIT_GROUP] : VIT_NEG_INF;
                 }
@@ -356,27 +363,15 @@ __global__ __launch_bounds__(3 * WAVE) void viterbi3_kernel(const float *__restr
         const int par = wave - 1;                               // this wave's steps: t = par (mod 2)
         const bool odd = par != 0;
         const int st_to = odd ? sub : grp;                      // the state a lane's candidate belongs to
-        const bool valid = odd ? validB : validA;
-        const unsigned ld4 = odd ? ld4B : ld4A;
         const unsigned lane_tb = (unsigned)((size_t)n * VIT_GRP + st_to);
         const unsigned lane_o4 = 4u * (unsigned)((size_t)n * F::NS + min(st_to, F::NS - 1));
         const size_t pstride = (size_t)npad * VIT_GRP;           // traceback bytes [t][npad][8]
         const size_t ostride = (size_t)N * F::NS;
         constexpr bool ALL_GROUPS_LIVE = F::NS == VIT_GRP;
-        constexpr int HALF = VIT_GROUP / 2, TH = VIT_TILE / 2;   // this wave's steps per group / per tile
+        constexpr int TH = VIT_TILE / 2;                         // this wave's steps per tile
         if (FULLOUT && par == 0 && sub == 0 && grp < F::NS) fwd_out[(size_t)n * F::NS + grp] = (grp < NB) ? 0.f : NEG_LARGE;
-        const float f_init = (sub < NB) ? 0.f : ((sub < F::NS) ? NEG_LARGE : VIT_NEG_INF);
-        float sc[HALF];
-        {
-            const __amdgpu_buffer_rsrc_t rs = rows_from(0);
-#pragma unroll
-            for (int q = 0; q < HALF; ++q)
-                sc[q] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rs, ld4, rs4 * (unsigned)min(2 * q + par, Tm1), 0));
-        }
         auto group = [&](int t0, auto full) {
             constexpr bool FULL = decltype(full)::value;
-            const __amdgpu_buffer_rsrc_t rnext = rows_from(t0 + VIT_GROUP);
-            const int lastn = max(Tm1 - min(t0 + VIT_GROUP, Tm1), 0);
             const __amdgpu_buffer_rsrc_t rtb = __builtin_amdgcn_make_buffer_rsrc(packed + (size_t)t0 * pstride, 0, 0x7fffffff, RSRC3);
             const __amdgpu_buffer_rsrc_t rfo = __builtin_amdgcn_make_buffer_rsrc(
                 FULLOUT ? fwd_out + (size_t)(t0 + 1) * ostride : nullptr, 0, 0x7fffffff, RSRC3);
@@ -389,22 +384,18 @@ __global__ __launch_bounds__(3 * WAVE) void viterbi3_kernel(const float *__restr
                     continue;                                       // lab: the chain wave alone
 #endif
                     const int slot0 = tile * VIT_TILE;              // (the ring is exactly one group)
-                    float mm[TH], fp[TH];
+                    float mm[TH], cd[TH];
 #pragma unroll
                     for (int q = 0; q < TH; ++q) {
                         const int k = 2 * q + par;                  // step inside the tile
-                        mm[q] = ring_lane[(slot0 + k) * WAVE];
-                        // the vector before: the previous step's (the slot before, around the ring), or the initial one
-                        fp[q] = ring_lane[((slot0 + k + VIT_RING * VIT_TILE - 1) % (VIT_RING * VIT_TILE)) * WAVE];
+                        mm[q] = ring_lane[(2 * (slot0 + k)) * WAVE];
+                        cd[q] = ring_lane[(2 * (slot0 + k) + 1) * WAVE];
                     }
 #pragma unroll
                     for (int q = 0; q < TH; ++q) {
                         const int kk = tile * VIT_TILE + 2 * q + par;   // step inside the group
                         if (FULL || t0 + kk < T) {
-                            const int qq = tile * TH + q;
-                            const float fprev = (t0 + kk == 0) ? f_init : fp[q];
-                            const float cand = fprev + (valid ? sc[qq] : VIT_NEG_INF);
-                            sc[qq] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rnext, ld4, rs4 * (unsigned)min(kk, lastn), 0));
+                            const float cand = cd[q];
                             // "first index wins": the lowest set bit among the ballot bits (candidate == maximum)
                             // of the state's eight candidates is the traceback byte
                             const unsigned long long eq = __ballot(cand == mm[q]);
@@ -454,10 +445,11 @@ static int viterbi_launch(const float *scores, size_t T, size_t N, float *fwd, i
     const int npad = (int)((N + VIT_GRP - 1) / VIT_GRP * VIT_GRP);
     if (N == 0) return 0;
     // Three waves per read while the reads do not fill the chip's wave slots anyway (a read is bound by its serial
-    // chain: T 4000 / N 256 342 -> 210 us path only, N 1024 529 -> 442); beyond ~2000 reads the launch is bound
-    // by throughput and three waves per read cost more slots than the chain saves (N 4096: 1776 against 1427 us)
+    // chain: T 4000 / N 256 342 -> 217 us path only, 404 -> 224 with the full outputs; N 1024 529 -> 345); at 2048
+    // reads the two forms measure the same (743 / 733 us) and beyond the launch is bound by throughput, where
+    // three waves per read cost more slots than the chain saves (tools/vitbench.py, profiles/r5_vitbench.txt)
     const char *v1 = TK_LAB_ENV("TK_VIT_V1");                   // lab: 1 = the one-wave kernel of rounds 1-4, 0 = three waves, for A/B
-    const bool three = v1 ? v1[0] != '1' : N <= 2048;
+    const bool three = v1 ? v1[0] != '1' : N <= 1536;
     if (three) {
         if (fwd != nullptr && tb != nullptr)
             hipLaunchKernelGGL((viterbi3_kernel<NB, true>), dim3((unsigned)N), dim3(3 * WAVE), 0, stream, scores, (int)T,

@@ -127,6 +127,30 @@ size_t tk_crf_flipflop_workspace_bytes(size_t ntrans, size_t nblk, size_t nbatch
 size_t tk_crf_flipflop_workspace_bytes_sharp(size_t ntrans, size_t nblk, size_t nbatch,
                                              size_t max_seqlen, int want_grad, float sharpfact);
 
+/* The same operator with the INDEX BUILD INSIDE ITS FIRST LAUNCH (round 5): instead of the arrays
+ * tk_flipflop_build_indices_dev made, hand over what that call takes -- the flip-flop codes (and, cat-mod, the
+ * modification categories and tables) in a tk_seq_labels -- and the index arrays as SCRATCH OUTPUTS of the same
+ * sizes (seqoff nbatch + 1; stayidx / moveidx / modidx / modfact total_len entries).  The sweep workgroups form
+ * their ids from the codes themselves and leave the arrays for the launches behind; labels are range-checked as
+ * there (TK_STATUS_BAD_LABEL).  Saves a launch per call: ~5 us of the op's ~99 at the train step's shape.  Calls the
+ * linear path does not take (sharpening beyond 3.5, workspace-bound batches) build the indices with the stand-alone
+ * kernel first: same results either way.  Cat-mod: modfact is filled from mod_cat_weights BY COLUMN, so the
+ * per-column form of the kernels (mod_col_weights above) applies. */
+typedef struct tk_seq_labels {
+    const int32_t *seqs;                /* (total_len) flip-flop codes 0 .. 2 nbase - 1, reads concatenated (device) */
+    size_t total_len;
+    size_t nbase;
+    const int32_t *mod_cats;            /* (total_len) or NULL -- with the two tables below (device) */
+    const int32_t *can_mods_offsets;    /* (nbase + 1) */
+    const float *mod_cat_weights;       /* (nbase + nmod) */
+} tk_seq_labels;
+int tk_crf_flipflop_labels_dev(const float *logprob, size_t ntrans, size_t nblk, size_t nbatch,
+                               const tk_seq_labels *labels, const int32_t *seqlen,
+                               int64_t *seqoff, int32_t *stayidx, int32_t *moveidx, int32_t *modidx, float *modfact,
+                               size_t max_seqlen, size_t ncan, float sharp_can, float sharp_mod,
+                               float out_scale, float *cost, float *grad, void *workspace,
+                               size_t workspace_bytes, uint32_t *status, void *stream);
+
 int tk_crf_flipflop_dev(const float *logprob, size_t ntrans, size_t nblk,
                         size_t nbatch, const int32_t *stayidx,
                         const int32_t *moveidx, const int32_t *modidx,
@@ -180,6 +204,15 @@ int tk_flipflop_loss_fused_dev(const float *scores, size_t nblk, size_t nbatch, 
                                size_t logz_workspace_bytes, void *aux, size_t aux_bytes,
                                uint32_t *status, void *stream,
                                const float *mod_col_weights);
+/* ... with the index build inside its first launch (see tk_crf_flipflop_labels_dev): nbase comes with the labels */
+int tk_flipflop_loss_fused_labels_dev(const float *scores, size_t nblk, size_t nbatch, size_t ntrans,
+                                      const tk_seq_labels *labels, const int32_t *seqlen,
+                                      int64_t *seqoff, int32_t *stayidx, int32_t *moveidx, int32_t *modidx, float *modfact,
+                                      size_t max_seqlen, float sharpfact, float grad_scale,
+                                      const float *grad_scale_per_read, float *lossvector,
+                                      float *grad, float *logz, void *crf_workspace, size_t crf_workspace_bytes,
+                                      void *logz_workspace, size_t logz_workspace_bytes, void *aux, size_t aux_bytes,
+                                      uint32_t *status, void *stream);
 
 /* ------------------------------------------------------------------------- *
  * Hash beam search (replaces taiyaki/decodeutil/c_hashdecode.h:10

@@ -34,6 +34,10 @@ SIGNATURES = {
     "tk_crf_flipflop_workspace_bytes_sharp": (_sz, [_sz, _sz, _sz, _sz, _i, _f]),
     "tk_crf_flipflop_dev": (_i, [_vp, _sz, _sz, _sz, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _sz,
                                  _f, _f, _f, _vp, _vp, _vp, _sz, _vp, _vp, _vp]),
+    "tk_crf_flipflop_labels_dev": (_i, [_vp, _sz, _sz, _sz, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _sz,
+                                        _f, _f, _f, _vp, _vp, _vp, _sz, _vp, _vp]),
+    "tk_flipflop_loss_fused_labels_dev": (_i, [_vp, _sz, _sz, _sz, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _f, _f, _vp, _vp,
+                                              _vp, _vp, _vp, _sz, _vp, _sz, _vp, _sz, _vp, _vp]),
     "tk_flipflop_loss_fused_aux_bytes": (_sz, [_sz, _sz, _sz, _sz]),
     "tk_flipflop_loss_overlap": (ctypes.c_int, [ctypes.c_int]),
     "tk_flipflop_loss_fused_dev": (_i, [_vp, _sz, _sz, _sz, _sz, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _f, _f, _vp, _vp,
@@ -75,6 +79,13 @@ RCCL_SIGNATURES = {
     "tk_broadcast_f32_dev": (_i, [_vp, _vp, _sz, _i, _vp]),
     "tk_rccl_comm_destroy": (_i, [_vp]),
 }
+
+class SeqLabels(ctypes.Structure):
+    """include/taiyaki_amd_flipflop.h: tk_seq_labels (what tk_flipflop_build_indices_dev takes, for the entry points
+    that build their indices inside their first launch)."""
+    _fields_ = [("seqs", _vp), ("total_len", _sz), ("nbase", _sz), ("mod_cats", _vp), ("can_mods_offsets", _vp),
+                ("mod_cat_weights", _vp)]
+
 
 ERRORS = {1: "bad argument (NULL / shape / 16-byte alignment)",
           2: "unsupported nbase / ntrans / sequence length for this build",

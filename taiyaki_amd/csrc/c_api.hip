@@ -10,6 +10,7 @@
 #include <vector>
 
 #include "../../include/taiyaki_amd_flipflop.h"
+#include "crf_band.h"
 
 namespace tk {
 size_t logz_workspace_bytes(size_t T, size_t N, size_t nbase);
@@ -32,7 +33,8 @@ int crf_dispatch(const float *logprob, size_t ntrans, size_t nblk, size_t nbatch
                  float out_scale, float grad_scale, const float *grad_scale_vec, float *cost, float *grad,
                  void *workspace, size_t workspace_bytes, uint32_t *status, hipStream_t stream,
                  const float *add_grad = nullptr, const float *add_cost = nullptr, int add_S = 0,
-                 float add_scale = 0.f, hipEvent_t add_ready = nullptr, const float *mod_col_weights = nullptr);
+                 float add_scale = 0.f, hipEvent_t add_ready = nullptr, const float *mod_col_weights = nullptr,
+                 const SeqLabels *labels = nullptr);
 bool logz_side_stream(hipStream_t *s, hipEvent_t *fork, hipEvent_t *join);
 #ifdef TK_LAB
 void crf_band_lab_phase(int phase);
@@ -199,12 +201,20 @@ size_t tk_crf_flipflop_workspace_bytes_sharp(size_t ntrans, size_t nblk, size_t 
     return tk::crf_workspace_bytes_sharp(ntrans, nblk, nbatch, max_seqlen, want_grad, sharpfact);
 }
 
-int tk_crf_flipflop_dev(const float *logprob, size_t ntrans, size_t nblk, size_t nbatch,
-                        const int32_t *stayidx, const int32_t *moveidx, const int32_t *modidx,
-                        const float *modfact, const int32_t *seqlen, const int64_t *seqoff,
-                        size_t max_seqlen, size_t ncan, float sharp_can, float sharp_mod,
-                        float out_scale, float *cost, float *grad, void *workspace,
-                        size_t workspace_bytes, uint32_t *status, void *stream, const float *mod_col_weights) {
+static bool labels_ok(const tk_seq_labels *labels, tk::SeqLabels *out) {
+    if (labels == nullptr || labels->nbase == 0 || (labels->seqs == nullptr && labels->total_len != 0)) return false;
+    *out = tk::SeqLabels{labels->seqs, labels->total_len, labels->nbase, labels->mod_cats, labels->can_mods_offsets,
+                         labels->mod_cat_weights};
+    return true;
+}
+
+static int crf_flipflop_impl(const float *logprob, size_t ntrans, size_t nblk, size_t nbatch,
+                             const int32_t *stayidx, const int32_t *moveidx, const int32_t *modidx,
+                             const float *modfact, const int32_t *seqlen, const int64_t *seqoff,
+                             size_t max_seqlen, size_t ncan, float sharp_can, float sharp_mod,
+                             float out_scale, float *cost, float *grad, void *workspace,
+                             size_t workspace_bytes, uint32_t *status, void *stream, const float *mod_col_weights,
+                             const tk::SeqLabels *labels) {
     if (!logprob || !stayidx || !moveidx || !seqlen || !seqoff || !cost || !workspace) return TK_ERR_BAD_ARG;
     if (ntrans == 0 || nblk == 0 || nbatch == 0) return TK_ERR_BAD_ARG;
     if ((modidx == nullptr) != (modfact == nullptr)) return TK_ERR_BAD_ARG;
@@ -212,7 +222,33 @@ int tk_crf_flipflop_dev(const float *logprob, size_t ntrans, size_t nblk, size_t
                             seqlen, seqoff, max_seqlen, ncan, sharp_can, sharp_mod, out_scale, 1.0f, nullptr,
                             cost, grad, workspace, workspace_bytes, status,
                             static_cast<hipStream_t>(stream), nullptr, nullptr, 0, 0.f, nullptr,
-                            modidx != nullptr ? mod_col_weights : nullptr);
+                            modidx != nullptr ? mod_col_weights : nullptr, labels);
+}
+
+int tk_crf_flipflop_dev(const float *logprob, size_t ntrans, size_t nblk, size_t nbatch,
+                        const int32_t *stayidx, const int32_t *moveidx, const int32_t *modidx,
+                        const float *modfact, const int32_t *seqlen, const int64_t *seqoff,
+                        size_t max_seqlen, size_t ncan, float sharp_can, float sharp_mod,
+                        float out_scale, float *cost, float *grad, void *workspace,
+                        size_t workspace_bytes, uint32_t *status, void *stream, const float *mod_col_weights) {
+    return crf_flipflop_impl(logprob, ntrans, nblk, nbatch, stayidx, moveidx, modidx, modfact, seqlen, seqoff, max_seqlen,
+                             ncan, sharp_can, sharp_mod, out_scale, cost, grad, workspace, workspace_bytes, status, stream,
+                             mod_col_weights, nullptr);
+}
+
+int tk_crf_flipflop_labels_dev(const float *logprob, size_t ntrans, size_t nblk, size_t nbatch,
+                               const tk_seq_labels *labels, const int32_t *seqlen,
+                               int64_t *seqoff, int32_t *stayidx, int32_t *moveidx, int32_t *modidx, float *modfact,
+                               size_t max_seqlen, size_t ncan, float sharp_can, float sharp_mod,
+                               float out_scale, float *cost, float *grad, void *workspace,
+                               size_t workspace_bytes, uint32_t *status, void *stream) {
+    tk::SeqLabels lab;
+    if (!labels_ok(labels, &lab)) return TK_ERR_BAD_ARG;
+    if ((labels->mod_cats != nullptr) != (modidx != nullptr)) return TK_ERR_BAD_ARG;
+    // (modfact is filled from mod_cat_weights by column: the per-column form of the cat-mod kernels applies)
+    return crf_flipflop_impl(logprob, ntrans, nblk, nbatch, stayidx, moveidx, modidx, modfact, seqlen, seqoff, max_seqlen,
+                             ncan, sharp_can, sharp_mod, out_scale, cost, grad, workspace, workspace_bytes, status, stream,
+                             labels->mod_cat_weights, &lab);
 }
 
 // rows of S floats -> their first S0 columns, contiguous (the canonical block of a cat-mod tensor)
@@ -263,14 +299,14 @@ size_t tk_flipflop_loss_fused_aux_bytes(size_t nblk, size_t nbatch, size_t nbase
     return 2 * one;                                             // canonical scores + their logZ gradient
 }
 
-int tk_flipflop_loss_fused_dev(const float *scores, size_t nblk, size_t nbatch, size_t nbase, size_t ntrans,
-                               const int32_t *stayidx, const int32_t *moveidx, const int32_t *modidx,
-                               const float *modfact, const int32_t *seqlen,
-                               const int64_t *seqoff, size_t max_seqlen, float sharpfact, float grad_scale,
-                               const float *grad_scale_per_read, float *lossvector,
-                               float *grad, float *logz, void *crf_workspace, size_t crf_workspace_bytes,
-                               void *logz_workspace, size_t logz_workspace_bytes, void *aux, size_t aux_bytes,
-                               uint32_t *status, void *stream, const float *mod_col_weights) {
+static int loss_fused_impl(const float *scores, size_t nblk, size_t nbatch, size_t nbase, size_t ntrans,
+                           const int32_t *stayidx, const int32_t *moveidx, const int32_t *modidx,
+                           const float *modfact, const int32_t *seqlen,
+                           const int64_t *seqoff, size_t max_seqlen, float sharpfact, float grad_scale,
+                           const float *grad_scale_per_read, float *lossvector,
+                           float *grad, float *logz, void *crf_workspace, size_t crf_workspace_bytes,
+                           void *logz_workspace, size_t logz_workspace_bytes, void *aux, size_t aux_bytes,
+                           uint32_t *status, void *stream, const float *mod_col_weights, const tk::SeqLabels *labels) {
     if (!scores || !stayidx || !moveidx || !seqlen || !seqoff || !lossvector || !grad || !logz || !crf_workspace ||
         !logz_workspace || nblk == 0 || nbatch == 0 || nbase == 0 || !(sharpfact > 0.f))
         return TK_ERR_BAD_ARG;
@@ -290,7 +326,8 @@ int tk_flipflop_loss_fused_dev(const float *scores, size_t nblk, size_t nbatch, 
         // are whole coalesced row sets
         int rc = tk::crf_dispatch(scores, ntrans, nblk, nbatch, stayidx, moveidx, nullptr, nullptr, seqlen, seqoff,
                                   max_seqlen, ntrans, sharpfact, sharpfact, 1.0f / sharpfact, grad_scale,
-                                  grad_scale_per_read, lossvector, grad, crf_workspace, crf_workspace_bytes, status, st);
+                                  grad_scale_per_read, lossvector, grad, crf_workspace, crf_workspace_bytes, status, st,
+                                  nullptr, nullptr, 0, 0.f, nullptr, nullptr, labels);
         if (rc != 0) return rc;
         return tk::logz_dispatch(scores, nblk, nbatch, nbase, logz, grad, logz_workspace, logz_workspace_bytes, status,
                                  st, lossvector, 1.0f / (float)nblk, grad_scale, grad_scale_per_read);
@@ -328,9 +365,40 @@ int tk_flipflop_loss_fused_dev(const float *scores, size_t nblk, size_t nbatch, 
     rc = tk::crf_dispatch(scores, ntrans, nblk, nbatch, stayidx, moveidx, modidx, modfact, seqlen, seqoff, max_seqlen,
                           ncan, sharpfact, catmod ? 1.0f : sharpfact, 1.0f / sharpfact, grad_scale, grad_scale_per_read,
                           lossvector, grad, crf_workspace, crf_workspace_bytes, status, st, g40, logz, (int)ncan,
-                          1.0f / (float)nblk, side ? join : nullptr, catmod ? mod_col_weights : nullptr);
+                          1.0f / (float)nblk, side ? join : nullptr, catmod ? mod_col_weights : nullptr, labels);
     if (rc != 0 && side) (void)hipStreamWaitEvent(st, join, 0);
     return rc;
+}
+
+int tk_flipflop_loss_fused_dev(const float *scores, size_t nblk, size_t nbatch, size_t nbase, size_t ntrans,
+                               const int32_t *stayidx, const int32_t *moveidx, const int32_t *modidx,
+                               const float *modfact, const int32_t *seqlen,
+                               const int64_t *seqoff, size_t max_seqlen, float sharpfact, float grad_scale,
+                               const float *grad_scale_per_read, float *lossvector,
+                               float *grad, float *logz, void *crf_workspace, size_t crf_workspace_bytes,
+                               void *logz_workspace, size_t logz_workspace_bytes, void *aux, size_t aux_bytes,
+                               uint32_t *status, void *stream, const float *mod_col_weights) {
+    return loss_fused_impl(scores, nblk, nbatch, nbase, ntrans, stayidx, moveidx, modidx, modfact, seqlen, seqoff, max_seqlen,
+                           sharpfact, grad_scale, grad_scale_per_read, lossvector, grad, logz, crf_workspace,
+                           crf_workspace_bytes, logz_workspace, logz_workspace_bytes, aux, aux_bytes, status, stream,
+                           mod_col_weights, nullptr);
+}
+
+int tk_flipflop_loss_fused_labels_dev(const float *scores, size_t nblk, size_t nbatch, size_t ntrans,
+                                      const tk_seq_labels *labels, const int32_t *seqlen,
+                                      int64_t *seqoff, int32_t *stayidx, int32_t *moveidx, int32_t *modidx, float *modfact,
+                                      size_t max_seqlen, float sharpfact, float grad_scale,
+                                      const float *grad_scale_per_read, float *lossvector,
+                                      float *grad, float *logz, void *crf_workspace, size_t crf_workspace_bytes,
+                                      void *logz_workspace, size_t logz_workspace_bytes, void *aux, size_t aux_bytes,
+                                      uint32_t *status, void *stream) {
+    tk::SeqLabels lab;
+    if (!labels_ok(labels, &lab)) return TK_ERR_BAD_ARG;
+    if ((labels->mod_cats != nullptr) != (modidx != nullptr)) return TK_ERR_BAD_ARG;
+    return loss_fused_impl(scores, nblk, nbatch, labels->nbase, ntrans, stayidx, moveidx, modidx, modfact, seqlen, seqoff,
+                           max_seqlen, sharpfact, grad_scale, grad_scale_per_read, lossvector, grad, logz, crf_workspace,
+                           crf_workspace_bytes, logz_workspace, logz_workspace_bytes, aux, aux_bytes, status, stream,
+                           labels->mod_cat_weights, &lab);
 }
 
 typedef float tk_f4 __attribute__((ext_vector_type(4)));

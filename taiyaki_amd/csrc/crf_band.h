@@ -51,6 +51,27 @@ struct BandArgs {
     float wbias;                // every step weight carries 2^-wbias (crf_band.hip: BK_MAX); the scores get wbias T back
     hipEvent_t before_gradient; // host side: the stream waits for this event between the sweeps and the gradient
                                 // pass (what `add_grad` / `add_cost` hold was produced on another stream); null: none
+    // Round 5 -- the index build INSIDE the sweep launch (codes != null): stay / move / mod / modfact / seqoff above
+    // are then OUTPUTS of this launch, not inputs.  Every sweep workgroup forms its read's offset and its cells'
+    // ids from the flip-flop codes itself; the rank workgroups (a cost-only call: the forward sweeps) also write
+    // the arrays for the launches behind (gradient pass, crf_kernel).  Saves tk_flipflop_build_indices_dev's
+    // launch: ~5 us of the op's ~99 at the train step's shape.
+    const int32_t *codes;       // (total_len) flip-flop codes 0 .. 2 nbase - 1, reads concatenated; null: ids are inputs
+    const int32_t *mod_cats;    // (total_len) or null
+    const int32_t *cmo;         // can_mods_offsets (nbase + 1)
+    const float *mcw;           // mod_cat_weights (nbase + nmod)
+    long long total_len;
+    int nbase;
+};
+
+// what tk_crf_flipflop_labels_dev / tk_flipflop_loss_fused_labels_dev hand down (include/taiyaki_amd_flipflop.h: tk_seq_labels)
+struct SeqLabels {
+    const int32_t *seqs;
+    size_t total_len;
+    size_t nbase;
+    const int32_t *mod_cats;
+    const int32_t *can_mods_offsets;
+    const float *mod_cat_weights;
 };
 
 struct BandBlock {

@@ -295,14 +295,98 @@ __device__ __forceinline__ void band_frames(float (&m)[R], int (&f)[R], float (&
     }
 }
 
+// ---------------------------------------------------------------------------
+// Ids from flip-flop codes (BandArgs::codes; flipflopfings.py:6-31, ctc.pyx:127-134, 282-292) -- the arithmetic
+// of build_indices_kernel (crf_kernels.hip), per cell, where the sweep launch builds its indices itself.
+// ---------------------------------------------------------------------------
+__device__ __forceinline__ int band_code(const BandArgs &a, int64_t i) {
+    return min(max(a.codes[i], 0), 2 * a.nbase - 1);            // (a bad label is clamped here and REPORTED by the writer)
+}
+__device__ __forceinline__ int band_stay_id(const BandArgs &a, int cp) { return cp + min(cp, a.nbase) * (2 * a.nbase); }
+__device__ __forceinline__ int band_move_id(const BandArgs &a, int cp, int cn) { return cp + min(cn, a.nbase) * (2 * a.nbase); }
+// the modification column and factor of the move INTO the position whose code is `cn` and whose category is mod_cats[i_next]
+__device__ __forceinline__ int band_mod_seq(const BandArgs &a, int cn, int64_t i_next, bool *bad) {
+    const int lo = a.cmo[cn % a.nbase], hi = a.cmo[cn % a.nbase + 1];
+    const int mseq = lo + a.mod_cats[i_next];
+    if (bad != nullptr) *bad |= mseq < lo || mseq >= hi;
+    return min(max(mseq, lo), hi - 1);
+}
+
+// This read's offset into the label arrays = the sum of the lengths before it, clamped to the label array; every
+// workgroup sums for itself (a batch is a few hundred reads).  All threads of the workgroup take part; `sh`: two
+// shared 64-bit words.  Returns (offset, total announced).
+__device__ __forceinline__ void band_offset_of(const BandArgs &a, int n, long long *sh, long long *off_out, long long *all_out) {
+    long long mine = 0, all = 0;
+    for (int i = threadIdx.x; i < a.N; i += blockDim.x) {
+        const long long v = a.seqlen[i];
+        all += v;
+        if (i < n) mine += v;
+    }
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) {
+        mine += __shfl_xor(mine, m, WAVE);
+        all += __shfl_xor(all, m, WAVE);
+    }
+    if (threadIdx.x == 0) sh[0] = sh[1] = 0;
+    __syncthreads();
+    if ((threadIdx.x & (WAVE - 1)) == 0) {
+        atomicAdd(reinterpret_cast<unsigned long long *>(&sh[0]), (unsigned long long)mine);     // (integers: order does not matter)
+        atomicAdd(reinterpret_cast<unsigned long long *>(&sh[1]), (unsigned long long)all);
+    }
+    __syncthreads();
+    *off_out = sh[0];
+    *all_out = sh[1];
+}
+
+// The writer of a read's index arrays (rank workgroups; a cost-only call: the forward sweeps): what
+// build_indices_kernel leaves for the launches behind this one, and the label checks.
+template <bool MOD>
+__device__ __forceinline__ void band_write_indices(const BandArgs &a, int n, long long off_raw, long long all, int L) {
+    const int64_t off = min(off_raw, a.total_len);
+    int32_t *stay = const_cast<int32_t *>(a.stay), *move = const_cast<int32_t *>(a.move);
+    int32_t *mod = const_cast<int32_t *>(a.mod);
+    float *fact = const_cast<float *>(a.modfact);
+    int64_t *seqoff = const_cast<int64_t *>(a.seqoff);
+    if (threadIdx.x == 0) {
+        seqoff[n] = off;
+        if (n == a.N - 1) {
+            seqoff[a.N] = min(all, a.total_len);
+            if (all > a.total_len && a.status) atomicOr(a.status, 8u);      // more labels announced than handed over
+        }
+    }
+    const int ns = 2 * a.nbase;
+    bool bad = false;
+    for (int p = threadIdx.x; p < L; p += blockDim.x) {
+        const int craw = a.codes[off + p];
+        bad |= craw < 0 || craw >= ns;
+        const int cp = min(max(craw, 0), ns - 1);
+        stay[off + p] = band_stay_id(a, cp);
+        if (p + 1 < L) {
+            const int cn = band_code(a, off + p + 1);
+            move[off + p] = band_move_id(a, cp, cn);
+            if (MOD) {
+                const int mseq = band_mod_seq(a, cn, off + p + 1, &bad);
+                mod[off + p] = a.ncan + mseq;
+                fact[off + p] = a.mcw[mseq];
+            }
+        } else {
+            move[off + p] = 0;
+            if (MOD) {
+                mod[off + p] = a.ncan;
+                fact[off + p] = 0.f;
+            }
+        }
+    }
+    if (bad && a.status) atomicOr(a.status, 8u);
+}
+
 template <int R, bool MOD, bool FWD, bool GRAD, bool ROWS, bool CW, int BK>
-__device__ __forceinline__ void band_sweep(const BandArgs &a, int n, int L, float *E, int *Ef, const float *Ezero,
+__device__ __forceinline__ void band_sweep(const BandArgs &a, int n, int L, int64_t off, float *E, int *Ef, const float *Ezero,
                                            const f4 *Wt) {
     constexpr int PW = R * WAVE;
     // the wave index is wave-uniform: keep everything derived from it in SGPRs
     const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & (WAVE - 1);
     const int N = a.N, T = a.T, S = a.S, W = a.W;
-    const int64_t off = a.seqoff[n];
     const int a0 = w * PW;
     const int NB = (T + BK - 1) / BK, NPH = NB + W - 1;
     const int src = FWD ? w - 1 : w + 1;                        // the chunk our boundary cell comes from
@@ -342,11 +426,23 @@ __device__ __forceinline__ void band_sweep(const BandArgs &a, int n, int L, floa
         const int q = lane * R + j, p = FWD ? a0 + q : a0 + PW - 1 - q;
         const int ms = FWD ? p - 1 : p;                         // the move's source position
         has[j] = ms >= 0 && ms < L - 1;
-        st4[j] = 4 * ((p < L) ? a.stay[off + p] : 0);           // (a padding cell is 0 and stays 0)
-        mv4[j] = 4 * (has[j] ? a.move[off + ms] : 0);
-        if (MOD) {
-            md4[MOD ? j : 0] = 4 * (has[j] ? a.mod[off + ms] : 0);
-            fw[MOD ? j : 0] = has[j] ? a.modfact[off + ms] * a.c_mod : 0.f;
+        if (a.codes != nullptr) {
+            // (the launch builds its indices itself: ids straight from the flip-flop codes)
+            st4[j] = 4 * ((p < L) ? band_stay_id(a, band_code(a, off + p)) : 0);
+            const int c0 = has[j] ? band_code(a, off + ms) : 0, c1 = has[j] ? band_code(a, off + ms + 1) : 0;
+            mv4[j] = 4 * (has[j] ? band_move_id(a, c0, c1) : 0);
+            if (MOD) {
+                const int mseq = has[j] ? band_mod_seq(a, c1, off + ms + 1, nullptr) : 0;
+                md4[MOD ? j : 0] = 4 * (has[j] ? a.ncan + mseq : 0);
+                fw[MOD ? j : 0] = has[j] ? a.mcw[mseq] * a.c_mod : 0.f;
+            }
+        } else {
+            st4[j] = 4 * ((p < L) ? a.stay[off + p] : 0);       // (a padding cell is 0 and stays 0)
+            mv4[j] = 4 * (has[j] ? a.move[off + ms] : 0);
+            if (MOD) {
+                md4[MOD ? j : 0] = 4 * (has[j] ? a.mod[off + ms] : 0);
+                fw[MOD ? j : 0] = has[j] ? a.modfact[off + ms] * a.c_mod : 0.f;
+            }
         }
         m[j] = (p == (FWD ? 0 : L - 1)) ? 1.f : 0.f;            // c_crf_flipflop.c:113-116, 216-220
         f[j] = 0;
@@ -765,7 +861,19 @@ __global__ __launch_bounds__(WCAP *WAVE) void crf_band_sweep_kernel(BandArgs a) 
     const int slot3 = blockIdx.x / N;
     const int role = want_grad ? (slot3 + 2) % 3 : slot3;       // 0 forward, 1 backward, 2 rank (cost only: 2 N workgroups, the two sweeps)
     const int n = blockIdx.x - slot3 * N;
-    const int L = min(a.seqlen[n], (int)(a.seqoff[n + 1] - a.seqoff[n]));      // (offsets are clamped to the label array)
+    __shared__ long long offsh[2];
+    long long off_raw = 0, all_raw = 0;
+    int L;
+    if (a.codes != nullptr) {
+        // the launch builds its indices itself: this read's offset from the lengths (see band_offset_of)
+        band_offset_of(a, n, offsh, &off_raw, &all_raw);
+        L = (int)max(0ll, min((long long)a.seqlen[n], a.total_len - min(off_raw, a.total_len)));
+    } else {
+        L = min(a.seqlen[n], (int)(a.seqoff[n + 1] - a.seqoff[n]));            // (offsets are clamped to the label array)
+    }
+    // (the writer of the index arrays: the rank workgroup of a gradient call, the forward sweep of a cost-only call)
+    const bool writer = a.codes != nullptr && role == (want_grad ? 2 : 0);
+    if (writer) band_write_indices<MOD>(a, n, off_raw, all_raw, L);
     if (role == 2 && tid == 0) a.gate[n] = 0;
     if (!want_grad && role == 0 && tid == 0) a.gate[n] = 2;     // cost only: pending -- crf_kernel compares the two sweep scores
     if (role == 2 && tid < 16) const_cast<float *>(a.zeros)[tid] = 0.f;   // (every rank workgroup: the same zeros)
@@ -779,7 +887,7 @@ __global__ __launch_bounds__(WCAP *WAVE) void crf_band_sweep_kernel(BandArgs a) 
         }
         return;
     }
-    const int64_t off = a.seqoff[n];
+    const int64_t off = a.codes != nullptr ? (int64_t)min(off_raw, a.total_len) : a.seqoff[n];
     (void)PW;
 
     if (role == 2) {
@@ -793,9 +901,16 @@ __global__ __launch_bounds__(WCAP *WAVE) void crf_band_sweep_kernel(BandArgs a) 
             int key[KINDS];
             const int p = ck * WAVE + lane;
             const bool has = p >= 1 && p < L;
-            key[0] = (p < L) ? a.stay[off + p] : KEY_DEAD;
-            key[1] = has ? a.move[off + p - 1] : KEY_DEAD;
-            if (MOD) key[MOD ? 2 : 0] = has ? a.mod[off + p - 1] : KEY_DEAD;
+            if (a.codes != nullptr) {
+                const int cp = (p < L) ? band_code(a, off + p) : 0, cb = has ? band_code(a, off + p - 1) : 0;
+                key[0] = (p < L) ? band_stay_id(a, cp) : KEY_DEAD;
+                key[1] = has ? band_move_id(a, cb, cp) : KEY_DEAD;
+                if (MOD) key[MOD ? 2 : 0] = has ? a.ncan + band_mod_seq(a, cp, off + p, nullptr) : KEY_DEAD;
+            } else {
+                key[0] = (p < L) ? a.stay[off + p] : KEY_DEAD;
+                key[1] = has ? a.move[off + p - 1] : KEY_DEAD;
+                if (MOD) key[MOD ? 2 : 0] = has ? a.mod[off + p - 1] : KEY_DEAD;
+            }
             int cnt = 0;                    // lane b: instances with key b ranked so far
             int rank[KINDS];
 #pragma unroll
@@ -839,13 +954,13 @@ __global__ __launch_bounds__(WCAP *WAVE) void crf_band_sweep_kernel(BandArgs a) 
         }
     }
     if (!want_grad && role == 0)
-        band_sweep<R, MOD, true, false, ROWS, CW, BK>(a, n, L, E, Ef, Ezero, Wt);
+        band_sweep<R, MOD, true, false, ROWS, CW, BK>(a, n, L, off, E, Ef, Ezero, Wt);
     else if (!want_grad)
-        band_sweep<R, MOD, false, false, ROWS, CW, BK>(a, n, L, E, Ef, Ezero, Wt);
+        band_sweep<R, MOD, false, false, ROWS, CW, BK>(a, n, L, off, E, Ef, Ezero, Wt);
     else if (role == 0)
-        band_sweep<R, MOD, true, true, ROWS, CW, BK>(a, n, L, E, Ef, Ezero, Wt);
+        band_sweep<R, MOD, true, true, ROWS, CW, BK>(a, n, L, off, E, Ef, Ezero, Wt);
     else
-        band_sweep<R, MOD, false, true, ROWS, CW, BK>(a, n, L, E, Ef, Ezero, Wt);
+        band_sweep<R, MOD, false, true, ROWS, CW, BK>(a, n, L, off, E, Ef, Ezero, Wt);
 }
 
 // Inclusive wave prefix sum in six fused DPP adds (the row_bcast steps write only the rows they
@@ -1052,6 +1167,12 @@ __global__ __launch_bounds__(POST_WAVES *WAVE) __attribute__((amdgpu_waves_per_e
     // LDS round trips, the two recurrence chains and the RG prefix scans of a row group overlap
     // (FULL = all BK rows exist; the last block of a T that is not a multiple of BK runs the
     // guarded form).
+    // (Round 5, measured and not kept: touching the NEXT live chunk's checkpoint rows and boundary cells -- four loads
+    // into registers nothing reads -- once this chunk's own loads have landed, so that they are L2 hits when their
+    // turn comes.  Issued right behind the chunk's loads or behind its backward columns the op LOSES 7 % at the train
+    // step's shape and 11 % at T = 4000 / N = 256 (profiles/r5_gradient_pass_prefetch_ab.txt): the four live
+    // registers push the kernel from 8 to 60 bytes of scratch under its 96-register cap, and a wave's round trips
+    // are already covered by the other four waves of its SIMD.)
     auto chunk_body = [&](int ck, int fF0, int fB0, auto full_tag) {
         constexpr bool FULL = decltype(full_tag)::value;
         const int a0 = ck * PW;

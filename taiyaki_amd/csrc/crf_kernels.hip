@@ -88,8 +88,30 @@ __host__ __device__ inline size_t crf_lds_bytes(int R, int W, int S, int kinds) 
     f += (size_t)2 * CK + 2;
     f += (size_t)kinds * (SP + 1);
     f += (size_t)W * WAVE;
-    f += (size_t)5 * W + 8;
+    f += (size_t)9 * W + 10;            // edgeF, edgeB: [2][W] doubles each; red [W]; misc; alignment
     return (f * 4 + 15) / 16 * 16;
+}
+
+// The lattice state of this kernel is kept in DOUBLE (round 5).  In fp32 -- the reference's own arithmetic -- a cell
+// carries one rounding of its magnitude (tens to hundreds of bits below the column maximum) per step, and over
+// T in the thousands with raw cat-mod logits x 8 the posteriors sit 5e-3 .. 1e-2 from a float64 evaluation: the
+// reference's level, but two fp32 algorithms' noise is two different samples, and round 4's fuzz sweep drew one
+// at twice the reference's (the criterion was widened for it).  With the cells in double the only fp32 left on
+// the chain is the correction term log2(1 + 2^-|d|) in [0, 1] (absolute error ~1e-7 per step): 1e-5 .. 1e-4 from
+// float64 on the same cases.  fp64 adds run at the fp32 rate on this chip; the kernel redoes disowned reads and
+// serves the fallback modes, it is not the fast path.
+__device__ __forceinline__ double lse2d(double a, double b) {
+    const double mx = fmax(a, b);
+    const float d = (float)(fmin(a, b) - mx);           // <= 0 (the two are finite: "nothing" is -1.44e30)
+    return mx + (double)fast_log2(1.0f + fast_exp2(d));
+}
+__device__ __forceinline__ double wave_shift_up1(double src, double fill) {
+    return __hiloint2double(wave_shift_up1(__double2hiint(src), __double2hiint(fill)),
+                            wave_shift_up1(__double2loint(src), __double2loint(fill)));
+}
+__device__ __forceinline__ double wave_shift_down1(double src, double fill) {
+    return __hiloint2double(__builtin_amdgcn_update_dpp(__double2hiint(fill), __double2hiint(src), 0x130, 0xF, 0xF, false),
+                            __builtin_amdgcn_update_dpp(__double2loint(fill), __double2loint(src), 0x130, 0xF, 0xF, false));
 }
 
 // One read, all three passes.  `ckslot`: which set of checkpoint columns of the workspace this workgroup uses.
@@ -118,10 +140,12 @@ __device__ __forceinline__ void crf_read(const CrfArgs &a, const int n, const in
     double *offs = reinterpret_cast<double *>(after);           // [CK]
     int *segstart = reinterpret_cast<int *>(offs + CK);         // [KINDS][SP + 1]
     float *lanebase = reinterpret_cast<float *>(segstart + KINDS * (SP + 1));   // [W][64]
-    float *edgeF = lanebase + W * WAVE;                         // [2][W]
-    float *edgeB = edgeF + 2 * W;                               // [2][W]
-    float *red = edgeB + 2 * W;                                 // [W]
-    float *misc = red + W;                                      // [4]
+    float *after2 = lanebase + W * WAVE;
+    after2 += ((after2 - tile) & 1);                            // 8-byte alignment for the doubles
+    double *edgeF = reinterpret_cast<double *>(after2);         // [2][W]
+    double *edgeB = edgeF + 2 * W;                              // [2][W]
+    float *red = reinterpret_cast<float *>(edgeB + 2 * W);      // [W]
+    double *misc = reinterpret_cast<double *>(red + W + (W & 1));   // [2]
 
     const size_t rowstride = (size_t)N * S;
     const float *lpn = a.lp + (size_t)n * S;
@@ -194,7 +218,7 @@ __device__ __forceinline__ void crf_read(const CrfArgs &a, const int n, const in
         tile[r * SP + S + 1] = 0.f;
     }
     const float c = a.c_can;
-    const float neg = NEG_LARGE * LOG2E;
+    const double neg = (double)(NEG_LARGE * LOG2E);
 
     // ---- sorted slots for the posterior streams (gradient path only) -------------------
     // Every (position, kind) gets a slot such that slots with the same transition id are
@@ -258,52 +282,53 @@ __device__ __forceinline__ void crf_read(const CrfArgs &a, const int n, const in
 
     // block-wide column max of step t rides on the step barrier: every wave drops
     // its max into red[] at the end of step t, everybody folds it in at step t+1
-    auto fold_norm = [&](float (&x)[R], float &edge_val, double &offacc) {
+    auto fold_norm = [&](double (&x)[R], double &edge_val, double &offacc) {
         float mx = red[0];
 #pragma unroll
         for (int w = 1; w < W; ++w) mx = fmaxf(mx, red[w]);
         if (!(mx > -1e29f)) mx = 0.f;           // nothing reachable yet: keep the scale
+        // (the fold is a float -- the column maximum rounded down to fp32 -- taken off doubles exactly)
 #pragma unroll
-        for (int j = 0; j < R; ++j) x[j] -= mx;
-        edge_val -= mx;
+        for (int j = 0; j < R; ++j) x[j] -= (double)mx;
+        edge_val -= (double)mx;
         offacc += (double)mx;
     };
-    auto post_max = [&](const float (&x)[R]) {
-        float mx = x[0];
+    auto post_max = [&](const double (&x)[R]) {
+        float mx = (float)x[0];
 #pragma unroll
-        for (int j = 1; j < R; ++j) mx = fmaxf(mx, x[j]);
+        for (int j = 1; j < R; ++j) mx = fmaxf(mx, (float)x[j]);
         mx = wave_allmax_dpp(mx);
         if (lane == 0) red[wave] = mx;
     };
 
     // ---- one forward column update (c_crf_flipflop.c:43-78); t = index of the row
     //      consumed; ends with the step barrier ------------------------------------------
-    auto fwd_step = [&](float (&f)[R], const float *row, int t, bool norm_in, double &offacc) {
-        float ein = (W > 1 && wave > 0) ? edgeF[((t - 1) & 1) * W + wave - 1] : neg;
+    auto fwd_step = [&](double (&f)[R], const float *row, int t, bool norm_in, double &offacc) {
+        double ein = (W > 1 && wave > 0) ? edgeF[((t - 1) & 1) * W + wave - 1] : neg;
         if (norm_in) fold_norm(f, ein, offacc);
-        float left0 = wave_shift_up1(f[R - 1], neg);
+        double left0 = wave_shift_up1(f[R - 1], neg);
         if (W > 1 && lane == 0) left0 = ein;
 #pragma unroll
         for (int j = R - 1; j >= 0; --j) {
             const float ls = row[st[j]];
             const int mi = (j == 0) ? mvin0 : mv[j > 0 ? j - 1 : 0];
             const float lm = row[mi];
-            const float left = (j == 0) ? left0 : f[j > 0 ? j - 1 : 0];
-            const float av = fmaf(ls, c, f[j]);
-            float bv = fmaf(lm, c, left);
+            const double left = (j == 0) ? left0 : f[j > 0 ? j - 1 : 0];
+            const double av = fma((double)ls, (double)c, f[j]);
+            double bv = fma((double)lm, (double)c, left);
             if (MOD) {
                 const int di = (j == 0) ? mdin0 : md[j > 0 ? j - 1 : 0];
                 const float dw = (j == 0) ? fwin0 : fw[j > 0 ? j - 1 : 0];
-                bv = fmaf(row[di], dw, bv);
+                bv = fma((double)row[di], (double)dw, bv);
             }
-            f[j] = lse2(av, bv);
+            f[j] = lse2d(av, bv);
         }
         if (W > 1 && lane == WAVE - 1) edgeF[(t & 1) * W + wave] = f[R - 1];
         if (((t + 1) & 3) == 0) post_max(f);
         __syncthreads();
     };
     // publish the column's wave-boundary values before the first step from it
-    auto fwd_edge_init = [&](const float (&f)[R], int t0) {
+    auto fwd_edge_init = [&](const double (&f)[R], int t0) {
         if (W > 1 && lane == WAVE - 1) edgeF[((t0 - 1) & 1) * W + wave] = f[R - 1];
         __syncthreads();
     };
@@ -313,9 +338,9 @@ __device__ __forceinline__ void crf_read(const CrfArgs &a, const int n, const in
     double *ckoff_n = a.ckoff + (size_t)ckslot * NK;
 
     // ======================= forward sweep ===================================
-    float f[R];
+    double f[R];
 #pragma unroll
-    for (int j = 0; j < R; ++j) f[j] = (p0 + j == 0) ? 0.f : neg;           // :113-116
+    for (int j = 0; j < R; ++j) f[j] = (p0 + j == 0) ? 0.0 : neg;           // :113-116
     double offF = 0.0;
     fwd_edge_init(f, 0);
     {
@@ -328,7 +353,9 @@ __device__ __forceinline__ void crf_read(const CrfArgs &a, const int n, const in
             if (k + 1 < NK) tile_fetch(t0 + CK, pre);
             if (want_grad) {
 #pragma unroll
-                for (int j = 0; j < R; ++j) ck_n[((size_t)k * R + j) * NT + tid] = f[j];
+                // (a checkpoint column is a float snapshot of the double chain: ONE rounding per tile, which the
+                // tile's recompute starts from -- it does not accumulate from tile to tile)
+                for (int j = 0; j < R; ++j) ck_n[((size_t)k * R + j) * NT + tid] = (float)f[j];
                 if (tid == 0) ckoff_n[k] = offF;
             }
             for (int i = 0; i < nrows; ++i) {
@@ -341,14 +368,14 @@ __device__ __forceinline__ void crf_read(const CrfArgs &a, const int n, const in
     // score = sum of factors + fwd[T][L-1]  (c_crf_flipflop.c:131)
     if (tid == (L - 1) / R) {
         const int jj = (L - 1) % R;
-        float last = 0.f;
+        double last = 0.0;
 #pragma unroll
         for (int j = 0; j < R; ++j)
             if (j == jj) last = f[j];
         misc[0] = last;
     }
     __syncthreads();
-    const double fwd_score2 = offF + (double)misc[0];
+    const double fwd_score2 = offF + misc[0];
     if (!want_grad) {
         if (tid == 0) {
             const float cst = crf_add_cost(a, n, (float)(-(fwd_score2 * 0.6931471805599453) / (double)T) * a.out_scale);
@@ -359,9 +386,9 @@ __device__ __forceinline__ void crf_read(const CrfArgs &a, const int n, const in
     }
 
     // ======================= backward sweep + posterior =======================
-    float b[R];
+    double b[R];
 #pragma unroll
-    for (int j = 0; j < R; ++j) b[j] = (p0 + j == L - 1) ? 0.f : neg;       // :216-220
+    for (int j = 0; j < R; ++j) b[j] = (p0 + j == L - 1) ? 0.0 : neg;       // :216-220
     double offB = 0.0;
     bool bad = false;
     int nbwd = 0;                       // backward steps done so far
@@ -378,7 +405,7 @@ __device__ __forceinline__ void crf_read(const CrfArgs &a, const int n, const in
             if (k > 0) tile_fetch(t0 - CK, pre);
             // -- recompute the forward columns of this tile from its checkpoint
 #pragma unroll
-            for (int j = 0; j < R; ++j) f[j] = ck_n[((size_t)k * R + j) * NT + tid];
+            for (int j = 0; j < R; ++j) f[j] = (double)ck_n[((size_t)k * R + j) * NT + tid];
             offF = ckoff_n[k];
             fwd_edge_init(f, t0);       // barrier: tile and edges are visible
             for (int i = 0; i < nrows; ++i) {
@@ -392,7 +419,7 @@ __device__ __forceinline__ void crf_read(const CrfArgs &a, const int n, const in
                 }
                 // (column, offset) are stored pre-fold: a consistent pair
 #pragma unroll
-                for (int j = 0; j < R; ++j) Fblk[((size_t)i * R + j) * NT + tid] = f[j];
+                for (int j = 0; j < R; ++j) Fblk[((size_t)i * R + j) * NT + tid] = (float)f[j];
                 if (tid == 0) offs[i] = offF;
                 fwd_step(f, tile + i * SP, t, t > 0 && (t & 3) == 0, offF);
             }
@@ -400,26 +427,26 @@ __device__ __forceinline__ void crf_read(const CrfArgs &a, const int n, const in
             for (int i = nrows - 1; i >= 0; --i) {
                 const float *row = tile + i * SP;
                 float *prow = Psort + (size_t)i * KINDS * LPAD;
-                float ein = (W > 1 && wave < W - 1) ? edgeB[((nbwd - 1) & 1) * W + wave + 1] : neg;
+                double ein = (W > 1 && wave < W - 1) ? edgeB[((nbwd - 1) & 1) * W + wave + 1] : neg;
                 if (bnorm_pending) fold_norm(b, ein, offB);
-                const float ct = (float)(fwd_score2 - offs[i] - offB);
-                float right0 = wave_shift_down1(b[0], neg);
+                const double ct = fwd_score2 - offs[i] - offB;
+                double right0 = wave_shift_down1(b[0], neg);
                 if (W > 1 && lane == WAVE - 1) right0 = ein;
 #pragma unroll
                 for (int j = 0; j < R; ++j) {
                     const float ls = row[st[j]];
                     const float lm = row[mv[j]];
-                    const float br = (j == R - 1) ? right0 : b[j < R - 1 ? j + 1 : 0];
-                    const float as = fmaf(ls, c, b[j]);
-                    float am = fmaf(lm, c, br);
-                    if (MOD) am = fmaf(row[md[j]], fw[j], am);
-                    const float fc = Fblk[((size_t)i * R + j) * NT + tid] - ct;
-                    const float ps = fast_exp2(fc + as);
-                    const float pm = fast_exp2(fc + am);
+                    const double br = (j == R - 1) ? right0 : b[j < R - 1 ? j + 1 : 0];
+                    const double as = fma((double)ls, (double)c, b[j]);
+                    double am = fma((double)lm, (double)c, br);
+                    if (MOD) am = fma((double)row[md[j]], (double)fw[j], am);
+                    const double fc = (double)Fblk[((size_t)i * R + j) * NT + tid] - ct;
+                    const float ps = fast_exp2((float)(fc + as));
+                    const float pm = fast_exp2((float)(fc + am));
                     prow[slot[0][j]] = ps;
                     prow[LPAD + slot[1][j]] = pm;
                     if (MOD) prow[2 * LPAD + slot[MOD ? 2 : 0][j]] = pm * (fw[j] * inv_cmod);
-                    b[j] = lse2(as, am);
+                    b[j] = lse2d(as, am);
                 }
                 if (W > 1 && lane == 0) edgeB[(nbwd & 1) * W + wave] = b[0];
                 ++nbwd;
@@ -484,11 +511,11 @@ __device__ __forceinline__ void crf_read(const CrfArgs &a, const int n, const in
     }
     // bwd score = bwd[0][0] + sum of factors (c_crf_flipflop.c:234); score = mean (:482-491)
     if (bnorm_pending) {
-        float ein = 0.f;
+        double ein = 0.0;
         fold_norm(b, ein, offB);
     }
     if (tid == 0) {
-        const double bwd_score2 = offB + (double)b[0];
+        const double bwd_score2 = offB + b[0];
         const double score2 = 0.5 * (fwd_score2 + bwd_score2);
         const float cst = crf_add_cost(a, n, (float)(-(score2 * 0.6931471805599453) / (double)T) * a.out_scale);
         a.cost[n] = cst;
@@ -839,8 +866,13 @@ int crf_dispatch(const float *logprob, size_t ntrans, size_t nblk, size_t nbatch
                  float out_scale, float grad_scale, const float *grad_scale_vec, float *cost, float *grad,
                  void *workspace, size_t workspace_bytes, uint32_t *status, hipStream_t stream,
                  const float *add_grad, const float *add_cost, int add_S, float add_scale,
-                 hipEvent_t add_ready, const float *mod_col_weights) {
+                 hipEvent_t add_ready, const float *mod_col_weights, const SeqLabels *labels) {
     if (ntrans > 62 || ncan > ntrans || ncan == 0) return 2;
+    if (labels != nullptr && ((labels->seqs == nullptr && labels->total_len != 0) || labels->nbase == 0 ||
+                              2 * labels->nbase * (labels->nbase + 1) != ncan ||
+                              ((modidx != nullptr) != (labels->mod_cats != nullptr)) ||
+                              (labels->mod_cats != nullptr && (labels->can_mods_offsets == nullptr || labels->mod_cat_weights == nullptr))))
+        return 1;
     if (max_seqlen == 0) max_seqlen = nblk + 1;
     const CrfShape sh = crf_pick_shape(max_seqlen);
     if ((size_t)sh.R * sh.W * WAVE < max_seqlen || sh.R > 4) return 2;
@@ -854,6 +886,16 @@ int crf_dispatch(const float *logprob, size_t ntrans, size_t nblk, size_t nbatch
                         crf_band_layout(ntrans, nblk, nbatch, max_seqlen, mod, grad != nullptr, blk.bk).total > workspace_bytes)
         band = false;
     if (!band && crf_ckpt_bytes(nblk, nbatch, sh, grad != nullptr) > workspace_bytes) return 3;
+    if (labels != nullptr && !band) {
+        // the index arrays are OUTPUTS of this call; the band launch builds them itself, this path takes the
+        // stand-alone kernel (tk_flipflop_build_indices_dev's)
+        const int rc = build_indices_dispatch(labels->seqs, seqlen, nbatch, labels->nbase, labels->mod_cats,
+                                              labels->can_mods_offsets, labels->mod_cat_weights, const_cast<int64_t *>(seqoff),
+                                              const_cast<int32_t *>(stayidx), const_cast<int32_t *>(moveidx),
+                                              const_cast<int32_t *>(modidx), const_cast<float *>(modfact), labels->total_len,
+                                              status, stream);
+        if (rc != 0) return rc;
+    }
     CrfArgs a;
     a.lp = logprob;
     a.T = (int)nblk;
@@ -935,6 +977,13 @@ int crf_dispatch(const float *logprob, size_t ntrans, size_t nblk, size_t nbatch
         b.before_gradient = add_ready;
         b.colw = mod ? mod_col_weights : nullptr;
         b.wbias = blk.wbias;
+        // (a batch of empty reads has no label array: any non-null pointer says "build here", nothing reads it)
+        b.codes = labels != nullptr ? (labels->seqs != nullptr ? labels->seqs : stayidx) : nullptr;
+        b.mod_cats = labels != nullptr ? labels->mod_cats : nullptr;
+        b.cmo = labels != nullptr ? labels->can_mods_offsets : nullptr;
+        b.mcw = labels != nullptr ? labels->mod_cat_weights : nullptr;
+        b.total_len = labels != nullptr ? (long long)labels->total_len : 0;
+        b.nbase = labels != nullptr ? (int)labels->nbase : 0;
         const int rc = crf_band_dispatch(b, l.R, mod, blk.bk, stream);
         if (rc != 0) return rc;
         if (TK_LAB_ENV("TK_CRF_GATE_DUMP")) {                       // lab: how many reads did the band path disown?

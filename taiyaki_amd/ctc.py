@@ -6,6 +6,7 @@ kernels through the C ABI on ``torch.cuda.current_stream()``: no device->host co
 of the score tensor, no Python index building, no host->device copy of the
 gradient (ctc.pyx:119, 127-132, 139-141 in the reference).
 """
+import ctypes
 import os
 
 import numpy as np
@@ -15,10 +16,14 @@ from taiyaki_amd import _lib, flipflopfings
 
 
 def _indices(seqs, seqlen, nbase, device, mod_cats=None, can_mods_offsets=None,
-             mod_cat_weights=None, status=None):
-    """Device-side move/stay(/mod) ids in the padded per-position layout."""
+             mod_cat_weights=None, status=None, defer=False):
+    """Device-side move/stay(/mod) ids in the padded per-position layout.  `defer`: allocate the arrays and
+    return the `tk_seq_labels` as the 8th element instead of launching the build -- the operator's `_labels_dev`
+    entry point builds them inside its first launch (round 5: one launch less per call)."""
     L = _lib.lib()
     seqs_d = seqs.to(device=device, dtype=torch.int32, non_blocking=True).contiguous()
+    if seqs_d.numel() == 0:
+        seqs_d = torch.zeros(1, dtype=torch.int32, device=device)[:0]       # (a pointer for the C ABI; nothing reads it)
     seqlen_d = seqlen.to(device=device, dtype=torch.int32, non_blocking=True).contiguous()
     nbatch = seqlen_d.numel()
     total = seqs_d.numel()
@@ -32,6 +37,9 @@ def _indices(seqs, seqlen, nbase, device, mod_cats=None, can_mods_offsets=None,
         mcw = _device_constant(mod_cat_weights, torch.float32, device)
         mod = torch.empty(max(total, 1), dtype=torch.int32, device=device)
         fact = torch.empty(max(total, 1), dtype=torch.float32, device=device)
+    if defer:
+        labels = _lib.SeqLabels(_lib.ptr(seqs_d), total, nbase, _lib.ptr(mc), _lib.ptr(cmo), _lib.ptr(mcw))
+        return seqlen_d, seqoff, stay, move, mod, fact, (seqs_d, mc, cmo, mcw), labels
     rc = L.tk_flipflop_build_indices_dev(
         _lib.ptr(seqs_d), _lib.ptr(seqlen_d), nbatch, total, nbase, _lib.ptr(mc),
         _lib.ptr(cmo), _lib.ptr(mcw), _lib.ptr(seqoff), _lib.ptr(stay), _lib.ptr(move),
@@ -127,8 +135,11 @@ def _run(logprob, seqs, seqlen, sharp_can, sharp_mod, out_scale, ncan, want_grad
     dev = lp.device
     with torch.cuda.device(dev):
         status = _lib.status_word(dev)
-        seqlen_d, seqoff, stay, move, mod, fact, keep = _indices(
-            seqs, seqlen, nbase, dev, mod_cats, can_mods_offsets, mod_cat_weights, status)
+        # TK_CATMOD_GENERAL=1 / TK_SEPARATE_INDEX_BUILD=1 (lab / tests): the stand-alone index kernel and the
+        # entry point that takes its arrays; default: the index build rides in the operator's first launch
+        separate = bool(os.environ.get("TK_CATMOD_GENERAL") or os.environ.get("TK_SEPARATE_INDEX_BUILD"))
+        res = _indices(seqs, seqlen, nbase, dev, mod_cats, can_mods_offsets, mod_cat_weights, status, defer=not separate)
+        seqlen_d, seqoff, stay, move, mod, fact, keep = res[:7]
         maxlen = _max_seqlen(seqlen)
         cost = torch.empty(nbatch, dtype=torch.float32, device=dev)
         grad = torch.empty_like(lp) if want_grad else None
@@ -136,13 +147,21 @@ def _run(logprob, seqs, seqlen, sharp_can, sharp_mod, out_scale, ncan, want_grad
         ws = _workspace(wsb, dev, "crf")
         if _KEEP_WS is not None:
             ws.zero_()
-        rc = L.tk_crf_flipflop_dev(
-            _lib.ptr(lp), ntrans, nblk, nbatch, _lib.ptr(stay), _lib.ptr(move), _lib.ptr(mod),
-            _lib.ptr(fact), _lib.ptr(seqlen_d), _lib.ptr(seqoff), maxlen, ncan,
-            float(sharp_can), float(sharp_mod), float(out_scale), _lib.ptr(cost),
-            _lib.ptr(grad), _lib.ptr(ws), wsb, _lib.ptr(status), _lib.stream_ptr(),
-            _col_weights(keep, mod))     # (the per-column factors modfact was filled from)
-        _lib.check(rc, "tk_crf_flipflop_dev")
+        if separate:
+            rc = L.tk_crf_flipflop_dev(
+                _lib.ptr(lp), ntrans, nblk, nbatch, _lib.ptr(stay), _lib.ptr(move), _lib.ptr(mod),
+                _lib.ptr(fact), _lib.ptr(seqlen_d), _lib.ptr(seqoff), maxlen, ncan,
+                float(sharp_can), float(sharp_mod), float(out_scale), _lib.ptr(cost),
+                _lib.ptr(grad), _lib.ptr(ws), wsb, _lib.ptr(status), _lib.stream_ptr(),
+                _col_weights(keep, mod))     # (the per-column factors modfact was filled from)
+            _lib.check(rc, "tk_crf_flipflop_dev")
+        else:
+            rc = L.tk_crf_flipflop_labels_dev(
+                _lib.ptr(lp), ntrans, nblk, nbatch, ctypes.byref(res[7]), _lib.ptr(seqlen_d), _lib.ptr(seqoff),
+                _lib.ptr(stay), _lib.ptr(move), _lib.ptr(mod), _lib.ptr(fact), maxlen, ncan,
+                float(sharp_can), float(sharp_mod), float(out_scale), _lib.ptr(cost),
+                _lib.ptr(grad), _lib.ptr(ws), wsb, _lib.ptr(status), _lib.stream_ptr())
+            _lib.check(rc, "tk_crf_flipflop_labels_dev")
         _lib.finish(status)
     del keep
     if _KEEP_WS is not None:
@@ -319,8 +338,10 @@ def _run_fused(outputs, seqs, seqlen, sharpfact, want_grad, grad_scale=1.0, grad
     dev = lp.device
     with torch.cuda.device(dev):
         status = _lib.status_word(dev)
-        seqlen_d, seqoff, stay, move, mod, fact, keep = _indices(
-            seqs, seqlen, nbase, dev, mod_cats, can_mods_offsets, mod_cat_weights, status=status)
+        separate = bool(os.environ.get("TK_CATMOD_GENERAL") or os.environ.get("TK_SEPARATE_INDEX_BUILD"))
+        res = _indices(seqs, seqlen, nbase, dev, mod_cats, can_mods_offsets, mod_cat_weights, status=status,
+                       defer=not separate)
+        seqlen_d, seqoff, stay, move, mod, fact, keep = res[:7]
         maxlen = _max_seqlen(seqlen)
         lossvector = torch.empty(nbatch, dtype=torch.float32, device=dev)
         logz = torch.empty(nbatch, dtype=torch.float32, device=dev)
@@ -336,13 +357,22 @@ def _run_fused(outputs, seqs, seqlen, sharpfact, want_grad, grad_scale=1.0, grad
         gvec = None
         if grad_scale_per_read is not None:
             gvec = grad_scale_per_read.detach().to(device=dev, dtype=torch.float32).contiguous()
-        rc = L.tk_flipflop_loss_fused_dev(
-            _lib.ptr(lp), nblk, nbatch, nbase, ntrans, _lib.ptr(stay), _lib.ptr(move), _lib.ptr(mod), _lib.ptr(fact),
-            _lib.ptr(seqlen_d), _lib.ptr(seqoff), maxlen, float(sharpfact), float(grad_scale), _lib.ptr(gvec),
-            _lib.ptr(lossvector), _lib.ptr(grad), _lib.ptr(logz),
-            _lib.ptr(ws_a), wsa, _lib.ptr(ws_b), wsb, _lib.ptr(ws_x), wsx, _lib.ptr(status), _lib.stream_ptr(),
-            _col_weights(keep, mod))
-        _lib.check(rc, "tk_flipflop_loss_fused_dev")
+        if separate:
+            rc = L.tk_flipflop_loss_fused_dev(
+                _lib.ptr(lp), nblk, nbatch, nbase, ntrans, _lib.ptr(stay), _lib.ptr(move), _lib.ptr(mod), _lib.ptr(fact),
+                _lib.ptr(seqlen_d), _lib.ptr(seqoff), maxlen, float(sharpfact), float(grad_scale), _lib.ptr(gvec),
+                _lib.ptr(lossvector), _lib.ptr(grad), _lib.ptr(logz),
+                _lib.ptr(ws_a), wsa, _lib.ptr(ws_b), wsb, _lib.ptr(ws_x), wsx, _lib.ptr(status), _lib.stream_ptr(),
+                _col_weights(keep, mod))
+            _lib.check(rc, "tk_flipflop_loss_fused_dev")
+        else:
+            # (the index build rides in kernel A's first launch: one launch less in the captured step)
+            rc = L.tk_flipflop_loss_fused_labels_dev(
+                _lib.ptr(lp), nblk, nbatch, ntrans, ctypes.byref(res[7]), _lib.ptr(seqlen_d), _lib.ptr(seqoff),
+                _lib.ptr(stay), _lib.ptr(move), _lib.ptr(mod), _lib.ptr(fact), maxlen, float(sharpfact),
+                float(grad_scale), _lib.ptr(gvec), _lib.ptr(lossvector), _lib.ptr(grad), _lib.ptr(logz),
+                _lib.ptr(ws_a), wsa, _lib.ptr(ws_b), wsb, _lib.ptr(ws_x), wsx, _lib.ptr(status), _lib.stream_ptr())
+            _lib.check(rc, "tk_flipflop_loss_fused_labels_dev")
         _lib.finish(status)
     del keep, gvec, ws_x
     return lossvector, (grad if want_grad else None), logz

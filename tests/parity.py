@@ -111,18 +111,18 @@ def crf_loss_ok(r, rtol=1e-5, atol=2e-6):
 def crf_grad_ok(r, atol=GRAD_T_ATOL):
     """The gradient criterion of every CRF / cat-mod parity test, on the posterior scale:
       * within `atol` of the float64 witness -- or, where the fp32 reference itself is further than
-        that from the witness (long T; raw cat-mod logits times a weight of 8, whose reads the
-        log-domain kernel redoes in the reference's own fp32 arithmetic), no further than 2.5 x
-        the reference's own distance.  (Both are maxima over millions of elements of two fp32 algorithms'
-        rounding noise: over the 188 cat-mod cases of the round-4 fuzz sweeps the ratio kernel / reference
-        has median 0.84 and reaches 2.04 -- one case of seed 13, T = 3601, sat at 1.0e-2 against 5.1e-3 and
-        failed the factor 2 this criterion started with; folding the log-domain kernel's column maximum
-        every step instead of every fourth changes single cases in both directions, not the level);
-      * within `atol` + the reference's own distance of the fp32 oracle (triangle inequality).
-    Measured (profiles/r4_pytest_gpu_*.log, fuzz lines): plain CRF on the linear path 2e-6 of the
-    witness at T = 3600, where the reference is 1.3e-3 away from it."""
+        that from the witness (long T; raw cat-mod logits times a weight of 8), no further than 1.5 x
+        the reference's own distance;
+      * within `atol` + 2.5 x the reference's own distance of the fp32 oracle (triangle inequality).
+    History: the factor was 2, then 2.5 in round 4 -- widened for one fuzz case (seed 13, T = 3601, cat-mod with
+    raw logits, every read redone by the log-domain kernel: 1.0e-2 from float64 where the reference is 5.1e-3;
+    both were fp32 algorithms' rounding noise, ratio over 188 cases: median 0.84, maximum 2.04).  Round 5 put
+    the log-domain kernel's lattice state in double: the same case now sits at 2.9e-4, the three T = 3601
+    cat-mod cases of seeds 5 / 11 / 13 at 2.7 .. 3.0e-4 against the reference's 3.5 .. 5.8e-3
+    (profiles/r5_fuzz_summary.txt), and the factor is back below where it started.
+    Measured: plain CRF on the linear path 2e-6 of the witness at T = 3600, where the reference is 1.3e-3 away."""
     noise = r["ref_noise_scaled"]
-    return r["grad_f64_scaled"] < max(atol, 2.5 * noise) and r["grad_scaled_abs"] < atol + 3.0 * noise
+    return r["grad_f64_scaled"] < max(atol, 1.5 * noise) and r["grad_scaled_abs"] < atol + 2.5 * noise
 
 
 def run_logz(scores, dev, want_grad=True):

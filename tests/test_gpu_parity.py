@@ -792,6 +792,46 @@ def test_catmod_column_weights_form_agrees_with_the_general_form(oracle_mod, gpu
     assert parity.rel_err(out[""][0], out["1"][0]) < 1e-5 and parity.abs_err(out[""][1], out["1"][1]) < 5e-6
 
 
+@pytest.mark.parametrize("catmod", [False, True])
+def test_index_build_inside_the_launch_changes_no_bit(gpu_device, catmod, monkeypatch):
+    """Round 5: the operators hand the flip-flop codes to `tk_crf_flipflop_labels_dev` /
+    `tk_flipflop_loss_fused_labels_dev`, whose sweep workgroups form their ids from the codes themselves (the rank
+    workgroups leave the index arrays for the launches behind) -- one launch less than
+    `tk_flipflop_build_indices_dev` + the entry points that take its arrays (TK_SEPARATE_INDEX_BUILD=1).  Same
+    ids, same arithmetic: gradient call, cost-only call and fused loss agree bit for bit, on a ragged batch with an
+    empty read, a one-base read and L = T + 1, and on a batch the log-domain kernel takes (sharpening 9)."""
+    import torch
+    from taiyaki_amd import ctc, synth
+    T = 203
+    seqlens = np.array([150, 1, T + 1, 64, 0, 65, 97, 128, 33], dtype=np.int32)
+    inp = synth.crf_case(T, len(seqlens), 31, seqlens=seqlens, nmods_per_base=(1, 1, 0, 0) if catmod else None)
+    extra = ()
+    if catmod:
+        synth.normalise_mod_columns(inp, logit_scale=0.2)
+        extra = (torch.from_numpy(inp["mod_cats"]), inp["can_mods_offsets"], inp["mod_cat_weights"])
+    x = torch.from_numpy(inp["scores"]).to(gpu_device)
+    seqs, sl = torch.from_numpy(inp["seqs"]), torch.from_numpy(inp["seqlens"])
+
+    def run_all():
+        out = []
+        for sharp in (1.0, 9.0):
+            for want_grad in (True, False):
+                c, g = ctc._run(x, seqs, sl, sharp, 1.0 if catmod else sharp, 1.0 / sharp, 40, want_grad, *extra)
+                torch.cuda.synchronize()
+                out += [c.cpu().numpy()] + ([g.cpu().numpy()] if want_grad else [])
+        lv, g, lz = ctc._run_fused(x, seqs, sl, 1.0, True, 1.0, None, *extra)
+        torch.cuda.synchronize()
+        return out + [lv.cpu().numpy(), g.cpu().numpy(), lz.cpu().numpy()]
+
+    monkeypatch.delenv("TK_SEPARATE_INDEX_BUILD", raising=False)
+    inside = run_all()
+    monkeypatch.setenv("TK_SEPARATE_INDEX_BUILD", "1")
+    separate = run_all()
+    assert np.isfinite(inside[0]).all()
+    for a, b in zip(inside, separate):
+        assert np.array_equal(a, b)
+
+
 @pytest.mark.parametrize("mods", [(2, 2, 1, 0), (3, 2, 2, 1), (5, 5, 4, 4)])
 def test_catmod_rows_wider_than_the_shared_row_image(oracle_mod, gpu_device, mods):
     """Round 4's shared-rows feed keeps 48 columns per exponentiated row in LDS; cat-mod with five or

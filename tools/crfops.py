@@ -23,6 +23,7 @@ def main():
     ap.add_argument("--catmod", action="store_true")
     ap.add_argument("--cfg5", action="store_true")
     ap.add_argument("--reps", type=int, default=20)
+    ap.add_argument("--separate", action="store_true", help="round 4's form: tk_flipflop_build_indices_dev as a launch of its own")
     ap.add_argument("--shapes", default="", help="extra shapes name:T:N:chunk_len[:spb], comma separated (chunk_len 0 = SPEED_TEST lengths)")
     args = ap.parse_args()
     dev = torch.device("cuda:0")
@@ -41,6 +42,7 @@ def main():
     out = []
     for name, T, N, cl, spb, cm in shapes:
         ops = bench.LossOps(T, N, dev, realistic_chunk_len=cl, spb=spb, cat_mod=cm)
+        ops.separate_index_build = args.separate
         reps = args.reps if T < 4000 else 5
         crf, crf_min = bench._events_mean_min(ops.crf, reps, warm=5)
         both, _ = bench._events_mean_min(ops.both, reps, warm=5)

@@ -707,6 +707,12 @@ __device__ __forceinline__ double img_M(const float *img) {
     return __hiloint2double(__float_as_int(img[NS * NS + NS + 1]), __float_as_int(img[NS * NS + NS]));
 }
 
+// (Round 5, measured and not kept: a second, TRANSPOSED copy of every matrix in the LDS image, both halves 16-byte
+// aligned, so that a column / row share is two ds_read_b128 instead of nine scalar reads -- a third of a step's ~70
+// instructions.  Stamps at T = 4000 / N = 256: scan 5212 -> 5016 cycles, expand 4608 -> 4408 (-4 %): the steps are
+// bound by the latency of their dependent 8-lane chain, not by their instruction count -- and the scatter that
+// writes the transposed half took stage + combine from 13.0 to 32.7 thousand cycles: middle kernel 14.3 -> 25.6 us.)
+//
 // The serial steps below are issued by ONE wave in order, so every instruction in the
 // loop body is latency: bookkeeping that is not on the dependency chain (the fp64 M sums,
 // 64-bit exponent sums, register copies of the prefetched share) is kept out of them.

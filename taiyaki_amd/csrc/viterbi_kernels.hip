@@ -265,8 +265,29 @@ constexpr int VIT_GROUP = TK_VIT_GROUP;     // steps of straight-line code = sco
 constexpr int VIT_RING = VIT_GROUP / VIT_TILE;  // tiles in the ring: at least the one being written and the one being read
 
 // maximum over the eight lanes that share lane % 8 (one per 8-lane group), in all of them: within a
-// 16-lane row by DPP, across the rows and halves by the lane-swap instructions of gfx950
+// 16-lane row by DPP, across the rows and halves by the lane-swap instructions of gfx950.  A swap
+// exchanges halves of TWO registers in place, so max(x, swapped x) needs x twice: the copies are made by
+// issuing the level's maximum twice (independent instructions) instead of a v_mov behind it -- two
+// dependent hops less on the recursion's chain (the intrinsic form: max, mov, swap, max, mov, swap, max).
+#ifndef TK_VIT_DUPMAX
+#define TK_VIT_DUPMAX 1
+#endif
 __device__ __forceinline__ float vit_cross_max(float x) {
+#if TK_VIT_DUPMAX
+    float a, b, c;
+    asm("s_nop 1\n\t"
+        "v_max_f32_dpp %0, %3, %3 row_ror:8 row_mask:0xf bank_mask:0xf\n\t"
+        "v_max_f32_dpp %1, %3, %3 row_ror:8 row_mask:0xf bank_mask:0xf\n\t"
+        "s_nop 1\n\t"
+        "v_permlane16_swap_b32 %0, %1\n\t"
+        "v_max_f32 %2, %0, %1\n\t"
+        "v_max_f32 %0, %0, %1\n\t"
+        "s_nop 1\n\t"
+        "v_permlane32_swap_b32 %2, %0\n\t"
+        "v_max_f32 %0, %2, %0"
+        : "=&v"(a), "=&v"(b), "=&v"(c) : "v"(x));
+    return a;
+#else
     float r;
     asm("s_nop 1\n\t"
         "v_max_f32_dpp %0, %1, %1 row_ror:8 row_mask:0xf bank_mask:0xf"
@@ -280,6 +301,7 @@ __device__ __forceinline__ float vit_cross_max(float x) {
         asm("v_max_f32 %0, %1, %2" : "=v"(r) : "v"(__uint_as_float(sw[0])), "v"(__uint_as_float(sw[1])));
     }
     return r;
+#endif
 }
 
 __device__ __forceinline__ void vit_handover() {

@@ -1,0 +1,28 @@
+#!/bin/bash
+# The round's evidence files on one GPU box (what profiles/README.md's table cites), written under gpurun_out/$TAG/:
+#   gpurun --timeout 2400 -- 'TAG=r5_v1 bash tools/evidence.sh'
+# PMC passes never share a run with a trace domain other than --kernel-trace (MI355X guide; tools/pmc_traffic.py,
+# tools/sq_counters.py wrap rocprofv3 themselves).  Every step is bounded by `timeout`.
+cd "$(dirname "$0")/.."; TAG=${TAG:-r5}; O=gpurun_out/$TAG; mkdir -p $O
+export TMPDIR=/tmp
+H=$(python -c "import bench; print(bench.kernel_hash())" 2>/dev/null | tail -1); echo "kernel hash $H" | tee $O/hash.txt
+# fuzz sweeps beside everything else (CPU-heavy: the float64 witness)
+for s in ${FUZZ_SEEDS:-21 22}; do timeout 2000 python -m tests.helpers.fuzz_shapes --cases ${FUZZ_CASES:-100} --seed $s > $O/fuzz_shapes_$s.log 2>&1 & done
+timeout 900 python -m pytest tests -m gpu -q > $O/pytest_gpu.log 2>&1; grep -E "passed|failed" $O/pytest_gpu.log | tail -1
+timeout 900 python bench.py > $O/bench_default.json 2> $O/bench_default.err; python tools/show_bench.py $O/bench_default.json
+for c in 4 5; do timeout 600 python bench.py --config $c --no-forced-group --no-varlen > $O/bench_cfg$c.json 2> $O/bench_cfg$c.err; done
+# kernel summary of the bench command under rocprofv3 (kernel trace only)
+rm -rf /tmp/tk_prof; (cd /tmp && timeout 900 rocprofv3 --kernel-trace --stats -d /tmp/tk_prof -o bench -- python $OLDPWD/bench.py --steps 10 --warmup 3 --no-forced-group --no-cpu-baseline --no-pmc --no-varlen > /dev/null 2> $OLDPWD/$O/rocprof_bench.err)
+DB=$(find /tmp/tk_prof -name "*.db" | head -1)
+if [ -n "$DB" ]; then python tools/rocpd_stats.py $DB 30 > $O/bench_kernel_stats.txt; python tools/prof_by_shape.py $DB "%tk%" > $O/bench_loss_kernels_by_shape.txt; fi
+find /tmp/tk_prof -name "*kernel_stats.csv" | head -1 | xargs -r -I{} cp {} $O/bench_rocprofv3_kernel_stats.csv
+# HBM traffic of the loss-path operators, shader-sequencer counters of kernel A
+timeout 900 python tools/pmc_traffic.py --ops logz:4000:256:0,logz:800:128:0,crf:800:128:4000,crf:4000:256:0,catmod:800:128:4000 --save $O/${TAG%%_*} > $O/pmc.log 2>&1
+timeout 900 python tools/sq_counters.py --save $O/${TAG%%_*}_sq_counters.json > $O/sq_counters.txt 2>&1
+# operator timings outside the step
+timeout 300 python tools/vitbench.py > $O/vitbench.txt 2>&1
+for v in "" "--separate"; do echo "== crfops $v"; timeout 300 python tools/crfops.py --rowk --catmod --cfg5 $v 2>&1 | tail -1; done > $O/crfops.txt
+timeout 300 python tools/crf_gate_probe.py > $O/crf_gate_probe.log 2>&1
+wait
+tail -n 2 $O/fuzz_shapes_*.log; grep -h FAIL $O/fuzz_shapes_*.log | head
+ls -la $O

@@ -313,29 +313,40 @@ __device__ __forceinline__ int band_mod_seq(const BandArgs &a, int cn, int64_t i
 }
 
 // This read's offset into the label arrays = the sum of the lengths before it, clamped to the label array; every
-// workgroup sums for itself (a batch is a few hundred reads).  All threads of the workgroup take part; `sh`: two
-// shared 64-bit words.  Returns (offset, total announced).
-__device__ __forceinline__ void band_offset_of(const BandArgs &a, int n, long long *sh, long long *off_out, long long *all_out) {
-    long long mine = 0, all = 0;
+// workgroup sums for itself (a batch is a few hundred reads).  All threads of the workgroup take part; `sh`:
+// 3 x BAND_MAXW shared 64-bit words.  One round trip (the lengths -- this read's own among them) and ONE barrier:
+// per-wave partial sums, no atomics.  Returns (offset, total announced, this read's length).
+__device__ __forceinline__ void band_offset_of(const BandArgs &a, int n, long long *sh, long long *off_out, long long *all_out,
+                                               int *len_out) {
+    long long mine = 0, all = 0, own = 0;
     for (int i = threadIdx.x; i < a.N; i += blockDim.x) {
         const long long v = a.seqlen[i];
         all += v;
         if (i < n) mine += v;
+        if (i == n) own = v;
     }
 #pragma unroll
     for (int m = 32; m >= 1; m >>= 1) {
         mine += __shfl_xor(mine, m, WAVE);
         all += __shfl_xor(all, m, WAVE);
+        own += __shfl_xor(own, m, WAVE);
     }
-    if (threadIdx.x == 0) sh[0] = sh[1] = 0;
-    __syncthreads();
+    const int w = threadIdx.x >> 6, nw = (int)(blockDim.x >> 6);
     if ((threadIdx.x & (WAVE - 1)) == 0) {
-        atomicAdd(reinterpret_cast<unsigned long long *>(&sh[0]), (unsigned long long)mine);     // (integers: order does not matter)
-        atomicAdd(reinterpret_cast<unsigned long long *>(&sh[1]), (unsigned long long)all);
+        sh[3 * w] = mine;
+        sh[3 * w + 1] = all;
+        sh[3 * w + 2] = own;
     }
     __syncthreads();
-    *off_out = sh[0];
-    *all_out = sh[1];
+    mine = all = own = 0;
+    for (int k = 0; k < nw; ++k) {
+        mine += sh[3 * k];
+        all += sh[3 * k + 1];
+        own += sh[3 * k + 2];
+    }
+    *off_out = mine;
+    *all_out = all;
+    *len_out = (int)own;
 }
 
 // The writer of a read's index arrays (rank workgroups; a cost-only call: the forward sweeps): what
@@ -861,13 +872,14 @@ __global__ __launch_bounds__(WCAP *WAVE) void crf_band_sweep_kernel(BandArgs a) 
     const int slot3 = blockIdx.x / N;
     const int role = want_grad ? (slot3 + 2) % 3 : slot3;       // 0 forward, 1 backward, 2 rank (cost only: 2 N workgroups, the two sweeps)
     const int n = blockIdx.x - slot3 * N;
-    __shared__ long long offsh[2];
+    __shared__ long long offsh[3 * BAND_MAXW];
     long long off_raw = 0, all_raw = 0;
     int L;
     if (a.codes != nullptr) {
-        // the launch builds its indices itself: this read's offset from the lengths (see band_offset_of)
-        band_offset_of(a, n, offsh, &off_raw, &all_raw);
-        L = (int)max(0ll, min((long long)a.seqlen[n], a.total_len - min(off_raw, a.total_len)));
+        // the launch builds its indices itself: this read's offset and length from the lengths (see band_offset_of)
+        int len_n = 0;
+        band_offset_of(a, n, offsh, &off_raw, &all_raw, &len_n);
+        L = (int)max(0ll, min((long long)len_n, a.total_len - min(off_raw, a.total_len)));
     } else {
         L = min(a.seqlen[n], (int)(a.seqoff[n + 1] - a.seqoff[n]));            // (offsets are clamped to the label array)
     }

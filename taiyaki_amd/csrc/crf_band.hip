@@ -296,20 +296,17 @@ __device__ __forceinline__ void band_frames(float (&m)[R], int (&f)[R], float (&
 }
 
 // ---------------------------------------------------------------------------
-// Ids from flip-flop codes (BandArgs::codes; flipflopfings.py:6-31, ctc.pyx:127-134, 282-292) -- the arithmetic
-// of build_indices_kernel (crf_kernels.hip), per cell, where the sweep launch builds its indices itself.
+// Ids from flip-flop codes (BandArgs::codes): ff_common.h lbl_*.  No launch of the linear path reads an index ARRAY
+// when the call brings its labels: the sweeps, the rank workgroups and the gradient pass form ids from the codes
+// (read-only inputs that stay in every XCD's L2 from call to call; the arrays a build kernel has just written are
+// misses in seven of eight L2s).  A first version let the rank workgroups write the arrays for the gradient pass:
+// that alone cost the sweep launch 7.6 us (profiles/r5_index_build_ab.txt).
 // ---------------------------------------------------------------------------
-__device__ __forceinline__ int band_code(const BandArgs &a, int64_t i) {
-    return min(max(a.codes[i], 0), 2 * a.nbase - 1);            // (a bad label is clamped here and REPORTED by the writer)
-}
-__device__ __forceinline__ int band_stay_id(const BandArgs &a, int cp) { return cp + min(cp, a.nbase) * (2 * a.nbase); }
-__device__ __forceinline__ int band_move_id(const BandArgs &a, int cp, int cn) { return cp + min(cn, a.nbase) * (2 * a.nbase); }
-// the modification column and factor of the move INTO the position whose code is `cn` and whose category is mod_cats[i_next]
+__device__ __forceinline__ int band_code(const BandArgs &a, int64_t i) { return lbl_code(a, i); }
+__device__ __forceinline__ int band_stay_id(const BandArgs &a, int cp) { return lbl_stay(a, cp); }
+__device__ __forceinline__ int band_move_id(const BandArgs &a, int cp, int cn) { return lbl_move(a, cp, cn); }
 __device__ __forceinline__ int band_mod_seq(const BandArgs &a, int cn, int64_t i_next, bool *bad) {
-    const int lo = a.cmo[cn % a.nbase], hi = a.cmo[cn % a.nbase + 1];
-    const int mseq = lo + a.mod_cats[i_next];
-    if (bad != nullptr) *bad |= mseq < lo || mseq >= hi;
-    return min(max(mseq, lo), hi - 1);
+    return lbl_mod_seq(a, cn, a.mod_cats[i_next], bad);
 }
 
 // This read's offset into the label arrays = the sum of the lengths before it, clamped to the label array; every
@@ -347,48 +344,6 @@ __device__ __forceinline__ void band_offset_of(const BandArgs &a, int n, long lo
     *off_out = mine;
     *all_out = all;
     *len_out = (int)own;
-}
-
-// The writer of a read's index arrays (rank workgroups; a cost-only call: the forward sweeps): what
-// build_indices_kernel leaves for the launches behind this one, and the label checks.
-template <bool MOD>
-__device__ __forceinline__ void band_write_indices(const BandArgs &a, int n, long long off_raw, long long all, int L) {
-    const int64_t off = min(off_raw, a.total_len);
-    int32_t *stay = const_cast<int32_t *>(a.stay), *move = const_cast<int32_t *>(a.move);
-    int32_t *mod = const_cast<int32_t *>(a.mod);
-    float *fact = const_cast<float *>(a.modfact);
-    int64_t *seqoff = const_cast<int64_t *>(a.seqoff);
-    if (threadIdx.x == 0) {
-        seqoff[n] = off;
-        if (n == a.N - 1) {
-            seqoff[a.N] = min(all, a.total_len);
-            if (all > a.total_len && a.status) atomicOr(a.status, 8u);      // more labels announced than handed over
-        }
-    }
-    const int ns = 2 * a.nbase;
-    bool bad = false;
-    for (int p = threadIdx.x; p < L; p += blockDim.x) {
-        const int craw = a.codes[off + p];
-        bad |= craw < 0 || craw >= ns;
-        const int cp = min(max(craw, 0), ns - 1);
-        stay[off + p] = band_stay_id(a, cp);
-        if (p + 1 < L) {
-            const int cn = band_code(a, off + p + 1);
-            move[off + p] = band_move_id(a, cp, cn);
-            if (MOD) {
-                const int mseq = band_mod_seq(a, cn, off + p + 1, &bad);
-                mod[off + p] = a.ncan + mseq;
-                fact[off + p] = a.mcw[mseq];
-            }
-        } else {
-            move[off + p] = 0;
-            if (MOD) {
-                mod[off + p] = a.ncan;
-                fact[off + p] = 0.f;
-            }
-        }
-    }
-    if (bad && a.status) atomicOr(a.status, 8u);
 }
 
 template <int R, bool MOD, bool FWD, bool GRAD, bool ROWS, bool CW, int BK>
@@ -432,18 +387,24 @@ __device__ __forceinline__ void band_sweep(const BandArgs &a, int n, int L, int6
     bool has[R];
     float m[R], sc[R];
     int f[R];
+    bool bad_label = false;
 #pragma unroll
     for (int j = 0; j < R; ++j) {
         const int q = lane * R + j, p = FWD ? a0 + q : a0 + PW - 1 - q;
         const int ms = FWD ? p - 1 : p;                         // the move's source position
         has[j] = ms >= 0 && ms < L - 1;
         if (a.codes != nullptr) {
-            // (the launch builds its indices itself: ids straight from the flip-flop codes)
-            st4[j] = 4 * ((p < L) ? band_stay_id(a, band_code(a, off + p)) : 0);
+            // (the launch builds its indices itself: ids straight from the flip-flop codes.  The FORWARD sweep's
+            // waves see every label of the read here -- position p and the move into it -- so they are also the
+            // label check of tk_flipflop_build_indices_dev, TK_STATUS_BAD_LABEL, at no load of its own)
+            const int craw = (p < L) ? a.codes[off + p] : 0;
+            const int cp = min(max(craw, 0), 2 * a.nbase - 1);
+            if (FWD) bad_label |= craw != cp;
+            st4[j] = 4 * ((p < L) ? band_stay_id(a, cp) : 0);
             const int c0 = has[j] ? band_code(a, off + ms) : 0, c1 = has[j] ? band_code(a, off + ms + 1) : 0;
             mv4[j] = 4 * (has[j] ? band_move_id(a, c0, c1) : 0);
             if (MOD) {
-                const int mseq = has[j] ? band_mod_seq(a, c1, off + ms + 1, nullptr) : 0;
+                const int mseq = has[j] ? band_mod_seq(a, c1, off + ms + 1, FWD ? &bad_label : nullptr) : 0;
                 md4[MOD ? j : 0] = 4 * (has[j] ? a.ncan + mseq : 0);
                 fw[MOD ? j : 0] = has[j] ? a.mcw[mseq] * a.c_mod : 0.f;
             }
@@ -460,6 +421,7 @@ __device__ __forceinline__ void band_sweep(const BandArgs &a, int n, int L, int6
         sc[j] = 0.f;
     }
 
+    if (FWD && bad_label && a.status) atomicOr(a.status, 8u);
     const unsigned rs4 = 4u * (unsigned)rowstride;
     float *ckm = GRAD ? (FWD ? a.ckFm : a.ckBm) + (size_t)n * NB * a.LP + a0 : nullptr;
     int16_t *ckf = GRAD ? (FWD ? a.ckFf : a.ckBf) + (size_t)n * NB * a.LP + a0 : nullptr;
@@ -867,10 +829,15 @@ __global__ __launch_bounds__(WCAP *WAVE) void crf_band_sweep_kernel(BandArgs a) 
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int N = a.N, S = a.S, W = a.W;
     const bool want_grad = a.grad != nullptr;
-    // dispatch order: rank workgroups first (short; they leave their CUs within microseconds),
-    // then the forward, then the backward sweeps
     const int slot3 = blockIdx.x / N;
-    const int role = want_grad ? (slot3 + 2) % 3 : slot3;       // 0 forward, 1 backward, 2 rank (cost only: 2 N workgroups, the two sweeps)
+    // dispatch order (round 5): the two sweeps first -- 2 N workgroups onto the chip's CUs, one each at the train step's
+    // shape --, the rank workgroups behind them (short; they share a CU with a sweep for a few microseconds).  Rank
+    // workgroups first (rounds 3-4) left it to their lifetime where the backward sweeps landed: 67.0 against 69.6 us
+    // for the launch at the train step's shape, cat-mod 81.4 against 85.0 (profiles/r5_index_build_ab.txt).
+#ifndef TK_RANK_LAST
+#define TK_RANK_LAST 1
+#endif
+    const int role = (want_grad && !TK_RANK_LAST) ? (slot3 + 2) % 3 : slot3;       // 0 forward, 1 backward, 2 rank (cost only: 2 N workgroups, the two sweeps)
     const int n = blockIdx.x - slot3 * N;
     __shared__ long long offsh[3 * BAND_MAXW];
     long long off_raw = 0, all_raw = 0;
@@ -883,9 +850,16 @@ __global__ __launch_bounds__(WCAP *WAVE) void crf_band_sweep_kernel(BandArgs a) 
     } else {
         L = min(a.seqlen[n], (int)(a.seqoff[n + 1] - a.seqoff[n]));            // (offsets are clamped to the label array)
     }
-    // (the writer of the index arrays: the rank workgroup of a gradient call, the forward sweep of a cost-only call)
-    const bool writer = a.codes != nullptr && role == (want_grad ? 2 : 0);
-    if (writer) band_write_indices<MOD>(a, n, off_raw, all_raw, L);
+    // (what is left of build_indices_kernel's outputs: the read's offset, for the launches behind -- the gradient pass
+    // and crf_kernel take a read's offset and length from seqoff; its label checks ride in the forward sweep's set-up)
+    if (a.codes != nullptr && role == 0 && tid == 0) {
+        int64_t *seqoff = const_cast<int64_t *>(a.seqoff);
+        seqoff[n] = min(off_raw, a.total_len);
+        if (n == N - 1) {
+            seqoff[N] = min(all_raw, a.total_len);
+            if (all_raw > a.total_len && a.status) atomicOr(a.status, 8u);      // more labels announced than handed over
+        }
+    }
     if (role == 2 && tid == 0) a.gate[n] = 0;
     if (!want_grad && role == 0 && tid == 0) a.gate[n] = 2;     // cost only: pending -- crf_kernel compares the two sweep scores
     if (role == 2 && tid < 16) const_cast<float *>(a.zeros)[tid] = 0.f;   // (every rank workgroup: the same zeros)
@@ -1166,14 +1140,20 @@ __global__ __launch_bounds__(POST_WAVES *WAVE) __attribute__((amdgpu_waves_per_e
     // 0 that cells past the end of the read take (stay ids at p >= L, move ids at p - 1 < 0 or p >= L - 1).
     const __amdgpu_buffer_rsrc_t rFm = __builtin_amdgcn_make_buffer_rsrc(a.ckFm + ckrow, 0, (int)(a.LP * 4), BUF_WORD3);
     const __amdgpu_buffer_rsrc_t rBm = __builtin_amdgcn_make_buffer_rsrc(a.ckBm + ckrow, 0, (int)(a.LP * 4), BUF_WORD3);
-    const __amdgpu_buffer_rsrc_t rSt = __builtin_amdgcn_make_buffer_rsrc(const_cast<int32_t *>(a.stay + off), 0, L * 4, BUF_WORD3);
-    const __amdgpu_buffer_rsrc_t rMv = __builtin_amdgcn_make_buffer_rsrc(const_cast<int32_t *>(a.move + off), 0, (L - 1) * 4, BUF_WORD3);
+    // (a call that brought its labels: ids from the flip-flop codes -- descriptor over the read's codes -- instead of
+    // from index arrays nobody wrote; see band_code)
+    const bool from_codes = a.codes != nullptr;
+    const __amdgpu_buffer_rsrc_t rSt = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<int32_t *>((from_codes ? a.codes : a.stay) + off), 0, L * 4, BUF_WORD3);
+    const __amdgpu_buffer_rsrc_t rMv = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<int32_t *>((from_codes ? a.codes : a.move) + off), 0, (from_codes ? L : L - 1) * 4, BUF_WORD3);
     const __amdgpu_buffer_rsrc_t rRec = __builtin_amdgcn_make_buffer_rsrc(a.rec + (size_t)n * W * EPL * WAVE, 0, (int)(W * EPL * WAVE * 4), BUF_WORD3);
     const __amdgpu_buffer_rsrc_t rSeg = __builtin_amdgcn_make_buffer_rsrc(a.segend + (size_t)n * W * WAVE, 0, (int)(W * WAVE * 4), BUF_WORD3);
     const __amdgpu_buffer_rsrc_t rMd = __builtin_amdgcn_make_buffer_rsrc(
-        const_cast<int32_t *>(MOD ? a.mod + off : a.move + off), 0, (L - 1) * 4, BUF_WORD3);
+        const_cast<int32_t *>(MOD ? (from_codes ? a.mod_cats : a.mod) + off : (from_codes ? a.codes : a.move) + off), 0,
+        (from_codes ? L : L - 1) * 4, BUF_WORD3);
     const __amdgpu_buffer_rsrc_t rMf = __builtin_amdgcn_make_buffer_rsrc(
-        const_cast<float *>(MOD ? a.modfact + off : a.zeros), 0, MOD ? (L - 1) * 4 : 0, BUF_WORD3);
+        const_cast<float *>(MOD && !from_codes ? a.modfact + off : a.zeros), 0, MOD && !from_codes ? (L - 1) * 4 : 0, BUF_WORD3);
 
     // One chunk of the wave's time block.  Everything is straight-line and branch-free so that the
     // LDS round trips, the two recurrence chains and the RG prefix scans of a row group overlap
@@ -1205,15 +1185,36 @@ __global__ __launch_bounds__(POST_WAVES *WAVE) __attribute__((amdgpu_waves_per_e
             haso[j] = p < L - 1;
             // (R = 1: p = a0 + lane; the moves' descriptor ends at L - 1, the vector offset of p - 1 wraps to
             // "far out of range" at p = 0)
-            st4[j] = 4 * (int)__builtin_amdgcn_raw_buffer_load_b32(rSt, lane4, 4u * (unsigned)a0, 0);
-            mi4[j] = 4 * (int)__builtin_amdgcn_raw_buffer_load_b32(rMv, 4u * (unsigned)p - 4u, 0, 0);
-            mo4[j] = 4 * (int)__builtin_amdgcn_raw_buffer_load_b32(rMv, lane4, 4u * (unsigned)a0, 0);
-            if (MOD) {
-                di4[MOD ? j : 0] = 4 * (int)__builtin_amdgcn_raw_buffer_load_b32(rMd, 4u * (unsigned)p - 4u, 0, 0);
-                do4[MOD ? j : 0] = 4 * (int)__builtin_amdgcn_raw_buffer_load_b32(rMd, lane4, 4u * (unsigned)a0, 0);
-                mfi[MOD ? j : 0] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rMf, 4u * (unsigned)p - 4u, 0, 0));
-                fwi[MOD ? j : 0] = mfi[MOD ? j : 0] * a.c_mod;
-                fwo[MOD ? j : 0] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rMf, lane4, 4u * (unsigned)a0, 0)) * a.c_mod;
+            if (from_codes) {
+                // codes of p - 1, p, p + 1 (0 outside the read: the descriptor's bounds), ids by the build kernel's arithmetic
+                const int ns1 = 2 * a.nbase - 1;
+                const int cb = min(max((int)__builtin_amdgcn_raw_buffer_load_b32(rSt, 4u * (unsigned)p - 4u, 0, 0), 0), ns1);
+                const int cp = min(max((int)__builtin_amdgcn_raw_buffer_load_b32(rSt, lane4, 4u * (unsigned)a0, 0), 0), ns1);
+                const int cn = min(max((int)__builtin_amdgcn_raw_buffer_load_b32(rSt, 4u * (unsigned)p + 4u, 0, 0), 0), ns1);
+                st4[j] = 4 * ((p < L) ? lbl_stay(a, cp) : 0);
+                mi4[j] = 4 * (hasi[j] ? lbl_move(a, cb, cp) : 0);
+                mo4[j] = 4 * (haso[j] ? lbl_move(a, cp, cn) : 0);
+                if (MOD) {
+                    const int cati = (int)__builtin_amdgcn_raw_buffer_load_b32(rMd, lane4, 4u * (unsigned)a0, 0);
+                    const int cato = (int)__builtin_amdgcn_raw_buffer_load_b32(rMd, 4u * (unsigned)p + 4u, 0, 0);
+                    const int mqi = lbl_mod_seq(a, cp, cati, nullptr), mqo = lbl_mod_seq(a, cn, cato, nullptr);
+                    di4[MOD ? j : 0] = 4 * (hasi[j] ? a.ncan + mqi : 0);
+                    do4[MOD ? j : 0] = 4 * (haso[j] ? a.ncan + mqo : 0);
+                    mfi[MOD ? j : 0] = hasi[j] ? a.mcw[mqi] : 0.f;
+                    fwi[MOD ? j : 0] = mfi[MOD ? j : 0] * a.c_mod;
+                    fwo[MOD ? j : 0] = (haso[j] ? a.mcw[mqo] : 0.f) * a.c_mod;
+                }
+            } else {
+                st4[j] = 4 * (int)__builtin_amdgcn_raw_buffer_load_b32(rSt, lane4, 4u * (unsigned)a0, 0);
+                mi4[j] = 4 * (int)__builtin_amdgcn_raw_buffer_load_b32(rMv, 4u * (unsigned)p - 4u, 0, 0);
+                mo4[j] = 4 * (int)__builtin_amdgcn_raw_buffer_load_b32(rMv, lane4, 4u * (unsigned)a0, 0);
+                if (MOD) {
+                    di4[MOD ? j : 0] = 4 * (int)__builtin_amdgcn_raw_buffer_load_b32(rMd, 4u * (unsigned)p - 4u, 0, 0);
+                    do4[MOD ? j : 0] = 4 * (int)__builtin_amdgcn_raw_buffer_load_b32(rMd, lane4, 4u * (unsigned)a0, 0);
+                    mfi[MOD ? j : 0] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rMf, 4u * (unsigned)p - 4u, 0, 0));
+                    fwi[MOD ? j : 0] = mfi[MOD ? j : 0] * a.c_mod;
+                    fwo[MOD ? j : 0] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rMf, lane4, 4u * (unsigned)a0, 0)) * a.c_mod;
+                }
             }
             fv[j] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rFm, lane4, 4u * (unsigned)a0, 0));
             fF[j] = fF0;                                            // (the loop loaded them for its skip test)

@@ -48,6 +48,11 @@ struct CrfArgs {
     // "pending": the read is the linear path's -- and its cost is written here -- iff both scores are finite and agree
     const double *bandF, *bandB;
     float band_wbias;           // the band sweeps' weight bias: their scores get band_wbias * T back
+    // behind a band launch that built its indices from the caller's labels (crf_band.h: BandArgs::codes): no index
+    // array was written -- the reads redone here form their ids from the codes, too (null: the arrays above are inputs)
+    const int32_t *codes, *mod_cats, *cmo;
+    const float *mcw;
+    int nbase;
     float grad_scale;           // gradient multiplier (1 for the reference's operators)
     const float *grad_scale_vec;    // nullable; (N): a further per-read multiplier    // fused cat-mod loss: kernel B ran first into a compact buffer; this operator adds
     // add_scale * add_cost[n] to the cost and add_scale * (gradient multiplier) * add_grad[t][n][s]
@@ -200,18 +205,43 @@ __device__ __forceinline__ void crf_read(const CrfArgs &a, const int n, const in
 #pragma unroll
     for (int j = 0; j < R; ++j) {
         const int p = p0 + j;
-        st[j] = (p < L) ? a.stay[off + p] : S;                // S   = -LARGE sentinel slot
-        mv[j] = (p < L - 1) ? a.move[off + p] : S;
-        if (MOD) {
-            md[j] = (p < L - 1) ? a.mod[off + p] : S + 1;     // S+1 = 0.0 sentinel slot
-            fw[j] = (p < L - 1) ? a.modfact[off + p] * a.c_mod : 0.f;
+        if (a.codes != nullptr) {
+            const int cp = (p < L) ? lbl_code(a, off + p) : 0, cn = (p < L - 1) ? lbl_code(a, off + p + 1) : 0;
+            st[j] = (p < L) ? lbl_stay(a, cp) : S;
+            mv[j] = (p < L - 1) ? lbl_move(a, cp, cn) : S;
+            if (MOD) {
+                const int mq = (p < L - 1) ? lbl_mod_seq(a, cn, a.mod_cats[off + p + 1], nullptr) : 0;
+                md[j] = (p < L - 1) ? a.ncan + mq : S + 1;
+                fw[j] = (p < L - 1) ? a.mcw[mq] * a.c_mod : 0.f;
+            }
+        } else {
+            st[j] = (p < L) ? a.stay[off + p] : S;            // S   = -LARGE sentinel slot
+            mv[j] = (p < L - 1) ? a.move[off + p] : S;
+            if (MOD) {
+                md[j] = (p < L - 1) ? a.mod[off + p] : S + 1; // S+1 = 0.0 sentinel slot
+                fw[j] = (p < L - 1) ? a.modfact[off + p] * a.c_mod : 0.f;
+            }
         }
     }
     // transition INTO this thread's first position (from position p0 - 1)
     const bool has_in = (p0 >= 1) && (p0 - 1 < L - 1);
-    const int mvin0 = has_in ? a.move[off + p0 - 1] : S;
-    const int mdin0 = (MOD && has_in) ? a.mod[off + p0 - 1] : S + 1;
-    const float fwin0 = (MOD && has_in) ? a.modfact[off + p0 - 1] * a.c_mod : 0.f;
+    int mvin0 = S, mdin0 = S + 1;
+    float fwin0 = 0.f;
+    if (has_in && a.codes != nullptr) {
+        const int cb = lbl_code(a, off + p0 - 1), cp = lbl_code(a, off + p0);
+        mvin0 = lbl_move(a, cb, cp);
+        if (MOD) {
+            const int mq = lbl_mod_seq(a, cp, a.mod_cats[off + p0], nullptr);
+            mdin0 = a.ncan + mq;
+            fwin0 = a.mcw[mq] * a.c_mod;
+        }
+    } else if (has_in) {
+        mvin0 = a.move[off + p0 - 1];
+        if (MOD) {
+            mdin0 = a.mod[off + p0 - 1];
+            fwin0 = a.modfact[off + p0 - 1] * a.c_mod;
+        }
+    }
     // sentinel slots of every LDS row (tile loads never touch them)
     for (int r = tid; r < CK; r += NT) {
         tile[r * SP + S] = NEG_LARGE;
@@ -922,6 +952,9 @@ int crf_dispatch(const float *logprob, size_t ntrans, size_t nblk, size_t nbatch
     a.gate = nullptr;
     a.bandF = a.bandB = nullptr;
     a.band_wbias = 0.f;
+    a.codes = a.mod_cats = a.cmo = nullptr;
+    a.mcw = nullptr;
+    a.nbase = 0;
     a.status = status;
     char *wb = static_cast<char *>(workspace);
     // (what add_grad / add_cost hold may come from another stream: the band path waits between its sweeps
@@ -1003,6 +1036,11 @@ int crf_dispatch(const float *logprob, size_t ntrans, size_t nblk, size_t nbatch
         }
         // the reads the linear path disowned, redone in the log domain
         a.gate = b.gate;
+        a.codes = b.codes;      // (ids from the labels wherever the band launch took them: it wrote no index array)
+        a.mod_cats = b.mod_cats;
+        a.cmo = b.cmo;
+        a.mcw = b.mcw;
+        a.nbase = b.nbase;
         if (!g) {               // cost only: the vote pass compares the sweeps and writes the costs
             a.bandF = b.scoreF;
             a.bandB = b.scoreB;

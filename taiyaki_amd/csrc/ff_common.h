@@ -78,6 +78,26 @@ __device__ __forceinline__ float lse2(float a, float b) {
     return mx + fast_log2(1.0f + fast_exp2(d));
 }
 
+// ---- ids from flip-flop codes (flipflopfings.py:6-31, ctc.pyx:127-134, 282-292): the arithmetic of
+//      build_indices_kernel (crf_kernels.hip), per cell, for the launches that build their indices themselves
+//      (`A`: BandArgs / CrfArgs with codes, mod_cats, cmo, mcw, nbase, ncan)
+template <class A>
+__device__ __forceinline__ int lbl_code(const A &a, int64_t i) {
+    return min(max(a.codes[i], 0), 2 * a.nbase - 1);            // (a bad label is clamped here and REPORTED by the checker)
+}
+template <class A>
+__device__ __forceinline__ int lbl_stay(const A &a, int cp) { return cp + min(cp, a.nbase) * (2 * a.nbase); }
+template <class A>
+__device__ __forceinline__ int lbl_move(const A &a, int cp, int cn) { return cp + min(cn, a.nbase) * (2 * a.nbase); }
+// the modification column (minus ncan) of the move INTO the position whose code is `cn` and whose category is `cat`
+template <class A>
+__device__ __forceinline__ int lbl_mod_seq(const A &a, int cn, int cat, bool *bad) {
+    const int lo = a.cmo[cn % a.nbase], hi = a.cmo[cn % a.nbase + 1];
+    const int mseq = lo + cat;
+    if (bad != nullptr) *bad |= mseq < lo || mseq >= hi;
+    return min(max(mseq, lo), hi - 1);
+}
+
 // ---- DPP cross-lane primitives (GFX9 data-parallel-primitive controls) ------
 // quad_perm[1,0,3,2] = 0xB1, quad_perm[2,3,0,1] = 0x4E, row_half_mirror = 0x141,
 // row_mirror = 0x140, wave_shl:1 = 0x130, wave_shr:1 = 0x138.

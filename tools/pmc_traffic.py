@@ -47,16 +47,24 @@ def worker(specs):
     dev = torch.device("cuda:0")
     from taiyaki_amd import _lib
     _lib.set_strict(False)
+    mark_buf = torch.zeros(2, 1024, dtype=torch.float32, device=dev)
+
+    def mark():
+        """A MARKER launch (the library's tiny device copy) cuts the kernel timeline into groups: gaps in time did,
+        until a slow host under the counters left a 20 ms gap inside a group (round 5)."""
+        torch.cuda.synchronize()
+        _lib.check(_lib.lib().tk_devcopy_f32_dev(_lib.ptr(mark_buf[1]), _lib.ptr(mark_buf[0]), 1024, _lib.stream_ptr()), "marker")
+        torch.cuda.synchronize()
+
     for name, T, N, real in specs:
         ops = bench.LossOps(T, N, dev, realistic_chunk_len=real or None, cat_mod=(name == "catmod"))
         fn = ops.logz_op if name == "logz" else ops.crf
-        fn()
-        torch.cuda.synchronize()
-        time.sleep(0.05)            # a gap in the kernel timeline marks the start of the counted launches
+        mark()
+        fn()                        # warm-up group
+        mark()
         for _ in range(LAUNCHES):
             fn()
-        torch.cuda.synchronize()
-        time.sleep(0.05)
+        mark()
         del ops
     print("pmc-worker-done")
 
@@ -75,16 +83,16 @@ def read_db(db):
 
 
 def group_launches(rows, nspecs):
-    """Our kernels (namespace tk) in time order, cut at gaps > 20 ms: per spec one warm-up group and
-    one group of LAUNCHES counted launches."""
-    ours = [r for r in rows if "2tk" in r[0]]
-    groups, cur, last_end = [], [], None
-    for r in ours:
-        if last_end is not None and r[1] - last_end > 20e6:
-            groups.append(cur)
+    """Our kernels (namespace tk) in time order, cut at the worker's marker launches: per spec one warm-up group
+    and one group of LAUNCHES counted launches."""
+    groups, cur = [], []
+    for r in rows:
+        if "devcopy_f4_kernel" in r[0]:
+            if cur:
+                groups.append(cur)
             cur = []
-        cur.append(r)
-        last_end = r[2]
+        elif "2tk" in r[0]:
+            cur.append(r)
     if cur:
         groups.append(cur)
     if len(groups) != 2 * nspecs:

@@ -127,14 +127,15 @@ size_t tk_crf_flipflop_workspace_bytes(size_t ntrans, size_t nblk, size_t nbatch
 size_t tk_crf_flipflop_workspace_bytes_sharp(size_t ntrans, size_t nblk, size_t nbatch,
                                              size_t max_seqlen, int want_grad, float sharpfact);
 
-/* The same operator with the INDEX BUILD INSIDE ITS FIRST LAUNCH (round 5): instead of the arrays
- * tk_flipflop_build_indices_dev made, hand over what that call takes -- the flip-flop codes (and, cat-mod, the
- * modification categories and tables) in a tk_seq_labels -- and the index arrays as SCRATCH OUTPUTS of the same
- * sizes (seqoff nbatch + 1; stayidx / moveidx / modidx / modfact total_len entries).  The sweep workgroups form
- * their ids from the codes themselves and leave the arrays for the launches behind; labels are range-checked as
- * there (TK_STATUS_BAD_LABEL).  Saves a launch per call: ~5 us of the op's ~99 at the train step's shape.  Calls the
- * linear path does not take (sharpening beyond 3.5, workspace-bound batches) build the indices with the stand-alone
- * kernel first: same results either way.  Cat-mod: modfact is filled from mod_cat_weights BY COLUMN, so the
+/* The same operator WITHOUT the index-build launch (round 5): instead of the arrays tk_flipflop_build_indices_dev
+ * made, hand over what that call takes -- the flip-flop codes (and, cat-mod, the modification categories and
+ * tables) in a tk_seq_labels.  Every launch of the linear path then forms its ids from the codes itself (the
+ * arithmetic of the build kernel, per cell; the codes are read-only inputs that stay in the L2s from call to call);
+ * labels are range-checked as there (TK_STATUS_BAD_LABEL, offending codes clamped).  seqoff (nbatch + 1) is
+ * written; stayidx / moveidx / modidx / modfact (total_len entries each) are SCRATCH: written only by calls the
+ * linear path does not take (sharpening beyond 3.5, workspace-bound batches), which run the stand-alone build
+ * kernel first -- same results either way.  Saves a launch per call: -1.5 .. -4 us of the op's ~100 at the train
+ * step's shape (profiles/r5_index_build_ab.txt).  Cat-mod: a move's factor is mod_cat_weights BY COLUMN, so the
  * per-column form of the kernels (mod_col_weights above) applies. */
 typedef struct tk_seq_labels {
     const int32_t *seqs;                /* (total_len) flip-flop codes 0 .. 2 nbase - 1, reads concatenated (device) */

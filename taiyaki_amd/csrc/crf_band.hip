@@ -85,6 +85,9 @@ constexpr int BK_MAX = 12;          // (the longest; sizes nothing -- every arra
 static_assert(BK_MAX % 4 == 0, "blocks move through the ring as float4");
 constexpr int KLIP = 6;             // frame slope along the flow (bits per cell)
 constexpr int ROW_PITCH = 48;       // shared-rows feed (band_rowmaker): floats per row image in LDS (S <= 46)
+#ifndef TK_ROWS_PAIR
+#define TK_ROWS_PAIR 1
+#endif
 constexpr int BAND_MAXW = 16;       // waves per workgroup
 constexpr int POST_WAVES = 2;       // waves (= time blocks) per gradient-pass workgroup (8: +1.5 % in the step, +4 % at row K: coarser tail)
 constexpr int KEY_DEAD = 63;        // sort key of padding instances
@@ -114,15 +117,36 @@ __device__ __forceinline__ Win band_window(int w, int PW, int L, int T) {
     return {tlo / BK, thi / BK};
 }
 
+#ifndef TK_BARRIER_BUILTIN
+#define TK_BARRIER_BUILTIN 1
+#endif
 __device__ __forceinline__ void band_barrier() {
     // LDS traffic only: the checkpoint stores stay in flight across the barrier
+#if TK_BARRIER_BUILTIN
+    // (as builtins between two compiler fences, not as one asm string: the compiler's wait-count bookkeeping then KNOWS
+    // that no LDS operation is pending behind the barrier -- with the asm it assumed the ring writes still were, and
+    // the first phase of every loop trip waited for the ring reads with lgkmcnt(0) BEFORE it issued its gathers: two
+    // LDS round trips one after the other at the head of the phase)
+    asm volatile("" ::: "memory");
+    __builtin_amdgcn_s_waitcnt(0xc07f);         // lgkmcnt(0), vmcnt / expcnt untouched
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+#else
     asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+#endif
 }
 
 // ... and the same with a register pinned in front of it: what computes `v` is issued BEFORE the barrier
 // (hipcc is free to sink register-only work past an asm with a memory clobber, and did)
 __device__ __forceinline__ void band_barrier_after(int &v) {
+#if TK_BARRIER_BUILTIN
+    asm volatile("" : "+v"(v) : : "memory");
+    __builtin_amdgcn_s_waitcnt(0xc07f);
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+#else
     asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" : "+v"(v) : : "memory");
+#endif
 }
 
 __device__ __forceinline__ float bperm(int byteaddr, float v) {
@@ -522,6 +546,28 @@ __device__ __forceinline__ void band_sweep(const BandArgs &a, int n, int L, int6
                 // workgroup; a weight is one LDS read at (row, transition id) -- the value ds_bpermute would
                 // have fetched from this wave's own copy of the row, bit for bit
                 const float *rp = reinterpret_cast<const float *>(Wt) + (size_t)rslot * (BK * ROW_PITCH);
+#if TK_ROWS_PAIR
+                // (the image holds the rows in PAIRS, [pair][id][2]: both rows of a pair at one id are one ds_read_b64 --
+                // 2 LDS cycles per wave-instruction where ds_read2_b32 takes 4; same banks per lane group, same values)
+                typedef float f2a __attribute__((ext_vector_type(2)));
+#pragma unroll
+                for (int g = 0; g < GH; g += 2) {
+                    const int i0 = FWD ? ii0 + g : BK - 1 - (ii0 + g);     // the row of step g; the pair's other row is step g + 1's
+                    const int pr = i0 >> 1;
+                    const int ga = FWD ? g : g + 1, gb = FWD ? g + 1 : g;   // .x = the even row, .y = the odd row
+                    const f2a *pp = reinterpret_cast<const f2a *>(rp + pr * (2 * ROW_PITCH));
+#pragma unroll
+                    for (int jj = 0; jj < R; ++jj) {
+                        const f2a s2 = pp[st4[jj] >> 2];
+                        es[ga][jj] = s2.x;
+                        es[gb][jj] = s2.y;
+                        f2a m2 = pp[mv4[jj] >> 2];
+                        if constexpr (MOD) m2 = m2 * pp[md4[MOD ? jj : 0] >> 2];
+                        em[ga][jj] = m2.x;
+                        em[gb][jj] = m2.y;
+                    }
+                }
+#else
 #pragma unroll
                 for (int g = 0; g < GH; ++g) {
                     const int i = FWD ? ii0 + g : BK - 1 - (ii0 + g);
@@ -534,6 +580,7 @@ __device__ __forceinline__ void band_sweep(const BandArgs &a, int n, int L, int6
                             em[g][jj] = rp[i * ROW_PITCH + (mv4[jj] >> 2)];
                     }
                 }
+#endif
                 return;
             }
 #pragma unroll
@@ -785,11 +832,21 @@ __device__ __forceinline__ void band_rowmaker(const BandArgs &a, int n, float *E
     auto block_of = [&](int ph) { return FWD ? ph : NB - 1 - ph; };
     auto emit = [&](int j, const float (&row)[BK]) {
         if (j < 0 || j >= NB) return;                           // (wave-uniform)
+#if TK_ROWS_PAIR
+        typedef float f2a __attribute__((ext_vector_type(2)));
+        f2a *dst = reinterpret_cast<f2a *>(Er + (size_t)(j % (W + 1)) * (BK * ROW_PITCH)) + lane;
+        if (lane < ROW_PITCH) {
+#pragma unroll
+            for (int i = 0; i < BK; i += 2)
+                dst[(i >> 1) * ROW_PITCH] = f2a{fast_exp2(fmaf(row[i], cw_lane, -wb_lane)), fast_exp2(fmaf(row[i + 1], cw_lane, -wb_lane))};
+        }
+#else
         float *dst = Er + (size_t)(j % (W + 1)) * (BK * ROW_PITCH) + lane;
         if (lane < ROW_PITCH) {
 #pragma unroll
             for (int i = 0; i < BK; ++i) dst[i * ROW_PITCH] = fast_exp2(fmaf(row[i], cw_lane, -wb_lane));
         }
+#endif
     };
     float r0[BK], r1[BK];
     load_block(block_of(0), r0);

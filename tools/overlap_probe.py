@@ -4,7 +4,7 @@ same CUs?  (Feasibility of fusing the posterior pass into the sweep launch.)  Tw
 hardware queues: stream B loops posterior-only launches on a finished lattice, stream A times
 sweep-only launches with HIP events.
 
-    python tools/overlap_probe.py        # (do not set GPU_MAX_HW_QUEUES=1)
+    GPU_MAX_HW_QUEUES=4 python tools/overlap_probe.py    # (bench.py's import pins it to 1: one queue serialises the two streams)
 """
 import ctypes
 import os

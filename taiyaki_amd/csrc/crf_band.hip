@@ -88,6 +88,9 @@ constexpr int ROW_PITCH = 48;       // shared-rows feed (band_rowmaker): floats 
 #ifndef TK_ROWS_PAIR
 #define TK_ROWS_PAIR 1
 #endif
+#ifndef TK_ROWS_VOL
+#define TK_ROWS_VOL 0
+#endif
 constexpr int BAND_MAXW = 16;       // waves per workgroup
 constexpr int POST_WAVES = 2;       // waves (= time blocks) per gradient-pass workgroup (8: +1.5 % in the step, +4 % at row K: coarser tail)
 constexpr int KEY_DEAD = 63;        // sort key of padding instances
@@ -370,7 +373,7 @@ __device__ __forceinline__ void band_offset_of(const BandArgs &a, int n, long lo
     *len_out = (int)own;
 }
 
-template <int R, bool MOD, bool FWD, bool GRAD, bool ROWS, bool CW, int BK>
+template <int R, bool MOD, bool FWD, bool GRAD, bool ROWS, bool CW, int BK, bool PRE4 = false>
 __device__ __forceinline__ void band_sweep(const BandArgs &a, int n, int L, int64_t off, float *E, int *Ef, const float *Ezero,
                                            const f4 *Wt) {
     constexpr int PW = R * WAVE;
@@ -555,7 +558,11 @@ __device__ __forceinline__ void band_sweep(const BandArgs &a, int n, int L, int6
                     const int i0 = FWD ? ii0 + g : BK - 1 - (ii0 + g);     // the row of step g; the pair's other row is step g + 1's
                     const int pr = i0 >> 1;
                     const int ga = FWD ? g : g + 1, gb = FWD ? g + 1 : g;   // .x = the even row, .y = the odd row
+#if TK_ROWS_VOL
+                    const volatile f2a *pp = reinterpret_cast<const volatile f2a *>(rp + pr * (2 * ROW_PITCH));
+#else
                     const f2a *pp = reinterpret_cast<const f2a *>(rp + pr * (2 * ROW_PITCH));
+#endif
 #pragma unroll
                     for (int jj = 0; jj < R; ++jj) {
                         const f2a s2 = pp[st4[jj] >> 2];
@@ -607,8 +614,8 @@ __device__ __forceinline__ void band_sweep(const BandArgs &a, int n, int L, int6
             constexpr bool FULLBLK = decltype(full_tag)::value;
             // everything that does not depend on the cells first: move weights in the cells' frames,
             // the boundary lane's inflow
-            // (R = 4 has no registers to spare for that: 16 waves leave 128 per lane)
-            constexpr bool PRE = R < 4;
+            // (R = 4 has the registers for that in launches of up to 12 waves -- 170 per lane -- and not at 16 waves: PRE4)
+            constexpr bool PRE = R < 4 || PRE4;
             float mt[PRE ? GH : 1][R], u[PRE ? GH : 1];
             if constexpr (PRE && (!MOD || CW)) {
                 // (two steps per instruction: v_pk_mul_f32 -- -1 % for the plain CRF, -2 % for cat-mod with
@@ -886,6 +893,12 @@ __global__ __launch_bounds__(WCAP *WAVE) void crf_band_sweep_kernel(BandArgs a) 
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int N = a.N, S = a.S, W = a.W;
     const bool want_grad = a.grad != nullptr;
+#ifndef TK_PRE4
+#define TK_PRE4 1
+#endif
+    // four cells per lane: the step weights' frame factors two steps per v_pk_mul_f32 ahead of the steps (what the
+    // narrower forms do) where the launch bound leaves registers for them
+    constexpr bool PRE4 = TK_PRE4 && R == 4 && WCAP <= 12;
     const int slot3 = blockIdx.x / N;
     // dispatch order (round 5): the two sweeps first -- 2 N workgroups onto the chip's CUs, one each at the train step's
     // shape --, the rank workgroups behind them (short; they share a CU with a sweep for a few microseconds).  Rank
@@ -997,13 +1010,13 @@ __global__ __launch_bounds__(WCAP *WAVE) void crf_band_sweep_kernel(BandArgs a) 
         }
     }
     if (!want_grad && role == 0)
-        band_sweep<R, MOD, true, false, ROWS, CW, BK>(a, n, L, off, E, Ef, Ezero, Wt);
+        band_sweep<R, MOD, true, false, ROWS, CW, BK, PRE4>(a, n, L, off, E, Ef, Ezero, Wt);
     else if (!want_grad)
-        band_sweep<R, MOD, false, false, ROWS, CW, BK>(a, n, L, off, E, Ef, Ezero, Wt);
+        band_sweep<R, MOD, false, false, ROWS, CW, BK, PRE4>(a, n, L, off, E, Ef, Ezero, Wt);
     else if (role == 0)
-        band_sweep<R, MOD, true, true, ROWS, CW, BK>(a, n, L, off, E, Ef, Ezero, Wt);
+        band_sweep<R, MOD, true, true, ROWS, CW, BK, PRE4>(a, n, L, off, E, Ef, Ezero, Wt);
     else
-        band_sweep<R, MOD, false, true, ROWS, CW, BK>(a, n, L, off, E, Ef, Ezero, Wt);
+        band_sweep<R, MOD, false, true, ROWS, CW, BK, PRE4>(a, n, L, off, E, Ef, Ezero, Wt);
 }
 
 // Inclusive wave prefix sum in six fused DPP adds (the row_bcast steps write only the rows they

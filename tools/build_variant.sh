@@ -9,7 +9,8 @@ OUT=../../tools/lab
 FILES=${VARIANT_FILES:-crf_band.hip}
 OBJS=""
 for f in $FILES; do
-  /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wall -Wno-unused-function -DTK_LAB "$@" -c -o $OUT/${NAME}_${f%.hip}.o $f
+  EXTRA=""; [ "$f" = crf_band.hip ] && [ -z "$VARIANT_SLP" ] && EXTRA="-fno-slp-vectorize"     # (the Makefile's per-file flag)
+  /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wall -Wno-unused-function -DTK_LAB $EXTRA "$@" -c -o $OUT/${NAME}_${f%.hip}.o $f
   OBJS="$OBJS $OUT/${NAME}_${f%.hip}.o"
 done
 REST=""

@@ -670,7 +670,8 @@ def kernel_records(out, args, cfg, dev, world, T, nbatch, chunk_len, cat_mod, S)
                               "T=%d N=%d S=%d, max L %d (%s)" % (ops.T, ops.N, ops.S, ops.maxlen, label),
                               3.0 * ops.T * ops.N * ops.S * 4, mean_s, min_s, reps, tr, src)
         # the bound that applies: instruction issue (the HBM fraction above is reported because SURVEY 8d asks for it)
-        R = 1 if ops.maxlen <= 960 else (2 if ops.maxlen <= 1920 else 4)      # (crf_band_pick_R: 15 chunk waves + the row maker)
+        # (crf_band_pick_R: 15 chunk waves + the row maker; the plain CRF takes two cells per lane from 513 bases on)
+        R = 1 if ops.maxlen <= (960 if ops.mod is not None else 512) else (2 if ops.maxlen <= 1920 else 4)
         W = -(-ops.maxlen // (64 * R))
         BK = 8 if ops.mod is not None else 12
         fl = issue_floor("catmod" if ops.mod is not None else "crf", ops.T, ops.N, realistic, W, BK)

@@ -1608,8 +1608,14 @@ __global__ __launch_bounds__(POST_WAVES *WAVE) __attribute__((amdgpu_waves_per_e
 // host side
 // ---------------------------------------------------------------------------
 // Cells per lane: the smallest R whose chunks fit the 16 waves of a workgroup.
-int crf_band_pick_R(size_t max_seqlen) {
+int crf_band_pick_R(size_t max_seqlen, bool mod) {
     int R = 1;
+    // The plain CRF takes two cells per lane from 513 bases on (nine chunk waves and a row maker at one cell per lane
+    // are ten waves per workgroup: every wave shares its SIMD, and no second workgroup fits a CU beside it -- batches of
+    // more than 128 reads run their 2 N sweeps in two rounds.  Measured, round 5, profiles/r5_cells_per_lane.txt: reads up
+    // to 533 bases at T 800: N 128 102.2 -> 100.4 us, N 192 156.5 -> 125.2, N 256 179.6 -> 144.7; reads up to 399 bases
+    // (seven chunk waves) and every cat-mod shape tried are faster at one cell per lane.)
+    if (!mod && max_seqlen > (size_t)8 * WAVE) R = 2;
     if (const char *e = TK_LAB_ENV("TK_CRF_BAND_R")) {
         R = atoi(e);
         if (R != 1 && R != 2 && R != 4) R = 1;
@@ -1648,7 +1654,7 @@ BandLayout crf_band_layout(size_t ntrans, size_t nblk, size_t nbatch, size_t max
     BandLayout l;
     const size_t BK = (size_t)(bk > 0 ? bk : 8);
     l.BK = (int)BK;
-    l.R = crf_band_pick_R(max_seqlen);
+    l.R = crf_band_pick_R(max_seqlen, mod);
     const size_t PW = (size_t)l.R * WAVE;
     l.W = (int)((max_seqlen + PW - 1) / PW);
     if (l.W < 1) l.W = 1;

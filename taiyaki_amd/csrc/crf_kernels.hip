@@ -817,11 +817,18 @@ static size_t crf_lattice_cap_bytes() {
     return cap[dev];
 }
 // `bk`: the block length the linear path would use for this call (crf_band_pick_block; 0 = it does not take it)
+// the band layout's size for workspace queries: the plain CRF and cat-mod may pick different cells per lane
+// (crf_band_pick_R), hence different padded read lengths -- the bound covers both
+static size_t crf_band_total_bound(size_t ntrans, size_t nblk, size_t nbatch, size_t max_seqlen, bool want_grad, int bk) {
+    const size_t a = crf_band_layout(ntrans, nblk, nbatch, max_seqlen, true, want_grad, bk).total;
+    const size_t b = crf_band_layout(ntrans, nblk, nbatch, max_seqlen, false, want_grad, bk).total;
+    return a > b ? a : b;
+}
 static CrfMode crf_pick_mode(size_t ntrans, size_t nblk, size_t nbatch, size_t max_seqlen, bool want_grad, int bk) {
     const char *e = TK_LAB_ENV("TK_CRF_MODE");
     const bool force_ckpt = e && e[0] == 'c';
     if (!force_ckpt && bk > 0 && crf_band_fits(max_seqlen) &&
-        crf_band_layout(ntrans, nblk, nbatch, max_seqlen, true, want_grad, bk).total <= crf_lattice_cap_bytes())
+        crf_band_total_bound(ntrans, nblk, nbatch, max_seqlen, want_grad, bk) <= crf_lattice_cap_bytes())
         return CRF_BAND;
     return CRF_CKPT;
 }
@@ -852,7 +859,7 @@ size_t crf_workspace_bytes_sharp(size_t ntrans, size_t nblk, size_t nbatch, size
     // sizing every workspace for that case would be 8.0 instead of 4.7 GB at T = 4000 / N = 256)
     if (crf_pick_mode(ntrans, nblk, nbatch, max_seqlen, want_grad != 0, bk) == CRF_BAND)
         return crf_ckpt_bytes(nblk, crf_redo_slots(nbatch), sh, want_grad != 0) +
-               crf_band_layout(ntrans, nblk, nbatch, max_seqlen, true, want_grad != 0, bk).total;
+               crf_band_total_bound(ntrans, nblk, nbatch, max_seqlen, want_grad != 0, bk);
     return crf_ckpt_bytes(nblk, nbatch, sh, want_grad != 0);
 }
 

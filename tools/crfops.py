@@ -24,7 +24,7 @@ def main():
     ap.add_argument("--cfg5", action="store_true")
     ap.add_argument("--reps", type=int, default=20)
     ap.add_argument("--separate", action="store_true", help="round 4's form: tk_flipflop_build_indices_dev as a launch of its own")
-    ap.add_argument("--shapes", default="", help="extra shapes name:T:N:chunk_len[:spb], comma separated (chunk_len 0 = SPEED_TEST lengths)")
+    ap.add_argument("--shapes", default="", help="extra shapes name:T:N:chunk_len[:spb[:cm]], comma separated (cm: the cat-mod form; (chunk_len 0 = SPEED_TEST lengths)")
     args = ap.parse_args()
     dev = torch.device("cuda:0")
     _lib.lib()
@@ -38,7 +38,8 @@ def main():
         shapes.append(("rowK", 4000, 256, None, 9.0, False))
     for item in [x for x in args.shapes.split(",") if x]:
         f = item.split(":")
-        shapes.append((f[0], int(f[1]), int(f[2]), int(f[3]) or None, float(f[4]) if len(f) > 4 else 9.0, False))
+        shapes.append((f[0], int(f[1]), int(f[2]), int(f[3]) or None, float(f[4]) if len(f) > 4 and f[4] else 9.0,
+                       len(f) > 5 and f[5] == "cm"))
     out = []
     for name, T, N, cl, spb, cm in shapes:
         ops = bench.LossOps(T, N, dev, realistic_chunk_len=cl, spb=spb, cat_mod=cm)

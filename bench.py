@@ -673,7 +673,7 @@ def kernel_records(out, args, cfg, dev, world, T, nbatch, chunk_len, cat_mod, S)
         # (crf_band_pick_R: 15 chunk waves + the row maker; the plain CRF takes two cells per lane from 513 bases on)
         R = 1 if ops.maxlen <= (960 if ops.mod is not None else 512) else (2 if ops.maxlen <= 1920 else 4)
         W = -(-ops.maxlen // (64 * R))
-        BK = 8 if ops.mod is not None else 12
+        BK = 12 if (ops.mod is None or ops.maxlen > 704) else 8         # (crf_band_pick_block)
         fl = issue_floor("catmod" if ops.mod is not None else "crf", ops.T, ops.N, realistic, W, BK)
         if fl is not None:
             rec["issue_floor_us"] = fl["issue_floor_us"]

@@ -86,7 +86,7 @@ struct BandLayout {
 };
 
 bool crf_band_fits(size_t max_seqlen);
-BandBlock crf_band_pick_block(float sharp, bool mod, size_t max_seqlen);
+BandBlock crf_band_pick_block(float sharp, bool mod, size_t max_seqlen, bool colw = false);
 BandLayout crf_band_layout(size_t ntrans, size_t nblk, size_t nbatch, size_t max_seqlen, bool mod,
                            bool want_grad, int bk);
 int crf_band_dispatch(const BandArgs &a, int R, bool mod, int bk, hipStream_t stream);

@@ -73,8 +73,9 @@ namespace tk {
 // section 4, LABNOTES.md round 4); what limits the length is the
 // mantissas' growth between two frame updates, (1 + 2^KLIP) x the largest step weight per step inside
 // fp32's exponent range.  band_pick_block() chooses:
-//    BK = 12, weights biased by 2^-3   plain CRF, |sharp x score| <= 5.18 (the network's 5 tanh, unsharpened)
-//    BK = 8,  no bias                  round 3's arithmetic: cat-mod; plain CRF sharpened up to 1.36
+//    BK = 12, weights biased by 2^-3   plain CRF, |sharp x score| <= 5.18 (the network's 5 tanh, unsharpened); cat-mod with
+//                                      per-column factors from 705 bases on (round 5)
+//    BK = 8,  no bias                  round 3's arithmetic: cat-mod on shorter reads; plain CRF sharpened up to 1.36
 //    BK = 8,  weights biased by 2^-3   sharpening factors up to 1.76
 //    BK = 4,  no bias                  sharpening factors up to 3.5
 // The BIAS (BandArgs::wbias): every step weight carries a factor 2^-wbias, folded into the argument of its
@@ -1083,7 +1084,8 @@ __global__ __launch_bounds__(POST_WAVES *WAVE) __attribute__((amdgpu_waves_per_e
     constexpr int PW = R * WAVE;
     constexpr int KINDS = MOD ? 3 : 2;
     constexpr int EPL = KINDS * R;
-    constexpr int RG = BK;                                      // rows evaluated together
+    constexpr int RG = (MOD && BK > 8) ? 4 : BK;                // rows evaluated together (cat-mod at 12 steps: three instances per
+                                                                // cell and row -- groups of four keep it under the register cap)
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & (WAVE - 1);
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);      // wave-uniform: SGPR
@@ -1631,18 +1633,23 @@ bool crf_band_fits(size_t max_seqlen) { return max_seqlen <= (size_t)4 * WAVE * 
 // Block length and weight bias for a call (see BK_MAX): `sharp` = the sharpening factor of the canonical
 // columns.  bk = 0: the linear path does not take this call (the log-domain kernel does every read).
 // TK_CRF_BK = 4 | 8 | 12 forces a block length, TK_CRF_WBIAS a bias (lab: tools/crf_gate_probe.py).
-BandBlock crf_band_pick_block(float sharp, bool mod, size_t max_seqlen) {
+BandBlock crf_band_pick_block(float sharp, bool mod, size_t max_seqlen, bool colw) {
     BandBlock b{8, 0.f};
     const float x = sharp > 0.f ? sharp : 1.f;
-    (void)max_seqlen;
     if (!mod && x <= 1.03f) b = {12, 3.f};
+    // cat-mod with per-column factors (round 5): the same 12-step blocks and bias from 705 bases on -- measured,
+    // profiles/r5_catmod_bk12.txt: reads up to 799 bases 215 -> 199 us, T 1600 (two cells per lane) 255 -> 230, T 4000 / N 256
+    // 1997 -> 1815, and fewer reads disowned at long T; reads up to 533 / 666 bases are faster at 8 (128.6 / 162.2 against
+    // 132.4 / 164.8 us; N 256: two ten-wave workgroups no longer share a CU at 12 steps' registers).  The general
+    // per-position form has no 12-step instantiation.
+    else if (mod && colw && x <= 1.03f && max_seqlen > (size_t)11 * WAVE) b = {12, 3.f};
     else if (x <= 1.36f) b = {8, 0.f};
     else if (x <= 1.76f) b = {8, 3.f};
     else if (x <= 3.5f) b = {4, 0.f};
     else b = {0, 0.f};
     if (const char *e = TK_LAB_ENV("TK_CRF_BK")) {
         const int v = atoi(e);
-        if (v == 4 || v == 8 || (v == 12 && !mod)) b.bk = v;
+        if (v == 4 || v == 8 || (v == 12 && (!mod || colw))) b.bk = v;
     }
     if (const char *e = TK_LAB_ENV("TK_CRF_WBIAS")) b.wbias = (float)atof(e);
     return b;
@@ -1751,13 +1758,14 @@ static int band_launch(const BandArgs &a, hipStream_t stream) {
     return hipGetLastError() == hipSuccess ? 0 : 4;
 }
 
-// block lengths per form: the plain CRF has all three, cat-mod (whose frames' slope already follows its
-// weakest moves) stays at 8 and takes 4 for sharpened calls
+// block lengths per form: the plain CRF and cat-mod with per-column factors have all three (crf_band_pick_block says which
+// a call takes), the general per-position cat-mod form 8 and 4
 template <int R, bool MOD, bool CW>
 static int band_launch_bk(const BandArgs &a, int bk, hipStream_t stream) {
     if (bk == 4) return band_launch<R, MOD, CW, 4>(a, stream);
     if (bk == 8) return band_launch<R, MOD, CW, 8>(a, stream);
-    if constexpr (!MOD) {
+    // (12-step blocks: the plain CRF and cat-mod with per-column factors; the general per-position cat-mod form stays at 8)
+    if constexpr (!MOD || CW) {
         if (bk == 12) return band_launch<R, MOD, CW, 12>(a, stream);
     }
     return 2;

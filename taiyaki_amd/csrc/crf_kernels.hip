@@ -917,7 +917,7 @@ int crf_dispatch(const float *logprob, size_t ntrans, size_t nblk, size_t nbatch
     // the linear path's block length for this sharpening factor; when the workspace the caller brought is
     // too small for it (sized without the factor: tk_crf_flipflop_workspace_bytes) but large enough for the
     // log-domain kernel on every read, that kernel does the call
-    BandBlock blk = crf_band_pick_block(sharp_can, mod, max_seqlen);
+    BandBlock blk = crf_band_pick_block(sharp_can, mod, max_seqlen, mod && mod_col_weights != nullptr);
     bool band = crf_pick_mode(ntrans, nblk, nbatch, max_seqlen, grad != nullptr, blk.bk) == CRF_BAND;
     if (band && crf_ckpt_bytes(nblk, crf_redo_slots(nbatch), sh, grad != nullptr) +
                         crf_band_layout(ntrans, nblk, nbatch, max_seqlen, mod, grad != nullptr, blk.bk).total > workspace_bytes)

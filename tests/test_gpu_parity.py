@@ -912,8 +912,6 @@ def test_crf_block_lengths_and_weight_bias_agree_with_the_oracle(oracle_mod, gpu
     of one row, reads of 1 / 64 / 65 / T / T + 1 bases, two cells per lane.  The bias must come back out
     of the scores exactly (costs to 1e-5) and leave the posteriors alone."""
     from taiyaki_amd import synth
-    if bk == "12" and mods is not None:
-        pytest.skip("cat-mod has no 12-step form")
     labenv.setenv("TK_CRF_MODE", "band")
     labenv.setenv("TK_CRF_BK", bk)
     labenv.setenv("TK_CRF_WBIAS", wbias)

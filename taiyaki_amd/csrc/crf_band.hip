@@ -86,8 +86,10 @@ constexpr int BK_MAX = 12;          // (the longest; sizes nothing -- every arra
 static_assert(BK_MAX % 4 == 0, "blocks move through the ring as float4");
 constexpr int KLIP = 6;             // frame slope along the flow (bits per cell)
 constexpr int ROW_PITCH = 48;       // shared-rows feed (band_rowmaker): floats per row image in LDS (S <= 46)
+// layout of a block's exponentiated rows in the shared-rows image (lab builds: 0 = [row][id], round 4; 1 = [row pair][id][2];
+// 2 = [id][row], the default: four rows at one id are one ds_read_b128 -- profiles/r5_rows_pair_ab.txt, r5_rows_quad_ab.txt)
 #ifndef TK_ROWS_PAIR
-#define TK_ROWS_PAIR 1
+#define TK_ROWS_PAIR 2
 #endif
 #ifndef TK_ROWS_VOL
 #define TK_ROWS_VOL 0
@@ -550,7 +552,26 @@ __device__ __forceinline__ void band_sweep(const BandArgs &a, int n, int L, int6
                 // workgroup; a weight is one LDS read at (row, transition id) -- the value ds_bpermute would
                 // have fetched from this wave's own copy of the row, bit for bit
                 const float *rp = reinterpret_cast<const float *>(Wt) + (size_t)rslot * (BK * ROW_PITCH);
-#if TK_ROWS_PAIR
+#if TK_ROWS_PAIR == 2
+                // (the image holds a block's rows PER ID, [id][row]: four rows at one id are one ds_read_b128 -- 4 LDS cycles
+                // per wave-instruction for 16 bytes per lane, the rate of the MI355X guide's table; the compiler had merged
+                // the pair form's two ds_read_b64 into ds_read2_b64 at 8 cycles)
+#pragma unroll
+                for (int g = 0; g < GH; g += 4) {
+                    const int ib = FWD ? ii0 + g : BK - 4 - (ii0 + g);      // the four rows of steps g .. g + 3 (backward: descending)
+#pragma unroll
+                    for (int jj = 0; jj < R; ++jj) {
+                        const f4 s4 = *reinterpret_cast<const f4 *>(rp + (st4[jj] >> 2) * BK + ib);
+                        f4 m4 = *reinterpret_cast<const f4 *>(rp + (mv4[jj] >> 2) * BK + ib);
+                        if constexpr (MOD) m4 = m4 * *reinterpret_cast<const f4 *>(rp + (md4[MOD ? jj : 0] >> 2) * BK + ib);
+#pragma unroll
+                        for (int k = 0; k < 4; ++k) {
+                            es[g + k][jj] = s4[FWD ? k : 3 - k];
+                            em[g + k][jj] = m4[FWD ? k : 3 - k];
+                        }
+                    }
+                }
+#elif TK_ROWS_PAIR
                 // (the image holds the rows in PAIRS, [pair][id][2]: both rows of a pair at one id are one ds_read_b64 --
                 // 2 LDS cycles per wave-instruction where ds_read2_b32 takes 4; same banks per lane group, same values)
                 typedef float f2a __attribute__((ext_vector_type(2)));
@@ -840,7 +861,15 @@ __device__ __forceinline__ void band_rowmaker(const BandArgs &a, int n, float *E
     auto block_of = [&](int ph) { return FWD ? ph : NB - 1 - ph; };
     auto emit = [&](int j, const float (&row)[BK]) {
         if (j < 0 || j >= NB) return;                           // (wave-uniform)
-#if TK_ROWS_PAIR
+#if TK_ROWS_PAIR == 2
+        f4 *dst = reinterpret_cast<f4 *>(Er + (size_t)(j % (W + 1)) * (BK * ROW_PITCH) + (size_t)lane * BK);
+        if (lane < ROW_PITCH) {
+#pragma unroll
+            for (int i = 0; i < BK; i += 4)
+                dst[i >> 2] = f4{fast_exp2(fmaf(row[i], cw_lane, -wb_lane)), fast_exp2(fmaf(row[i + 1], cw_lane, -wb_lane)),
+                                 fast_exp2(fmaf(row[i + 2], cw_lane, -wb_lane)), fast_exp2(fmaf(row[i + 3], cw_lane, -wb_lane))};
+        }
+#elif TK_ROWS_PAIR
         typedef float f2a __attribute__((ext_vector_type(2)));
         f2a *dst = reinterpret_cast<f2a *>(Er + (size_t)(j % (W + 1)) * (BK * ROW_PITCH)) + lane;
         if (lane < ROW_PITCH) {

@@ -261,6 +261,9 @@ __global__ __launch_bounds__(WAVE) void viterbi_kernel(const float *__restrict__
 #define TK_VIT_GROUP 64
 #endif
 constexpr int VIT_TILE = TK_VIT_TILE;       // steps per hand-over (one s_barrier)
+#ifndef TK_VIT_RING2
+#define TK_VIT_RING2 1
+#endif
 constexpr int VIT_GROUP = TK_VIT_GROUP;     // steps of straight-line code = score rows in flight = the LDS ring
 constexpr int VIT_RING = VIT_GROUP / VIT_TILE;  // tiles in the ring: at least the one being written and the one being read
 
@@ -318,7 +321,7 @@ __global__ __launch_bounds__(3 * WAVE) void viterbi3_kernel(const float *__restr
     using F = FF<NB>;
     static_assert(F::NS <= VIT_GRP, "one lane group per state");
     static_assert(VIT_GROUP == VIT_RING * VIT_TILE && VIT_RING >= 2 && VIT_TILE % 2 == 0, "the ring holds one group; tiles start with an even step");
-    __shared__ float ring[VIT_RING * VIT_TILE * 2 * WAVE];      // per step: the maxima (the new state vector) and the candidates
+    __shared__ __attribute__((aligned(16))) float ring[VIT_RING * VIT_TILE * 2 * WAVE];      // per step: the maxima (the new state vector) and the candidates
     const int lane = lane_id();
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int grp = lane >> 3, sub = lane & 7;          // even steps: (to, from) = (grp, sub); odd steps: (sub, grp)
@@ -344,6 +347,9 @@ __global__ __launch_bounds__(3 * WAVE) void viterbi3_kernel(const float *__restr
                                                  0x7fffffff, RSRC3);
     };
     float *const ring_lane = ring + lane;
+    f2 *const ring2_lane = reinterpret_cast<f2 *>(ring) + lane;
+    (void)ring_lane;
+    (void)ring2_lane;
     float m = VIT_NEG_INF;
 
     if (wave == 0) {
@@ -369,8 +375,14 @@ __global__ __launch_bounds__(3 * WAVE) void viterbi3_kernel(const float *__restr
                     m = odd ? vit_cross_max(cand) : vit_grp_max(cand);
                     f = m;                                          // the next step's lane holds what it needs
                     // ---- off the chain: the vector for the trace waves, the row 64 steps ahead, the next mask
+#if TK_VIT_RING2
+                    // (the ring is exactly one group: slot = step inside the group; a step's maximum and candidate are ONE
+                    // 8-byte store per lane -- one issue slot of the chain wave instead of two, one ds_read_b64 for the trace waves)
+                    ring2_lane[k * WAVE] = f2{m, cand};
+#else
                     ring_lane[(2 * k) * WAVE] = m;                  // (the ring is exactly one group: slot = step inside the group)
                     ring_lane[(2 * k + 1) * WAVE] = cand;
+#endif
                     sc[k] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rnext, odd ? ld4B : ld4A, rs4 * (unsigned)min(k, lastn), 0));
                     snext = (odd ? validA : validB) ? sc[(k + 1) % VIT_GROUP] : VIT_NEG_INF;
                 }
@@ -410,8 +422,14 @@ __global__ __launch_bounds__(3 * WAVE) void viterbi3_kernel(const float *__restr
 #pragma unroll
                     for (int q = 0; q < TH; ++q) {
                         const int k = 2 * q + par;                  // step inside the tile
+#if TK_VIT_RING2
+                        const f2 mc = ring2_lane[(slot0 + k) * WAVE];
+                        mm[q] = mc.x;
+                        cd[q] = mc.y;
+#else
                         mm[q] = ring_lane[(2 * (slot0 + k)) * WAVE];
                         cd[q] = ring_lane[(2 * (slot0 + k) + 1) * WAVE];
+#endif
                     }
 #pragma unroll
                     for (int q = 0; q < TH; ++q) {

@@ -59,7 +59,11 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--shapes", default="cfg2r,rowK")
     ap.add_argument("--save", default=None)
+    ap.add_argument("--passes", default=None, help="other counter passes, ';' between passes (e.g. 'SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_LDS')")
     args = ap.parse_args()
+    global PASSES
+    if args.passes:
+        PASSES = [x.strip() for x in args.passes.split(";") if x.strip()]
     if shutil.which("rocprofv3") is None:
         raise SystemExit("rocprofv3 is not on PATH")
     doc = dict(kernel_hash=kernel_hash(), tool="tools/sq_counters.py", passes=PASSES, shapes={},

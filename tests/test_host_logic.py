@@ -443,7 +443,9 @@ def test_crf_workspace_is_sized_for_what_runs():
     MB = 1 << 20
     step = L.tk_crf_flipflop_workspace_bytes(40, 800, 128, 533, 1)
     rowk = L.tk_crf_flipflop_workspace_bytes(40, 4000, 256, 2198, 1)
-    assert step < 110 * MB and rowk < 4800 * MB, (step / MB, rowk / MB)
+    # (round 5: 116 MB at the step's shape -- the query bounds the plain CRF's two-cells-per-lane layout, padded to 640 cells
+    # per read, and cat-mod's one-cell layout with its third instance array, whichever is larger; round 4: 106 MB)
+    assert step < 120 * MB and rowk < 4800 * MB, (step / MB, rowk / MB)
     assert L.tk_crf_flipflop_workspace_bytes_sharp(40, 800, 128, 533, 1, 1.0) == step
     s2 = L.tk_crf_flipflop_workspace_bytes_sharp(40, 800, 128, 533, 1, 2.0)
     assert step < s2 < 2 * step + 64 * MB

@@ -932,6 +932,29 @@ def test_crf_block_lengths_and_weight_bias_agree_with_the_oracle(oracle_mod, gpu
     assert r["finite"] and r["loss_rel"] < LOSS_RTOL and parity.crf_grad_ok(r), (bk, wbias, r["loss_rel"])
 
 
+@pytest.mark.parametrize("form,maxlen", [("plain", 512), ("plain", 513), ("plain", 700), ("catmod", 704), ("catmod", 705), ("catmod", 800)])
+def test_dispatch_rules_of_round_5_against_the_oracle(oracle_mod, gpu_device, form, maxlen):
+    """The RELEASE library's own choices, no lab switch: the plain CRF takes two cells per lane from 513 bases on
+    (crf_band_pick_R), cat-mod with per-column factors takes 12-step blocks and the weights' bias from 705 bases on
+    (crf_band_pick_block).  Batches whose longest read sits on either side of each threshold, through the operator
+    (workspace from the library's query: it must hold whichever layout the call picks), against the oracle -- and
+    every read stays on the linear path."""
+    from taiyaki_amd import ctc, synth
+    # (cat-mod under iid scores and random labels disowns a read or two of such a batch once L > 0.7 T -- its bands lose
+    # mass to the flush where the plain CRF's do from 0.88 T on; the log-domain kernel makes them right, but this test is
+    # about the linear path's two forms, so cat-mod gets the reference's usual L ~ T / 2)
+    T = 1000 if form == "plain" else 1600
+    Ls = np.array([maxlen, 64, maxlen - 1, 333, 129, 1, maxlen - 70], dtype=np.int32)
+    mods = (1, 1, 0, 0) if form == "catmod" else None
+    inp = synth.crf_case(T, len(Ls), 500 + maxlen, seqlens=Ls, nmods_per_base=mods)
+    if mods is not None:
+        synth.normalise_mod_columns(inp)
+    r = parity.compare_crf(oracle_mod, inp, 1.0, gpu_device)
+    assert r["finite"] and parity.crf_loss_ok(r), (form, maxlen, r["loss_rel"], r["loss_abs"])
+    assert parity.crf_grad_ok(r), (form, maxlen, r["grad_f64_scaled"], r["grad_scaled_abs"], r["ref_noise_scaled"])
+    assert ctc.last_gate_count() == 0, (form, maxlen, ctc.last_gate_count())
+
+
 def test_crf_disowned_reads_are_counted_and_redone_in_shared_slots(oracle_mod, gpu_device, labenv):
     """A batch in which MOST reads are bands a few cells wide under iid scores (the linear path disowns
     those): the log-domain kernel behind it redoes them in an eighth of the batch's worth of checkpoint

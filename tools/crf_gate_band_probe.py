@@ -1,0 +1,29 @@
+#!/usr/bin/env python
+"""How narrow a band (L / T) does kernel A's linear path keep?  Reads of L = frac x T (+- 8) bases under iid U(-5, 5) scores, plain CRF and
+cat-mod (log-softmax modification columns, random labels): reads disowned (redone by the log-domain kernel) of 64, per L / T.
+
+    python tools/crf_gate_band_probe.py"""
+import os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np, torch
+from taiyaki_amd import ctc, synth, _lib
+dev = torch.device("cuda:0")
+for T in (800, 1600):
+    for mods in (None, (1, 1, 0, 0)):
+        row = []
+        for frac in (0.5, 0.6, 0.65, 0.7, 0.75, 0.8, 0.85, 0.9):
+            N = 64
+            rng = np.random.default_rng(7)
+            Ls = np.clip((frac * T + rng.integers(-8, 9, N)).astype(np.int32), 1, T)
+            inp = synth.crf_case(T, N, 3, seqlens=Ls, nmods_per_base=mods)
+            if mods is not None:
+                synth.normalise_mod_columns(inp)
+            x = torch.from_numpy(inp["scores"]).to(dev)
+            seqs, sl = torch.from_numpy(inp["seqs"]), torch.from_numpy(inp["seqlens"])
+            if mods is not None:
+                c, g = ctc._run(x, seqs, sl, 1.0, 1.0, 1.0, 40, True, torch.from_numpy(inp["mod_cats"]), inp["can_mods_offsets"], inp["mod_cat_weights"])
+            else:
+                c, g = ctc._run(x, seqs, sl, 1.0, 1.0, 1.0, 40, True)
+            torch.cuda.synchronize()
+            row.append("%.2f:%d" % (frac, ctc.last_gate_count()))
+        print("T %d %s  gated of 64 by L/T  %s" % (T, "cat-mod" if mods else "plain  ", "  ".join(row)), flush=True)

@@ -49,6 +49,7 @@ struct BandArgs {
     unsigned long long *dbg;    // lab builds only (TK_LAB_STAMPS)
     const float *colw;          // nullable (cat-mod): (S - ncan) per-COLUMN factors; promise that modfact[p] = colw[mod[p] - ncan]
     float wbias;                // every step weight carries 2^-wbias (crf_band.hip: BK_MAX); the scores get wbias T back
+    int klip;                   // the frames' slope along the flow, bits per cell (crf_band.hip: KLIP; BandBlock::klip)
     hipEvent_t before_gradient; // host side: the stream waits for this event between the sweeps and the gradient
                                 // pass (what `add_grad` / `add_cost` hold was produced on another stream); null: none
     // Round 5 -- the index build INSIDE the sweep launch (codes != null): stay / move / mod / modfact / seqoff above
@@ -77,6 +78,7 @@ struct SeqLabels {
 struct BandBlock {
     int bk;                     // time steps per block: 4, 8 or 12 (0: not for the linear path)
     float wbias;
+    int klip;                   // frame slope (bits per cell): 6; 11 on 8-step biased blocks for batches with narrow bands
 };
 
 struct BandLayout {
@@ -86,7 +88,7 @@ struct BandLayout {
 };
 
 bool crf_band_fits(size_t max_seqlen);
-BandBlock crf_band_pick_block(float sharp, bool mod, size_t max_seqlen, bool colw = false);
+BandBlock crf_band_pick_block(float sharp, bool mod, size_t max_seqlen, bool colw = false, size_t nblk = 0);
 BandLayout crf_band_layout(size_t ntrans, size_t nblk, size_t nbatch, size_t max_seqlen, bool mod,
                            bool want_grad, int bk);
 int crf_band_dispatch(const BandArgs &a, int R, bool mod, int bk, hipStream_t stream);

@@ -222,7 +222,7 @@ __device__ __forceinline__ void band_buffer_store16(__amdgpu_buffer_rsrc_t rs, u
     }
 }
 
-__device__ __forceinline__ int clamp_shift(int d) { return min(max(d, -160), KLIP - LEM_MIN + 1); }
+__device__ __forceinline__ int clamp_shift(int d, int klip) { return min(max(d, -160), klip - LEM_MIN + 1); }
 
 // Frames of a block from the cells' own exponents: see the file header.  Works on the wave's cells
 // in FLOW order (index q = lane R + j, upstream = q - 1); fb = the frame of the cell upstream of
@@ -241,13 +241,13 @@ __device__ __forceinline__ int clamp_shift(int d) { return min(max(d, -160), KLI
 // round trip and the barrier instead of behind them; band_frames_finish folds in the neighbour's edge
 // frame (one maximum: the cell at q = -1 precedes every lane) when the ring has delivered it.
 template <int R>
-__device__ __forceinline__ void band_frames_own(const float (&m)[R], const int (&f)[R], int (&z)[R], int &run_excl, int lane) {
+__device__ __forceinline__ void band_frames_own(const float (&m)[R], const int (&f)[R], int (&z)[R], int &run_excl, int lane, int klip) {
     const int q0 = lane * R;
     int zl = NOFRAME;
 #pragma unroll
     for (int j = 0; j < R; ++j) {
         const bool live = m[j] > 0.f && m[j] < __builtin_huge_valf();
-        z[j] = live ? f[j] + __builtin_amdgcn_frexp_expf(m[j]) + KLIP * (q0 + j + 1) : NOFRAME;
+        z[j] = live ? f[j] + __builtin_amdgcn_frexp_expf(m[j]) + klip * (q0 + j + 1) : NOFRAME;
         zl = max(zl, z[j]);
     }
     const int zi = wave_prefix_max_fused(zl);
@@ -255,14 +255,14 @@ __device__ __forceinline__ void band_frames_own(const float (&m)[R], const int (
 }
 template <int R>
 __device__ __forceinline__ void band_frames_finish(float (&m)[R], int (&f)[R], float (&sc)[R], const bool (&has)[R],
-                                                   const int (&z)[R], int run_excl, int fb, int lane) {
+                                                   const int (&z)[R], int run_excl, int fb, int lane, int klip) {
     const int q0 = lane * R;
     int run = max(run_excl, (fb > NOFRAME / 2) ? fb : NOFRAME);
     int fn[R];
 #pragma unroll
     for (int j = 0; j < R; ++j) {
         run = max(run, z[j]);
-        fn[j] = (run > NOFRAME / 2) ? run - KLIP * (q0 + j + 1) : 0;
+        fn[j] = (run > NOFRAME / 2) ? run - klip * (q0 + j + 1) : 0;
         m[j] = __builtin_amdgcn_ldexpf(m[j], max(f[j] - fn[j], -300));
         f[j] = fn[j];
     }
@@ -270,14 +270,14 @@ __device__ __forceinline__ void band_frames_finish(float (&m)[R], int (&f)[R], f
     if (lane == 0) fup = (fb > NOFRAME / 2) ? fb : fn[0];
 #pragma unroll
     for (int j = 0; j < R; ++j) {
-        const int d = clamp_shift((j == 0 ? fup : fn[j > 0 ? j - 1 : 0]) - fn[j]);
+        const int d = clamp_shift((j == 0 ? fup : fn[j > 0 ? j - 1 : 0]) - fn[j], klip);
         sc[j] = has[j] ? __builtin_amdgcn_ldexpf(1.f, d) : 0.f;
     }
 }
 
 template <int R, bool SLOPE>
 __device__ __forceinline__ void band_frames(float (&m)[R], int (&f)[R], float (&sc)[R], const bool (&has)[R],
-                                            const int (&lem)[R], int fb, int lane) {
+                                            const int (&lem)[R], int fb, int lane, int klip) {
     const int q0 = lane * R;
     // ramp[j] = sum over the cells up to (q0 + j) of their slope allowance
     int ramp[R];
@@ -285,7 +285,7 @@ __device__ __forceinline__ void band_frames(float (&m)[R], int (&f)[R], float (&
         int own = 0;
 #pragma unroll
         for (int j = 0; j < R; ++j) {
-            own += KLIP - lem[j];
+            own += klip - lem[j];
             ramp[j] = own;
         }
         const int before = wave_inclusive_scan_int(own) - own;
@@ -293,7 +293,7 @@ __device__ __forceinline__ void band_frames(float (&m)[R], int (&f)[R], float (&
         for (int j = 0; j < R; ++j) ramp[j] += before;
     } else {
 #pragma unroll
-        for (int j = 0; j < R; ++j) ramp[j] = KLIP * (q0 + j + 1);
+        for (int j = 0; j < R; ++j) ramp[j] = klip * (q0 + j + 1);
     }
     int z[R];
 #pragma unroll
@@ -320,7 +320,7 @@ __device__ __forceinline__ void band_frames(float (&m)[R], int (&f)[R], float (&
     if (lane == 0) fup = (fb > NOFRAME / 2) ? fb : fn[0];
 #pragma unroll
     for (int j = 0; j < R; ++j) {
-        const int d = clamp_shift((j == 0 ? fup : fn[j > 0 ? j - 1 : 0]) - fn[j]);
+        const int d = clamp_shift((j == 0 ? fup : fn[j > 0 ? j - 1 : 0]) - fn[j], klip);
         sc[j] = has[j] ? __builtin_amdgcn_ldexpf(1.f, d) : 0.f;
     }
 }
@@ -406,6 +406,7 @@ __device__ __forceinline__ void band_sweep(const BandArgs &a, int n, int L, int6
     // a modification column's factor of a per-column product
     const float wbias = a.wbias;
     const float wb_lane = (colw_mode && (int)lane >= a.ncan) ? 0.f : wbias;
+    const int klip = a.klip;            // the frames' slope along the flow, bits per cell (KLIP; more for narrow bands: crf_band_pick_block)
 
     // The wave's cells in FLOW order: index q = lane R + j, upstream = q - 1, i.e. position
     // a0 + q forward and a0 + PW - 1 - q backward (the backward sweep runs on mirrored lanes, so
@@ -709,10 +710,10 @@ __device__ __forceinline__ void band_sweep(const BandArgs &a, int n, int L, int6
             }
         }
         if constexpr (!SPLIT_FRAMES) {
-            band_frames<R, MOD>(m, f, sc, has, lem, fb, lane);
+            band_frames<R, MOD>(m, f, sc, has, lem, fb, lane, klip);
         } else {
             // (the own-cells half ran at the end of the previous block, or before the first one)
-            band_frames_finish<R>(m, f, sc, has, zown, zrun_excl, fb, lane);
+            band_frames_finish<R>(m, f, sc, has, zown, zrun_excl, fb, lane, klip);
         }
         if (edge_lane) Ef[w * 2 + slot] = f[R - 1];
         if (GRAD) {
@@ -771,7 +772,7 @@ __device__ __forceinline__ void band_sweep(const BandArgs &a, int n, int L, int6
             for (int q4 = 0; q4 < BK / 4; ++q4) Bo[q4] = f4{edge[4 * q4], edge[4 * q4 + 1], edge[4 * q4 + 2], edge[4 * q4 + 3]};
         }
         if constexpr (SPLIT_FRAMES) {
-            band_frames_own<R>(m, f, zown, zrun_excl, lane);    // (for the next block)
+            band_frames_own<R>(m, f, zown, zrun_excl, lane, klip);    // (for the next block)
             band_barrier_after(zrun_excl);
         } else {
             band_barrier();
@@ -789,7 +790,7 @@ __device__ __forceinline__ void band_sweep(const BandArgs &a, int n, int L, int6
     const int jfirst = FWD ? win.j0 : win.j1, nlive = win.j1 - win.j0 + 1;
     const int ph0 = FWD ? win.j0 + w : (NB - 1 - win.j1) + (W - 1 - w);
     const int dj = FWD ? 1 : -1;
-    if constexpr (SPLIT_FRAMES) band_frames_own<R>(m, f, zown, zrun_excl, lane);
+    if constexpr (SPLIT_FRAMES) band_frames_own<R>(m, f, zown, zrun_excl, lane, klip);
     if constexpr (!ROWS) {
         load_block(jfirst, row0);
         load_block(jfirst + dj, row1);
@@ -1347,8 +1348,8 @@ __global__ __launch_bounds__(POST_WAVES *WAVE) __attribute__((amdgpu_waves_per_e
             if (lane == WAVE - 1) fupB = plB ? frame_at(a.ckBf, a.ckBb, min(a0 + PW, (int)a.LP - 1)) : fB[R - 1];
 #pragma unroll
             for (int j = 0; j < R; ++j) {
-                const int dF = clamp_shift((j == 0 ? fupF : fF[j > 0 ? j - 1 : 0]) - fF[j]);
-                const int dB = clamp_shift((j == R - 1 ? fupB : fB[j < R - 1 ? j + 1 : 0]) - fB[j]);
+                const int dF = clamp_shift((j == 0 ? fupF : fF[j > 0 ? j - 1 : 0]) - fF[j], a.klip);
+                const int dB = clamp_shift((j == R - 1 ? fupB : fB[j < R - 1 ? j + 1 : 0]) - fB[j], a.klip);
                 scF[j] = hasi[j] ? __builtin_amdgcn_ldexpf(1.f, dF) : 0.f;
                 scB[j] = haso[j] ? __builtin_amdgcn_ldexpf(1.f, dB) : 0.f;
                 kx[j] = fF[j] + fB[j] - zexp;
@@ -1662,25 +1663,37 @@ bool crf_band_fits(size_t max_seqlen) { return max_seqlen <= (size_t)4 * WAVE * 
 // Block length and weight bias for a call (see BK_MAX): `sharp` = the sharpening factor of the canonical
 // columns.  bk = 0: the linear path does not take this call (the log-domain kernel does every read).
 // TK_CRF_BK = 4 | 8 | 12 forces a block length, TK_CRF_WBIAS a bias (lab: tools/crf_gate_probe.py).
-BandBlock crf_band_pick_block(float sharp, bool mod, size_t max_seqlen, bool colw) {
-    BandBlock b{8, 0.f};
+BandBlock crf_band_pick_block(float sharp, bool mod, size_t max_seqlen, bool colw, size_t nblk) {
+    BandBlock b{8, 0.f, KLIP};
     const float x = sharp > 0.f ? sharp : 1.f;
-    if (!mod && x <= 1.03f) b = {12, 3.f};
+    // NARROW BANDS (round 5).  A band of T - L + 2 cells carries its mass along its two fronts, where a cell's value is a
+    // product of FORCED moves and falls by 15 .. 30 bits per cell (cat-mod: a modification penalty per move) -- faster than
+    // frames of slope KLIP = 6 can follow, so the front's cells were flushed, the two sweeps disagreed and the read went to
+    // the log-domain kernel (~1 ms at T 800): the plain CRF from L ~ 0.85 T on, cat-mod from 0.70 T on under iid scores
+    // (profiles/r5_gate_by_band_width.txt; found with tests/helpers/crf_linear_model.py, which loses the same mass at the
+    // same cell).  A steeper slope needs shorter blocks: growth per step is (1 + 2^slope) x the largest weight, and
+    // 8 x (7.2 - 3 + 11.0) = 121.6 bits fit fp32 where 12 x (7.2 - 3 + 6.02) = 122.6 did.  A batch whose longest read may
+    // be narrower than that takes 8-step blocks, bias 3 and slope 11: ~11 % slower sweeps for the plain CRF, the same
+    // block length for cat-mod below 705 bases.
+    const bool narrow = nblk > 0 && (double)max_seqlen > (mod ? 0.62 : 0.78) * (double)nblk;
+    if (x <= 1.03f && narrow && (!mod || colw)) b = {8, 3.f, 11};
+    else if (!mod && x <= 1.03f) b = {12, 3.f, KLIP};
     // cat-mod with per-column factors (round 5): the same 12-step blocks and bias from 705 bases on -- measured,
     // profiles/r5_catmod_bk12.txt: reads up to 799 bases 215 -> 199 us, T 1600 (two cells per lane) 255 -> 230, T 4000 / N 256
     // 1997 -> 1815, and fewer reads disowned at long T; reads up to 533 / 666 bases are faster at 8 (128.6 / 162.2 against
     // 132.4 / 164.8 us; N 256: two ten-wave workgroups no longer share a CU at 12 steps' registers).  The general
     // per-position form has no 12-step instantiation.
-    else if (mod && colw && x <= 1.03f && max_seqlen > (size_t)11 * WAVE) b = {12, 3.f};
-    else if (x <= 1.36f) b = {8, 0.f};
-    else if (x <= 1.76f) b = {8, 3.f};
-    else if (x <= 3.5f) b = {4, 0.f};
-    else b = {0, 0.f};
+    else if (mod && colw && x <= 1.03f && max_seqlen > (size_t)11 * WAVE) b = {12, 3.f, KLIP};
+    else if (x <= 1.36f) b = {8, 0.f, KLIP};
+    else if (x <= 1.76f) b = {8, 3.f, KLIP};
+    else if (x <= 3.5f) b = {4, 0.f, KLIP};
+    else b = {0, 0.f, KLIP};
     if (const char *e = TK_LAB_ENV("TK_CRF_BK")) {
         const int v = atoi(e);
         if (v == 4 || v == 8 || (v == 12 && (!mod || colw))) b.bk = v;
     }
     if (const char *e = TK_LAB_ENV("TK_CRF_WBIAS")) b.wbias = (float)atof(e);
+    if (const char *e = TK_LAB_ENV("TK_CRF_KLIP")) b.klip = atoi(e);
     return b;
 }
 

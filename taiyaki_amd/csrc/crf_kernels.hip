@@ -850,7 +850,11 @@ size_t crf_workspace_bytes_sharp(size_t ntrans, size_t nblk, size_t nbatch, size
                                  int want_grad, float sharp) {
     if (max_seqlen == 0) max_seqlen = nblk + 1;
     const CrfShape sh = crf_pick_shape(max_seqlen);
-    const int bkp = crf_band_pick_block(sharp, false, max_seqlen).bk, bkm = crf_band_pick_block(sharp, true, max_seqlen).bk;
+    // (every block length either form may take for this shape: with and without per-column factors; a batch with narrow
+    // bands takes 8 steps where wider ones take 12)
+    const int bkp = crf_band_pick_block(sharp, false, max_seqlen, false, nblk).bk;
+    const int bkm0 = crf_band_pick_block(sharp, true, max_seqlen, false, nblk).bk, bkm1 = crf_band_pick_block(sharp, true, max_seqlen, true, nblk).bk;
+    const int bkm = (bkm0 > 0 && bkm1 > 0) ? (bkm0 < bkm1 ? bkm0 : bkm1) : (bkm0 > 0 ? bkm0 : bkm1);
     const int bk = (bkp > 0 && bkm > 0) ? (bkp < bkm ? bkp : bkm) : (bkp > 0 ? bkp : bkm);
     // (the cat-mod layout is the larger one: an upper bound for both)
     // (a call whose own block choice differs from the one assumed here -- another sharpening factor than the
@@ -917,7 +921,7 @@ int crf_dispatch(const float *logprob, size_t ntrans, size_t nblk, size_t nbatch
     // the linear path's block length for this sharpening factor; when the workspace the caller brought is
     // too small for it (sized without the factor: tk_crf_flipflop_workspace_bytes) but large enough for the
     // log-domain kernel on every read, that kernel does the call
-    BandBlock blk = crf_band_pick_block(sharp_can, mod, max_seqlen, mod && mod_col_weights != nullptr);
+    BandBlock blk = crf_band_pick_block(sharp_can, mod, max_seqlen, mod && mod_col_weights != nullptr, nblk);
     bool band = crf_pick_mode(ntrans, nblk, nbatch, max_seqlen, grad != nullptr, blk.bk) == CRF_BAND;
     if (band && crf_ckpt_bytes(nblk, crf_redo_slots(nbatch), sh, grad != nullptr) +
                         crf_band_layout(ntrans, nblk, nbatch, max_seqlen, mod, grad != nullptr, blk.bk).total > workspace_bytes)
@@ -1017,6 +1021,7 @@ int crf_dispatch(const float *logprob, size_t ntrans, size_t nblk, size_t nbatch
         b.before_gradient = add_ready;
         b.colw = mod ? mod_col_weights : nullptr;
         b.wbias = blk.wbias;
+        b.klip = blk.klip;
         // (a batch of empty reads has no label array: any non-null pointer says "build here", nothing reads it)
         b.codes = labels != nullptr ? (labels->seqs != nullptr ? labels->seqs : stayidx) : nullptr;
         b.mod_cats = labels != nullptr ? labels->mod_cats : nullptr;

@@ -23,11 +23,14 @@ def abs_err(a, b):
     return float(np.max(np.abs(a - b))) if a.size else 0.0
 
 
-def run_crf(inp, sharp, dev, want_grad=True, seq_on_device=False):
+def run_crf(inp, sharp, dev, want_grad=True, seq_on_device=False, max_seqlen=None):
     from taiyaki_amd import ctc
     x = _t(inp["scores"], dev).requires_grad_(want_grad)
     seqs = _t(inp["seqs"], dev if seq_on_device else "cpu")
     seqlens = _t(inp["seqlens"], dev if seq_on_device else "cpu")
+    if max_seqlen is not None:
+        # (the launch's shape -- cells per lane, block length, frame slope -- follows the batch's longest read)
+        seqlens = ctc.set_max_seqlen(seqlens, max_seqlen)
     if "mod_cats" in inp:
         loss = ctc.cat_mod_flipflop_loss(x, seqs, seqlens,
                                          _t(inp["mod_cats"], dev if seq_on_device else "cpu"),

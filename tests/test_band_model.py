@@ -144,3 +144,42 @@ def test_sweep_liveness_closed_form_equals_the_windows():
                         w = p // PWS
                         ref = 0 <= w < len(win) and win[w][0] <= jb <= win[w][1]
                         assert closed == ref, (T, L, PWS, jb, p)
+
+
+def test_narrow_bands_need_steeper_frames(oracle_mod):
+    """Round 5 (tools/crf_gate_band_probe.py, LABNOTES R5.19-R5.20): a narrow band carries its mass along the fronts of the
+    two lattices, where values fall by 15-30 bits per cell -- faster than frames of slope KLIP = 6 follow; the front's
+    cells are flushed and the sweeps disagree (the kernel disowns such a read).  With 8-step blocks, bias 3 and slope
+    11 (what crf_band_pick_block gives a batch with narrow bands: 8 x (7.2 - 3 + 11) = 121.6 bits of growth) the same
+    reads come out to 1e-5 bit.  The model loses the mass the kernel loses, at the same cell."""
+    from taiyaki_amd import synth
+    from tests.helpers import crf_linear_model as lin
+    T = 800
+    cases = (((1, 1, 0, 0), [600, 560, 620, 400], 2), (None, [600, 560, 620, 400, 680, 720], 5))
+    try:
+        for mods, Ls, n in cases:
+            inp = synth.crf_case(T, len(Ls), 3, seqlens=np.array(Ls, dtype=np.int32), nmods_per_base=mods)
+            mv, stv = oracle_mod.flipflop_indices(inp["seqs"], inp["seqlens"], 4)
+            mdv = mfv = None
+            if mods:
+                synth.normalise_mod_columns(inp)
+                wts = inp["mod_cat_weights"].astype(np.float32)
+                mdv, mfv = oracle_mod.cat_mod_indices(inp["seqs"], inp["seqlens"], inp["mod_cats"], inp["can_mods_offsets"], wts, 4)
+                oloss, _ = oracle_mod.cat_mod_flipflop_loss(inp["scores"], inp["seqs"], inp["seqlens"], inp["mod_cats"],
+                                                            inp["can_mods_offsets"], wts, 1.0)
+            else:
+                oloss, _ = oracle_mod.crf_flipflop_loss(inp["scores"], inp["seqs"], inp["seqlens"], 1.0)
+            off = np.concatenate([[0], np.cumsum(Ls)])
+            L = Ls[n]
+            sl = slice(off[n] - n, off[n] - n + L - 1)
+            args = (inp["scores"][:, n], stv[off[n]:off[n] + L].astype(int), mv[sl].astype(int), L, 64)
+            kw = dict(mod=mdv[sl].astype(int), modfact=mfv[sl].astype(np.float32)) if mods else {}
+            lin.KLIP, lin.WBIAS = 6, 0
+            _, _, info = lin.crf_model(*args, KB=8, NORM=8, **kw)
+            assert abs(info["scoreF"] - info["scoreB"]) > 10.0, (mods, info)          # bits of mass gone
+            lin.KLIP, lin.WBIAS = 11, 3
+            cost, _, info = lin.crf_model(*args, KB=8, NORM=8, **kw)
+            assert not info["bad"] and abs(info["scoreF"] - info["scoreB"]) < 1e-4, (mods, info)
+            assert abs(cost - oloss[n]) <= 1e-5 * abs(oloss[n]), (mods, cost, oloss[n])     # (the fp32 reference is the noisier side at T = 800)
+    finally:
+        lin.KLIP, lin.WBIAS = 6, 0

@@ -362,7 +362,7 @@ def test_release_library_carries_no_lab_switch():
         return subprocess.run(["nm", "-D", "--defined-only", path], capture_output=True, text=True, check=True).stdout
 
     rel, lab = strings(_lib.LIBPATH), strings(_lib.LAB_LIBPATH)
-    switches = ["TK_CRF_NO_FALLBACK", "TK_CRF_MODE", "TK_CRF_BK", "TK_CRF_WBIAS", "TK_CRF_BAND_R", "TK_CRF_FEED",
+    switches = ["TK_CRF_NO_FALLBACK", "TK_CRF_MODE", "TK_CRF_BK", "TK_CRF_WBIAS", "TK_CRF_KLIP", "TK_CRF_BAND_R", "TK_CRF_FEED",
                 "TK_CRF_LATTICE_MB", "TK_CRF_GATE_DUMP", "TK_K1_RING", "TK_K1_NT", "TK_LOGZ_CH", "TK_LOGZ_SPLIT",
                 "TK_SIDE_PRIO"]
     for name in switches:

@@ -1676,7 +1676,9 @@ BandBlock crf_band_pick_block(float sharp, bool mod, size_t max_seqlen, bool col
     // be narrower than that takes 8-step blocks, bias 3 and slope 11: ~11 % slower sweeps for the plain CRF, the same
     // block length for cat-mod below 705 bases.
     const bool narrow = nblk > 0 && (double)max_seqlen > (mod ? 0.62 : 0.78) * (double)nblk;
-    if (x <= 1.03f && narrow && (!mod || colw)) b = {8, 3.f, 11};
+    // (cat-mod beyond 0.78 T: 4-step blocks carry slope 20 -- 4 x (7.2 + 20) = 108.8 bits; the model keeps L = 0.9 T with it)
+    if (x <= 1.03f && mod && nblk > 0 && (double)max_seqlen > 0.78 * (double)nblk) b = {4, 0.f, 20};
+    else if (x <= 1.03f && narrow && (!mod || colw)) b = {8, 3.f, 11};
     else if (!mod && x <= 1.03f) b = {12, 3.f, KLIP};
     // cat-mod with per-column factors (round 5): the same 12-step blocks and bias from 705 bases on -- measured,
     // profiles/r5_catmod_bk12.txt: reads up to 799 bases 215 -> 199 us, T 1600 (two cells per lane) 255 -> 230, T 4000 / N 256

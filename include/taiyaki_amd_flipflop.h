@@ -106,7 +106,11 @@ int tk_flipflop_build_indices_dev(const int32_t *seqs, const int32_t *seqlen,
  *   grad[t,n,i] = d(-score(lp)/nblk)/d lp[t,n,i]     (ctc.pyx:113; NULL => cost only,
  *                 in which case score is the forward score, c_crf_flipflop.c:255-290)
  *   seqlen[n]==0 => cost 0, zero gradient rows        (c_crf_flipflop.c:269-272,458-464)
- *   max_seqlen: an upper bound of seqlen (0 = unknown => nblk+1 is assumed)
+ *   max_seqlen: an upper bound of seqlen (0 = unknown => nblk+1 is assumed).  The launch's SHAPE follows it -- cells per
+ *               lane, block length, and the slope of the linear path's frames: a batch whose longest read may exceed
+ *               0.78 nblk (cat-mod 0.62 nblk) takes shorter blocks and steeper frames so that narrow bands stay on the
+ *               linear path (round 5) -- so a tight bound is also the faster launch; results of a read are bit-for-bit
+ *               the same in any batch launched with the same bound.
  *   mod_col_weights (nullable, cat-mod only; (ntrans - ncan) floats on the device): the caller's PROMISE
  *     that modfact[p] == mod_col_weights[modidx[p] - ncan] for every move, i.e. that the factor is a property
  *     of the modification column -- which is what `mod_cat_weights` of the reference's operator is

@@ -934,11 +934,15 @@ def test_crf_block_lengths_and_weight_bias_agree_with_the_oracle(oracle_mod, gpu
     assert r["finite"] and r["loss_rel"] < LOSS_RTOL and parity.crf_grad_ok(r), (bk, wbias, r["loss_rel"])
 
 
-@pytest.mark.parametrize("form,maxlen", [("plain", 512), ("plain", 513), ("plain", 700), ("catmod", 704), ("catmod", 705), ("catmod", 800)])
+@pytest.mark.parametrize("form,maxlen", [("plain", 512), ("plain", 513), ("plain", 700), ("catmod", 704), ("catmod", 705), ("catmod", 800),
+                                         ("plain", 780), ("plain", 781), ("plain", 900), ("catmod", 992), ("catmod", 993), ("catmod", 1248),
+                                         ("catmod", 1249), ("catmod", 1400)])
 def test_dispatch_rules_of_round_5_against_the_oracle(oracle_mod, gpu_device, form, maxlen):
     """The RELEASE library's own choices, no lab switch: the plain CRF takes two cells per lane from 513 bases on
     (crf_band_pick_R), cat-mod with per-column factors takes 12-step blocks and the weights' bias from 705 bases on
-    (crf_band_pick_block).  Batches whose longest read sits on either side of each threshold, through the operator
+    (crf_band_pick_block); a batch with narrow bands -- a read beyond 0.78 T, cat-mod 0.62 T -- takes 8-step blocks, bias 3 and
+    frames of slope 11, cat-mod beyond 0.78 T 4-step blocks and slope 20 (T = 1000 plain, 1600 cat-mod: 780 / 781, 992 / 993,
+    1248 / 1249).  Batches whose longest read sits on either side of each threshold, through the operator
     (workspace from the library's query: it must hold whichever layout the call picks), against the oracle -- and
     every read stays on the linear path."""
     from taiyaki_amd import ctc, synth
@@ -952,7 +956,9 @@ def test_dispatch_rules_of_round_5_against_the_oracle(oracle_mod, gpu_device, fo
     if mods is not None:
         synth.normalise_mod_columns(inp)
     r = parity.compare_crf(oracle_mod, inp, 1.0, gpu_device)
-    assert r["finite"] and parity.crf_loss_ok(r), (form, maxlen, r["loss_rel"], r["loss_abs"])
+    # (the loss against the fp32 oracle -- or, where that reference is itself 1e-5 off at T = 1600 on a narrow band, against
+    # the float64 witness)
+    assert r["finite"] and (parity.crf_loss_ok(r) or r["loss_f64_rel"] < 1e-5), (form, maxlen, r["loss_rel"], r["loss_abs"], r["loss_f64_rel"])
     assert parity.crf_grad_ok(r), (form, maxlen, r["grad_f64_scaled"], r["grad_scaled_abs"], r["ref_noise_scaled"])
     assert ctc.last_gate_count() == 0, (form, maxlen, ctc.last_gate_count())
 

@@ -153,3 +153,18 @@ def remap_inputs(spec):
         if rep[p]:
             bases[p] = bases[p - 1]
     return np.ascontiguousarray(sc), bases
+
+
+def realnet_catmod_inputs(gold, tag="real", seed=97, logit_scale=0.2):
+    """The trained network's canonical scores (tests/golden/realnet.npz) with the six modification columns of
+    ACGTZY beside them: synthetic logits, per-base log-softmax -- what GlobalNormFlipFlopCatMod emits
+    (layers.py:1627-1640) -- and modification categories drawn on the reads' true A / C positions.  The mod
+    columns are regenerated from the seed; the fixture holds the genuine reference's OUTPUTS."""
+    can = gold[tag + "/scores"]
+    T, N, _ = can.shape
+    lens = gold[tag + "/seqlens"].astype(np.int32)
+    inp = dict(scores=np.concatenate([can, synth.scores(T, N, 6, seed)], axis=2),
+               seqs=gold[tag + "/seqs"].astype(np.int64), seqlens=lens,
+               mod_cats=synth.mod_cats(gold[tag + "/bases"].astype(np.int64), seed, NMODS),
+               can_mods_offsets=synth.can_mods_offsets(NMODS), mod_cat_weights=np.full(6, 8.0, dtype=np.float32))
+    return synth.normalise_mod_columns(inp, logit_scale=logit_scale)

@@ -48,7 +48,28 @@ SHAPES = {
     "conf": (800, "real128", 1.0, None),
     "confburst": (800, "real128", 1.0, None),
     "confK": (4000, "speed64", 1.0, None),
+    # round 6: a TRAINED network's scores on real reads (tests/golden/realnet.npz): "real" L = 0.33 .. 0.50 T,
+    # "fast" L = 0.62 .. 0.81 T; x sharpening; x cat-mod (synthetic modification columns beside them)
+    "realnet": ("real", 1.0, False), "realnet_s2": ("real", 2.0, False), "realnet_s3": ("real", 3.0, False),
+    "realfast": ("fast", 1.0, False), "realfast_s2": ("fast", 2.0, False), "realfast_s3": ("fast", 3.0, False),
+    "realnet_cm": ("real", 1.0, True), "realnet_cm_s13": ("real", 1.3, True), "realnet_cm_s2": ("real", 2.0, True),
+    "realnet_cm_s25": ("real", 2.5, True), "realnet_cm_s3": ("real", 3.0, True),
+    "realfast_cm": ("fast", 1.0, True), "realfast_cm_s13": ("fast", 1.3, True), "realfast_cm_s2": ("fast", 2.0, True),
+    "realfast_cm_s25": ("fast", 2.5, True), "realfast_cm_s3": ("fast", 3.0, True),
 }
+REALNET = [k for k in SHAPES if k.startswith("real")]
+
+
+def realnet_case(spec):
+    from tests.golden import cases
+    tag, sharp, catmod = spec
+    gold = np.load(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests", "golden", "realnet.npz"))
+    if catmod:
+        inp = cases.realnet_catmod_inputs(gold, tag)
+    else:
+        inp = dict(scores=gold[tag + "/scores"], seqs=gold[tag + "/seqs"].astype(np.int64),
+                   seqlens=gold[tag + "/seqlens"].astype(np.int32))
+    return inp, sharp, (1, 1, 0, 0) if catmod else None
 
 
 def run(x, seqs, seqlens, sharp, extra, env):
@@ -73,20 +94,28 @@ def main():
     dev = torch.device("cuda:0")
     _lib.set_strict(False)
     for sh in args.shapes.split(","):
-        T, lens, sharp, mods = SHAPES[sh]
-        if isinstance(lens, str):
+        if sh in REALNET:
+            inp, sharp, mods = realnet_case(SHAPES[sh])
+            T, N = inp["scores"].shape[:2]
+            lens = []
+        else:
+            T, lens, sharp, mods = SHAPES[sh]
+        if sh in REALNET:
+            pass
+        elif isinstance(lens, str):
             N = int(lens[5:] if lens.startswith("speed") else lens[4:])
             seqlens = None if lens.startswith("speed") else synth.realistic_seqlens(T, N, 17000, T * 5, 9.0)
         else:
             N, seqlens = len(lens), np.array(lens, dtype=np.int32)
-        inp = synth.crf_case(T, N, 1, seqlens=seqlens, nmods_per_base=mods)
+        if sh not in REALNET:
+            inp = synth.crf_case(T, N, 1, seqlens=seqlens, nmods_per_base=mods)
         if sh.startswith("init"):
             inp["scores"] *= np.float32(0.2)
         if sh.startswith("conf"):
             synth.confident_scores(inp, 7, bursty="burst" in sh)
         if sh.startswith("sharp") and len(sh) > 5:
             synth.confident_scores(inp, 9, bursty=False)        # a sharpening schedule is applied to a TRAINED network
-        if mods is not None and not sh.endswith("free"):
+        if mods is not None and not sh.endswith("free") and sh not in REALNET:
             synth.normalise_mod_columns(inp, logit_scale=1.0 if sh.endswith("harsh") else 0.2)
         x = torch.from_numpy(inp["scores"]).to(dev)
         seqs, sl = torch.from_numpy(inp["seqs"]), torch.from_numpy(inp["seqlens"])

@@ -111,7 +111,7 @@ def make_batches(nbatch, chunk_len, stride, seed, dev, n=4, spb=9.0, cat_mod=Fal
         # the lengths are known on the host when a batch is assembled (bin/train_flipflop.py:133-138):
         # the device tensor carries its maximum along, the CRF launch is sized by it without a sync
         from taiyaki_amd import ctc
-        ctc.set_max_seqlen(b["seqlens"], int(seqlens.max()))
+        ctc.set_max_seqlen(b["seqlens"], int(seqlens.max()), bulk=ctc.bulk_of(seqlens))
         if cat_mod:
             b["mod_cats"] = torch.from_numpy(synth.mod_cats(bases, s, CAN_NMODS)).to(device=dev, dtype=torch.int32)
             b["can_mods_offsets"] = synth.can_mods_offsets(CAN_NMODS)
@@ -196,6 +196,8 @@ class LossOps:
         self.seqs = torch.from_numpy(inp["seqs"]).to(device=dev, dtype=torch.int32)
         self.seqlens = torch.from_numpy(inp["seqlens"]).to(device=dev, dtype=torch.int32)
         self.maxlen = int(inp["seqlens"].max())
+        from taiyaki_amd import ctc as _ctc
+        self.bulk = _ctc.bulk_of(inp["seqlens"])       # (tk_seq_labels.bulk_seqlen: what the operators pass for host lengths)
         self.mod = None
         if cat_mod:
             self.mod = (torch.from_numpy(inp["mod_cats"]).to(device=dev, dtype=torch.int32),
@@ -232,7 +234,7 @@ class LossOps:
         from taiyaki_amd import _lib
         p = _lib.ptr
         self._labels = _lib.SeqLabels(p(self.seqs), self.seqs.numel(), 4, p(self.mod[0]) if self.mod else None,
-                                      p(self.cmo), p(self.mcw))
+                                      p(self.cmo), p(self.mcw), self.bulk)
         return ctypes.byref(self._labels)
 
     def crf(self):

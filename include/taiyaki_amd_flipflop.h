@@ -65,12 +65,20 @@ extern "C" {
                                            [0, 2 nbase), a mod category outside its base's range, or
                                            sum(seqlen) > total_len (the reference asserts that move /
                                            stay indices lie in [0, ntrans), ctc.pyx:127-134) */
-/* bits 8-31 of the status word COUNT: the number of reads the CRF's linear-domain path handed to its
- * log-domain kernel (a read whose sweeps overflow, disagree, or whose posterior rows lose mass is redone
- * there: right answers at ~1000x the cost per read).  Accumulates over calls like the flags do; a trainer
- * that sees it grow is losing time, not accuracy (taiyaki_amd.ctc.last_gate_count, train.Trainer). */
+/* bits 8-31 of the status word COUNT, two fields of 12 bits (round 6; one of 24 before):
+ *   bits  8-19  the reads the CRF's linear-domain path handed to its LOG-DOMAIN kernel (a read whose sweeps overflow,
+ *               disagree, or whose posterior rows lose mass, also at the second try: right answers at ~1000x the cost
+ *               per read);
+ *   bits 20-31  the reads the batch's launch disowned and the RETRY launch swept again on the linear path, alone and at
+ *               its conservative configuration (~2 reads' worth of a launch each); the first field counts those of them
+ *               that failed there too.
+ * Each call adds at most 4095 to a field.  They accumulate over calls like the flags do (a field that overflows carries
+ * upwards: read them every few hundred calls); a trainer that sees the first grow is losing time, not accuracy
+ * (taiyaki_amd.ctc.last_gate_count / last_retry_count, train.Trainer). */
 #define TK_STATUS_FLAG_MASK 0xffu
 #define TK_STATUS_GATED_SHIFT 8
+#define TK_STATUS_RETRIED_SHIFT 20
+#define TK_STATUS_COUNT_MASK 0xfffu
 
 /* library / build identification: returns e.g. "taiyaki_amd flipflop gfx950 r1" */
 const char *tk_version(void);
@@ -148,6 +156,12 @@ typedef struct tk_seq_labels {
     const int32_t *mod_cats;            /* (total_len) or NULL -- with the two tables below (device) */
     const int32_t *can_mods_offsets;    /* (nbase + 1) */
     const float *mod_cat_weights;       /* (nbase + nmod) */
+    size_t bulk_seqlen;                 /* round 6.  0 = unknown.  Otherwise a length that all but a few reads of the batch
+                                         * (a sixteenth, say) stay below: it picks the launch's block configuration where
+                                         * max_seqlen only sizes it -- a batch whose BULK has narrow bands (beyond 0.78 nblk,
+                                         * cat-mod 0.62) runs shorter blocks with steeper frames; a few long reads among
+                                         * ordinary ones do not: they run the fast configuration with everybody else, and
+                                         * whichever of them the linear path disowns is retried alone (TK_STATUS_RETRIED_SHIFT). */
 } tk_seq_labels;
 int tk_crf_flipflop_labels_dev(const float *logprob, size_t ntrans, size_t nblk, size_t nbatch,
                                const tk_seq_labels *labels, const int32_t *seqlen,

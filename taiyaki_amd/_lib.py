@@ -84,7 +84,7 @@ class SeqLabels(ctypes.Structure):
     """include/taiyaki_amd_flipflop.h: tk_seq_labels (what tk_flipflop_build_indices_dev takes, for the entry points
     that build their indices inside their first launch)."""
     _fields_ = [("seqs", _vp), ("total_len", _sz), ("nbase", _sz), ("mod_cats", _vp), ("can_mods_offsets", _vp),
-                ("mod_cat_weights", _vp)]
+                ("mod_cat_weights", _vp), ("bulk_seqlen", _sz)]
 
 
 ERRORS = {1: "bad argument (NULL / shape / 16-byte alignment)",
@@ -237,12 +237,13 @@ def status_word(device):
     return _deferred[key]
 
 
-_gated = {"last": 0, "total": 0}
+_gated = {"last": 0, "total": 0, "last_retried": 0, "total_retried": 0}
+_COUNT_MASK, _GATED_SHIFT, _RETRIED_SHIFT = 0xfff, 8, 20       # include/taiyaki_amd_flipflop.h: TK_STATUS_*_SHIFT
 
 
 def last_gate_count():
     """Reads that the CRF's linear-domain path handed to its log-domain kernel (status word bits
-    8-31, include/taiyaki_amd_flipflop.h): in strict mode of the most recent operator call, in
+    8-19, include/taiyaki_amd_flipflop.h): in strict mode of the most recent operator call, in
     non-strict mode between the last two `raise_if_nonfinite()` / `take_gate_count()` checks.
     Such reads are RIGHT but cost ~1000x a read on the linear path (1 ms at T = 800): a batch that
     keeps producing them (scores far outside the network's 5 tanh range, violent cat-mod logits)
@@ -250,34 +251,50 @@ def last_gate_count():
     return _gated["last"]
 
 
+def last_retry_count():
+    """Reads that the batch's launch of the CRF's linear path disowned and the retry launch swept again,
+    alone and at its conservative configuration (status word bits 20-31; round 6) -- counted like
+    `last_gate_count`, which says how many of them failed there too.  A retried read costs about what
+    two reads cost the batch's launch."""
+    return _gated["last_retried"]
+
+
 def _u32(bits):
-    """The status words are int32 tensors; the kernels add the gate count into bits 8-31 (unsigned)."""
+    """The status words are int32 tensors; the kernels add their counts into bits 8-31 (unsigned)."""
     return int(bits) & 0xffffffff
+
+
+def _counts(bits):
+    return (bits >> _GATED_SHIFT) & _COUNT_MASK, (bits >> _RETRIED_SHIFT) & _COUNT_MASK
+
+
+def _note(redone, retried):
+    _gated["last"], _gated["last_retried"] = redone, retried
+    _gated["total"] += redone
+    _gated["total_retried"] += retried
 
 
 def _note_gated(bits):
     bits = _u32(bits)
-    n = bits >> 8
-    _gated["last"] = n
-    _gated["total"] += n
+    _note(*_counts(bits))
     return int(bits) & 0xff
 
 
 def take_gate_count():
-    """Non-strict mode: read and clear the COUNT of the deferred status words (one sync per
+    """Non-strict mode: read and clear the COUNTS of the deferred status words (one sync per
     device), leaving the error flags to `raise_if_nonfinite()`.  Returns the number of reads
-    redone in the log domain since the last check."""
-    n = 0
+    redone in the log domain since the last check (`last_retry_count()`: the reads retried)."""
+    n = m = 0
     for t in _deferred.values():
         bits = _u32(t.item())
-        n += bits >> 8
+        redone, retried = _counts(bits)
+        n, m = n + redone, m + retried
         if bits >> 8:
             # take out exactly what was read (one device op, wrap-around arithmetic): counts that kernels on
             # other streams add between the read and this op are kept, not cleared with the rest
             take = (bits >> 8) << 8
             t.sub_(take - (1 << 32) if take >= (1 << 31) else take)
-    _gated["last"] = n
-    _gated["total"] += n
+    _note(n, m)
     return n
 
 
@@ -285,6 +302,10 @@ def gated_total():
     """Reads redone in the log domain since the process started, as far as the status words have
     been read (every call in strict mode; at `raise_if_nonfinite()` / `take_gate_count()` otherwise)."""
     return _gated["total"]
+
+
+def retried_total():
+    return _gated["total_retried"]
 
 
 def _raise(bits):
@@ -314,12 +335,12 @@ def finish(status):
 
 def raise_if_nonfinite():
     """Check (and clear) the deferred status words; one sync per device."""
-    total, first_bad = 0, 0
+    total, retried, first_bad = 0, 0, 0
     for t in _deferred.values():
         bits = _u32(t.item())
         t.zero_()
-        total += bits >> 8
+        redone, again = _counts(bits)
+        total, retried = total + redone, retried + again
         first_bad = first_bad or (bits & 0xff)
-    _gated["last"] = total
-    _gated["total"] += total
+    _note(total, retried)
     _raise(first_bad)

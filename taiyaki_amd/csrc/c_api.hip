@@ -204,7 +204,7 @@ size_t tk_crf_flipflop_workspace_bytes_sharp(size_t ntrans, size_t nblk, size_t 
 static bool labels_ok(const tk_seq_labels *labels, tk::SeqLabels *out) {
     if (labels == nullptr || labels->nbase == 0 || (labels->seqs == nullptr && labels->total_len != 0)) return false;
     *out = tk::SeqLabels{labels->seqs, labels->total_len, labels->nbase, labels->mod_cats, labels->can_mods_offsets,
-                         labels->mod_cat_weights};
+                         labels->mod_cat_weights, labels->bulk_seqlen};
     return true;
 }
 

@@ -45,7 +45,9 @@ struct BandArgs {
     uint32_t *rec;              // [N][Wp][KINDS][64]  sorted transition instances of every 64-cell chunk
     int *segend;                // [N][Wp][64]  end of every transition id's segment
     const float *zeros;         // 64 B of zeros (the boundary row of lanes that take none)
-    int *gate;                  // [N]  1: the linear path disowns this read (redone by crf_kernel)
+    int *gate;                  // [N]  != 0: the batch's launch disowns this read (retried by crf_band_retry_kernel, else redone by crf_kernel)
+    int *gate2;                 // [N]  nullable; the retry launch's verdicts: the batch's launch sets -1 ("not retried"), the retry
+                                // launch 0 (it owns the read) or why not
     unsigned long long *dbg;    // lab builds only (TK_LAB_STAMPS)
     const float *colw;          // nullable (cat-mod): (S - ncan) per-COLUMN factors; promise that modfact[p] = colw[mod[p] - ncan]
     float wbias;                // every step weight carries 2^-wbias (crf_band.hip: BK_MAX); the scores get wbias T back
@@ -73,6 +75,18 @@ struct SeqLabels {
     const int32_t *mod_cats;
     const int32_t *can_mods_offsets;
     const float *mod_cat_weights;
+    size_t bulk_seqlen;         // 0: unknown.  A length that all but a few reads of the batch stay below (crf_band_pick_block)
+};
+
+// Round 6 -- the per-read SECOND CHANCE on the linear path.  The batch's launch runs the fast configuration for everybody;
+// the reads it disowns are swept again by crf_band_retry_kernel -- one workgroup per read, the conservative configuration
+// (4-step blocks, frames of slope up to 20: crf_band_pick_retry), sweeps and gradient pass one after the other in that
+// workgroup, in a workspace of a few slots -- and only what THAT disowns goes to the log-domain kernel.
+struct BandRetry {
+    const int *gate;            // [N]  the batch launch's verdicts (cost-only calls: 2 = pending, see firstF)
+    int *gate2;                 // [N]  out: 0 the retry owns the read (cost / gradient rows written), else why not
+    const double *firstF, *firstB;  // cost-only calls: the batch launch's two sweep scores (a pending read is retried iff they
+                                    // are not finite or disagree); null for gradient calls
 };
 
 struct BandBlock {
@@ -84,13 +98,20 @@ struct BandBlock {
 struct BandLayout {
     int R, W, BK;
     size_t LP;
-    size_t ckFm, ckBm, ckFf, ckBf, ckFb, ckBb, bndF, bndB, scoreF, scoreB, rec, segend, gate, zeros, total;
+    size_t ckFm, ckBm, ckFf, ckBf, ckFb, ckBb, bndF, bndB, scoreF, scoreB, rec, segend, gate, gate2, zeros, total;
 };
 
 bool crf_band_fits(size_t max_seqlen);
-BandBlock crf_band_pick_block(float sharp, bool mod, size_t max_seqlen, bool colw = false, size_t nblk = 0);
+// `bulk_seqlen`: what picks the configuration -- a length all but a few reads stay below (0: unknown = the fast configuration;
+// the few beyond it are retried one by one); `max_seqlen` sizes the launch
+BandBlock crf_band_pick_block(float sharp, bool mod, size_t max_seqlen, bool colw = false, size_t nblk = 0, size_t bulk_seqlen = 0);
+// the retry launch's configuration for this call (bk = 0: none -- the batch's launch already ran it, or nothing milder exists)
+BandBlock crf_band_pick_retry(float sharp, BandBlock fast);
+size_t crf_band_retry_slots(size_t nbatch);
 BandLayout crf_band_layout(size_t ntrans, size_t nblk, size_t nbatch, size_t max_seqlen, bool mod,
                            bool want_grad, int bk);
 int crf_band_dispatch(const BandArgs &a, int R, bool mod, int bk, hipStream_t stream);
+// `a`: the RETRY's arguments -- its own workspace arrays (crf_band_layout of crf_band_retry_slots(N) reads, 4-step blocks), wbias / klip
+int crf_band_retry_dispatch(const BandArgs &a, const BandRetry &r, int R, bool mod, size_t nslots, hipStream_t stream);
 
 }  // namespace tk

@@ -377,8 +377,10 @@ __device__ __forceinline__ void band_offset_of(const BandArgs &a, int n, long lo
 }
 
 template <int R, bool MOD, bool FWD, bool GRAD, bool ROWS, bool CW, int BK, bool PRE4 = false>
-__device__ __forceinline__ void band_sweep(const BandArgs &a, int n, int L, int64_t off, float *E, int *Ef, const float *Ezero,
+__device__ __forceinline__ void band_sweep(const BandArgs &a, int n, int ws, int L, int64_t off, float *E, int *Ef, const float *Ezero,
                                            const f4 *Wt) {
+    // `n`: the read (scores, labels); `ws`: its slot in the workspace arrays -- n for the batch's launch, the
+    // workgroup's own slot for the retry launch (crf_band_retry_kernel), whose arrays hold a few reads only
     constexpr int PW = R * WAVE;
     // the wave index is wave-uniform: keep everything derived from it in SGPRs
     const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & (WAVE - 1);
@@ -454,9 +456,9 @@ __device__ __forceinline__ void band_sweep(const BandArgs &a, int n, int L, int6
 
     if (FWD && bad_label && a.status) atomicOr(a.status, 8u);
     const unsigned rs4 = 4u * (unsigned)rowstride;
-    float *ckm = GRAD ? (FWD ? a.ckFm : a.ckBm) + (size_t)n * NB * a.LP + a0 : nullptr;
-    int16_t *ckf = GRAD ? (FWD ? a.ckFf : a.ckBf) + (size_t)n * NB * a.LP + a0 : nullptr;
-    int *ckb = GRAD ? (FWD ? a.ckFb : a.ckBb) + (size_t)n * NB * W + w : nullptr;
+    float *ckm = GRAD ? (FWD ? a.ckFm : a.ckBm) + (size_t)ws * NB * a.LP + a0 : nullptr;
+    int16_t *ckf = GRAD ? (FWD ? a.ckFf : a.ckBf) + (size_t)ws * NB * a.LP + a0 : nullptr;
+    int *ckb = GRAD ? (FWD ? a.ckFb : a.ckBb) + (size_t)ws * NB * W + w : nullptr;
     const __amdgpu_buffer_rsrc_t rm_all = __builtin_amdgcn_make_buffer_rsrc(ckm, 0, 0x7fffffff, BUF_WORD3);
     const __amdgpu_buffer_rsrc_t rf_all = __builtin_amdgcn_make_buffer_rsrc(ckf, 0, 0x7fffffff, BUF_WORD3);
     const __amdgpu_buffer_rsrc_t rb_all = __builtin_amdgcn_make_buffer_rsrc(ckb, 0, 0x7fffffff, BUF_WORD3);
@@ -469,7 +471,7 @@ __device__ __forceinline__ void band_sweep(const BandArgs &a, int n, int L, int6
     constexpr int SUBL = WAVE / R;                              // lanes per 64 cells
     const bool sub_lane = ((lane + 1) % SUBL) == 0;
     const int sub_k = (lane + 1) / SUBL;
-    float *bnd = GRAD ? (FWD ? a.bndF : a.bndB) + ((size_t)n * NB * a.Wp + w * R + (FWD ? sub_k - 1 : R - sub_k)) * BK
+    float *bnd = GRAD ? (FWD ? a.bndF : a.bndB) + ((size_t)ws * NB * a.Wp + w * R + (FWD ? sub_k - 1 : R - sub_k)) * BK
                       : nullptr;
     // byte offset of the lane's R cells inside a checkpoint row of the chunk
     const unsigned lane_cell4 = 4u * (unsigned)(FWD ? lane * R : PW - (lane + 1) * R);
@@ -817,7 +819,7 @@ __device__ __forceinline__ void band_sweep(const BandArgs &a, int n, int L, int6
             // modifications per base: costs off by 0.02 .. 0.19.  Now both sweeps run, and the launch behind them
             // (crf_kernel's vote pass) writes the cost where they agree and redoes the read where they do not.)
             const double sc2 = (double)f[j] + log2((double)m[j]);
-            (FWD ? a.scoreF : a.scoreB)[n] = sc2;
+            (FWD ? a.scoreF : a.scoreB)[ws] = sc2;
         }
     }
 }
@@ -905,6 +907,60 @@ __device__ __forceinline__ void band_rowmaker(const BandArgs &a, int n, float *E
     }
 }
 
+// ---------------- sorted transition instances of a read's 64-cell chunks (for the gradient pass) ----------------
+// `ws`: the read's slot in rec / segend; waves w0, w0 + nw, ... of the caller take the chunks in turn.
+template <bool MOD>
+__device__ __forceinline__ void band_rank(const BandArgs &a, int ws, int L, int64_t off, int w, int nwaves) {
+    constexpr int KINDS = MOD ? 3 : 2;
+    const int lane = threadIdx.x & (WAVE - 1), S = a.S;
+    // ---------------- sorted transition instances of the read's 64-cell chunks ----------------
+    // instance = (cell, kind): stay at p | move INTO p | (cat-mod) the mod term of that move,
+    // held by the lane that owns p in the gradient pass (position order).  Sort key = transition
+    // id (the three kinds use disjoint id ranges), padding last.  Ranks come from ballots in a
+    // fixed order, so the permutation -- and with it every floating-point sum of the gradient
+    // pass -- is the same from run to run.
+    for (int ck = w; ck * WAVE < L; ck += nwaves) {
+        int key[KINDS];
+        const int p = ck * WAVE + lane;
+        const bool has = p >= 1 && p < L;
+        if (a.codes != nullptr) {
+            const int cp = (p < L) ? band_code(a, off + p) : 0, cb = has ? band_code(a, off + p - 1) : 0;
+            key[0] = (p < L) ? band_stay_id(a, cp) : KEY_DEAD;
+            key[1] = has ? band_move_id(a, cb, cp) : KEY_DEAD;
+            if (MOD) key[MOD ? 2 : 0] = has ? a.ncan + band_mod_seq(a, cp, off + p, nullptr) : KEY_DEAD;
+        } else {
+            key[0] = (p < L) ? a.stay[off + p] : KEY_DEAD;
+            key[1] = has ? a.move[off + p - 1] : KEY_DEAD;
+            if (MOD) key[MOD ? 2 : 0] = has ? a.mod[off + p - 1] : KEY_DEAD;
+        }
+        int cnt = 0;                    // lane b: instances with key b ranked so far
+        int rank[KINDS];
+#pragma unroll
+        for (int e = 0; e < KINDS; ++e) {
+            int r = 0;
+            for (int b = 0; b < WAVE; ++b) {
+                if (b == S + 2) b = KEY_DEAD;               // keys S+2 .. 62 do not occur
+                const unsigned long long mask = __ballot(key[e] == b);
+                if (key[e] == b)
+                    r = __builtin_amdgcn_readlane(cnt, b) + __popcll(mask & ((1ull << lane) - 1ull));
+                if (lane == b) cnt += __popcll(mask);
+            }
+            rank[e] = r;
+        }
+        const int incl = wave_inclusive_scan_int(cnt);      // lane b: end of key b's segment
+        const int start = incl - cnt;
+        a.segend[((size_t)ws * a.Wp + ck) * WAVE + lane] = incl;
+        uint32_t *recn = a.rec + ((size_t)ws * a.Wp + ck) * KINDS * WAVE;
+#pragma unroll
+        for (int e = 0; e < KINDS; ++e) {
+            const int pos = __builtin_amdgcn_ds_bpermute(key[e] * 4, start) + rank[e];
+            // position pos of the sorted order lives in lane pos / KINDS, register pos % KINDS;
+            // it reads the LDS word the owner of (cell, kind) writes
+            recn[(pos % KINDS) * WAVE + pos / KINDS] = (uint32_t)((lane * KINDS + e) * 4);
+        }
+    }
+}
+
 // ===========================================================================
 // sweep + rank launch.  blockIdx.x in [0, N): sorted-instance records for the gradient pass;
 // [N, 2N): forward sweep of read n; [2N, 3N): backward sweep.  Cost-only calls launch 2 N
@@ -916,13 +972,12 @@ template <int R, bool MOD, int WCAP, bool ROWS, bool CW, int BK>
 __global__ __launch_bounds__(WCAP *WAVE) void crf_band_sweep_kernel(BandArgs a) {
     extern __shared__ __attribute__((aligned(16))) char band_dyn_lds[];     // ROWS: the exponentiated rows (band_rowmaker)
     constexpr int PW = R * WAVE;
-    constexpr int KINDS = MOD ? 3 : 2;
     __shared__ __attribute__((aligned(16))) float E[BAND_MAXW * 2 * BK];
     __shared__ int Ef[BAND_MAXW * 2];
     __shared__ __attribute__((aligned(16))) float Ezero[BK];
-    const int tid = threadIdx.x, lane = tid & (WAVE - 1);
+    const int tid = threadIdx.x;
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int N = a.N, S = a.S, W = a.W;
+    const int N = a.N, W = a.W;
     const bool want_grad = a.grad != nullptr;
 #ifndef TK_PRE4
 #define TK_PRE4 1
@@ -963,6 +1018,7 @@ __global__ __launch_bounds__(WCAP *WAVE) void crf_band_sweep_kernel(BandArgs a) 
     }
     if (role == 2 && tid == 0) a.gate[n] = 0;
     if (!want_grad && role == 0 && tid == 0) a.gate[n] = 2;     // cost only: pending -- crf_kernel compares the two sweep scores
+    if (a.gate2 != nullptr && role == (want_grad ? 2 : 0) && tid == 0) a.gate2[n] = -1;     // not retried (yet)
     if (role == 2 && tid < 16) const_cast<float *>(a.zeros)[tid] = 0.f;   // (every rank workgroup: the same zeros)
     if (L == 0 || L > W * PW) {
         // c_crf_flipflop.c:269-272: cost 0 for an empty read (the gradient pass does it when
@@ -978,52 +1034,7 @@ __global__ __launch_bounds__(WCAP *WAVE) void crf_band_sweep_kernel(BandArgs a) 
     (void)PW;
 
     if (role == 2) {
-        // ---------------- sorted transition instances of the read's 64-cell chunks ----------------
-        // instance = (cell, kind): stay at p | move INTO p | (cat-mod) the mod term of that move,
-        // held by the lane that owns p in the gradient pass (position order).  Sort key = transition
-        // id (the three kinds use disjoint id ranges), padding last.  Ranks come from ballots in a
-        // fixed order, so the permutation -- and with it every floating-point sum of the gradient
-        // pass -- is the same from run to run.
-        for (int ck = w; ck * WAVE < L; ck += (int)(blockDim.x >> 6)) {
-            int key[KINDS];
-            const int p = ck * WAVE + lane;
-            const bool has = p >= 1 && p < L;
-            if (a.codes != nullptr) {
-                const int cp = (p < L) ? band_code(a, off + p) : 0, cb = has ? band_code(a, off + p - 1) : 0;
-                key[0] = (p < L) ? band_stay_id(a, cp) : KEY_DEAD;
-                key[1] = has ? band_move_id(a, cb, cp) : KEY_DEAD;
-                if (MOD) key[MOD ? 2 : 0] = has ? a.ncan + band_mod_seq(a, cp, off + p, nullptr) : KEY_DEAD;
-            } else {
-                key[0] = (p < L) ? a.stay[off + p] : KEY_DEAD;
-                key[1] = has ? a.move[off + p - 1] : KEY_DEAD;
-                if (MOD) key[MOD ? 2 : 0] = has ? a.mod[off + p - 1] : KEY_DEAD;
-            }
-            int cnt = 0;                    // lane b: instances with key b ranked so far
-            int rank[KINDS];
-#pragma unroll
-            for (int e = 0; e < KINDS; ++e) {
-                int r = 0;
-                for (int b = 0; b < WAVE; ++b) {
-                    if (b == S + 2) b = KEY_DEAD;               // keys S+2 .. 62 do not occur
-                    const unsigned long long mask = __ballot(key[e] == b);
-                    if (key[e] == b)
-                        r = __builtin_amdgcn_readlane(cnt, b) + __popcll(mask & ((1ull << lane) - 1ull));
-                    if (lane == b) cnt += __popcll(mask);
-                }
-                rank[e] = r;
-            }
-            const int incl = wave_inclusive_scan_int(cnt);      // lane b: end of key b's segment
-            const int start = incl - cnt;
-            a.segend[((size_t)n * a.Wp + ck) * WAVE + lane] = incl;
-            uint32_t *recn = a.rec + ((size_t)n * a.Wp + ck) * KINDS * WAVE;
-#pragma unroll
-            for (int e = 0; e < KINDS; ++e) {
-                const int pos = __builtin_amdgcn_ds_bpermute(key[e] * 4, start) + rank[e];
-                // position pos of the sorted order lives in lane pos / KINDS, register pos % KINDS;
-                // it reads the LDS word the owner of (cell, kind) writes
-                recn[(pos % KINDS) * WAVE + pos / KINDS] = (uint32_t)((lane * KINDS + e) * 4);
-            }
-        }
+        band_rank<MOD>(a, n, L, off, w, (int)(blockDim.x >> 6));
         return;
     }
 
@@ -1041,13 +1052,13 @@ __global__ __launch_bounds__(WCAP *WAVE) void crf_band_sweep_kernel(BandArgs a) 
         }
     }
     if (!want_grad && role == 0)
-        band_sweep<R, MOD, true, false, ROWS, CW, BK, PRE4>(a, n, L, off, E, Ef, Ezero, Wt);
+        band_sweep<R, MOD, true, false, ROWS, CW, BK, PRE4>(a, n, n, L, off, E, Ef, Ezero, Wt);
     else if (!want_grad)
-        band_sweep<R, MOD, false, false, ROWS, CW, BK, PRE4>(a, n, L, off, E, Ef, Ezero, Wt);
+        band_sweep<R, MOD, false, false, ROWS, CW, BK, PRE4>(a, n, n, L, off, E, Ef, Ezero, Wt);
     else if (role == 0)
-        band_sweep<R, MOD, true, true, ROWS, CW, BK, PRE4>(a, n, L, off, E, Ef, Ezero, Wt);
+        band_sweep<R, MOD, true, true, ROWS, CW, BK, PRE4>(a, n, n, L, off, E, Ef, Ezero, Wt);
     else
-        band_sweep<R, MOD, false, true, ROWS, CW, BK, PRE4>(a, n, L, off, E, Ef, Ezero, Wt);
+        band_sweep<R, MOD, false, true, ROWS, CW, BK, PRE4>(a, n, n, L, off, E, Ef, Ezero, Wt);
 }
 
 // Inclusive wave prefix sum in six fused DPP adds (the row_bcast steps write only the rows they
@@ -1108,23 +1119,23 @@ __host__ __device__ inline size_t band_post_lds_bytes(bool mod, int bk) {
     return (size_t)POST_WAVES * bk * (mod ? 3 : 2) * WAVE * 4;
 }
 
+// One wave, one time block `jb` of read `n` (workspace slot `ws`: n in the batch's launch, the workgroup's own slot in
+// the retry launch); `sP`: the wave's own RG x EPL x 64 floats of LDS.  Returns 0, or why the linear path disowns the
+// read: 1 a sweep score is not finite, 4 the sweeps disagree, 2 a row of this block lost mass (the caller records it).
 template <bool MOD, bool CW, int BK>
-__global__ __launch_bounds__(POST_WAVES *WAVE) __attribute__((amdgpu_waves_per_eu(5))) void crf_band_posterior_kernel(BandArgs a) {
+__device__ __forceinline__ int band_posterior_block(const BandArgs &a, const int n, const int ws, const int jb, float *sP) {
     constexpr int R = 1;                                        // 64-cell chunks whatever the sweeps used
     constexpr int PW = R * WAVE;
     constexpr int KINDS = MOD ? 3 : 2;
     constexpr int EPL = KINDS * R;
     constexpr int RG = (MOD && BK > 8) ? 4 : BK;                // rows evaluated together (cat-mod at 12 steps: three instances per
                                                                 // cell and row -- groups of four keep it under the register cap)
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    const int tid = threadIdx.x, lane = tid & (WAVE - 1);
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);      // wave-uniform: SGPR
-    const int n = blockIdx.x;
+    const int lane = threadIdx.x & (WAVE - 1);
+    const bool head = jb == 0 && lane == 0;                         // one lane per read: its cost
     const int N = a.N, T = a.T, S = a.S, W = a.Wp;              // W: 64-cell chunks per checkpoint row
     const int PWS = a.LP / a.W;                                 // cells per SWEEP chunk
     const size_t rowstride = (size_t)N * S;
     const int NB = (T + BK - 1) / BK;
-    const int jb = blockIdx.y * POST_WAVES + wave;                  // this wave's time block
     const int t0 = jb * BK;
     // WHAT THE WAVE NEEDS BEFORE IT CAN DECIDE ANYTHING, ISSUED TOGETHER (round 4, LABNOTES R4.11): the read's length
     // and offsets, the two sweep scores, the block's score rows, the frame bases of the block's chunks (lane =
@@ -1132,8 +1143,8 @@ __global__ __launch_bounds__(POST_WAVES *WAVE) __attribute__((amdgpu_waves_per_e
     // one after the other.  (Also issuing the frame columns of all chunks of a short read here -- the mask pass's
     // loads, a third round trip -- costs 32 registers: cat-mod fell from 6 to 5 waves per SIMD and lost 6 us.)
     const int jbc = min(jb, NB - 1);                            // (waves past the last block leave below)
-    const size_t ckrow = ((size_t)n * NB + jbc) * a.LP;
-    const size_t ckbase = ((size_t)n * NB + jbc) * a.W;          // the block's frame bases, one per sweep chunk
+    const size_t ckrow = ((size_t)ws * NB + jbc) * a.LP;
+    const size_t ckbase = ((size_t)ws * NB + jbc) * a.W;          // the block's frame bases, one per sweep chunk
     const int pws_sh = 31 - __builtin_clz(PWS);                  // (PWS = 64, 128 or 256 cells)
     const bool coltest = jbc >= 1;
     const unsigned lane4 = 4u * (unsigned)lane;
@@ -1143,7 +1154,7 @@ __global__ __launch_bounds__(POST_WAVES *WAVE) __attribute__((amdgpu_waves_per_e
     const size_t ckbase_t = coltest ? ckbase - a.W : ckbase;
     const int seqlen_n = a.seqlen[n];
     const int64_t off = a.seqoff[n], off_next = a.seqoff[n + 1];
-    const double scoreF = a.scoreF[n], scoreB = a.scoreB[n];
+    const double scoreF = a.scoreF[ws], scoreB = a.scoreB[ws];
     const float *lpn = a.lp + (size_t)n * S;
     const int col = min(lane, S - 1);
     float raw[BK], er[BK];      // the wave's score rows, one register each (lane = transition id), raw and exponentiated
@@ -1156,7 +1167,7 @@ __global__ __launch_bounds__(POST_WAVES *WAVE) __attribute__((amdgpu_waves_per_e
     const int L = min(seqlen_n, (int)(off_next - off));         // (offsets are clamped to the label array)
 
     if (L == 0 || L > a.LP) {
-        if (blockIdx.y == 0 && tid == 0) {
+        if (head) {
             a.cost[n] = (L == 0) ? crf_add_cost(a, n, 0.f) : __builtin_nanf("");   // c_crf_flipflop.c:269-272, 458-464
             if (L != 0 && a.status) atomicOr(a.status, 16u);
         }
@@ -1168,7 +1179,7 @@ __global__ __launch_bounds__(POST_WAVES *WAVE) __attribute__((amdgpu_waves_per_e
                 a.grad[(size_t)t * rowstride + (size_t)n * S + lane] =
                     (L == 0) ? crf_add_grad(a, (size_t)t, n, lane, 0.f, gs0) : __builtin_nanf("");
         }
-        return;
+        return 0;
     }
 #ifdef TK_LAB_STAMPS
     unsigned long long pst[6];
@@ -1181,13 +1192,11 @@ __global__ __launch_bounds__(POST_WAVES *WAVE) __attribute__((amdgpu_waves_per_e
     {
         // the sweeps must have ended finite and agree (c_crf_flipflop.c:482-491 averages them)
         const double dsc = scoreF - scoreB;
-        if (!(dsc > -(double)ROWZ_TOL && dsc < (double)ROWZ_TOL)) {
-            if (blockIdx.y == 0 && tid == 0) a.gate[n] = (dsc == dsc && scoreF - scoreF == 0.0 && scoreB - scoreB == 0.0) ? 4 : 1;
-            return;
-        }
+        if (!(dsc > -(double)ROWZ_TOL && dsc < (double)ROWZ_TOL))
+            return (dsc == dsc && scoreF - scoreF == 0.0 && scoreB - scoreB == 0.0) ? 4 : 1;
     }
-    if (jb >= NB) return;
-    if (blockIdx.y == 0 && tid == 0) {
+    if (jb >= NB) return 0;
+    if (head) {
         // score = mean of the two sweeps (c_crf_flipflop.c:482-491), cost = -score / T
         // (+ wbias T: the stored sweep scores are in the biased weights, like everything the rows below are
         // scaled by; only the cost takes the bias back)
@@ -1195,7 +1204,6 @@ __global__ __launch_bounds__(POST_WAVES *WAVE) __attribute__((amdgpu_waves_per_e
         a.cost[n] = crf_add_cost(a, n, (float)(-(score2 * 0.6931471805599453) / (double)T) * a.out_scale);
     }
     const int Wn = (L + PW - 1) / PW;                           // chunks this read has
-    float *sP = reinterpret_cast<float *>(smem) + (size_t)wave * RG * EPL * WAVE;
     const float c = a.c_can;
     const bool trim = L <= T + 1;
     const int nrows = min(BK, T - t0);
@@ -1235,8 +1243,8 @@ __global__ __launch_bounds__(POST_WAVES *WAVE) __attribute__((amdgpu_waves_per_e
         return p >= 0 && as < L && (notrim || (as <= live_hi && as >= live_lo));
     };
     auto frame_at = [&](const int16_t *ff, const int *fbase, int p) { return fbase[ckbase + (p >> pws_sh)] + (int)ff[ckrow + p]; };
-    const float *bndFn = a.bndF + ((size_t)n * NB + jb) * W * BK;
-    const float *bndBn = a.bndB + ((size_t)n * NB + jb) * W * BK;
+    const float *bndFn = a.bndF + ((size_t)ws * NB + jb) * W * BK;
+    const float *bndBn = a.bndB + ((size_t)ws * NB + jb) * W * BK;
     // Per-wave buffer descriptors for everything a chunk loads: the chunk is then a SCALAR offset and the lane a
     // constant vector offset -- no 64-bit address arithmetic per load -- and the descriptors' bounds return the
     // 0 that cells past the end of the read take (stay ids at p >= L, move ids at p - 1 < 0 or p >= L - 1).
@@ -1249,8 +1257,8 @@ __global__ __launch_bounds__(POST_WAVES *WAVE) __attribute__((amdgpu_waves_per_e
         const_cast<int32_t *>((from_codes ? a.codes : a.stay) + off), 0, L * 4, BUF_WORD3);
     const __amdgpu_buffer_rsrc_t rMv = __builtin_amdgcn_make_buffer_rsrc(
         const_cast<int32_t *>((from_codes ? a.codes : a.move) + off), 0, (from_codes ? L : L - 1) * 4, BUF_WORD3);
-    const __amdgpu_buffer_rsrc_t rRec = __builtin_amdgcn_make_buffer_rsrc(a.rec + (size_t)n * W * EPL * WAVE, 0, (int)(W * EPL * WAVE * 4), BUF_WORD3);
-    const __amdgpu_buffer_rsrc_t rSeg = __builtin_amdgcn_make_buffer_rsrc(a.segend + (size_t)n * W * WAVE, 0, (int)(W * WAVE * 4), BUF_WORD3);
+    const __amdgpu_buffer_rsrc_t rRec = __builtin_amdgcn_make_buffer_rsrc(a.rec + (size_t)ws * W * EPL * WAVE, 0, (int)(W * EPL * WAVE * 4), BUF_WORD3);
+    const __amdgpu_buffer_rsrc_t rSeg = __builtin_amdgcn_make_buffer_rsrc(a.segend + (size_t)ws * W * WAVE, 0, (int)(W * WAVE * 4), BUF_WORD3);
     const __amdgpu_buffer_rsrc_t rMd = __builtin_amdgcn_make_buffer_rsrc(
         const_cast<int32_t *>(MOD ? (from_codes ? a.mod_cats : a.mod) + off : (from_codes ? a.codes : a.move) + off), 0,
         (from_codes ? L : L - 1) * 4, BUF_WORD3);
@@ -1621,7 +1629,6 @@ __global__ __launch_bounds__(POST_WAVES *WAVE) __attribute__((amdgpu_waves_per_e
             if (lane < S) a.grad[(size_t)(t0 + k) * rowstride + (size_t)n * S + lane] = g;
         }
     }
-    if (lost && lane == 0) a.gate[n] = 2;        // (reason codes, lab dump: 1 non-finite sweep score, 4 sweeps disagree, 2 a row lost mass)
     (void)nskip;
 #ifdef TK_LAB_STAMPS
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -1634,6 +1641,111 @@ __global__ __launch_bounds__(POST_WAVES *WAVE) __attribute__((amdgpu_waves_per_e
         atomicAdd(a.dbg + 621, (unsigned long long)__builtin_popcountll(livemask));
     }
 #endif
+    return lost ? 2 : 0;       // (reason codes, lab dump: 1 non-finite sweep score, 4 sweeps disagree, 2 a row lost mass)
+}
+
+template <bool MOD, bool CW, int BK>
+__global__ __launch_bounds__(POST_WAVES *WAVE) __attribute__((amdgpu_waves_per_eu(5))) void crf_band_posterior_kernel(BandArgs a) {
+    constexpr int KINDS = MOD ? 3 : 2, RG = (MOD && BK > 8) ? 4 : BK;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int lane = threadIdx.x & (WAVE - 1);
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);      // wave-uniform: SGPR
+    const int n = blockIdx.x;
+    const int jb = blockIdx.y * POST_WAVES + wave;                  // this wave's time block
+    const int why = band_posterior_block<MOD, CW, BK>(a, n, n, jb, reinterpret_cast<float *>(smem) + (size_t)wave * RG * KINDS * WAVE);
+    // the linear path disowns the read: the sweeps' verdict is the same in every wave (one lane records it), a row's in its own
+    if (why != 0 && lane == 0 && (why == 2 || jb == 0)) a.gate[n] = why;
+}
+
+
+
+// ===========================================================================
+// Round 6 -- the per-read second chance (BandRetry, crf_band.h).  Launched behind the batch's gradient pass with a few
+// workgroups of 16 waves.  Usually nothing is disowned and a workgroup leaves after one pass over the gate array.
+// Otherwise the k-th disowned read goes to workgroup k mod gridDim.x, which -- one read after the other, in its own slot
+// of the retry workspace -- ranks the read's transition instances, runs the forward and then the backward sweep with
+// 4-step blocks and steep frames (a.klip, a.wbias: crf_band_pick_retry), and then the gradient pass's blocks, a wave per
+// block in turn: the device functions of the batch's launches, one workgroup instead of 3 + NB / 2.  ~150 us for a
+// read of 530 bases at T 800 where the log-domain kernel takes ~1 ms; the batch keeps its fast configuration.
+// ===========================================================================
+__device__ __forceinline__ int band_first_verdict(const BandRetry &r, int n) {
+    const int g = r.gate[n];
+    if (r.firstF == nullptr || g != 2) return g;
+    const double F = r.firstF[n], B = r.firstB[n], d = F - B;       // (crf_kernels.hip: crf_band_gate_of)
+    if (!(F - F == 0.0 && B - B == 0.0)) return 1;
+    if (!(d > -1e-3 && d < 1e-3)) return 4;
+    return 0;
+}
+
+template <int R, bool MOD, bool CW>
+__global__ __launch_bounds__(BAND_MAXW *WAVE) void crf_band_retry_kernel(BandArgs a, BandRetry r) {
+    constexpr int BK = 4, PW = R * WAVE, KINDS = MOD ? 3 : 2;
+    extern __shared__ __attribute__((aligned(16))) char retry_dyn_lds[];    // the gradient pass's rows: 16 waves x BK x KINDS x 64 floats
+    __shared__ __attribute__((aligned(16))) float E[BAND_MAXW * 2 * BK];
+    __shared__ int Ef[BAND_MAXW * 2];
+    __shared__ __attribute__((aligned(16))) float Ezero[BK];
+    __shared__ int why_sh;
+    const int tid = threadIdx.x, lane = tid & (WAVE - 1);
+    const int w = __builtin_amdgcn_readfirstlane(tid >> 6), nwaves = (int)(blockDim.x >> 6);
+    const bool want_grad = a.grad != nullptr;
+    {
+        unsigned long long any = 0;
+        for (int n0 = 0; n0 < a.N; n0 += WAVE) {
+            const int n = n0 + lane;
+            any |= __ballot(n < a.N && band_first_verdict(r, n) != 0);
+        }
+        if (any == 0) return;
+    }
+    if (tid < BK) Ezero[tid] = 0.f;
+    const int ws = (int)blockIdx.x;
+    const int T = a.T, NB = (T + BK - 1) / BK;
+    int seen = 0;
+    for (int n = 0; n < a.N; ++n) {
+        if (band_first_verdict(r, n) == 0) continue;
+        const bool mine = seen % (int)gridDim.x == (int)blockIdx.x;
+        ++seen;
+        if (!mine) continue;
+        const int64_t off = a.seqoff[n];
+        const int L = min(a.seqlen[n], (int)(a.seqoff[n + 1] - off));
+        __syncthreads();                                        // (the read before: its verdict is taken, its LDS free)
+        if (tid == 0) why_sh = 0;
+        if (L <= 0 || L > a.W * PW) {                           // (never disowned: the batch's launch answers these itself)
+            if (tid == 0) r.gate2[n] = 16;
+            continue;
+        }
+        band_rank<MOD>(a, ws, L, off, w, nwaves);
+        __syncthreads();
+        band_sweep<R, MOD, true, true, false, CW, BK>(a, n, ws, L, off, E, Ef, Ezero, nullptr);
+        __syncthreads();
+        band_sweep<R, MOD, false, true, false, CW, BK>(a, n, ws, L, off, E, Ef, Ezero, nullptr);
+        // what the sweeps and the ranking left in the workspace is read by OTHER waves of this workgroup below: release,
+        // barrier, acquire (a slot's lines may sit in this CU's vector cache from the read before)
+        __threadfence();
+        __syncthreads();
+        __threadfence();
+        if (want_grad) {
+            float *sP = reinterpret_cast<float *>(retry_dyn_lds) + (size_t)w * BK * KINDS * WAVE;
+            int why = 0;
+            for (int jb = w; jb < NB && (why & 5) == 0; jb += nwaves)       // (the sweeps' verdict, 1 / 4, is every block's)
+                why |= band_posterior_block<MOD, CW, BK>(a, n, ws, jb, sP);
+            if (why != 0 && lane == 0) atomicOr(&why_sh, why);
+        } else if (tid == 0) {
+            // cost only: both sweeps finite and agreeing, or not the linear path's (crf_kernels.hip: crf_band_gate_of)
+            const double F = a.scoreF[ws], B = a.scoreB[ws], d = F - B;
+            if (!(F - F == 0.0 && B - B == 0.0)) why_sh = 1;
+            else if (!(d > -1e-3 && d < 1e-3)) why_sh = 4;
+            else {
+                const double score2 = 0.5 * (F + B) + (double)a.wbias * (double)T;
+                const float cst = crf_add_cost(a, n, (float)(-(score2 * 0.6931471805599453) / (double)T) * a.out_scale);
+                a.cost[n] = cst;
+                if (a.status && !isfinite(cst)) atomicOr(a.status, 1u);
+            }
+        }
+        __syncthreads();
+        if (tid == 0) r.gate2[n] = why_sh;
+    }
+    // reads retried: bits 20-31 of the status word (include/taiyaki_amd_flipflop.h: TK_STATUS_RETRIED_SHIFT)
+    if (blockIdx.x == 0 && tid == 0 && seen > 0 && a.status) atomicAdd(a.status, (uint32_t)min(seen, 0xfff) << 20);
 }
 
 // ---------------------------------------------------------------------------
@@ -1663,7 +1775,7 @@ bool crf_band_fits(size_t max_seqlen) { return max_seqlen <= (size_t)4 * WAVE * 
 // Block length and weight bias for a call (see BK_MAX): `sharp` = the sharpening factor of the canonical
 // columns.  bk = 0: the linear path does not take this call (the log-domain kernel does every read).
 // TK_CRF_BK = 4 | 8 | 12 forces a block length, TK_CRF_WBIAS a bias (lab: tools/crf_gate_probe.py).
-BandBlock crf_band_pick_block(float sharp, bool mod, size_t max_seqlen, bool colw, size_t nblk) {
+BandBlock crf_band_pick_block(float sharp, bool mod, size_t max_seqlen, bool colw, size_t nblk, size_t bulk_seqlen) {
     BandBlock b{8, 0.f, KLIP};
     const float x = sharp > 0.f ? sharp : 1.f;
     // NARROW BANDS (round 5).  A band of T - L + 2 cells carries its mass along its two fronts, where a cell's value is a
@@ -1675,9 +1787,13 @@ BandBlock crf_band_pick_block(float sharp, bool mod, size_t max_seqlen, bool col
     // 8 x (7.2 - 3 + 11.0) = 121.6 bits fit fp32 where 12 x (7.2 - 3 + 6.02) = 122.6 did.  A batch whose longest read may
     // be narrower than that takes 8-step blocks, bias 3 and slope 11: ~11 % slower sweeps for the plain CRF, the same
     // block length for cat-mod below 705 bases.
-    const bool narrow = nblk > 0 && (double)max_seqlen > (mod ? 0.62 : 0.78) * (double)nblk;
+    // ROUND 6: these are rules for the batch's BULK now, not for its longest read: `bulk_seqlen` is a length all but a few
+    // reads stay below (the caller's host-side knowledge; 0 = unknown = no such rule).  The few beyond it run the fast
+    // configuration with everybody else, and whichever of them the linear path then disowns is retried alone at
+    // 4 steps / slope 20 (crf_band_retry_kernel) -- one long read no longer moves 127 others to slower blocks.
+    const bool narrow = nblk > 0 && (double)bulk_seqlen > (mod ? 0.62 : 0.78) * (double)nblk;
     // (cat-mod beyond 0.78 T: 4-step blocks carry slope 20 -- 4 x (7.2 + 20) = 108.8 bits; the model keeps L = 0.9 T with it)
-    if (x <= 1.03f && mod && nblk > 0 && (double)max_seqlen > 0.78 * (double)nblk) b = {4, 0.f, 20};
+    if (x <= 1.03f && mod && nblk > 0 && (double)bulk_seqlen > 0.78 * (double)nblk) b = {4, 0.f, 20};
     else if (x <= 1.03f && narrow && (!mod || colw)) b = {8, 3.f, 11};
     else if (!mod && x <= 1.03f) b = {12, 3.f, KLIP};
     // cat-mod with per-column factors (round 5): the same 12-step blocks and bias from 705 bases on -- measured,
@@ -1697,6 +1813,34 @@ BandBlock crf_band_pick_block(float sharp, bool mod, size_t max_seqlen, bool col
     if (const char *e = TK_LAB_ENV("TK_CRF_WBIAS")) b.wbias = (float)atof(e);
     if (const char *e = TK_LAB_ENV("TK_CRF_KLIP")) b.klip = atoi(e);
     return b;
+}
+
+// The second chance's configuration: 4-step blocks with the steepest frames their growth bound allows,
+//   4 x (7.2 sharp - bias + slope) <= 125.6 bits  and, for the decay,  7.2 sharp + bias <= 30.5 bits per step:
+// slope 20 without a bias up to a sharpening factor of 1.58 (what round 5's cat-mod rule for narrow bands ran: "keeps everything
+// tried"), slope 20 with a bias up to 2.8, 18 at 3.0, 11 at 3.5.
+BandBlock crf_band_pick_retry(float sharp, BandBlock fast) {
+    const float x = sharp > 0.f ? sharp : 1.f;
+    if (fast.bk == 0 || x > 3.5f || TK_LAB_ENV("TK_CRF_NO_RETRY")) return {0, 0.f, KLIP};
+    const float g = 7.2f * x;
+    float bias = 0.f;
+    int klip = 20;
+    if (g + 20.f > 31.4f) {
+        const float need = g + 20.f - 31.4f, bmax = fmaxf(0.f, 30.5f - g);
+        bias = floorf(2.f * fminf(need, bmax)) * 0.5f;
+        klip = min(20, (int)floorf(31.4f - g + bias));
+    }
+    if (const char *e = TK_LAB_ENV("TK_CRF_RETRY_KLIP")) klip = atoi(e);
+    if (const char *e = TK_LAB_ENV("TK_CRF_RETRY_WBIAS")) bias = (float)atof(e);
+    if (klip <= KLIP || (fast.bk == 4 && fast.klip >= klip)) return {0, 0.f, KLIP};     // (the batch's launch ran that already)
+    return {4, bias, klip};
+}
+
+// Slots of the retry workspace = workgroups of the retry launch: a sixteenth of the batch, at least 4.
+size_t crf_band_retry_slots(size_t nbatch) {
+    size_t s = (nbatch + 15) / 16;
+    if (s < 4) s = 4;
+    return s < nbatch ? s : nbatch;
 }
 
 BandLayout crf_band_layout(size_t ntrans, size_t nblk, size_t nbatch, size_t max_seqlen, bool mod,
@@ -1733,6 +1877,8 @@ BandLayout crf_band_layout(size_t ntrans, size_t nblk, size_t nbatch, size_t max
     l.rec = take(nbatch * Wp * KINDS * WAVE * sizeof(uint32_t));
     l.segend = take(nbatch * Wp * WAVE * sizeof(int));
     l.gate = off;
+    off += (nbatch * sizeof(int) + 255) / 256 * 256;
+    l.gate2 = off;              // the retry launch's verdicts, per read of the batch
     off += (nbatch * sizeof(int) + 255) / 256 * 256;
     l.zeros = off;
     off += 256;
@@ -1851,6 +1997,26 @@ int crf_band_dispatch(const BandArgs &a0, int R, bool mod, int bk, hipStream_t s
         case 5: return a.colw ? band_launch_bk<2, true, true>(a, bk, stream) : band_launch_bk<2, true, false>(a, bk, stream);
         case 8: return band_launch_bk<4, false, false>(a, bk, stream);
         case 9: return a.colw ? band_launch_bk<4, true, true>(a, bk, stream) : band_launch_bk<4, true, false>(a, bk, stream);
+        default: return 2;
+    }
+}
+
+template <int R, bool MOD, bool CW>
+static int band_retry_launch(const BandArgs &a, const BandRetry &r, size_t nslots, hipStream_t stream) {
+    const size_t lds = (size_t)BAND_MAXW * 4 * (MOD ? 3 : 2) * WAVE * sizeof(float);
+    hipLaunchKernelGGL((crf_band_retry_kernel<R, MOD, CW>), dim3((unsigned)nslots), dim3(BAND_MAXW * WAVE), lds, stream, a, r);
+    return hipGetLastError() == hipSuccess ? 0 : 4;
+}
+
+int crf_band_retry_dispatch(const BandArgs &a, const BandRetry &r, int R, bool mod, size_t nslots, hipStream_t stream) {
+    if (a.W < 1 || a.W > BAND_MAXW || nslots == 0) return 2;
+    switch (R * 2 + (mod ? 1 : 0)) {
+        case 2: return band_retry_launch<1, false, false>(a, r, nslots, stream);
+        case 3: return a.colw ? band_retry_launch<1, true, true>(a, r, nslots, stream) : band_retry_launch<1, true, false>(a, r, nslots, stream);
+        case 4: return band_retry_launch<2, false, false>(a, r, nslots, stream);
+        case 5: return a.colw ? band_retry_launch<2, true, true>(a, r, nslots, stream) : band_retry_launch<2, true, false>(a, r, nslots, stream);
+        case 8: return band_retry_launch<4, false, false>(a, r, nslots, stream);
+        case 9: return a.colw ? band_retry_launch<4, true, true>(a, r, nslots, stream) : band_retry_launch<4, true, false>(a, r, nslots, stream);
         default: return 2;
     }
 }

@@ -44,6 +44,7 @@ struct CrfArgs {
     double *ckoff;              // workspace: checkpoint offsets
     uint32_t *status;
     const int *gate;            // nullable; (N): only reads with gate[n] != 0 are computed (the band path's rejects)
+    const int *gate2;           // nullable; (N): the retry launch's verdicts (crf_band.h: BandRetry) -- 0: that launch owns the read
     // behind a COST-ONLY band launch: the log2 scores of its two sweeps (null otherwise).  gate[n] == 2 then means
     // "pending": the read is the linear path's -- and its cost is written here -- iff both scores are finite and agree
     const double *bandF, *bandB;
@@ -564,14 +565,21 @@ __device__ __forceinline__ void crf_read(const CrfArgs &a, const int n, const in
 // Is read n one the linear band path disowned?  Grad calls: the gate array says so.  Cost-only calls leave
 // gate[n] == 2 ("pending") and the two sweep scores: the read is the linear path's iff both are finite and agree to
 // 1e-3 bit (the tolerance the gradient pass holds them to); `score2` = their mean then.
+// Returns 0: the batch's launch owns the read; -1: the retry launch does (round 6: it wrote the read's cost / gradient rows);
+// > 0: nobody on the linear path -- redone here.
 __device__ __forceinline__ int crf_band_gate_of(const CrfArgs &a, int n, double *score2) {
-    const int g = a.gate[n];
-    if (a.bandF == nullptr || g != 2) return g;
-    const double F = a.bandF[n], B = a.bandB[n], d = F - B;
-    if (!(F - F == 0.0 && B - B == 0.0)) return 1;              // overflow / nothing left: not representable
-    if (!(d > -1e-3 && d < 1e-3)) return 4;                     // mass lost on the way in one of them
-    *score2 = 0.5 * (F + B);
-    return 0;
+    int g = a.gate[n];
+    if (a.bandF != nullptr && g == 2) {
+        const double F = a.bandF[n], B = a.bandB[n], d = F - B;
+        if (!(F - F == 0.0 && B - B == 0.0)) g = 1;             // overflow / nothing left: not representable
+        else if (!(d > -1e-3 && d < 1e-3)) g = 4;               // mass lost on the way in one of them
+        else {
+            *score2 = 0.5 * (F + B);
+            return 0;
+        }
+    }
+    if (g != 0 && a.gate2 != nullptr && a.gate2[n] == 0) return -1;
+    return g;
 }
 
 template <int R, int W, bool MOD>
@@ -598,21 +606,21 @@ __global__ __launch_bounds__(W *WAVE) void crf_kernel(CrfArgs a) {
                 a.cost[n] = cst;
                 if (a.status && !isfinite(cst)) atomicOr(a.status, 1u);
             }
-            any |= __ballot(g != 0);
+            any |= __ballot(g > 0);
         }
         if (any == 0) return;
     }
     int seen = 0;
     for (int n = 0; n < a.N; ++n) {
         double unused;
-        if (crf_band_gate_of(a, n, &unused) == 0) continue;      // the linear band path owns this read
+        if (crf_band_gate_of(a, n, &unused) <= 0) continue;      // the linear band path owns this read
         if (seen % (int)gridDim.x == (int)blockIdx.x) {
             crf_read<R, W, MOD>(a, n, (int)blockIdx.x);
             __syncthreads();
         }
         ++seen;
     }
-    if (blockIdx.x == 0 && threadIdx.x == 0 && seen > 0 && a.status) atomicAdd(a.status, (uint32_t)min(seen, 0xffff) << 8);
+    if (blockIdx.x == 0 && threadIdx.x == 0 && seen > 0 && a.status) atomicAdd(a.status, (uint32_t)min(seen, 0xfff) << 8);
 }
 
 // ---------------------------------------------------------------------------
@@ -843,7 +851,13 @@ static size_t crf_redo_slots(size_t nbatch) {
     return s < nbatch ? s : nbatch;
 }
 
-// workspace = [band layout (band mode only)] [checkpoint columns + offsets of crf_kernel]
+// the retry launch's workspace (round 6): the band layout of 4-step blocks for crf_band_retry_slots(nbatch) reads (gradient
+// form whatever the call: a cost-only retry runs the same sweeps)
+static size_t crf_retry_bytes(size_t ntrans, size_t nblk, size_t nbatch, size_t max_seqlen) {
+    return crf_band_total_bound(ntrans, nblk, crf_band_retry_slots(nbatch), max_seqlen, true, 4);
+}
+
+// workspace = [band layout (band mode only)] [the retry launch's band layout] [checkpoint columns + offsets of crf_kernel]
 // `sharp`: the call's sharpening factor -- it picks the linear path's block length, and short blocks keep
 // more checkpoint columns.  The block lengths of the plain CRF and of cat-mod differ; the bound covers both.
 size_t crf_workspace_bytes_sharp(size_t ntrans, size_t nblk, size_t nbatch, size_t max_seqlen,
@@ -852,10 +866,12 @@ size_t crf_workspace_bytes_sharp(size_t ntrans, size_t nblk, size_t nbatch, size
     const CrfShape sh = crf_pick_shape(max_seqlen);
     // (every block length either form may take for this shape: with and without per-column factors; a batch with narrow
     // bands takes 8 steps where wider ones take 12)
-    const int bkp = crf_band_pick_block(sharp, false, max_seqlen, false, nblk).bk;
-    const int bkm0 = crf_band_pick_block(sharp, true, max_seqlen, false, nblk).bk, bkm1 = crf_band_pick_block(sharp, true, max_seqlen, true, nblk).bk;
-    const int bkm = (bkm0 > 0 && bkm1 > 0) ? (bkm0 < bkm1 ? bkm0 : bkm1) : (bkm0 > 0 ? bkm0 : bkm1);
-    const int bk = (bkp > 0 && bkm > 0) ? (bkp < bkm ? bkp : bkm) : (bkp > 0 ? bkp : bkm);
+    // (... and whatever the batch's bulk is: between "unknown" and "every read as long as the longest")
+    auto shortest = [](int x, int y) { return (x > 0 && y > 0) ? (x < y ? x : y) : (x > 0 ? x : y); };
+    int bk = 0;
+    for (int bulk = 0; bulk < 2; ++bulk)
+        for (int form = 0; form < 3; ++form)
+            bk = shortest(bk, crf_band_pick_block(sharp, form > 0, max_seqlen, form == 2, nblk, bulk ? max_seqlen : 0).bk);
     // (the cat-mod layout is the larger one: an upper bound for both)
     // (a call whose own block choice differs from the one assumed here -- another sharpening factor than the
     // query's -- needs what ITS factor's query returns; with less, crf_dispatch falls back to the log-domain
@@ -863,7 +879,7 @@ size_t crf_workspace_bytes_sharp(size_t ntrans, size_t nblk, size_t nbatch, size
     // sizing every workspace for that case would be 8.0 instead of 4.7 GB at T = 4000 / N = 256)
     if (crf_pick_mode(ntrans, nblk, nbatch, max_seqlen, want_grad != 0, bk) == CRF_BAND)
         return crf_ckpt_bytes(nblk, crf_redo_slots(nbatch), sh, want_grad != 0) +
-               crf_band_total_bound(ntrans, nblk, nbatch, max_seqlen, want_grad != 0, bk);
+               crf_band_total_bound(ntrans, nblk, nbatch, max_seqlen, want_grad != 0, bk) + crf_retry_bytes(ntrans, nblk, nbatch, max_seqlen);
     return crf_ckpt_bytes(nblk, nbatch, sh, want_grad != 0);
 }
 
@@ -921,10 +937,20 @@ int crf_dispatch(const float *logprob, size_t ntrans, size_t nblk, size_t nbatch
     // the linear path's block length for this sharpening factor; when the workspace the caller brought is
     // too small for it (sized without the factor: tk_crf_flipflop_workspace_bytes) but large enough for the
     // log-domain kernel on every read, that kernel does the call
-    BandBlock blk = crf_band_pick_block(sharp_can, mod, max_seqlen, mod && mod_col_weights != nullptr, nblk);
+    BandBlock blk = crf_band_pick_block(sharp_can, mod, max_seqlen, mod && mod_col_weights != nullptr, nblk,
+                                        labels != nullptr ? labels->bulk_seqlen : 0);
     bool band = crf_pick_mode(ntrans, nblk, nbatch, max_seqlen, grad != nullptr, blk.bk) == CRF_BAND;
-    if (band && crf_ckpt_bytes(nblk, crf_redo_slots(nbatch), sh, grad != nullptr) +
-                        crf_band_layout(ntrans, nblk, nbatch, max_seqlen, mod, grad != nullptr, blk.bk).total > workspace_bytes)
+    // the second chance for what the batch's launch disowns (round 6); left out when the workspace the caller brought has no
+    // room for it (sized by an older query): such reads go straight to the log-domain kernel, as in round 5
+    BandBlock rblk = band ? crf_band_pick_retry(sharp_can, blk) : BandBlock{0, 0.f, 0};
+    const size_t retry_slots = crf_band_retry_slots(nbatch);
+    const size_t band_bytes = band ? crf_band_layout(ntrans, nblk, nbatch, max_seqlen, mod, grad != nullptr, blk.bk).total : 0;
+    size_t retry_bytes = (band && rblk.bk > 0) ? crf_band_layout(ntrans, nblk, retry_slots, max_seqlen, mod, true, rblk.bk).total : 0;
+    if (band && crf_ckpt_bytes(nblk, crf_redo_slots(nbatch), sh, grad != nullptr) + band_bytes + retry_bytes > workspace_bytes) {
+        rblk.bk = 0;
+        retry_bytes = 0;
+    }
+    if (band && crf_ckpt_bytes(nblk, crf_redo_slots(nbatch), sh, grad != nullptr) + band_bytes > workspace_bytes)
         band = false;
     if (!band && crf_ckpt_bytes(nblk, nbatch, sh, grad != nullptr) > workspace_bytes) return 3;
     if (labels != nullptr && !band) {
@@ -960,7 +986,7 @@ int crf_dispatch(const float *logprob, size_t ntrans, size_t nblk, size_t nbatch
     a.add_scale = add_scale;
     a.cost = cost;
     a.grad = grad;
-    a.gate = nullptr;
+    a.gate = a.gate2 = nullptr;
     a.bandF = a.bandB = nullptr;
     a.band_wbias = 0.f;
     a.codes = a.mod_cats = a.cmo = nullptr;
@@ -1016,6 +1042,7 @@ int crf_dispatch(const float *logprob, size_t ntrans, size_t nblk, size_t nbatch
         b.rec = g ? reinterpret_cast<uint32_t *>(wb + l.rec) : nullptr;
         b.segend = g ? reinterpret_cast<int *>(wb + l.segend) : nullptr;
         b.gate = reinterpret_cast<int *>(wb + l.gate);
+        b.gate2 = rblk.bk > 0 ? reinterpret_cast<int *>(wb + l.gate2) : nullptr;
         b.zeros = reinterpret_cast<const float *>(wb + l.zeros);
         b.dbg = nullptr;
         b.before_gradient = add_ready;
@@ -1031,6 +1058,53 @@ int crf_dispatch(const float *logprob, size_t ntrans, size_t nblk, size_t nbatch
         b.nbase = labels != nullptr ? (int)labels->nbase : 0;
         const int rc = crf_band_dispatch(b, l.R, mod, blk.bk, stream);
         if (rc != 0) return rc;
+        if (rblk.bk > 0) {
+            // the reads the batch's launch disowned, once more on the linear path: alone, 4-step blocks, steep frames
+            const BandLayout q = crf_band_layout(ntrans, nblk, retry_slots, max_seqlen, mod, true, rblk.bk);
+            char *wr = wb + l.total;
+            BandArgs c = b;
+            c.ckFm = reinterpret_cast<float *>(wr + q.ckFm);
+            c.ckBm = reinterpret_cast<float *>(wr + q.ckBm);
+            c.ckFf = reinterpret_cast<int16_t *>(wr + q.ckFf);
+            c.ckBf = reinterpret_cast<int16_t *>(wr + q.ckBf);
+            c.ckFb = reinterpret_cast<int *>(wr + q.ckFb);
+            c.ckBb = reinterpret_cast<int *>(wr + q.ckBb);
+            c.bndF = reinterpret_cast<float *>(wr + q.bndF);
+            c.bndB = reinterpret_cast<float *>(wr + q.bndB);
+            c.scoreF = reinterpret_cast<double *>(wr + q.scoreF);
+            c.scoreB = reinterpret_cast<double *>(wr + q.scoreB);
+            c.rec = reinterpret_cast<uint32_t *>(wr + q.rec);
+            c.segend = reinterpret_cast<int *>(wr + q.segend);
+            c.gate = nullptr;
+            c.gate2 = nullptr;
+            c.wbias = rblk.wbias;
+            c.klip = rblk.klip;
+            // (the offsets and -- a call that brought index arrays -- the ids are the batch launch's; a launch that
+            // built its ids from the labels left seqoff behind and the retry forms its ids from the codes as well)
+            BandRetry r;
+            r.gate = b.gate;
+            r.gate2 = b.gate2;
+            r.firstF = g ? nullptr : b.scoreF;
+            r.firstB = g ? nullptr : b.scoreB;
+            if (q.R != l.R || q.W != l.W) return 2;
+            const int rr = crf_band_retry_dispatch(c, r, l.R, mod, retry_slots, stream);
+            if (rr != 0) return rr;
+            if (TK_LAB_ENV("TK_CRF_GATE_DUMP")) {
+                (void)hipStreamSynchronize(stream);
+                static int h1[1 << 16], h2[1 << 16];
+                const size_t ng = nbatch < (1u << 16) ? nbatch : (1u << 16);
+                (void)hipMemcpy(h1, b.gate, ng * sizeof(int), hipMemcpyDeviceToHost);
+                (void)hipMemcpy(h2, b.gate2, ng * sizeof(int), hipMemcpyDeviceToHost);
+                size_t tried = 0, kept = 0;
+                for (size_t i = 0; i < ng; ++i) {
+                    tried += h2[i] != -1;
+                    kept += h2[i] == 0;
+                }
+                fprintf(stderr, "crf band retry (bk %d, bias %.1f, slope %d): %zu reads retried, %zu kept\n", rblk.bk, rblk.wbias, rblk.klip, tried, kept);
+                for (size_t i = 0, shown = 0; i < ng && shown < 16; ++i)
+                    if (h2[i] > 0) fprintf(stderr, "crf band retry:   read %zu first %d retry %d\n", i, h1[i], h2[i]), ++shown;
+            }
+        }
         if (TK_LAB_ENV("TK_CRF_GATE_DUMP")) {                       // lab: how many reads did the band path disown?
             (void)hipStreamSynchronize(stream);
             static int hostg[1 << 16];
@@ -1048,6 +1122,7 @@ int crf_dispatch(const float *logprob, size_t ntrans, size_t nblk, size_t nbatch
         }
         // the reads the linear path disowned, redone in the log domain
         a.gate = b.gate;
+        a.gate2 = b.gate2;
         a.codes = b.codes;      // (ids from the labels wherever the band launch took them: it wrote no index array)
         a.mod_cats = b.mod_cats;
         a.cmo = b.cmo;
@@ -1058,7 +1133,7 @@ int crf_dispatch(const float *logprob, size_t ntrans, size_t nblk, size_t nbatch
             a.bandB = b.scoreB;
             a.band_wbias = blk.wbias;
         }
-        wb += l.total;
+        wb += l.total + retry_bytes;
         if (const char *e = TK_LAB_ENV("TK_CRF_NO_FALLBACK"))       // lab: time / test the band path alone
             if (e[0] == '1') return 0;
     }

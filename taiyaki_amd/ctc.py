@@ -38,7 +38,8 @@ def _indices(seqs, seqlen, nbase, device, mod_cats=None, can_mods_offsets=None,
         mod = torch.empty(max(total, 1), dtype=torch.int32, device=device)
         fact = torch.empty(max(total, 1), dtype=torch.float32, device=device)
     if defer:
-        labels = _lib.SeqLabels(_lib.ptr(seqs_d), total, nbase, _lib.ptr(mc), _lib.ptr(cmo), _lib.ptr(mcw))
+        labels = _lib.SeqLabels(_lib.ptr(seqs_d), total, nbase, _lib.ptr(mc), _lib.ptr(cmo), _lib.ptr(mcw),
+                                _bulk_seqlen(seqlen))
         return seqlen_d, seqoff, stay, move, mod, fact, (seqs_d, mc, cmo, mcw), labels
     rc = L.tk_flipflop_build_indices_dev(
         _lib.ptr(seqs_d), _lib.ptr(seqlen_d), nbatch, total, nbase, _lib.ptr(mc),
@@ -98,15 +99,42 @@ def _workspace(nbytes, dev, tag):
 
 release_workspaces = _lib.release_workspaces
 last_gate_count = _lib.last_gate_count
+last_retry_count = _lib.last_retry_count
 
 
-def set_max_seqlen(seqlen, value):
+def set_max_seqlen(seqlen, value, bulk=None):
     """Whoever assembles a batch knows its longest sequence on the host (bin/train_flipflop.py:133-138
     builds `seqlens` from Python lists); a `seqlens` tensor that lives on the device carries that
     number along as an attribute, so that the CRF launch is sized by it without a device sync
-    (mapped_signal.sample_chunks, bench.make_batches, the graph trainers' static buffers)."""
+    (mapped_signal.sample_chunks, bench.make_batches, the graph trainers' static buffers).
+    `bulk` (round 6, optional): a length all but a few of the batch's reads -- a sixteenth -- stay below
+    (`bulk_of`); it picks the launch's block configuration (tk_seq_labels.bulk_seqlen).  Unknown: the fast
+    configuration, and the few reads it may disown are retried one by one."""
     seqlen.tk_max_seqlen = int(value)
+    seqlen.tk_bulk_seqlen = None if bulk is None else int(bulk)
     return seqlen
+
+
+def bulk_of(lengths):
+    """The batch's BULK length from its lengths on the host: the longest read once the longest sixteenth of the
+    batch (at least one read) is set aside -- those few are what the retry launch has slots for."""
+    a = np.sort(np.asarray(lengths).reshape(-1))
+    if a.size == 0:
+        return 0
+    return int(a[max(0, a.size - 1 - max(1, a.size // 16))])
+
+
+def _bulk_seqlen(seqlen):
+    """tk_seq_labels.bulk_seqlen for this call: from the lengths where they live on the host, the hint of
+    `set_max_seqlen` where they carry one, else 0 (unknown) -- never a device sync."""
+    if not seqlen.numel():
+        return 0
+    if hasattr(seqlen, "tk_max_seqlen"):
+        hint = getattr(seqlen, "tk_bulk_seqlen", None)
+        return 0 if hint is None else int(hint)
+    if seqlen.is_cuda:
+        return 0
+    return bulk_of(seqlen.numpy())
 
 
 def _max_seqlen(seqlen):

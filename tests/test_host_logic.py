@@ -445,7 +445,9 @@ def test_crf_workspace_is_sized_for_what_runs():
     rowk = L.tk_crf_flipflop_workspace_bytes(40, 4000, 256, 2198, 1)
     # (round 5: 116 MB at the step's shape -- the query bounds the plain CRF's two-cells-per-lane layout, padded to 640 cells
     # per read, and cat-mod's one-cell layout with its third instance array, whichever is larger; round 4: 106 MB)
-    assert step < 120 * MB and rowk < 4800 * MB, (step / MB, rowk / MB)
+    # (round 6: + the retry launch's 4-step layout for a sixteenth of the batch: 116 -> 128 MB, 4.7 -> 5.1 GB; a cost-only call
+    # carries it too -- 12 MB at the step's shape)
+    assert step < 132 * MB and rowk < 5200 * MB, (step / MB, rowk / MB)
     assert L.tk_crf_flipflop_workspace_bytes_sharp(40, 800, 128, 533, 1, 1.0) == step
     s2 = L.tk_crf_flipflop_workspace_bytes_sharp(40, 800, 128, 533, 1, 2.0)
     assert step < s2 < 2 * step + 64 * MB
@@ -457,19 +459,20 @@ def test_crf_workspace_is_sized_for_what_runs():
 
 
 def test_gate_count_is_read_unsigned_and_taken_out_exactly():
-    """Round-4 advisor finding: the status words are int32 tensors, the kernels add the count of redone reads into
-    bits 8-31 -- 2^23 or more read back negative; and the count was cleared with an AND of whatever the word held
-    by then.  Read as uint32; take out exactly what was read (flags and later counts stay)."""
+    """Round-4 advisor finding: the status words are int32 tensors, the kernels add their counts into bits 8-31 --
+    2^23 or more read back negative; and the count was cleared with an AND of whatever the word held by then.  Read
+    as uint32; take out exactly what was read (flags and later counts stay).  Round 6: two counts of 12 bits -- reads
+    redone in the log domain (bits 8-19) and reads retried on the linear path (bits 20-31)."""
     from taiyaki_amd import _lib
     was = _lib.is_strict()
     try:
         _lib.set_strict(False)
         t = _lib.status_word(torch.device("cpu"))
-        t.fill_(-(1 << 31) + (5 << 8) + 2)              # count 2^23 + 5, flag 2 (gradients not finite)
-        assert _lib.take_gate_count() == (1 << 23) + 5 == _lib.last_gate_count()
+        t.fill_(-(1 << 31) + (7 << 20) + (5 << 8) + 2)  # 2^11 + 7 retried, 5 redone, flag 2 (gradients not finite)
+        assert _lib.take_gate_count() == 5 == _lib.last_gate_count() and _lib.last_retry_count() == (1 << 11) + 7
         assert int(t.item()) == 2
-        t.add_(3 << 8)
-        assert _lib.take_gate_count() == 3
+        t.add_((3 << 8) + (4 << 20))
+        assert _lib.take_gate_count() == 3 and _lib.last_retry_count() == 4
         with pytest.raises(AssertionError, match="Gradients not finite"):
             _lib.raise_if_nonfinite()
         assert int(t.item()) == 0

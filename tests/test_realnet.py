@@ -154,7 +154,7 @@ def test_hip_catmod_on_real_scores_stays_on_the_linear_path(oracle_mod, gpu_devi
     assert r["finite"] and r["loss_rel"] < 1e-5, r["loss_rel"]
     assert parity.crf_grad_ok(r), (r["grad_f64_scaled"], r["grad_scaled_abs"], r["ref_noise_scaled"])
     k = "%s/catmod_s%d" % (tag, int(sharp))
-    if k + "_loss" in gold.files:
+    if sharp == int(sharp):                 # (the genuine reference's numbers are held for 1.0 and 2.0)
         assert parity.rel_err(r["loss"], gold[k + "_loss"]) < 1e-5
         _check_grad(gold, k + "_grad", r["grad"] * parity.posterior_scale(inp), inp["scores"].shape[0], scaled=inp)
 

@@ -25,5 +25,30 @@ for T in (800, 1600):
             else:
                 c, g = ctc._run(x, seqs, sl, 1.0, 1.0, 1.0, 40, True)
             torch.cuda.synchronize()
-            row.append("%.2f:%d" % (frac, ctc.last_gate_count()))
-        print("T %d %s  gated of 64 by L/T  %s" % (T, "cat-mod" if mods else "plain  ", "  ".join(row)), flush=True)
+            row.append("%.2f:%d/%d" % (frac, ctc.last_gate_count(), ctc.last_retry_count()))
+        print("T %d %s  of 64, by L/T: redone in the log domain / retried on the linear path  %s" % (T, "cat-mod" if mods else "plain  ", "  ".join(row)), flush=True)
+# a batch of ordinary reads with ONE (and with four) long ones: the batch keeps its fast configuration, the long reads are retried
+import time
+for T, N in ((800, 128),):
+    for mods in (None, (1, 1, 0, 0)):
+        for nlong, frac in ((0, 0.0), (1, 0.86), (1, 0.9), (4, 0.9), (8, 0.9)):
+            Ls = synth.realistic_seqlens(T, N, 17000, T * 5, 9.0).copy()
+            Ls[:nlong] = int(frac * T)
+            inp = synth.crf_case(T, N, 3, seqlens=Ls, nmods_per_base=mods)
+            if mods is not None:
+                synth.normalise_mod_columns(inp)
+            x = torch.from_numpy(inp["scores"]).to(dev)
+            seqs, sl = torch.from_numpy(inp["seqs"]), torch.from_numpy(inp["seqlens"])
+            extra = (torch.from_numpy(inp["mod_cats"]), inp["can_mods_offsets"], inp["mod_cat_weights"]) if mods is not None else ()
+            def call():
+                return ctc._run(x, seqs, sl, 1.0, 1.0, 1.0, 40, True, *extra)
+            call(); torch.cuda.synchronize()
+            g, r = ctc.last_gate_count(), ctc.last_retry_count()
+            _lib.set_strict(False)
+            for _ in range(3): call()
+            torch.cuda.synchronize(); t0 = time.perf_counter()
+            for _ in range(20): call()
+            torch.cuda.synchronize(); dt = (time.perf_counter() - t0) / 20
+            _lib.take_gate_count(); _lib.set_strict(True)
+            print("T %d N %d %s  %d reads of %.2f T among ordinary ones (longest %d): redone %d retried %d, operator call %.0f us (host-inclusive)"
+                  % (T, N, "cat-mod" if mods else "plain  ", nlong, frac, int(Ls.max()), g, r, dt * 1e6), flush=True)

@@ -378,12 +378,13 @@ __device__ __forceinline__ void band_offset_of(const BandArgs &a, int n, long lo
 
 template <int R, bool MOD, bool FWD, bool GRAD, bool ROWS, bool CW, int BK, bool PRE4 = false>
 __device__ __forceinline__ void band_sweep(const BandArgs &a, int n, int ws, int L, int64_t off, float *E, int *Ef, const float *Ezero,
-                                           const f4 *Wt) {
+                                           const f4 *Wt, const int wofs = 0) {
     // `n`: the read (scores, labels); `ws`: its slot in the workspace arrays -- n for the batch's launch, the
     // workgroup's own slot for the retry launch (crf_band_retry_kernel), whose arrays hold a few reads only
     constexpr int PW = R * WAVE;
     // the wave index is wave-uniform: keep everything derived from it in SGPRs
-    const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & (WAVE - 1);
+    // (`wofs`: the workgroup's first wave of THIS sweep -- 0 but in the retry launch, whose two sweeps share a workgroup)
+    const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6) - wofs, lane = threadIdx.x & (WAVE - 1);
     const int N = a.N, T = a.T, S = a.S, W = a.W;
     const int a0 = w * PW;
     const int NB = (T + BK - 1) / BK, NPH = NB + W - 1;
@@ -1681,8 +1682,8 @@ template <int R, bool MOD, bool CW>
 __global__ __launch_bounds__(BAND_MAXW *WAVE) void crf_band_retry_kernel(BandArgs a, BandRetry r) {
     constexpr int BK = 4, PW = R * WAVE, KINDS = MOD ? 3 : 2;
     extern __shared__ __attribute__((aligned(16))) char retry_dyn_lds[];    // the gradient pass's rows: 16 waves x BK x KINDS x 64 floats
-    __shared__ __attribute__((aligned(16))) float E[BAND_MAXW * 2 * BK];
-    __shared__ int Ef[BAND_MAXW * 2];
+    __shared__ __attribute__((aligned(16))) float E[2][BAND_MAXW * 2 * BK];    // (a ring per sweep)
+    __shared__ int Ef[2][BAND_MAXW * 2];
     __shared__ __attribute__((aligned(16))) float Ezero[BK];
     __shared__ int why_sh;
     const int tid = threadIdx.x, lane = tid & (WAVE - 1);
@@ -1715,9 +1716,18 @@ __global__ __launch_bounds__(BAND_MAXW *WAVE) void crf_band_retry_kernel(BandArg
         }
         band_rank<MOD>(a, ws, L, off, w, nwaves);
         __syncthreads();
-        band_sweep<R, MOD, true, true, false, CW, BK>(a, n, ws, L, off, E, Ef, Ezero, nullptr);
-        __syncthreads();
-        band_sweep<R, MOD, false, true, false, CW, BK>(a, n, ws, L, off, E, Ef, Ezero, nullptr);
+        if (2 * a.W <= nwaves) {
+            // both sweeps at once: waves [0, W) forward, [W, 2 W) backward -- the same number of phases, hence of barriers;
+            // the rest of the workgroup keeps them company
+            if (w < a.W) band_sweep<R, MOD, true, true, false, CW, BK>(a, n, ws, L, off, E[0], Ef[0], Ezero, nullptr);
+            else if (w < 2 * a.W) band_sweep<R, MOD, false, true, false, CW, BK>(a, n, ws, L, off, E[1], Ef[1], Ezero, nullptr, a.W);
+            else
+                for (int ph = 0; ph < NB + a.W - 1; ++ph) band_barrier();
+        } else {
+            band_sweep<R, MOD, true, true, false, CW, BK>(a, n, ws, L, off, E[0], Ef[0], Ezero, nullptr);
+            __syncthreads();
+            band_sweep<R, MOD, false, true, false, CW, BK>(a, n, ws, L, off, E[1], Ef[1], Ezero, nullptr);
+        }
         // what the sweeps and the ranking left in the workspace is read by OTHER waves of this workgroup below: release,
         // barrier, acquire (a slot's lines may sit in this CU's vector cache from the read before)
         __threadfence();
@@ -1826,8 +1836,8 @@ BandBlock crf_band_pick_retry(float sharp, BandBlock fast) {
     float bias = 0.f;
     int klip = 20;
     if (g + 20.f > 31.4f) {
-        const float need = g + 20.f - 31.4f, bmax = fmaxf(0.f, 30.5f - g);
-        bias = floorf(2.f * fminf(need, bmax)) * 0.5f;
+        const float need = ceilf(2.f * (g + 20.f - 31.4f)) * 0.5f, bmax = floorf(2.f * fmaxf(0.f, 30.5f - g)) * 0.5f;
+        bias = fminf(need, bmax);
         klip = min(20, (int)floorf(31.4f - g + bias));
     }
     if (const char *e = TK_LAB_ENV("TK_CRF_RETRY_KLIP")) klip = atoi(e);

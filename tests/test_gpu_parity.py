@@ -813,6 +813,10 @@ def test_index_build_inside_the_launch_changes_no_bit(gpu_device, catmod, monkey
         extra = (torch.from_numpy(inp["mod_cats"]), inp["can_mods_offsets"], inp["mod_cat_weights"])
     x = torch.from_numpy(inp["scores"]).to(gpu_device)
     seqs, sl = torch.from_numpy(inp["seqs"]), torch.from_numpy(inp["seqlens"])
+    # (round 6: the labels entry points also take the batch's BULK length, which picks the block configuration; the entry
+    # points that take index arrays do not -- the comparison is between two index builds under ONE configuration, so the
+    # lengths carry their maximum and no bulk)
+    sl = ctc.set_max_seqlen(sl, int(seqlens.max()))
 
     def run_all():
         out = []
@@ -978,8 +982,16 @@ def test_crf_disowned_reads_are_counted_and_redone_in_shared_slots(oracle_mod, g
     r = parity.compare_crf(oracle_mod, inp, 1.0, gpu_device)
     assert r["finite"] and parity.crf_loss_ok(r), (r["loss_rel"], r["loss_abs"])
     assert parity.crf_grad_ok(r), (r["grad_f64_scaled"], r["grad_scaled_abs"], r["ref_noise_scaled"])
+    # round 6: the retry launch sweeps the disowned reads again, alone and at 4 steps / slope 20, in the 4 slots 40 reads
+    # get (its workgroups loop) -- it keeps most of them; what it disowns too is redone in the log domain
+    retried, redone = ctc.last_retry_count(), ctc.last_gate_count()
+    assert 10 <= retried <= 30 and redone < retried, (retried, redone)
+    # ... and without the retry launch (lab switch): all of them go to the log-domain kernel
+    labenv.setenv("TK_CRF_NO_RETRY", "1")
+    r = parity.compare_crf(oracle_mod, inp, 1.0, gpu_device)
+    assert r["finite"] and parity.crf_loss_ok(r) and parity.crf_grad_ok(r), (r["loss_rel"], r["grad_f64_scaled"])
     gated = ctc.last_gate_count()
-    assert 10 <= gated <= 30, gated                # (more than the 5 slots 40 reads get: workgroups looped)
+    assert 10 <= gated <= 30 and gated == retried and ctc.last_retry_count() == 0, (gated, retried)    # (more than the 5 slots 40 reads get: workgroups looped)
     # non-strict mode: the count accumulates in the deferred word until somebody looks
     _lib.set_strict(False)
     try:

@@ -36,6 +36,7 @@ SHAPES = {
     "sharp13": (800, "real32", 1.3, None), "sharp15": (800, "real32", 1.5, None), "sharp17": (800, "real32", 1.75, None),
     "sharp2": (800, "real32", 2.0, None), "sharp3": (800, "real32", 3.0, None), "sharp4": (800, "real32", 4.0, None),
     "sharp2K": (4000, "speed16", 2.0, None), "cfg4sharp2": (800, "real32", 2.0, (1, 1, 0, 0)),
+    "cfg4sharp25": (800, "real32", 2.5, (1, 1, 0, 0)), "cfg4sharp3": (800, "real32", 3.0, (1, 1, 0, 0)),
     "cfg4": (800, "speed128", 1.0, (1, 1, 0, 0)),
     "cfg4w1": (800, "speed128", 1.0, (1, 1, 0, 0)),
     "cfg4r": (800, "real128", 1.0, (1, 1, 0, 0)),
@@ -73,7 +74,7 @@ def realnet_case(spec):
 
 
 def run(x, seqs, seqlens, sharp, extra, env):
-    for k in ("TK_CRF_MODE", "TK_CRF_NO_FALLBACK"):
+    for k in ("TK_CRF_MODE", "TK_CRF_NO_FALLBACK", "TK_CRF_NO_RETRY"):
         os.environ.pop(k, None)
     os.environ.update(env)
     # poison what the caching allocator will hand out for the outputs: a read nobody computes shows as NaN

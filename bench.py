@@ -852,6 +852,29 @@ def direct_leg(args, arena, comm, rank, world, dev, timed_steps, event_time_us, 
     try:
         coll = parallel.DirectRccl(rank, world, exchange=lambda b: parallel.socket_rendezvous(
             rank, world, b, nbytes=len(b) if b is not None else 128), device=dev)
+        # (a) the two transports on the SAME seeded gradients, bit for bit: one ProcessGroupNCCL all-reduce against one
+        #     tk_allreduce_f32_dev of a copy (RCCL's ring order is a function of the communicator: two communicators over
+        #     the same devices may sum in another order -- `max_abs_diff` then says how far apart, `equal` whether at all)
+        equal = None
+        try:
+            import torch.distributed as dist
+            if dist.is_initialized():
+                gen = torch.Generator(device=dev).manual_seed(4242 + rank)
+                seeded = torch.randn(arena.flat.numel(), generator=gen, device=dev, dtype=torch.float32)
+                via_pg, via_abi = seeded.clone(), seeded.clone()
+                dist.all_reduce(via_pg, op=dist.ReduceOp.SUM)
+                coll.all_reduce(via_abi).wait()
+                torch.cuda.synchronize()
+                same = float(torch.equal(via_pg, via_abi))
+                diff = float((via_pg - via_abi).abs().max())
+                # ... and every rank holds the same sum (first / last rank's checksum against this one's)
+                csum = float(via_abi.double().sum())
+                sums = comm.gather(csum)
+                equal = dict(equal=bool(min(comm.gather(same)) == 1.0), max_abs_diff=max(comm.gather(diff)),
+                             ranks_agree=bool(max(sums) == min(sums)), elements=int(seeded.numel()))
+                del seeded, via_pg, via_abi
+        except Exception as exc:      # noqa: BLE001 -- report, never hide
+            equal = dict(failed="%s: %s" % (type(exc).__name__, str(exc)[:200]))
         arena.collective, saved_world = coll, arena.world
         try:
             us = event_time_us(lambda: arena._all_reduce(arena.flat).wait(), 20)
@@ -864,6 +887,8 @@ def direct_leg(args, arena, comm, rank, world, dev, timed_steps, event_time_us, 
                    allreduce_us=round(float(np.mean(us)), 1), allreduce_min_us=round(us[0], 1),
                    ms_per_step=round(el / args.steps * 1e3, 3), value=round(nbatch * world * args.steps / el, 2),
                    steps=args.steps)
+        if equal is not None:
+            out["vs_process_group"] = equal
         torch.cuda.synchronize()
         coll.close()
         return out
@@ -1183,6 +1208,18 @@ def main():
                           "hooks on RCCL's high-priority stream" % len(arena._buckets) if arena._buckets else
                           "one flat fp32 gradient arena, reduced by ONE all-reduce after backward"))
         rccl["debug"] = rccl_debug_summary()
+        # (b) every rank started from rank 0's weights: the parameters' checksum per rank after the timed steps (identical
+        #     gradients after the all-reduce + identical optimiser steps keep them identical; any difference is a lost or
+        #     reordered collective); (c) where each rank's host thread ran
+        psum = float(sum(float(p.detach().double().sum()) for p in net.parameters()))
+        sums = comm.gather(psum) if comm.active else [psum]
+        rccl["param_checksum"] = dict(all=[float(v) for v in sums], ranks_agree=bool(max(sums) == min(sums)))
+        spread = per_rank["max"] - per_rank["min"]
+        rccl["per_rank_spread_ms"] = round(spread, 3)
+        try:
+            rccl["host_cores_rank0"] = sorted(os.sched_getaffinity(0))[:64]
+        except (AttributeError, OSError):
+            rccl["host_cores_rank0"] = None
 
     if rank == 0:
         nglobal = nbatch * world

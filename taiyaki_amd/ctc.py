@@ -22,21 +22,32 @@ def _indices(seqs, seqlen, nbase, device, mod_cats=None, can_mods_offsets=None,
     entry point builds them inside its first launch (round 5: one launch less per call)."""
     L = _lib.lib()
     seqs_d = seqs.to(device=device, dtype=torch.int32, non_blocking=True).contiguous()
-    if seqs_d.numel() == 0:
-        seqs_d = torch.zeros(1, dtype=torch.int32, device=device)[:0]       # (a pointer for the C ABI; nothing reads it)
+    # (an empty batch of labels: data_ptr() of an empty tensor is NULL, and the C side takes seqs == NULL with total_len == 0)
     seqlen_d = seqlen.to(device=device, dtype=torch.int32, non_blocking=True).contiguous()
     nbatch = seqlen_d.numel()
     total = seqs_d.numel()
     seqoff = torch.empty(nbatch + 1, dtype=torch.int64, device=device)
-    stay = torch.empty(max(total, 1), dtype=torch.int32, device=device)
-    move = torch.empty(max(total, 1), dtype=torch.int32, device=device)
+    narr = 4 if mod_cats is not None else 2
+    if defer:
+        # the index arrays are SCRATCH of the labels entry points (written only by calls the linear path does not take):
+        # views of one cached per-(device, stream) buffer instead of up to four allocations per call
+        cap = max(total, 1)
+        scratch = _workspace(narr * cap * 4, device, "idx")
+        arrs = [scratch[k * cap * 4:(k + 1) * cap * 4] for k in range(narr)]
+        stay, move = arrs[0].view(torch.int32), arrs[1].view(torch.int32)
+    else:
+        stay = torch.empty(max(total, 1), dtype=torch.int32, device=device)
+        move = torch.empty(max(total, 1), dtype=torch.int32, device=device)
     mod = fact = mc = cmo = mcw = None
     if mod_cats is not None:
         mc = mod_cats.to(device=device, dtype=torch.int32, non_blocking=True).contiguous()
         cmo = _device_constant(can_mods_offsets, torch.int32, device)
         mcw = _device_constant(mod_cat_weights, torch.float32, device)
-        mod = torch.empty(max(total, 1), dtype=torch.int32, device=device)
-        fact = torch.empty(max(total, 1), dtype=torch.float32, device=device)
+        if defer:
+            mod, fact = arrs[2].view(torch.int32), arrs[3].view(torch.float32)
+        else:
+            mod = torch.empty(max(total, 1), dtype=torch.int32, device=device)
+            fact = torch.empty(max(total, 1), dtype=torch.float32, device=device)
     if defer:
         labels = _lib.SeqLabels(_lib.ptr(seqs_d), total, nbase, _lib.ptr(mc), _lib.ptr(cmo), _lib.ptr(mcw),
                                 _bulk_seqlen(seqlen))
@@ -84,13 +95,19 @@ def _col_weights(keep, mod):
     """The `mod_col_weights` argument of the C entry points: the device copy of `mod_cat_weights` that
     `tk_flipflop_build_indices_dev` filled `modfact` from -- the promise that a move's factor is a
     property of its modification column, which lets the kernels exponentiate a row once per wave.
-    TK_CATMOD_GENERAL=1 withholds it (lab / tests: the general per-position form)."""
-    if mod is None or os.environ.get("TK_CATMOD_GENERAL"):
+    TK_CATMOD_GENERAL=1 withholds it (lab build only / tests: the general per-position form)."""
+    if mod is None or _lab_switch("TK_CATMOD_GENERAL"):
         return None
     return _lib.ptr(keep[3])
 
 
 _KEEP_WS = None      # debugging aid: set to a list to keep the kernels' workspaces alive
+
+
+def _lab_switch(name):
+    """A dispatch switch of this module (TK_CATMOD_GENERAL, TK_SEPARATE_INDEX_BUILD): read from the environment only
+    while the process runs on the lab build -- like the kernels' own switches, the release path reads none."""
+    return bool(_lib.is_lab() and os.environ.get(name))
 
 
 def _workspace(nbytes, dev, tag):
@@ -165,7 +182,7 @@ def _run(logprob, seqs, seqlen, sharp_can, sharp_mod, out_scale, ncan, want_grad
         status = _lib.status_word(dev)
         # TK_CATMOD_GENERAL=1 / TK_SEPARATE_INDEX_BUILD=1 (lab / tests): the stand-alone index kernel and the
         # entry point that takes its arrays; default: the index build rides in the operator's first launch
-        separate = bool(os.environ.get("TK_CATMOD_GENERAL") or os.environ.get("TK_SEPARATE_INDEX_BUILD"))
+        separate = _lab_switch("TK_CATMOD_GENERAL") or _lab_switch("TK_SEPARATE_INDEX_BUILD")
         res = _indices(seqs, seqlen, nbase, dev, mod_cats, can_mods_offsets, mod_cat_weights, status, defer=not separate)
         seqlen_d, seqoff, stay, move, mod, fact, keep = res[:7]
         maxlen = _max_seqlen(seqlen)
@@ -366,7 +383,7 @@ def _run_fused(outputs, seqs, seqlen, sharpfact, want_grad, grad_scale=1.0, grad
     dev = lp.device
     with torch.cuda.device(dev):
         status = _lib.status_word(dev)
-        separate = bool(os.environ.get("TK_CATMOD_GENERAL") or os.environ.get("TK_SEPARATE_INDEX_BUILD"))
+        separate = _lab_switch("TK_CATMOD_GENERAL") or _lab_switch("TK_SEPARATE_INDEX_BUILD")
         res = _indices(seqs, seqlen, nbase, dev, mod_cats, can_mods_offsets, mod_cat_weights, status=status,
                        defer=not separate)
         seqlen_d, seqoff, stay, move, mod, fact, keep = res[:7]

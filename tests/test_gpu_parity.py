@@ -795,7 +795,7 @@ def test_catmod_column_weights_form_agrees_with_the_general_form(oracle_mod, gpu
 
 
 @pytest.mark.parametrize("catmod", [False, True])
-def test_index_build_inside_the_launch_changes_no_bit(gpu_device, catmod, monkeypatch):
+def test_index_build_inside_the_launch_changes_no_bit(gpu_device, catmod, labenv):
     """Round 5: the operators hand the flip-flop codes to `tk_crf_flipflop_labels_dev` /
     `tk_flipflop_loss_fused_labels_dev`, whose sweep workgroups form their ids from the codes themselves (the rank
     workgroups leave the index arrays for the launches behind) -- one launch less than
@@ -829,9 +829,10 @@ def test_index_build_inside_the_launch_changes_no_bit(gpu_device, catmod, monkey
         torch.cuda.synchronize()
         return out + [lv.cpu().numpy(), g.cpu().numpy(), lz.cpu().numpy()]
 
-    monkeypatch.delenv("TK_SEPARATE_INDEX_BUILD", raising=False)
+    labenv.lib()                        # (the switch is read on the lab build only: both runs there)
+    labenv.delenv("TK_SEPARATE_INDEX_BUILD", raising=False)
     inside = run_all()
-    monkeypatch.setenv("TK_SEPARATE_INDEX_BUILD", "1")
+    labenv.setenv("TK_SEPARATE_INDEX_BUILD", "1")
     separate = run_all()
     assert np.isfinite(inside[0]).all()
     for a, b in zip(inside, separate):

@@ -87,6 +87,9 @@ struct BandRetry {
     int *gate2;                 // [N]  out: 0 the retry owns the read (cost / gradient rows written), else why not
     const double *firstF, *firstB;  // cost-only calls: the batch launch's two sweep scores (a pending read is retried iff they
                                     // are not finite or disagree); null for gradient calls
+    float first_wbias;              // ... and that launch's weight bias: a pending read whose scores agree gets its cost here
+    int retry;                      // 0: no retry configuration for this call -- disowned reads go straight to the log domain
+    int log_domain;                 // 1; lab builds: 0 = leave what the linear path disowned alone (TK_CRF_NO_FALLBACK)
 };
 
 struct BandBlock {
@@ -111,7 +114,6 @@ size_t crf_band_retry_slots(size_t nbatch);
 BandLayout crf_band_layout(size_t ntrans, size_t nblk, size_t nbatch, size_t max_seqlen, bool mod,
                            bool want_grad, int bk);
 int crf_band_dispatch(const BandArgs &a, int R, bool mod, int bk, hipStream_t stream);
-// `a`: the RETRY's arguments -- its own workspace arrays (crf_band_layout of crf_band_retry_slots(N) reads, 4-step blocks), wbias / klip
-int crf_band_retry_dispatch(const BandArgs &a, const BandRetry &r, int R, bool mod, size_t nslots, hipStream_t stream);
+// (the tail launch -- retry, then the log domain: crf_log.h: crf_band_tail_dispatch)
 
 }  // namespace tk

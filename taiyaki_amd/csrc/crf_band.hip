@@ -61,8 +61,7 @@
 
 #include <type_traits>
 
-#include "crf_band.h"
-#include "ff_common.h"
+#include "crf_log.h"
 
 namespace tk {
 
@@ -1661,27 +1660,36 @@ __global__ __launch_bounds__(POST_WAVES *WAVE) __attribute__((amdgpu_waves_per_e
 
 
 // ===========================================================================
-// Round 6 -- the per-read second chance (BandRetry, crf_band.h).  Launched behind the batch's gradient pass with a few
-// workgroups of 16 waves.  Usually nothing is disowned and a workgroup leaves after one pass over the gate array.
-// Otherwise the k-th disowned read goes to workgroup k mod gridDim.x, which -- one read after the other, in its own slot
-// of the retry workspace -- ranks the read's transition instances, runs the forward and then the backward sweep with
-// 4-step blocks and steep frames (a.klip, a.wbias: crf_band_pick_retry), and then the gradient pass's blocks, a wave per
-// block in turn: the device functions of the batch's launches, one workgroup instead of 3 + NB / 2.  ~150 us for a
-// read of 530 bases at T 800 where the log-domain kernel takes ~1 ms; the batch keeps its fast configuration.
+// Round 6 -- THE TAIL LAUNCH of the linear path: the per-read second chance (BandRetry, crf_band.h), and behind it, in
+// the same workgroup, the log domain.  Launched behind the batch's gradient pass with a few workgroups of 16 waves.
+// Usually nothing is disowned and a workgroup leaves after one pass over the gate array (a cost-only call: one wave
+// writes the costs of the reads whose two sweeps agree on the way).  Otherwise the k-th disowned read goes to workgroup
+// k mod gridDim.x, which -- one read after the other, in its own slot of the retry workspace --
+//   1. ranks the read's transition instances, runs the forward and the backward sweep with 4-step blocks and steep
+//      frames (a.klip, a.wbias: crf_band_pick_retry; both sweeps at once where 2 W waves fit the workgroup), then the
+//      gradient pass's blocks, a wave per block in turn: the device functions of the batch's launches, one workgroup
+//      instead of 3 + NB / 2.  ~300 us for a read of 720 bases at T 800; the batch keeps its fast configuration;
+//   2. if that disowns the read as well (or the call has no retry configuration): crf_read (crf_log.h), the log-domain
+//      form that takes any input the reference takes, ~1 ms at T 800.
+// One launch does what round 5's gated crf_kernel launch did and what a retry launch of its own would: the op's fourth
+// launch is gone (each costs ~3 us on the stream whatever it finds: profiles/r6_tail_launches_ab.txt).
+// Status word: bits 20-31 count the reads retried, bits 8-19 the reads redone in the log domain.
 // ===========================================================================
-__device__ __forceinline__ int band_first_verdict(const BandRetry &r, int n) {
+__device__ __forceinline__ int band_first_verdict(const BandRetry &r, int n, double *score2) {
     const int g = r.gate[n];
     if (r.firstF == nullptr || g != 2) return g;
-    const double F = r.firstF[n], B = r.firstB[n], d = F - B;       // (crf_kernels.hip: crf_band_gate_of)
-    if (!(F - F == 0.0 && B - B == 0.0)) return 1;
-    if (!(d > -1e-3 && d < 1e-3)) return 4;
+    const double F = r.firstF[n], B = r.firstB[n], d = F - B;
+    if (!(F - F == 0.0 && B - B == 0.0)) return 1;              // overflow / nothing left: not representable
+    if (!(d > -1e-3 && d < 1e-3)) return 4;                     // mass lost on the way in one of them
+    *score2 = 0.5 * (F + B);
     return 0;
 }
 
 template <int R, bool MOD, bool CW>
-__global__ __launch_bounds__(BAND_MAXW *WAVE) void crf_band_retry_kernel(BandArgs a, BandRetry r) {
+__global__ __launch_bounds__(BAND_MAXW *WAVE) void crf_band_tail_kernel(BandArgs a, BandRetry r, CrfArgs ca) {
     constexpr int BK = 4, PW = R * WAVE, KINDS = MOD ? 3 : 2;
     extern __shared__ __attribute__((aligned(16))) char retry_dyn_lds[];    // the gradient pass's rows: 16 waves x BK x KINDS x 64 floats
+                                                                            // (crf_read lays its own image over the same bytes)
     __shared__ __attribute__((aligned(16))) float E[2][BAND_MAXW * 2 * BK];    // (a ring per sweep)
     __shared__ int Ef[2][BAND_MAXW * 2];
     __shared__ __attribute__((aligned(16))) float Ezero[BK];
@@ -1689,73 +1697,95 @@ __global__ __launch_bounds__(BAND_MAXW *WAVE) void crf_band_retry_kernel(BandArg
     const int tid = threadIdx.x, lane = tid & (WAVE - 1);
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6), nwaves = (int)(blockDim.x >> 6);
     const bool want_grad = a.grad != nullptr;
+    const int T = a.T, NB = (T + BK - 1) / BK;
     {
+        const bool writer = blockIdx.x == 0 && w == 0;          // (one wave writes the cost-only calls' costs)
         unsigned long long any = 0;
         for (int n0 = 0; n0 < a.N; n0 += WAVE) {
             const int n = n0 + lane;
-            any |= __ballot(n < a.N && band_first_verdict(r, n) != 0);
+            double score2 = 0.0;
+            const int g = n < a.N ? band_first_verdict(r, n, &score2) : 0;
+            if (writer && n < a.N && g == 0 && r.firstF != nullptr && r.gate[n] == 2) {
+                // score = mean of the two sweeps (c_crf_flipflop.c:482-491 does the same), cost = -score / T; the
+                // bias comes back: every one of the T step weights on a path carried 2^-wbias
+                const float cst = crf_add_cost(a, n, (float)(-((score2 + (double)r.first_wbias * (double)T) * 0.6931471805599453) / (double)T) * a.out_scale);
+                a.cost[n] = cst;
+                if (a.status && !isfinite(cst)) atomicOr(a.status, 1u);
+            }
+            any |= __ballot(g != 0);
         }
         if (any == 0) return;
     }
     if (tid < BK) Ezero[tid] = 0.f;
     const int ws = (int)blockIdx.x;
-    const int T = a.T, NB = (T + BK - 1) / BK;
-    int seen = 0;
+    int seen = 0, redone = 0;
     for (int n = 0; n < a.N; ++n) {
-        if (band_first_verdict(r, n) == 0) continue;
+        double unused;
+        if (band_first_verdict(r, n, &unused) == 0) continue;
         const bool mine = seen % (int)gridDim.x == (int)blockIdx.x;
         ++seen;
         if (!mine) continue;
         const int64_t off = a.seqoff[n];
         const int L = min(a.seqlen[n], (int)(a.seqoff[n + 1] - off));
         __syncthreads();                                        // (the read before: its verdict is taken, its LDS free)
-        if (tid == 0) why_sh = 0;
-        if (L <= 0 || L > a.W * PW) {                           // (never disowned: the batch's launch answers these itself)
-            if (tid == 0) r.gate2[n] = 16;
-            continue;
-        }
-        band_rank<MOD>(a, ws, L, off, w, nwaves);
-        __syncthreads();
-        if (2 * a.W <= nwaves) {
-            // both sweeps at once: waves [0, W) forward, [W, 2 W) backward -- the same number of phases, hence of barriers;
-            // the rest of the workgroup keeps them company
-            if (w < a.W) band_sweep<R, MOD, true, true, false, CW, BK>(a, n, ws, L, off, E[0], Ef[0], Ezero, nullptr);
-            else if (w < 2 * a.W) band_sweep<R, MOD, false, true, false, CW, BK>(a, n, ws, L, off, E[1], Ef[1], Ezero, nullptr, a.W);
-            else
-                for (int ph = 0; ph < NB + a.W - 1; ++ph) band_barrier();
-        } else {
-            band_sweep<R, MOD, true, true, false, CW, BK>(a, n, ws, L, off, E[0], Ef[0], Ezero, nullptr);
+        if (tid == 0) why_sh = (r.retry && L > 0 && L <= a.W * PW) ? 0 : 16;
+        if (r.retry && L > 0 && L <= a.W * PW) {
+            band_rank<MOD>(a, ws, L, off, w, nwaves);
             __syncthreads();
-            band_sweep<R, MOD, false, true, false, CW, BK>(a, n, ws, L, off, E[1], Ef[1], Ezero, nullptr);
-        }
-        // what the sweeps and the ranking left in the workspace is read by OTHER waves of this workgroup below: release,
-        // barrier, acquire (a slot's lines may sit in this CU's vector cache from the read before)
-        __threadfence();
-        __syncthreads();
-        __threadfence();
-        if (want_grad) {
-            float *sP = reinterpret_cast<float *>(retry_dyn_lds) + (size_t)w * BK * KINDS * WAVE;
-            int why = 0;
-            for (int jb = w; jb < NB && (why & 5) == 0; jb += nwaves)       // (the sweeps' verdict, 1 / 4, is every block's)
-                why |= band_posterior_block<MOD, CW, BK>(a, n, ws, jb, sP);
-            if (why != 0 && lane == 0) atomicOr(&why_sh, why);
-        } else if (tid == 0) {
-            // cost only: both sweeps finite and agreeing, or not the linear path's (crf_kernels.hip: crf_band_gate_of)
-            const double F = a.scoreF[ws], B = a.scoreB[ws], d = F - B;
-            if (!(F - F == 0.0 && B - B == 0.0)) why_sh = 1;
-            else if (!(d > -1e-3 && d < 1e-3)) why_sh = 4;
-            else {
-                const double score2 = 0.5 * (F + B) + (double)a.wbias * (double)T;
-                const float cst = crf_add_cost(a, n, (float)(-(score2 * 0.6931471805599453) / (double)T) * a.out_scale);
-                a.cost[n] = cst;
-                if (a.status && !isfinite(cst)) atomicOr(a.status, 1u);
+            if (2 * a.W <= nwaves) {
+                // both sweeps at once: waves [0, W) forward, [W, 2 W) backward -- the same number of phases, hence of barriers;
+                // the rest of the workgroup keeps them company
+                if (w < a.W) band_sweep<R, MOD, true, true, false, CW, BK>(a, n, ws, L, off, E[0], Ef[0], Ezero, nullptr);
+                else if (w < 2 * a.W) band_sweep<R, MOD, false, true, false, CW, BK>(a, n, ws, L, off, E[1], Ef[1], Ezero, nullptr, a.W);
+                else
+                    for (int ph = 0; ph < NB + a.W - 1; ++ph) band_barrier();
+            } else {
+                band_sweep<R, MOD, true, true, false, CW, BK>(a, n, ws, L, off, E[0], Ef[0], Ezero, nullptr);
+                __syncthreads();
+                band_sweep<R, MOD, false, true, false, CW, BK>(a, n, ws, L, off, E[1], Ef[1], Ezero, nullptr);
+            }
+            // what the sweeps and the ranking left in the workspace is read by OTHER waves of this workgroup below: release,
+            // barrier, acquire (a slot's lines may sit in this CU's vector cache from the read before)
+            __threadfence();
+            __syncthreads();
+            __threadfence();
+            if (want_grad) {
+                float *sP = reinterpret_cast<float *>(retry_dyn_lds) + (size_t)w * BK * KINDS * WAVE;
+                int why = 0;
+                for (int jb = w; jb < NB && (why & 5) == 0; jb += nwaves)       // (the sweeps' verdict, 1 / 4, is every block's)
+                    why |= band_posterior_block<MOD, CW, BK>(a, n, ws, jb, sP);
+                if (why != 0 && lane == 0) atomicOr(&why_sh, why);
+            } else if (tid == 0) {
+                // cost only: both sweeps finite and agreeing, or not the linear path's
+                const double F = a.scoreF[ws], B = a.scoreB[ws], d = F - B;
+                if (!(F - F == 0.0 && B - B == 0.0)) why_sh = 1;
+                else if (!(d > -1e-3 && d < 1e-3)) why_sh = 4;
+                else {
+                    const double score2 = 0.5 * (F + B) + (double)a.wbias * (double)T;
+                    const float cst = crf_add_cost(a, n, (float)(-(score2 * 0.6931471805599453) / (double)T) * a.out_scale);
+                    a.cost[n] = cst;
+                    if (a.status && !isfinite(cst)) atomicOr(a.status, 1u);
+                }
             }
         }
         __syncthreads();
-        if (tid == 0) r.gate2[n] = why_sh;
+        const int why_all = why_sh;
+        if (tid == 0 && r.gate2 != nullptr) r.gate2[n] = why_all;
+        if (why_all != 0 && r.log_domain) {
+            // nobody on the linear path: the log domain, in this workgroup (its cost and gradient rows overwrite whatever
+            // the linear attempts left)
+            __syncthreads();
+            crf_read<crf_tail_log_R(R), BAND_MAXW, MOD>(ca, n, (int)blockIdx.x);
+            ++redone;
+        }
     }
-    // reads retried: bits 20-31 of the status word (include/taiyaki_amd_flipflop.h: TK_STATUS_RETRIED_SHIFT)
-    if (blockIdx.x == 0 && tid == 0 && seen > 0 && a.status) atomicAdd(a.status, (uint32_t)min(seen, 0xfff) << 20);
+    if (tid == 0 && a.status) {
+        // reads retried (bits 20-31; counted once, by workgroup 0) and reads redone in the log domain (bits 8-19; every
+        // workgroup its own) -- include/taiyaki_amd_flipflop.h: TK_STATUS_RETRIED_SHIFT, TK_STATUS_GATED_SHIFT
+        uint32_t add = (uint32_t)min(redone, 0xfff) << 8;
+        if (blockIdx.x == 0 && r.retry) add += (uint32_t)min(seen, 0xfff) << 20;
+        if (add) atomicAdd(a.status, add);
+    }
 }
 
 // ---------------------------------------------------------------------------
@@ -2012,21 +2042,26 @@ int crf_band_dispatch(const BandArgs &a0, int R, bool mod, int bk, hipStream_t s
 }
 
 template <int R, bool MOD, bool CW>
-static int band_retry_launch(const BandArgs &a, const BandRetry &r, size_t nslots, hipStream_t stream) {
-    const size_t lds = (size_t)BAND_MAXW * 4 * (MOD ? 3 : 2) * WAVE * sizeof(float);
-    hipLaunchKernelGGL((crf_band_retry_kernel<R, MOD, CW>), dim3((unsigned)nslots), dim3(BAND_MAXW * WAVE), lds, stream, a, r);
+static int band_tail_launch(const BandArgs &a, const BandRetry &r, const CrfArgs &ca, size_t nslots, hipStream_t stream) {
+    // dynamic LDS: the gradient pass's rows of the retry, or the log-domain form's image, whichever is larger
+    const size_t lds_retry = (size_t)BAND_MAXW * 4 * (MOD ? 3 : 2) * WAVE * sizeof(float);
+    const size_t lds_log = crf_lds_bytes(crf_tail_log_R(R), BAND_MAXW, a.S, MOD ? 3 : 2);
+    const size_t lds = lds_retry > lds_log ? lds_retry : lds_log;
+    if (lds > 150 * 1024) return 2;
+    if (raise_dynamic_lds(reinterpret_cast<const void *>(&crf_band_tail_kernel<R, MOD, CW>), 150 * 1024)) return 4;    // (+ ~1.5 KB static)
+    hipLaunchKernelGGL((crf_band_tail_kernel<R, MOD, CW>), dim3((unsigned)nslots), dim3(BAND_MAXW * WAVE), lds, stream, a, r, ca);
     return hipGetLastError() == hipSuccess ? 0 : 4;
 }
 
-int crf_band_retry_dispatch(const BandArgs &a, const BandRetry &r, int R, bool mod, size_t nslots, hipStream_t stream) {
+int crf_band_tail_dispatch(const BandArgs &a, const BandRetry &r, const CrfArgs &ca, int R, bool mod, size_t nslots, hipStream_t stream) {
     if (a.W < 1 || a.W > BAND_MAXW || nslots == 0) return 2;
     switch (R * 2 + (mod ? 1 : 0)) {
-        case 2: return band_retry_launch<1, false, false>(a, r, nslots, stream);
-        case 3: return a.colw ? band_retry_launch<1, true, true>(a, r, nslots, stream) : band_retry_launch<1, true, false>(a, r, nslots, stream);
-        case 4: return band_retry_launch<2, false, false>(a, r, nslots, stream);
-        case 5: return a.colw ? band_retry_launch<2, true, true>(a, r, nslots, stream) : band_retry_launch<2, true, false>(a, r, nslots, stream);
-        case 8: return band_retry_launch<4, false, false>(a, r, nslots, stream);
-        case 9: return a.colw ? band_retry_launch<4, true, true>(a, r, nslots, stream) : band_retry_launch<4, true, false>(a, r, nslots, stream);
+        case 2: return band_tail_launch<1, false, false>(a, r, ca, nslots, stream);
+        case 3: return a.colw ? band_tail_launch<1, true, true>(a, r, ca, nslots, stream) : band_tail_launch<1, true, false>(a, r, ca, nslots, stream);
+        case 4: return band_tail_launch<2, false, false>(a, r, ca, nslots, stream);
+        case 5: return a.colw ? band_tail_launch<2, true, true>(a, r, ca, nslots, stream) : band_tail_launch<2, true, false>(a, r, ca, nslots, stream);
+        case 8: return band_tail_launch<4, false, false>(a, r, ca, nslots, stream);
+        case 9: return a.colw ? band_tail_launch<4, true, true>(a, r, ca, nslots, stream) : band_tail_launch<4, true, false>(a, r, ca, nslots, stream);
         default: return 2;
     }
 }

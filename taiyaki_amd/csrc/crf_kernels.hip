@@ -20,607 +20,15 @@
 #include <stdio.h>
 #include <stdlib.h>
 
-#include "crf_band.h"
-#include "ff_common.h"
+#include "crf_log.h"
 
 namespace tk {
 
-struct CrfArgs {
-    const float *lp;            // (T, N, S) scores (unsharpened)
-    int T, N, S;
-    int ncan;                   // canonical transition columns (== S for the plain CRF)
-    const int32_t *stay;        // padded per-position layout, see header
-    const int32_t *move;
-    const int32_t *mod;         // nullable
-    const float *modfact;       // nullable
-    const int32_t *seqlen;      // (N)
-    const int64_t *seqoff;      // (N + 1)
-    float c_can;                // sharp_can * log2(e)
-    float c_mod;                // sharp_mod * log2(e)
-    float out_scale;            // cost multiplier (1 / sharpfact)
-    float *cost;                // (N)
-    float *grad;                // (T, N, S) or null
-    float *ckpt;                // workspace: checkpoint columns
-    double *ckoff;              // workspace: checkpoint offsets
-    uint32_t *status;
-    const int *gate;            // nullable; (N): only reads with gate[n] != 0 are computed (the band path's rejects)
-    const int *gate2;           // nullable; (N): the retry launch's verdicts (crf_band.h: BandRetry) -- 0: that launch owns the read
-    // behind a COST-ONLY band launch: the log2 scores of its two sweeps (null otherwise).  gate[n] == 2 then means
-    // "pending": the read is the linear path's -- and its cost is written here -- iff both scores are finite and agree
-    const double *bandF, *bandB;
-    float band_wbias;           // the band sweeps' weight bias: their scores get band_wbias * T back
-    // behind a band launch that built its indices from the caller's labels (crf_band.h: BandArgs::codes): no index
-    // array was written -- the reads redone here form their ids from the codes, too (null: the arrays above are inputs)
-    const int32_t *codes, *mod_cats, *cmo;
-    const float *mcw;
-    int nbase;
-    float grad_scale;           // gradient multiplier (1 for the reference's operators)
-    const float *grad_scale_vec;    // nullable; (N): a further per-read multiplier    // fused cat-mod loss: kernel B ran first into a compact buffer; this operator adds
-    // add_scale * add_cost[n] to the cost and add_scale * (gradient multiplier) * add_grad[t][n][s]
-    // (s < add_S) to the gradient it writes.  Null: nothing to add.
-    const float *add_grad;      // (T, N, add_S)
-    const float *add_cost;      // (N)
-    int add_S;
-    float add_scale;
-};
-
-__host__ __device__ inline int crf_ck(int R, int W, int kinds) {
-    // recompute tile + sorted-posterior tile <= 112 KiB of LDS
-    const int c = 28672 / (R * W * WAVE * (kinds + 1));
-    return c >= 16 ? 16 : (c >= 8 ? 8 : (c >= 4 ? 4 : 2));
-}
-
-template <int R, int W, bool MOD>
-struct CrfCfg {
-    static constexpr int NT = W * WAVE;                 // threads per read
-    static constexpr int LPAD = R * NT;                 // lattice positions covered
-    static constexpr int KINDS = MOD ? 3 : 2;           // stay, move(, mod) posterior streams
-    static constexpr int CK0 = 28672 / (LPAD * (KINDS + 1));
-    static constexpr int CK = CK0 >= 16 ? 16 : (CK0 >= 8 ? 8 : (CK0 >= 4 ? 4 : 2));
-    static constexpr int MAXK = (CK + W - 1) / W;       // tile rows moved per wave (S <= 64)
-    static constexpr int EPL = LPAD / WAVE;             // sorted elements per lane in the flush
-};
-
-// LDS carve (floats): tile[CK][SP] | Psort[CK][KINDS][LPAD] | Fblk[CK][R][NT] | offs (2*CK) |
-// segstart[KINDS][SP+1] | lanebase[W][64] | edgeF[2][W] | edgeB[2][W] | red[W] | misc[8]
-// (the ranking scratch wcnt[KINDS][W][SP] overlays Fblk during set-up)
-__host__ __device__ inline size_t crf_lds_bytes(int R, int W, int S, int kinds) {
-    const int SP = S + 2, CK = crf_ck(R, W, kinds), NT = W * WAVE;
-    size_t f = 0;
-    f += (size_t)CK * SP;
-    f += (size_t)CK * kinds * R * NT;
-    size_t fb = (size_t)CK * R * NT, scratch = (size_t)kinds * W * SP + kinds * SP;
-    f += fb > scratch ? fb : scratch;
-    f += (size_t)2 * CK + 2;
-    f += (size_t)kinds * (SP + 1);
-    f += (size_t)W * WAVE;
-    f += (size_t)9 * W + 10;            // edgeF, edgeB: [2][W] doubles each; red [W]; misc; alignment
-    return (f * 4 + 15) / 16 * 16;
-}
-
-// The lattice state of this kernel is kept in DOUBLE (round 5).  In fp32 -- the reference's own arithmetic -- a cell
-// carries one rounding of its magnitude (tens to hundreds of bits below the column maximum) per step, and over
-// T in the thousands with raw cat-mod logits x 8 the posteriors sit 5e-3 .. 1e-2 from a float64 evaluation: the
-// reference's level, but two fp32 algorithms' noise is two different samples, and round 4's fuzz sweep drew one
-// at twice the reference's (the criterion was widened for it).  With the cells in double the only fp32 left on
-// the chain is the correction term log2(1 + 2^-|d|) in [0, 1] (absolute error ~1e-7 per step): 1e-5 .. 1e-4 from
-// float64 on the same cases.  fp64 adds run at the fp32 rate on this chip; the kernel redoes disowned reads and
-// serves the fallback modes, it is not the fast path.
-__device__ __forceinline__ double lse2d(double a, double b) {
-    const double mx = fmax(a, b);
-    const float d = (float)(fmin(a, b) - mx);           // <= 0 (the two are finite: "nothing" is -1.44e30)
-    return mx + (double)fast_log2(1.0f + fast_exp2(d));
-}
-__device__ __forceinline__ double wave_shift_up1(double src, double fill) {
-    return __hiloint2double(wave_shift_up1(__double2hiint(src), __double2hiint(fill)),
-                            wave_shift_up1(__double2loint(src), __double2loint(fill)));
-}
-__device__ __forceinline__ double wave_shift_down1(double src, double fill) {
-    return __hiloint2double(__builtin_amdgcn_update_dpp(__double2hiint(fill), __double2hiint(src), 0x130, 0xF, 0xF, false),
-                            __builtin_amdgcn_update_dpp(__double2loint(fill), __double2loint(src), 0x130, 0xF, 0xF, false));
-}
-
-// One read, all three passes.  `ckslot`: which set of checkpoint columns of the workspace this workgroup uses.
-template <int R, int W, bool MOD>
-__device__ __forceinline__ void crf_read(const CrfArgs &a, const int n, const int ckslot) {
-    using Cfg = CrfCfg<R, W, MOD>;
-    constexpr int CK = Cfg::CK, NT = Cfg::NT, MAXK = Cfg::MAXK, LPAD = Cfg::LPAD;
-    constexpr int KINDS = Cfg::KINDS, EPL = Cfg::EPL;
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & (WAVE - 1);
-    const int T = a.T, N = a.N, S = a.S, SP = S + 2;
-    const int L = min(a.seqlen[n], (int)(a.seqoff[n + 1] - a.seqoff[n]));      // (offsets are clamped to the label array)
-    const bool want_grad = a.grad != nullptr;
-    const float gsc = a.grad_scale * (a.grad_scale_vec != nullptr ? a.grad_scale_vec[n] : 1.0f);
-
-    float *tile = reinterpret_cast<float *>(smem);              // [CK][SP]
-    float *Psort = tile + CK * SP;                              // [CK][KINDS][LPAD]
-    float *Fblk = Psort + (size_t)CK * KINDS * LPAD;            // [CK][R][NT]
-    size_t fbsz = (size_t)CK * R * NT;
-    {
-        const size_t scratch = (size_t)KINDS * W * SP + KINDS * SP;
-        if (scratch > fbsz) fbsz = scratch;
-    }
-    float *after = Fblk + fbsz;
-    after += ((after - tile) & 1);                              // 8-byte alignment for the doubles
-    double *offs = reinterpret_cast<double *>(after);           // [CK]
-    int *segstart = reinterpret_cast<int *>(offs + CK);         // [KINDS][SP + 1]
-    float *lanebase = reinterpret_cast<float *>(segstart + KINDS * (SP + 1));   // [W][64]
-    float *after2 = lanebase + W * WAVE;
-    after2 += ((after2 - tile) & 1);                            // 8-byte alignment for the doubles
-    double *edgeF = reinterpret_cast<double *>(after2);         // [2][W]
-    double *edgeB = edgeF + 2 * W;                              // [2][W]
-    float *red = reinterpret_cast<float *>(edgeB + 2 * W);      // [W]
-    double *misc = reinterpret_cast<double *>(red + W + (W & 1));   // [2]
-
-    const size_t rowstride = (size_t)N * S;
-    const float *lpn = a.lp + (size_t)n * S;
-
-    if (L == 0) {
-        // c_crf_flipflop.c:269-272 / 458-464: cost 0, zero gradient rows
-        if (tid == 0) a.cost[n] = crf_add_cost(a, n, 0.f);
-        if (want_grad && lane < S) {
-            for (int t = wave; t < T; t += W)
-                a.grad[(size_t)t * rowstride + (size_t)n * S + lane] = crf_add_grad(a, (size_t)t, n, lane, 0.f, gsc);
-        }
-        return;
-    }
-    if (L > R * NT) {
-        if (tid == 0) {
-            a.cost[n] = __builtin_nanf("");
-            if (a.status) atomicOr(a.status, 16u);
-        }
-        if (want_grad && lane < S) {        // NaN rows, not uninitialised memory (see crf_band_posterior_kernel)
-            for (int t = wave; t < T; t += W)
-                a.grad[(size_t)t * rowstride + (size_t)n * S + lane] = __builtin_nanf("");
-        }
-        return;
-    }
-
-    // ---- tile movers: rows t0 .. t0+nrows-1 of this read <-> LDS.  Wave w moves
-    //      rows w, w+W, ...; lane = column (S <= 64): no index arithmetic, and the
-    //      loads are unconditional (indices clamped) so they pipeline freely. -----------
-    auto tile_fetch = [&](int t0, float (&pre)[MAXK]) {
-        const int nrows = min(CK, T - t0);
-        const int col = min(lane, S - 1);
-#pragma unroll
-        for (int k = 0; k < MAXK; ++k) {
-            const int row = min(wave + W * k, nrows - 1);
-            pre[k] = lpn[(size_t)(t0 + row) * rowstride + col];
-        }
-    };
-    auto tile_commit = [&](int t0, const float (&pre)[MAXK]) {
-        const int nrows = min(CK, T - t0);
-#pragma unroll
-        for (int k = 0; k < MAXK; ++k) {
-            const int row = wave + W * k;
-            if (row < nrows && lane < S) tile[row * SP + lane] = pre[k];
-        }
-    };
-
-    // ---- per-position transition ids -> registers ---------------------------
-    const int64_t off = a.seqoff[n];
-    const int p0 = tid * R;
-    int st[R], mv[R], md[MOD ? R : 1];
-    float fw[MOD ? R : 1];
-#pragma unroll
-    for (int j = 0; j < R; ++j) {
-        const int p = p0 + j;
-        if (a.codes != nullptr) {
-            const int cp = (p < L) ? lbl_code(a, off + p) : 0, cn = (p < L - 1) ? lbl_code(a, off + p + 1) : 0;
-            st[j] = (p < L) ? lbl_stay(a, cp) : S;
-            mv[j] = (p < L - 1) ? lbl_move(a, cp, cn) : S;
-            if (MOD) {
-                const int mq = (p < L - 1) ? lbl_mod_seq(a, cn, a.mod_cats[off + p + 1], nullptr) : 0;
-                md[j] = (p < L - 1) ? a.ncan + mq : S + 1;
-                fw[j] = (p < L - 1) ? a.mcw[mq] * a.c_mod : 0.f;
-            }
-        } else {
-            st[j] = (p < L) ? a.stay[off + p] : S;            // S   = -LARGE sentinel slot
-            mv[j] = (p < L - 1) ? a.move[off + p] : S;
-            if (MOD) {
-                md[j] = (p < L - 1) ? a.mod[off + p] : S + 1; // S+1 = 0.0 sentinel slot
-                fw[j] = (p < L - 1) ? a.modfact[off + p] * a.c_mod : 0.f;
-            }
-        }
-    }
-    // transition INTO this thread's first position (from position p0 - 1)
-    const bool has_in = (p0 >= 1) && (p0 - 1 < L - 1);
-    int mvin0 = S, mdin0 = S + 1;
-    float fwin0 = 0.f;
-    if (has_in && a.codes != nullptr) {
-        const int cb = lbl_code(a, off + p0 - 1), cp = lbl_code(a, off + p0);
-        mvin0 = lbl_move(a, cb, cp);
-        if (MOD) {
-            const int mq = lbl_mod_seq(a, cp, a.mod_cats[off + p0], nullptr);
-            mdin0 = a.ncan + mq;
-            fwin0 = a.mcw[mq] * a.c_mod;
-        }
-    } else if (has_in) {
-        mvin0 = a.move[off + p0 - 1];
-        if (MOD) {
-            mdin0 = a.mod[off + p0 - 1];
-            fwin0 = a.modfact[off + p0 - 1] * a.c_mod;
-        }
-    }
-    // sentinel slots of every LDS row (tile loads never touch them)
-    for (int r = tid; r < CK; r += NT) {
-        tile[r * SP + S] = NEG_LARGE;
-        tile[r * SP + S + 1] = 0.f;
-    }
-    const float c = a.c_can;
-    const double neg = (double)(NEG_LARGE * LOG2E);
-
-    // ---- sorted slots for the posterior streams (gradient path only) -------------------
-    // Every (position, kind) gets a slot such that slots with the same transition id are
-    // contiguous: key-major, then (wave, j, lane).  Ranks come from ballots, so the layout
-    // (and therefore every floating-point sum) is identical from run to run.
-    int slot[KINDS][R];
-    if (want_grad) {
-        const int K = SP;                                       // keys 0 .. S+1
-        int *wcnt = reinterpret_cast<int *>(Fblk);              // [KINDS][W][K]   (set-up scratch)
-        int *ktot = wcnt + KINDS * W * K;                       // [KINDS][K]
-#pragma unroll
-        for (int kind = 0; kind < KINDS; ++kind) {
-            int cnt = 0;            // lane b: occurrences of key b seen so far in this wave
-#pragma unroll
-            for (int j = 0; j < R; ++j) {
-                const int key = (kind == 0) ? st[j] : ((kind == 1) ? mv[j] : md[MOD ? j : 0]);
-                int rank = 0;
-                for (int b = 0; b < K; ++b) {
-                    const unsigned long long mask = __ballot(key == b);
-                    if (key == b)
-                        rank = __builtin_amdgcn_readlane(cnt, b) +
-                               __popcll(mask & ((1ull << lane) - 1ull));
-                    if (lane == b) cnt += __popcll(mask);
-                }
-                slot[kind][j] = rank;                           // rank within (wave, key) for now
-            }
-            if (lane < K) wcnt[(kind * W + wave) * K + lane] = cnt;
-        }
-        __syncthreads();
-        for (int e = tid; e < KINDS * K; e += NT) {
-            const int kind = e / K, b = e - kind * K;
-            int tot = 0;
-            for (int w = 0; w < W; ++w) tot += wcnt[(kind * W + w) * K + b];
-            ktot[e] = tot;
-        }
-        __syncthreads();
-        for (int e = tid; e < KINDS * K; e += NT) {
-            const int kind = e / K, b = e - kind * K;
-            int start = 0;
-            for (int bb = 0; bb < b; ++bb) start += ktot[kind * K + bb];
-            segstart[kind * (SP + 1) + b] = start;
-            if (b == K - 1) segstart[kind * (SP + 1) + K] = start + ktot[e];
-            // per-wave base of this key: overwrite the counts with exclusive prefix + start
-            int run = start;
-            for (int w = 0; w < W; ++w) {
-                const int cwb = wcnt[(kind * W + w) * K + b];
-                wcnt[(kind * W + w) * K + b] = run;
-                run += cwb;
-            }
-        }
-        __syncthreads();
-#pragma unroll
-        for (int kind = 0; kind < KINDS; ++kind)
-#pragma unroll
-            for (int j = 0; j < R; ++j) {
-                const int key = (kind == 0) ? st[j] : ((kind == 1) ? mv[j] : md[MOD ? j : 0]);
-                slot[kind][j] += wcnt[(kind * W + wave) * K + key];
-            }
-        __syncthreads();            // the scratch region becomes Fblk again
-    }
-
-    // block-wide column max of step t rides on the step barrier: every wave drops
-    // its max into red[] at the end of step t, everybody folds it in at step t+1
-    auto fold_norm = [&](double (&x)[R], double &edge_val, double &offacc) {
-        float mx = red[0];
-#pragma unroll
-        for (int w = 1; w < W; ++w) mx = fmaxf(mx, red[w]);
-        if (!(mx > -1e29f)) mx = 0.f;           // nothing reachable yet: keep the scale
-        // (the fold is a float -- the column maximum rounded down to fp32 -- taken off doubles exactly)
-#pragma unroll
-        for (int j = 0; j < R; ++j) x[j] -= (double)mx;
-        edge_val -= (double)mx;
-        offacc += (double)mx;
-    };
-    auto post_max = [&](const double (&x)[R]) {
-        float mx = (float)x[0];
-#pragma unroll
-        for (int j = 1; j < R; ++j) mx = fmaxf(mx, (float)x[j]);
-        mx = wave_allmax_dpp(mx);
-        if (lane == 0) red[wave] = mx;
-    };
-
-    // ---- one forward column update (c_crf_flipflop.c:43-78); t = index of the row
-    //      consumed; ends with the step barrier ------------------------------------------
-    auto fwd_step = [&](double (&f)[R], const float *row, int t, bool norm_in, double &offacc) {
-        double ein = (W > 1 && wave > 0) ? edgeF[((t - 1) & 1) * W + wave - 1] : neg;
-        if (norm_in) fold_norm(f, ein, offacc);
-        double left0 = wave_shift_up1(f[R - 1], neg);
-        if (W > 1 && lane == 0) left0 = ein;
-#pragma unroll
-        for (int j = R - 1; j >= 0; --j) {
-            const float ls = row[st[j]];
-            const int mi = (j == 0) ? mvin0 : mv[j > 0 ? j - 1 : 0];
-            const float lm = row[mi];
-            const double left = (j == 0) ? left0 : f[j > 0 ? j - 1 : 0];
-            const double av = fma((double)ls, (double)c, f[j]);
-            double bv = fma((double)lm, (double)c, left);
-            if (MOD) {
-                const int di = (j == 0) ? mdin0 : md[j > 0 ? j - 1 : 0];
-                const float dw = (j == 0) ? fwin0 : fw[j > 0 ? j - 1 : 0];
-                bv = fma((double)row[di], (double)dw, bv);
-            }
-            f[j] = lse2d(av, bv);
-        }
-        if (W > 1 && lane == WAVE - 1) edgeF[(t & 1) * W + wave] = f[R - 1];
-        if (((t + 1) & 3) == 0) post_max(f);
-        __syncthreads();
-    };
-    // publish the column's wave-boundary values before the first step from it
-    auto fwd_edge_init = [&](const double (&f)[R], int t0) {
-        if (W > 1 && lane == WAVE - 1) edgeF[((t0 - 1) & 1) * W + wave] = f[R - 1];
-        __syncthreads();
-    };
-
-    const int NK = (T + CK - 1) / CK;
-    float *ck_n = a.ckpt + (size_t)ckslot * NK * (R * NT);
-    double *ckoff_n = a.ckoff + (size_t)ckslot * NK;
-
-    // ======================= forward sweep ===================================
-    double f[R];
-#pragma unroll
-    for (int j = 0; j < R; ++j) f[j] = (p0 + j == 0) ? 0.0 : neg;           // :113-116
-    double offF = 0.0;
-    fwd_edge_init(f, 0);
-    {
-        float pre[MAXK];
-        tile_fetch(0, pre);
-        for (int k = 0; k < NK; ++k) {
-            const int t0 = k * CK, nrows = min(CK, T - t0);
-            tile_commit(t0, pre);           // (the previous tile's last step ended with a barrier)
-            __syncthreads();
-            if (k + 1 < NK) tile_fetch(t0 + CK, pre);
-            if (want_grad) {
-#pragma unroll
-                // (a checkpoint column is a float snapshot of the double chain: ONE rounding per tile, which the
-                // tile's recompute starts from -- it does not accumulate from tile to tile)
-                for (int j = 0; j < R; ++j) ck_n[((size_t)k * R + j) * NT + tid] = (float)f[j];
-                if (tid == 0) ckoff_n[k] = offF;
-            }
-            for (int i = 0; i < nrows; ++i) {
-                const int t = t0 + i;
-                fwd_step(f, tile + i * SP, t, t > 0 && (t & 3) == 0, offF);
-            }
-        }
-    }
-    // a column max published by the very last step is never folded in: harmless.
-    // score = sum of factors + fwd[T][L-1]  (c_crf_flipflop.c:131)
-    if (tid == (L - 1) / R) {
-        const int jj = (L - 1) % R;
-        double last = 0.0;
-#pragma unroll
-        for (int j = 0; j < R; ++j)
-            if (j == jj) last = f[j];
-        misc[0] = last;
-    }
-    __syncthreads();
-    const double fwd_score2 = offF + misc[0];
-    if (!want_grad) {
-        if (tid == 0) {
-            const float cst = crf_add_cost(a, n, (float)(-(fwd_score2 * 0.6931471805599453) / (double)T) * a.out_scale);
-            a.cost[n] = cst;
-            if (a.status && !isfinite(cst)) atomicOr(a.status, 1u);
-        }
-        return;
-    }
-
-    // ======================= backward sweep + posterior =======================
-    double b[R];
-#pragma unroll
-    for (int j = 0; j < R; ++j) b[j] = (p0 + j == L - 1) ? 0.0 : neg;       // :216-220
-    double offB = 0.0;
-    bool bad = false;
-    int nbwd = 0;                       // backward steps done so far
-    bool bnorm_pending = false;
-    const float inv_cmod = MOD ? (1.0f / a.c_mod) : 0.f;
-    if (W > 1 && lane == 0) edgeB[1 * W + wave] = b[0];        // slot (nbwd-1)&1 with nbwd = 0
-    __syncthreads();
-    {
-        float pre[MAXK];
-        tile_fetch((NK - 1) * CK, pre);
-        for (int k = NK - 1; k >= 0; --k) {
-            const int t0 = k * CK, nrows = min(CK, T - t0);
-            tile_commit(t0, pre);
-            if (k > 0) tile_fetch(t0 - CK, pre);
-            // -- recompute the forward columns of this tile from its checkpoint
-#pragma unroll
-            for (int j = 0; j < R; ++j) f[j] = (double)ck_n[((size_t)k * R + j) * NT + tid];
-            offF = ckoff_n[k];
-            fwd_edge_init(f, t0);       // barrier: tile and edges are visible
-            for (int i = 0; i < nrows; ++i) {
-                const int t = t0 + i;
-                // The checkpoint holds the column BEFORE the fold that was pending at
-                // the tile boundary (CK % 4 == 0): re-post its column max so the step
-                // folds exactly what the forward sweep folded.
-                if (i == 0 && t > 0 && (t & 3) == 0) {
-                    post_max(f);
-                    __syncthreads();
-                }
-                // (column, offset) are stored pre-fold: a consistent pair
-#pragma unroll
-                for (int j = 0; j < R; ++j) Fblk[((size_t)i * R + j) * NT + tid] = (float)f[j];
-                if (tid == 0) offs[i] = offF;
-                fwd_step(f, tile + i * SP, t, t > 0 && (t & 3) == 0, offF);
-            }
-            // -- walk the tile backwards (c_crf_flipflop.c:150-182 fused with 372-413)
-            for (int i = nrows - 1; i >= 0; --i) {
-                const float *row = tile + i * SP;
-                float *prow = Psort + (size_t)i * KINDS * LPAD;
-                double ein = (W > 1 && wave < W - 1) ? edgeB[((nbwd - 1) & 1) * W + wave + 1] : neg;
-                if (bnorm_pending) fold_norm(b, ein, offB);
-                const double ct = fwd_score2 - offs[i] - offB;
-                double right0 = wave_shift_down1(b[0], neg);
-                if (W > 1 && lane == WAVE - 1) right0 = ein;
-#pragma unroll
-                for (int j = 0; j < R; ++j) {
-                    const float ls = row[st[j]];
-                    const float lm = row[mv[j]];
-                    const double br = (j == R - 1) ? right0 : b[j < R - 1 ? j + 1 : 0];
-                    const double as = fma((double)ls, (double)c, b[j]);
-                    double am = fma((double)lm, (double)c, br);
-                    if (MOD) am = fma((double)row[md[j]], (double)fw[j], am);
-                    const double fc = (double)Fblk[((size_t)i * R + j) * NT + tid] - ct;
-                    const float ps = fast_exp2((float)(fc + as));
-                    const float pm = fast_exp2((float)(fc + am));
-                    prow[slot[0][j]] = ps;
-                    prow[LPAD + slot[1][j]] = pm;
-                    if (MOD) prow[2 * LPAD + slot[MOD ? 2 : 0][j]] = pm * (fw[j] * inv_cmod);
-                    b[j] = lse2d(as, am);
-                }
-                if (W > 1 && lane == 0) edgeB[(nbwd & 1) * W + wave] = b[0];
-                ++nbwd;
-                bnorm_pending = (nbwd & 3) == 0;
-                if (bnorm_pending) post_max(b);
-                __syncthreads();
-            }
-            // -- flush: one wave per row.  For each posterior stream the row's sorted
-            //    array becomes lane-local inclusive prefixes (+ a per-lane base from a DPP
-            //    wave scan); lane = transition id then takes the difference of the prefixes
-            //    at its segment boundaries.  The row total (stay + move streams) is the
-            //    reference's per-column softmax normaliser (c_crf_flipflop.c:400-401); output
-            //    scaling -1/T (ctc.pyx:113).
-            for (int row = wave; row < nrows; row += W) {
-                float colval = 0.f, total = 0.f;
-                float *lb = lanebase + wave * WAVE;
-#pragma unroll
-                for (int kind = 0; kind < KINDS; ++kind) {
-                    float *arr = Psort + ((size_t)row * KINDS + kind) * LPAD;
-                    float run = 0.f;
-                    if constexpr (EPL % 4 == 0) {
-                        // 16-byte LDS accesses (a scalar walk at stride EPL is 16-way bank-conflicted)
-                        f4 *av = reinterpret_cast<f4 *>(arr + lane * EPL);
-#pragma unroll
-                        for (int e = 0; e < EPL / 4; ++e) {
-                            f4 x = av[e];
-                            x[0] += run;
-                            x[1] += x[0];
-                            x[2] += x[1];
-                            x[3] += x[2];
-                            run = x[3];
-                            av[e] = x;
-                        }
-                    } else {
-#pragma unroll
-                        for (int e = 0; e < EPL; ++e) {
-                            run += arr[lane * EPL + e];
-                            arr[lane * EPL + e] = run;
-                        }
-                    }
-                    const float inc = wave_inclusive_scan_dpp(run);
-                    lb[lane] = inc - run;
-                    wave_lds_fence();
-                    if (kind < 2) total += __int_as_float(__builtin_amdgcn_readlane(__float_as_int(inc), 63));
-                    if (lane < S) {
-                        const int s0 = segstart[kind * (SP + 1) + lane];
-                        const int s1 = segstart[kind * (SP + 1) + lane + 1];
-                        const float p1 = (s1 > 0) ? arr[s1 - 1] + lb[(s1 - 1) / EPL] : 0.f;
-                        const float p0s = (s0 > 0) ? arr[s0 - 1] + lb[(s0 - 1) / EPL] : 0.f;
-                        colval += (s1 > s0) ? (p1 - p0s) : 0.f;
-                    }
-                    wave_lds_fence();
-                }
-                const float g = crf_add_grad(a, (size_t)(t0 + row), n, lane, colval * (-gsc / (total * (float)T)), gsc);
-                if (lane < S) {
-                    bad |= !isfinite(g);
-                    a.grad[(size_t)(t0 + row) * rowstride + (size_t)n * S + lane] = g;
-                }
-            }
-            __syncthreads();
-        }
-    }
-    // bwd score = bwd[0][0] + sum of factors (c_crf_flipflop.c:234); score = mean (:482-491)
-    if (bnorm_pending) {
-        double ein = 0.0;
-        fold_norm(b, ein, offB);
-    }
-    if (tid == 0) {
-        const double bwd_score2 = offB + b[0];
-        const double score2 = 0.5 * (fwd_score2 + bwd_score2);
-        const float cst = crf_add_cost(a, n, (float)(-(score2 * 0.6931471805599453) / (double)T) * a.out_scale);
-        a.cost[n] = cst;
-        if (a.status && !isfinite(cst)) atomicOr(a.status, 1u);
-    }
-    if (a.status && bad) atomicOr(a.status, 2u);
-}
-
-// Without a gate array (TK_CRF_MODE=ckpt, batches the band path does not take): workgroup n does read n.
-// Behind a band launch: the workgroups share out the reads the linear path DISOWNED (gate[n] != 0) -- the
-// k-th such read goes to workgroup k mod gridDim.x, which redoes its reads one after the other in its own
-// set of checkpoint columns, so the workspace holds gridDim.x sets (crf_redo_slots), not one per read of the
-// batch.  Usually there is nothing to redo and a workgroup leaves after one pass over the gate array.
-// Workgroup 0 adds the number of disowned reads to the status word's upper 24 bits
-// (TK_STATUS_GATED_SHIFT): what ctc.last_gate_count() / the trainer's warning read.
-// Is read n one the linear band path disowned?  Grad calls: the gate array says so.  Cost-only calls leave
-// gate[n] == 2 ("pending") and the two sweep scores: the read is the linear path's iff both are finite and agree to
-// 1e-3 bit (the tolerance the gradient pass holds them to); `score2` = their mean then.
-// Returns 0: the batch's launch owns the read; -1: the retry launch does (round 6: it wrote the read's cost / gradient rows);
-// > 0: nobody on the linear path -- redone here.
-__device__ __forceinline__ int crf_band_gate_of(const CrfArgs &a, int n, double *score2) {
-    int g = a.gate[n];
-    if (a.bandF != nullptr && g == 2) {
-        const double F = a.bandF[n], B = a.bandB[n], d = F - B;
-        if (!(F - F == 0.0 && B - B == 0.0)) g = 1;             // overflow / nothing left: not representable
-        else if (!(d > -1e-3 && d < 1e-3)) g = 4;               // mass lost on the way in one of them
-        else {
-            *score2 = 0.5 * (F + B);
-            return 0;
-        }
-    }
-    if (g != 0 && a.gate2 != nullptr && a.gate2[n] == 0) return -1;
-    return g;
-}
-
+// Workgroup n does read n (TK_CRF_MODE=ckpt, batches the band path does not take).  Behind a band launch the disowned
+// reads are redone by that path's own tail launch (crf_band.hip: crf_band_tail_kernel), which calls crf_read itself.
 template <int R, int W, bool MOD>
 __global__ __launch_bounds__(W *WAVE) void crf_kernel(CrfArgs a) {
-    if (a.gate == nullptr) {
-        crf_read<R, W, MOD>(a, (int)blockIdx.x, (int)blockIdx.x);
-        return;
-    }
-    // nothing disowned (the usual case): one parallel pass over the gate array and out
-    // (every wave looks at the whole array and comes to the same verdict: no LDS -- the kernel's dynamic
-    // LDS is at the limit, a static word for a workgroup-wide vote would not fit -- and no barrier)
-    {
-        const int lane = threadIdx.x & (WAVE - 1);
-        const bool writer = blockIdx.x == 0 && threadIdx.x < WAVE;      // (one wave writes the cost-only calls' costs)
-        unsigned long long any = 0;
-        for (int n0 = 0; n0 < a.N; n0 += WAVE) {
-            const int n = n0 + lane;
-            double score2 = 0.0;
-            const int g = n < a.N ? crf_band_gate_of(a, n, &score2) : 0;
-            if (writer && n < a.N && g == 0 && a.bandF != nullptr && a.gate[n] == 2) {
-                // score = mean of the two sweeps (c_crf_flipflop.c:482-491 does the same), cost = -score / T; the
-                // bias comes back: every one of the T step weights on a path carried 2^-wbias
-                const float cst = crf_add_cost(a, n, (float)(-((score2 + (double)a.band_wbias * (double)a.T) * 0.6931471805599453) / (double)a.T) * a.out_scale);
-                a.cost[n] = cst;
-                if (a.status && !isfinite(cst)) atomicOr(a.status, 1u);
-            }
-            any |= __ballot(g > 0);
-        }
-        if (any == 0) return;
-    }
-    int seen = 0;
-    for (int n = 0; n < a.N; ++n) {
-        double unused;
-        if (crf_band_gate_of(a, n, &unused) <= 0) continue;      // the linear band path owns this read
-        if (seen % (int)gridDim.x == (int)blockIdx.x) {
-            crf_read<R, W, MOD>(a, n, (int)blockIdx.x);
-            __syncthreads();
-        }
-        ++seen;
-    }
-    if (blockIdx.x == 0 && threadIdx.x == 0 && seen > 0 && a.status) atomicAdd(a.status, (uint32_t)min(seen, 0xfff) << 8);
+    crf_read<R, W, MOD>(a, (int)blockIdx.x, (int)blockIdx.x);
 }
 
 // ---------------------------------------------------------------------------
@@ -841,23 +249,28 @@ static CrfMode crf_pick_mode(size_t ntrans, size_t nblk, size_t nbatch, size_t m
     return CRF_CKPT;
 }
 
-// Sets of checkpoint columns of the log-domain kernel when it runs BEHIND the band path: it redoes only the
-// reads the linear path disowned -- none on the inputs a network produces -- so it gets an eighth of the
-// batch (at least 4, at most all) and loops (crf_kernel).  Round 3 sized it for the whole batch being
-// disowned: 8.4 of the 12.2 GB at T = 4000 / N = 256.
-static size_t crf_redo_slots(size_t nbatch) {
-    size_t s = (nbatch + 7) / 8;
-    if (s < 4) s = 4;
-    return s < nbatch ? s : nbatch;
-}
-
-// the retry launch's workspace (round 6): the band layout of 4-step blocks for crf_band_retry_slots(nbatch) reads (gradient
+// the retry's workspace (round 6): the band layout of 4-step blocks for crf_band_retry_slots(nbatch) reads (gradient
 // form whatever the call: a cost-only retry runs the same sweeps)
 static size_t crf_retry_bytes(size_t ntrans, size_t nblk, size_t nbatch, size_t max_seqlen) {
     return crf_band_total_bound(ntrans, nblk, crf_band_retry_slots(nbatch), max_seqlen, true, 4);
 }
+// the log-domain form's checkpoint columns behind the band path: one set per workgroup of the TAIL launch (crf_band.hip:
+// crf_band_tail_kernel -- 16 waves, cells per lane by the band launch's)
+static CrfShape crf_tail_shape(int band_R) { return {crf_tail_log_R(band_R), 16}; }
+static size_t crf_tail_ckpt_bound(size_t ntrans, size_t nblk, size_t nbatch, size_t max_seqlen, bool want_grad) {
+    size_t m = 0;
+    for (int mod = 0; mod < 2; ++mod) {
+        const int R = crf_band_layout(ntrans, nblk, nbatch, max_seqlen, mod != 0, want_grad, 8).R;
+        const size_t b = crf_ckpt_bytes(nblk, crf_band_retry_slots(nbatch), crf_tail_shape(R), want_grad);
+        m = b > m ? b : m;
+    }
+    return m;
+}
 
-// workspace = [band layout (band mode only)] [the retry launch's band layout] [checkpoint columns + offsets of crf_kernel]
+// workspace = [band layout (band mode only)] [the retry's band layout] [checkpoint columns + offsets of the log-domain form:
+// behind the band path one set per workgroup of the tail launch -- a sixteenth of the batch, at least 4: it redoes only what
+// the linear path disowned twice, none on the inputs a network produces (round 3 sized them for the whole batch: 8.4 of
+// 12.2 GB at T = 4000 / N = 256) --, else one per read]
 // `sharp`: the call's sharpening factor -- it picks the linear path's block length, and short blocks keep
 // more checkpoint columns.  The block lengths of the plain CRF and of cat-mod differ; the bound covers both.
 size_t crf_workspace_bytes_sharp(size_t ntrans, size_t nblk, size_t nbatch, size_t max_seqlen,
@@ -878,7 +291,7 @@ size_t crf_workspace_bytes_sharp(size_t ntrans, size_t nblk, size_t nbatch, size
     // kernel on every read if the workspace holds that kernel's whole-batch columns, and returns 3 otherwise:
     // sizing every workspace for that case would be 8.0 instead of 4.7 GB at T = 4000 / N = 256)
     if (crf_pick_mode(ntrans, nblk, nbatch, max_seqlen, want_grad != 0, bk) == CRF_BAND)
-        return crf_ckpt_bytes(nblk, crf_redo_slots(nbatch), sh, want_grad != 0) +
+        return crf_tail_ckpt_bound(ntrans, nblk, nbatch, max_seqlen, want_grad != 0) +
                crf_band_total_bound(ntrans, nblk, nbatch, max_seqlen, want_grad != 0, bk) + crf_retry_bytes(ntrans, nblk, nbatch, max_seqlen);
     return crf_ckpt_bytes(nblk, nbatch, sh, want_grad != 0);
 }
@@ -944,13 +357,16 @@ int crf_dispatch(const float *logprob, size_t ntrans, size_t nblk, size_t nbatch
     // room for it (sized by an older query): such reads go straight to the log-domain kernel, as in round 5
     BandBlock rblk = band ? crf_band_pick_retry(sharp_can, blk) : BandBlock{0, 0.f, 0};
     const size_t retry_slots = crf_band_retry_slots(nbatch);
-    const size_t band_bytes = band ? crf_band_layout(ntrans, nblk, nbatch, max_seqlen, mod, grad != nullptr, blk.bk).total : 0;
+    const BandLayout bl = crf_band_layout(ntrans, nblk, nbatch, max_seqlen, mod, grad != nullptr, blk.bk > 0 ? blk.bk : 8);
+    const size_t band_bytes = band ? bl.total : 0;
+    const CrfShape tsh = crf_tail_shape(bl.R);
+    const size_t tail_ckpt = crf_ckpt_bytes(nblk, retry_slots, tsh, grad != nullptr);
     size_t retry_bytes = (band && rblk.bk > 0) ? crf_band_layout(ntrans, nblk, retry_slots, max_seqlen, mod, true, rblk.bk).total : 0;
-    if (band && crf_ckpt_bytes(nblk, crf_redo_slots(nbatch), sh, grad != nullptr) + band_bytes + retry_bytes > workspace_bytes) {
+    if (band && tail_ckpt + band_bytes + retry_bytes > workspace_bytes) {
         rblk.bk = 0;
         retry_bytes = 0;
     }
-    if (band && crf_ckpt_bytes(nblk, crf_redo_slots(nbatch), sh, grad != nullptr) + band_bytes > workspace_bytes)
+    if (band && tail_ckpt + band_bytes > workspace_bytes)
         band = false;
     if (!band && crf_ckpt_bytes(nblk, nbatch, sh, grad != nullptr) > workspace_bytes) return 3;
     if (labels != nullptr && !band) {
@@ -986,9 +402,6 @@ int crf_dispatch(const float *logprob, size_t ntrans, size_t nblk, size_t nbatch
     a.add_scale = add_scale;
     a.cost = cost;
     a.grad = grad;
-    a.gate = a.gate2 = nullptr;
-    a.bandF = a.bandB = nullptr;
-    a.band_wbias = 0.f;
     a.codes = a.mod_cats = a.cmo = nullptr;
     a.mcw = nullptr;
     a.nbase = 0;
@@ -997,11 +410,9 @@ int crf_dispatch(const float *logprob, size_t ntrans, size_t nblk, size_t nbatch
     // (what add_grad / add_cost hold may come from another stream: the band path waits between its sweeps
     // and its gradient pass, the single-launch form before it starts)
     if (add_ready != nullptr && !(band && grad != nullptr) && hipStreamWaitEvent(stream, add_ready, 0) != hipSuccess) return 4;
-    size_t redo_slots = nbatch;
     if (band) {
         const bool g = grad != nullptr;
-        const BandLayout l = crf_band_layout(ntrans, nblk, nbatch, max_seqlen, mod, g, blk.bk);
-        redo_slots = crf_redo_slots(nbatch);
+        const BandLayout l = bl;
         BandArgs b;
         b.lp = logprob;
         b.T = (int)nblk;
@@ -1042,7 +453,7 @@ int crf_dispatch(const float *logprob, size_t ntrans, size_t nblk, size_t nbatch
         b.rec = g ? reinterpret_cast<uint32_t *>(wb + l.rec) : nullptr;
         b.segend = g ? reinterpret_cast<int *>(wb + l.segend) : nullptr;
         b.gate = reinterpret_cast<int *>(wb + l.gate);
-        b.gate2 = rblk.bk > 0 ? reinterpret_cast<int *>(wb + l.gate2) : nullptr;
+        b.gate2 = reinterpret_cast<int *>(wb + l.gate2);
         b.zeros = reinterpret_cast<const float *>(wb + l.zeros);
         b.dbg = nullptr;
         b.before_gradient = add_ready;
@@ -1058,53 +469,6 @@ int crf_dispatch(const float *logprob, size_t ntrans, size_t nblk, size_t nbatch
         b.nbase = labels != nullptr ? (int)labels->nbase : 0;
         const int rc = crf_band_dispatch(b, l.R, mod, blk.bk, stream);
         if (rc != 0) return rc;
-        if (rblk.bk > 0) {
-            // the reads the batch's launch disowned, once more on the linear path: alone, 4-step blocks, steep frames
-            const BandLayout q = crf_band_layout(ntrans, nblk, retry_slots, max_seqlen, mod, true, rblk.bk);
-            char *wr = wb + l.total;
-            BandArgs c = b;
-            c.ckFm = reinterpret_cast<float *>(wr + q.ckFm);
-            c.ckBm = reinterpret_cast<float *>(wr + q.ckBm);
-            c.ckFf = reinterpret_cast<int16_t *>(wr + q.ckFf);
-            c.ckBf = reinterpret_cast<int16_t *>(wr + q.ckBf);
-            c.ckFb = reinterpret_cast<int *>(wr + q.ckFb);
-            c.ckBb = reinterpret_cast<int *>(wr + q.ckBb);
-            c.bndF = reinterpret_cast<float *>(wr + q.bndF);
-            c.bndB = reinterpret_cast<float *>(wr + q.bndB);
-            c.scoreF = reinterpret_cast<double *>(wr + q.scoreF);
-            c.scoreB = reinterpret_cast<double *>(wr + q.scoreB);
-            c.rec = reinterpret_cast<uint32_t *>(wr + q.rec);
-            c.segend = reinterpret_cast<int *>(wr + q.segend);
-            c.gate = nullptr;
-            c.gate2 = nullptr;
-            c.wbias = rblk.wbias;
-            c.klip = rblk.klip;
-            // (the offsets and -- a call that brought index arrays -- the ids are the batch launch's; a launch that
-            // built its ids from the labels left seqoff behind and the retry forms its ids from the codes as well)
-            BandRetry r;
-            r.gate = b.gate;
-            r.gate2 = b.gate2;
-            r.firstF = g ? nullptr : b.scoreF;
-            r.firstB = g ? nullptr : b.scoreB;
-            if (q.R != l.R || q.W != l.W) return 2;
-            const int rr = crf_band_retry_dispatch(c, r, l.R, mod, retry_slots, stream);
-            if (rr != 0) return rr;
-            if (TK_LAB_ENV("TK_CRF_GATE_DUMP")) {
-                (void)hipStreamSynchronize(stream);
-                static int h1[1 << 16], h2[1 << 16];
-                const size_t ng = nbatch < (1u << 16) ? nbatch : (1u << 16);
-                (void)hipMemcpy(h1, b.gate, ng * sizeof(int), hipMemcpyDeviceToHost);
-                (void)hipMemcpy(h2, b.gate2, ng * sizeof(int), hipMemcpyDeviceToHost);
-                size_t tried = 0, kept = 0;
-                for (size_t i = 0; i < ng; ++i) {
-                    tried += h2[i] != -1;
-                    kept += h2[i] == 0;
-                }
-                fprintf(stderr, "crf band retry (bk %d, bias %.1f, slope %d): %zu reads retried, %zu kept\n", rblk.bk, rblk.wbias, rblk.klip, tried, kept);
-                for (size_t i = 0, shown = 0; i < ng && shown < 16; ++i)
-                    if (h2[i] > 0) fprintf(stderr, "crf band retry:   read %zu first %d retry %d\n", i, h1[i], h2[i]), ++shown;
-            }
-        }
         if (TK_LAB_ENV("TK_CRF_GATE_DUMP")) {                       // lab: how many reads did the band path disown?
             (void)hipStreamSynchronize(stream);
             static int hostg[1 << 16];
@@ -1120,33 +484,83 @@ int crf_dispatch(const float *logprob, size_t ntrans, size_t nblk, size_t nbatch
             for (size_t i = 0, shown = 0; i < ng && shown < 16; ++i)
                 if (hostg[i]) fprintf(stderr, "crf band:   read %zu (reason %d)\n", i, hostg[i]), ++shown;
         }
-        // the reads the linear path disowned, redone in the log domain
-        a.gate = b.gate;
-        a.gate2 = b.gate2;
+        // THE TAIL LAUNCH (round 6; crf_band.hip: crf_band_tail_kernel): the reads the batch's launch disowned, once more on
+        // the linear path -- alone, 4-step blocks, steep frames -- and what that disowns too, redone in the log domain by the
+        // same workgroup.  One launch; it finds nothing to do on the inputs a network produces.
+        BandArgs c = b;
+        c.gate = nullptr;
+        c.gate2 = nullptr;
+        if (rblk.bk > 0) {
+            const BandLayout q = crf_band_layout(ntrans, nblk, retry_slots, max_seqlen, mod, true, rblk.bk);
+            if (q.R != l.R || q.W != l.W) return 2;
+            char *wr = wb + l.total;
+            c.ckFm = reinterpret_cast<float *>(wr + q.ckFm);
+            c.ckBm = reinterpret_cast<float *>(wr + q.ckBm);
+            c.ckFf = reinterpret_cast<int16_t *>(wr + q.ckFf);
+            c.ckBf = reinterpret_cast<int16_t *>(wr + q.ckBf);
+            c.ckFb = reinterpret_cast<int *>(wr + q.ckFb);
+            c.ckBb = reinterpret_cast<int *>(wr + q.ckBb);
+            c.bndF = reinterpret_cast<float *>(wr + q.bndF);
+            c.bndB = reinterpret_cast<float *>(wr + q.bndB);
+            c.scoreF = reinterpret_cast<double *>(wr + q.scoreF);
+            c.scoreB = reinterpret_cast<double *>(wr + q.scoreB);
+            c.rec = reinterpret_cast<uint32_t *>(wr + q.rec);
+            c.segend = reinterpret_cast<int *>(wr + q.segend);
+            c.wbias = rblk.wbias;
+            c.klip = rblk.klip;
+        }
+        // (the offsets and -- a call that brought index arrays -- the ids are the batch launch's; a launch that built its
+        // ids from the labels left seqoff behind, and the tail forms its ids from the codes as well)
+        BandRetry r;
+        r.gate = b.gate;
+        r.gate2 = b.gate2;
+        r.firstF = g ? nullptr : b.scoreF;
+        r.firstB = g ? nullptr : b.scoreB;
+        r.first_wbias = blk.wbias;
+        r.retry = rblk.bk > 0 ? 1 : 0;
+        r.log_domain = 1;
+        if (const char *e = TK_LAB_ENV("TK_CRF_NO_FALLBACK"))       // lab: time / test the linear path alone
+            if (e[0] == '1') r.log_domain = 0;
         a.codes = b.codes;      // (ids from the labels wherever the band launch took them: it wrote no index array)
         a.mod_cats = b.mod_cats;
         a.cmo = b.cmo;
         a.mcw = b.mcw;
         a.nbase = b.nbase;
-        if (!g) {               // cost only: the vote pass compares the sweeps and writes the costs
-            a.bandF = b.scoreF;
-            a.bandB = b.scoreB;
-            a.band_wbias = blk.wbias;
-        }
         wb += l.total + retry_bytes;
-        // (a cost-only call's costs are written by crf_kernel's vote pass: that launch stays -- round-5 advisor finding: the
-        // switch left cost[] uninitialised for such calls)
-        if (const char *e = TK_LAB_ENV("TK_CRF_NO_FALLBACK"))       // lab: time / test the band path alone
-            if (e[0] == '1' && grad != nullptr) return 0;
+        {
+            const int CK = crf_ck(tsh.R, tsh.W, mod ? 3 : 2);
+            const size_t NK = (nblk + CK - 1) / CK;
+            const size_t ckb = (retry_slots * NK * (size_t)tsh.R * tsh.W * WAVE * sizeof(float) + 255) / 256 * 256;
+            a.ckpt = reinterpret_cast<float *>(wb);
+            a.ckoff = reinterpret_cast<double *>(wb + (grad ? ckb : 0));
+        }
+        const int rr = crf_band_tail_dispatch(c, r, a, l.R, mod, retry_slots, stream);
+        if (rr != 0) return rr;
+        if (TK_LAB_ENV("TK_CRF_GATE_DUMP")) {
+            (void)hipStreamSynchronize(stream);
+            static int h1[1 << 16], h2[1 << 16];
+            const size_t ng = nbatch < (1u << 16) ? nbatch : (1u << 16);
+            (void)hipMemcpy(h1, b.gate, ng * sizeof(int), hipMemcpyDeviceToHost);
+            (void)hipMemcpy(h2, b.gate2, ng * sizeof(int), hipMemcpyDeviceToHost);
+            size_t tried = 0, kept = 0;
+            for (size_t i = 0; i < ng; ++i) {
+                tried += h2[i] != -1;
+                kept += h2[i] == 0;
+            }
+            fprintf(stderr, "crf band tail (retry: bk %d, bias %.1f, slope %d): %zu reads taken, %zu kept on the linear path\n", rblk.bk, rblk.wbias, rblk.klip, tried, kept);
+            for (size_t i = 0, shown = 0; i < ng && shown < 16; ++i)
+                if (h2[i] > 0) fprintf(stderr, "crf band tail:   read %zu first %d retry %d\n", i, h1[i], h2[i]), ++shown;
+        }
+        return 0;
     }
     {
         const int CK = crf_ck(sh.R, sh.W, mod ? 3 : 2);
         const size_t NK = (nblk + CK - 1) / CK;
-        const size_t ckb = (redo_slots * NK * (size_t)sh.R * sh.W * WAVE * sizeof(float) + 255) / 256 * 256;
+        const size_t ckb = (nbatch * NK * (size_t)sh.R * sh.W * WAVE * sizeof(float) + 255) / 256 * 256;
         a.ckpt = reinterpret_cast<float *>(wb);
         a.ckoff = reinterpret_cast<double *>(wb + (grad ? ckb : 0));
     }
-    return mod ? crf_launch_mod<true>(sh, a, stream, redo_slots) : crf_launch_mod<false>(sh, a, stream, redo_slots);
+    return mod ? crf_launch_mod<true>(sh, a, stream, nbatch) : crf_launch_mod<false>(sh, a, stream, nbatch);
 }
 
 }  // namespace tk

@@ -29,11 +29,17 @@ for T in (800, 1600):
         print("T %d %s  of 64, by L/T: redone in the log domain / retried on the linear path  %s" % (T, "cat-mod" if mods else "plain  ", "  ".join(row)), flush=True)
 # a batch of ordinary reads with ONE (and with four) long ones: the batch keeps its fast configuration, the long reads are retried
 import time
-for T, N in ((800, 128),):
+MODES = (("as shipped", {}), ("lab build, TK_CRF_NO_RETRY=1: round 5's path, disowned reads straight to the log domain", {"TK_CRF_NO_RETRY": "1"}))
+for T, N, label, env in [(800, 128) + m for m in MODES] + [(2400, 64) + m for m in MODES]:
+    print("-- T %d N %d, %s" % (T, N, label), flush=True)
+    _lib.use_lab(bool(env))
+    for k in ("TK_CRF_NO_RETRY",):
+        os.environ.pop(k, None)
+    os.environ.update(env)
     for mods in (None, (1, 1, 0, 0)):
-        for nlong, frac in ((0, 0.0), (1, 0.86), (1, 0.9), (4, 0.9), (8, 0.9)):
+        for nlong, frac in ((0, 0.0), (1, 0.86), (1, 0.9), (1, 0.93), (4, 0.93), (8, 0.93)):
             Ls = synth.realistic_seqlens(T, N, 17000, T * 5, 9.0).copy()
-            Ls[:nlong] = int(frac * T)
+            Ls[:nlong] = int(frac * T) - np.arange(nlong)
             inp = synth.crf_case(T, N, 3, seqlens=Ls, nmods_per_base=mods)
             if mods is not None:
                 synth.normalise_mod_columns(inp)

@@ -1,9 +1,9 @@
 #!/bin/bash
 # The round's evidence files on one GPU box (what profiles/README.md's table cites), written under gpurun_out/$TAG/:
-#   gpurun --timeout 2400 -- 'TAG=r5_v1 bash tools/evidence.sh'
+#   gpurun --timeout 2400 -- 'TAG=r6_v1 bash tools/evidence.sh'
 # PMC passes never share a run with a trace domain other than --kernel-trace (MI355X guide; tools/pmc_traffic.py,
 # tools/sq_counters.py wrap rocprofv3 themselves).  Every step is bounded by `timeout`.
-cd "$(dirname "$0")/.."; TAG=${TAG:-r5}; O=gpurun_out/$TAG; mkdir -p $O
+cd "$(dirname "$0")/.."; TAG=${TAG:-r6}; O=gpurun_out/$TAG; mkdir -p $O
 export TMPDIR=/tmp
 H=$(python -c "import bench; print(bench.kernel_hash())" 2>/dev/null | tail -1); echo "kernel hash $H" | tee $O/hash.txt
 timeout 900 python -m pytest tests -m gpu -q > $O/pytest_gpu.log 2>&1; grep -E "passed|failed" $O/pytest_gpu.log | tail -1
@@ -23,7 +23,8 @@ timeout 900 python tools/sq_counters.py --save $O/${TAG%%_*}_sq_counters.json > 
 # operator timings outside the step
 timeout 300 python tools/vitbench.py > $O/vitbench.txt 2>&1
 for v in "" "--separate"; do echo "== crfops $v"; timeout 300 python tools/crfops.py --rowk --catmod --cfg5 $v 2>&1 | tail -1; done > $O/crfops.txt
-timeout 300 python tools/crf_gate_probe.py > $O/crf_gate_probe.log 2>&1
+timeout 300 python tools/crf_gate_probe.py --shapes tiny,t19,t37,t200,cfg2,cfg2r,narrow,pathbuf,lenramp,initramp,conframp,sharp,sharp13,sharp15,sharp17,sharp2,sharp3,sharp4,sharp2K,cfg4,cfg4r,cfg4rharsh,cfg4sharp2,cfg4sharp25,cfg4sharp3,cfg5,rowK,conf,confburst,confK,realnet,realnet_s2,realnet_s3,realfast,realfast_s2,realfast_s3,realnet_cm,realnet_cm_s13,realnet_cm_s2,realnet_cm_s25,realnet_cm_s3,realfast_cm,realfast_cm_s13,realfast_cm_s2,realfast_cm_s25,realfast_cm_s3 > $O/crf_gate_probe.log 2>&1
+timeout 600 python tools/crf_gate_band_probe.py > $O/gate_by_band_width.txt 2>&1
 wait
 tail -n 2 $O/fuzz_shapes_*.log; grep -h FAIL $O/fuzz_shapes_*.log | head
 ls -la $O

@@ -114,11 +114,14 @@ int tk_flipflop_build_indices_dev(const int32_t *seqs, const int32_t *seqlen,
  *   grad[t,n,i] = d(-score(lp)/nblk)/d lp[t,n,i]     (ctc.pyx:113; NULL => cost only,
  *                 in which case score is the forward score, c_crf_flipflop.c:255-290)
  *   seqlen[n]==0 => cost 0, zero gradient rows        (c_crf_flipflop.c:269-272,458-464)
- *   max_seqlen: an upper bound of seqlen (0 = unknown => nblk+1 is assumed).  The launch's SHAPE follows it -- cells per
- *               lane, block length, and the slope of the linear path's frames: a batch whose longest read may exceed
- *               0.78 nblk (cat-mod 0.62 nblk) takes shorter blocks and steeper frames so that narrow bands stay on the
- *               linear path (round 5) -- so a tight bound is also the faster launch; results of a read are bit-for-bit
- *               the same in any batch launched with the same bound.
+ *   max_seqlen: an upper bound of seqlen (0 = unknown => nblk+1 is assumed).  It SIZES the launch -- cells per lane, waves
+ *               per read, the workspace -- so a tight bound is also the smaller launch.  Round 6: the block length and the
+ *               slope of the linear path's frames no longer follow it (round 5: one read beyond 0.78 nblk moved the whole
+ *               batch to shorter blocks) but the batch's BULK (tk_seq_labels.bulk_seqlen below; unknown for the entry points
+ *               that take index arrays): everybody runs the fast configuration, and the few reads it disowns are swept again
+ *               alone by the TAIL launch -- 4-step blocks, frames of slope 20 -- and, only if that fails too, redone in the
+ *               log domain by the same workgroup.  Results of a read are bit-for-bit the same in any batch launched with
+ *               the same max_seqlen and configuration.
  *   mod_col_weights (nullable, cat-mod only; (ntrans - ncan) floats on the device): the caller's PROMISE
  *     that modfact[p] == mod_col_weights[modidx[p] - ncan] for every move, i.e. that the factor is a property
  *     of the modification column -- which is what `mod_cat_weights` of the reference's operator is
@@ -134,8 +137,10 @@ size_t tk_crf_flipflop_workspace_bytes(size_t ntrans, size_t nblk, size_t nbatch
  * (factors up to 3.5), which keep more checkpoint columns.  Size the workspace with the factor the call
  * will carry.  A call whose workspace is too small for its factor's layout is done by the log-domain kernel on
  * every read IF the workspace holds that kernel's whole-batch checkpoint columns (it does at the train step's
- * shapes; at T = 4000 / N = 256 those are 8.0 GB against the linear path's 4.7) and returns TK_ERR 3
- * (workspace too small) otherwise -- never a wrong result. */
+ * shapes; at T = 4000 / N = 256 those are 8.0 GB against the linear path's 4.6) and returns TK_ERR 3
+ * (workspace too small) otherwise -- never a wrong result.  (Round 6: the size includes the tail launch's slots --
+ * a 4-step layout and the log-domain form's checkpoint columns for a sixteenth of the batch; a workspace that
+ * holds the linear path's layout but not the retry's sends disowned reads straight to the log domain.) */
 size_t tk_crf_flipflop_workspace_bytes_sharp(size_t ntrans, size_t nblk, size_t nbatch,
                                              size_t max_seqlen, int want_grad, float sharpfact);
 

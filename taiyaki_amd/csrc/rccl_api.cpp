@@ -17,6 +17,7 @@
 #include <netdb.h>
 #include <netinet/in.h>
 #include <netinet/tcp.h>
+#include <fcntl.h>
 #include <poll.h>
 #include <rccl/rccl.h>
 #include <stdint.h>
@@ -86,49 +87,111 @@ struct Fds {
     }
 };
 
+// listening socket on `addr` (null / unbindable: the wildcard address -- torch's store binds it too, and MASTER_ADDR may be a
+// name that resolves to an address this host does not own behind a NAT or in a container)
+static int rv_listen(const char *addr, const char *ports, int backlog) {
+    for (int pass = 0; pass < 2; ++pass) {
+        addrinfo hints{}, *res = nullptr;
+        hints.ai_family = AF_UNSPEC;
+        hints.ai_socktype = SOCK_STREAM;
+        hints.ai_flags = AI_PASSIVE;
+        if (getaddrinfo(pass == 0 ? addr : nullptr, ports, &hints, &res) != 0 || res == nullptr) continue;
+        int ls = -1;
+        for (addrinfo *ai = res; ai != nullptr && ls < 0; ai = ai->ai_next) {
+            ls = socket(ai->ai_family, ai->ai_socktype, ai->ai_protocol);
+            if (ls < 0) continue;
+            const int one = 1;
+            (void)setsockopt(ls, SOL_SOCKET, SO_REUSEADDR, &one, sizeof(one));
+            if (bind(ls, ai->ai_addr, ai->ai_addrlen) != 0 || listen(ls, backlog) != 0) {
+                close(ls);
+                ls = -1;
+            }
+        }
+        freeaddrinfo(res);
+        if (ls >= 0) return ls;
+    }
+    return -1;
+}
+
 int rv_serve(const char *addr, int port, int nranks, const void *buf, size_t bytes, long long deadline) {
-    addrinfo hints{}, *res = nullptr;
-    hints.ai_family = AF_UNSPEC;
-    hints.ai_socktype = SOCK_STREAM;
-    hints.ai_flags = AI_PASSIVE;
     char ports[16];
     snprintf(ports, sizeof(ports), "%d", port);
-    if (getaddrinfo(addr, ports, &hints, &res) != 0 || res == nullptr) return TK_ERR_BAD_ARG;
     Fds fds;
-    int ls = -1;
-    for (addrinfo *ai = res; ai != nullptr && ls < 0; ai = ai->ai_next) {
-        ls = socket(ai->ai_family, ai->ai_socktype, ai->ai_protocol);
-        if (ls < 0) continue;
-        const int one = 1;
-        (void)setsockopt(ls, SOL_SOCKET, SO_REUSEADDR, &one, sizeof(one));
-        if (bind(ls, ai->ai_addr, ai->ai_addrlen) != 0 || listen(ls, nranks + 8) != 0) {
-            close(ls);
-            ls = -1;
-        }
-    }
-    freeaddrinfo(res);
+    const int ls = rv_listen(addr, ports, nranks + 8);
     if (ls < 0) return TK_ERR_LAUNCH;
     fds.v.push_back(ls);
+    (void)fcntl(ls, F_SETFL, fcntl(ls, F_GETFL, 0) | O_NONBLOCK);
+    // connections that have not said hello yet: read side by side (a silent stray one -- a port scanner, a health check --
+    // costs nobody anything and is dropped after 2 s), not one after the other
+    struct Pending {
+        int fd;
+        RvHello h;
+        size_t got;
+        long long until;
+    };
+    std::vector<Pending> pend;
     std::vector<int> peer(nranks, -1);
     int have = 0;
+    auto drop = [&](int fd) {
+        for (int &f : fds.v)
+            if (f == fd) f = -1;
+        close(fd);
+    };
     while (have < nranks - 1) {
-        const long long left = deadline - now_ms();
+        const long long now = now_ms(), left = deadline - now;
         if (left <= 0) return TK_ERR_LAUNCH;
-        pollfd pf{ls, POLLIN, 0};
-        if (poll(&pf, 1, (int)(left > 1000 ? 1000 : left)) <= 0) continue;
-        const int fd = accept(ls, nullptr, nullptr);
-        if (fd < 0) continue;
-        fds.v.push_back(fd);
-        const int one = 1;
-        (void)setsockopt(fd, IPPROTO_TCP, TCP_NODELAY, &one, sizeof(one));
-        RvHello h{};
-        // (a stray connection -- a port scanner, a health check -- is dropped, not an error)
-        if (!io_all(fd, &h, sizeof(h), false, now_ms() + 2000 < deadline ? now_ms() + 2000 : deadline) || h.magic != RV_MAGIC) continue;
-        if (h.version != 1 || (int)h.nranks != nranks || h.rank == 0 || (int)h.rank >= nranks || peer[h.rank] >= 0)
-            return TK_ERR_LAUNCH;                   // two jobs on one port, or a rank started twice
-        peer[h.rank] = fd;
-        ++have;
+        std::vector<pollfd> pfs;
+        pfs.push_back(pollfd{ls, POLLIN, 0});
+        for (const Pending &q : pend) pfs.push_back(pollfd{q.fd, POLLIN, 0});
+        const int pr = poll(pfs.data(), (nfds_t)pfs.size(), (int)(left > 250 ? 250 : left));
+        if (pr < 0) {
+            if (errno == EINTR) continue;
+            return TK_ERR_LAUNCH;                   // (not a spin until the deadline)
+        }
+        const bool incoming = (pfs[0].revents & POLLIN) != 0;
+        for (size_t i = 0; i < pend.size();) {
+            Pending &q = pend[i];
+            bool gone = now_ms() > q.until;
+            if (!gone && (pfs[i + 1].revents & (POLLIN | POLLHUP | POLLERR))) {
+                const ssize_t k = recv(q.fd, reinterpret_cast<char *>(&q.h) + q.got, sizeof(q.h) - q.got, 0);
+                if (k > 0) q.got += (size_t)k;
+                else if (k == 0 || (errno != EINTR && errno != EAGAIN && errno != EWOULDBLOCK)) gone = true;
+            }
+            bool taken = false;
+            if (!gone && q.got == sizeof(q.h)) {
+                // a well-formed hello of THIS job from a rank not seen yet; anything else -- another job on the port, a rank
+                // started twice, a scanner -- is closed and ignored: it must not take the other ranks down with it
+                const bool ok = q.h.magic == RV_MAGIC && q.h.version == 1 && (int)q.h.nranks == nranks && q.h.rank != 0 &&
+                                (int)q.h.rank < nranks && peer[q.h.rank] < 0;
+                if (ok) {
+                    peer[q.h.rank] = q.fd;
+                    ++have;
+                    taken = true;
+                } else {
+                    gone = true;
+                }
+            }
+            if (gone) drop(q.fd);
+            if (gone || taken) {
+                // (pfs indices follow pend: keep them aligned by erasing from both)
+                pend.erase(pend.begin() + (long)i);
+                pfs.erase(pfs.begin() + (long)i + 1);
+            } else {
+                ++i;
+            }
+        }
+        if (incoming) {                             // (after the pass over `pend`: its entries and `pfs` stay aligned)
+            const int fd = accept(ls, nullptr, nullptr);
+            if (fd >= 0) {
+                fds.v.push_back(fd);
+                const int one = 1;
+                (void)setsockopt(fd, IPPROTO_TCP, TCP_NODELAY, &one, sizeof(one));
+                (void)fcntl(fd, F_SETFL, fcntl(fd, F_GETFL, 0) | O_NONBLOCK);
+                pend.push_back(Pending{fd, RvHello{}, 0, now_ms() + 2000});
+            }
+        }
     }
+    for (const Pending &q : pend) drop(q.fd);
     RvHead head{RV_MAGIC, (uint32_t)bytes};
     for (int r = 1; r < nranks; ++r)
         if (!io_all(peer[r], &head, sizeof(head), true, deadline) ||
@@ -141,23 +204,44 @@ int rv_serve(const char *addr, int port, int nranks, const void *buf, size_t byt
     return TK_OK;
 }
 
+// connect within the deadline: non-blocking connect + poll (a blocking connect to an unroutable address sits in the kernel's
+// SYN timeout for about two minutes whatever the caller's deadline says)
+static int rv_connect(const addrinfo *ai, long long deadline) {
+    const int fd = socket(ai->ai_family, ai->ai_socktype, ai->ai_protocol);
+    if (fd < 0) return -1;
+    (void)fcntl(fd, F_SETFL, fcntl(fd, F_GETFL, 0) | O_NONBLOCK);
+    if (connect(fd, ai->ai_addr, ai->ai_addrlen) == 0) return fd;
+    if (errno != EINPROGRESS && errno != EINTR) {
+        close(fd);
+        return -1;
+    }
+    for (;;) {
+        const long long left = deadline - now_ms();
+        if (left <= 0) break;
+        pollfd pf{fd, POLLOUT, 0};
+        const int pr = poll(&pf, 1, (int)(left > 1000 ? 1000 : left));
+        if (pr < 0 && errno != EINTR) break;
+        if (pr <= 0) continue;
+        int err = 0;
+        socklen_t len = sizeof(err);
+        if (getsockopt(fd, SOL_SOCKET, SO_ERROR, &err, &len) == 0 && err == 0) return fd;
+        break;
+    }
+    close(fd);
+    return -1;
+}
+
 int rv_join(const char *addr, int port, int rank, int nranks, void *buf, size_t bytes, long long deadline) {
     char ports[16];
     snprintf(ports, sizeof(ports), "%d", port);
-    for (;;) {                                      // rank 0 may not be listening yet: retry
+    for (;;) {                                      // rank 0 may not be listening yet, or dropped us: retry until the deadline
         if (now_ms() >= deadline) return TK_ERR_LAUNCH;
         addrinfo hints{}, *res = nullptr;
         hints.ai_family = AF_UNSPEC;
         hints.ai_socktype = SOCK_STREAM;
         if (getaddrinfo(addr, ports, &hints, &res) != 0 || res == nullptr) return TK_ERR_BAD_ARG;
         int fd = -1;
-        for (addrinfo *ai = res; ai != nullptr && fd < 0; ai = ai->ai_next) {
-            fd = socket(ai->ai_family, ai->ai_socktype, ai->ai_protocol);
-            if (fd >= 0 && connect(fd, ai->ai_addr, ai->ai_addrlen) != 0) {
-                close(fd);
-                fd = -1;
-            }
-        }
+        for (addrinfo *ai = res; ai != nullptr && fd < 0; ai = ai->ai_next) fd = rv_connect(ai, deadline);
         freeaddrinfo(res);
         if (fd < 0) {
             usleep(50 * 1000);
@@ -169,8 +253,12 @@ int rv_join(const char *addr, int port, int rank, int nranks, void *buf, size_t 
         (void)setsockopt(fd, IPPROTO_TCP, TCP_NODELAY, &one, sizeof(one));
         RvHello h{RV_MAGIC, 1, (uint32_t)rank, (uint32_t)nranks};
         RvHead head{};
-        if (!io_all(fd, &h, sizeof(h), true, deadline) || !io_all(fd, &head, sizeof(head), false, deadline))
-            return TK_ERR_LAUNCH;
+        // (a connection rank 0 accepted and then lost -- it restarted, or a predecessor of ours still held the rank's slot --
+        // is tried again, not an error, while the deadline lasts; a WRONG answer is an error at once)
+        if (!io_all(fd, &h, sizeof(h), true, deadline) || !io_all(fd, &head, sizeof(head), false, deadline)) {
+            usleep(50 * 1000);
+            continue;
+        }
         if (head.magic != RV_MAGIC || head.bytes != (uint32_t)bytes) return TK_ERR_LAUNCH;
         if (!io_all(fd, buf, bytes, false, deadline)) return TK_ERR_LAUNCH;
         uint32_t ack = RV_MAGIC;

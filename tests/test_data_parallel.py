@@ -316,6 +316,41 @@ def test_own_rendezvous_hands_the_unique_id_to_every_rank(tmp_path):
         assert " rc 0 " in out and out.strip().endswith(want), (out, err)
 
 
+def test_own_rendezvous_is_not_disturbed_by_strangers(tmp_path):
+    """Round-5 advisor finding: one well-formed hello with a wrong world size, or a repeated rank, used to abort the
+    rendezvous for ALL ranks, and a silent stray connection stalled the real peers for 2 s each.  Now rank 0 closes
+    and ignores them: a silent connection, a peer of another job and the proper rank 1 arrive in that order, and the
+    job's two ranks end with the id."""
+    import socket
+    import time
+    port = _free_port()
+    script = tmp_path / "rv_worker.py"
+    script.write_text(RENDEZVOUS_WORKER)
+
+    def start(rank, announce):
+        return subprocess.Popen([sys.executable, str(script), str(rank), "2", str(port), str(announce)],
+                                stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)
+    p0 = start(0, 2)
+    stray = None
+    for _ in range(100):                        # (until rank 0 listens)
+        try:
+            stray = socket.create_connection(("127.0.0.1", port), timeout=1.0)
+            break
+        except OSError:
+            time.sleep(0.05)
+    assert stray is not None
+    other = start(1, 4)                         # another job's rank 1 on the same port
+    time.sleep(0.3)
+    p1 = start(1, 2)
+    want = bytes((7 * i + 3) % 251 for i in range(128)).hex()
+    for p in (p0, p1):
+        out, err = p.communicate(timeout=60)
+        assert p.returncode == 0 and " rc 0 " in out and out.strip().endswith(want), (out, err)
+    stray.close()
+    out, _ = other.communicate(timeout=60)
+    assert " rc 4 " in out, out                 # the stranger is refused (it retries until its own deadline)
+
+
 def test_own_rendezvous_refuses_a_rank_from_another_job(tmp_path):
     """A peer that announces another world size (two jobs pointed at one port) fails the rendezvous on both
     sides instead of handing a communicator id to the wrong job; bad arguments are refused at once."""

@@ -23,3 +23,6 @@ gcc -O1 -I/opt/conda/include -o /tmp/gen_heap_fixtures "$here/gen_heap_fixtures.
 /tmp/gen_heap_fixtures "$here/heap_150.hdf5" 150
 /tmp/gen_heap_fixtures "$here/heap_2000.hdf5" 2000 && gzip -9 -f "$here/heap_2000.hdf5"
 /tmp/gen_heap_fixtures "$here/heap_150_every7th_deleted.hdf5" 150 7
+# child indirect blocks (round 6): beyond ~25 thousand links the root indirect block's rows hold indirect blocks
+/tmp/gen_heap_fixtures "$here/heap_40000.hdf5" 40000 && gzip -9 -f "$here/heap_40000.hdf5"
+/tmp/gen_heap_fixtures "$here/heap_40000_every11th_deleted.hdf5" 40000 11 && gzip -9 -f "$here/heap_40000_every11th_deleted.hdf5"

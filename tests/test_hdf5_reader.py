@@ -307,13 +307,15 @@ def test_a_fractal_heap_that_saw_deletions_or_special_objects_is_refused_by_name
     assert hdf5_lite.read_mapped_signal_file(os.path.join(HERE, "generated_v108.hdf5"))[1]
 
 
-@pytest.mark.parametrize("n", [35, 150, 2000])
+@pytest.mark.parametrize("n", [35, 150, 2000, 40000])
 def test_fractal_heap_with_a_partially_filled_root_indirect_block_reads(tmp_path, n):
     """Round-4 advisor finding: the heap accounting check compared the bytes found with `allocated - free -
     headers`, but libhdf5 books the free space of every direct block a root indirect block's rows CAN hold when
     the indirect block is created or doubled, before those blocks exist -- valid never-modified files of 35, 50,
     100, 2000 links were refused (the announced byte count even negative).  Fixtures written by libhdf5 1.10.6
-    itself (gen_heap_fixtures.c): one group of n empty sub-groups (2, 7 and 22 direct blocks under one root indirect block)."""
+    itself (gen_heap_fixtures.c): one group of n empty sub-groups (2, 7 and 22 direct blocks under one root indirect block).
+    Round-5 advisor finding: none of them reaches the rows of CHILD indirect blocks (beyond the largest direct block, ~25 thousand
+    links): 40000 links do -- a root indirect block with three children, 115 direct blocks."""
     import gzip
     path = os.path.join(HERE, "heap_%d.hdf5" % n)
     if not os.path.exists(path):
@@ -321,9 +323,21 @@ def test_fractal_heap_with_a_partially_filled_root_indirect_block_reads(tmp_path
         with open(path, "wb") as fh:
             fh.write(gzip.open(os.path.join(HERE, "heap_%d.hdf5.gz" % n)).read())
     raw = open(path, "rb").read()
-    assert raw.count(b"FRHP") >= 1 and raw.count(b"FHIB") == 1 and raw.count(b"FHDB") == {35: 2, 150: 7, 2000: 22}[n]
+    assert raw.count(b"FRHP") >= 1 and raw.count(b"FHIB") == (4 if n == 40000 else 1)
+    assert raw.count(b"FHDB") == {35: 2, 150: 7, 2000: 22, 40000: 115}[n]
     f = hdf5_lite.File(path)
     assert sorted(f["Reads"].keys()) == ["read_%05d" % r for r in range(n)]
+
+
+def test_fractal_heap_with_child_indirect_blocks_that_lost_links_is_refused(tmp_path):
+    """... and its every-11th-deleted variant (40000 links, child indirect blocks) is refused like the small one below."""
+    import gzip
+    path = str(tmp_path / "heap_40000_del.hdf5")
+    with open(path, "wb") as fh:
+        fh.write(gzip.open(os.path.join(HERE, "heap_40000_every11th_deleted.hdf5.gz")).read())
+    with pytest.raises(hdf5_lite.Hdf5Error, match="deleted"):
+        f = hdf5_lite.File(path)
+        list(f["Reads"].keys())
 
 
 def test_fractal_heap_that_really_lost_links_is_refused():

@@ -1119,545 +1119,50 @@ __host__ __device__ inline size_t band_post_lds_bytes(bool mod, int bk) {
     return (size_t)POST_WAVES * bk * (mod ? 3 : 2) * WAVE * 4;
 }
 
-// One wave, one time block `jb` of read `n` (workspace slot `ws`: n in the batch's launch, the workgroup's own slot in
-// the retry launch); `sP`: the wave's own RG x EPL x 64 floats of LDS.  Returns 0, or why the linear path disowns the
-// read: 1 a sweep score is not finite, 4 the sweeps disagree, 2 a row of this block lost mass (the caller records it).
+// One wave, one time block `jb` of read `n` (workspace slot `ws`: the tail launch's retry, crf_band_tail_kernel); `sP`: the
+// wave's own RG x EPL x 64 floats of LDS.  Returns 0, or why the linear path disowns the read: 1 a sweep score is not
+// finite, 4 the sweeps disagree, 2 a row of this block lost mass (the caller records it).
 template <bool MOD, bool CW, int BK>
 __device__ __forceinline__ int band_posterior_block(const BandArgs &a, const int n, const int ws, const int jb, float *sP) {
-    constexpr int R = 1;                                        // 64-cell chunks whatever the sweeps used
-    constexpr int PW = R * WAVE;
-    constexpr int KINDS = MOD ? 3 : 2;
-    constexpr int EPL = KINDS * R;
-    constexpr int RG = (MOD && BK > 8) ? 4 : BK;                // rows evaluated together (cat-mod at 12 steps: three instances per
-                                                                // cell and row -- groups of four keep it under the register cap)
-    const int lane = threadIdx.x & (WAVE - 1);
-    const bool head = jb == 0 && lane == 0;                         // one lane per read: its cost
-    const int N = a.N, T = a.T, S = a.S, W = a.Wp;              // W: 64-cell chunks per checkpoint row
-    const int PWS = a.LP / a.W;                                 // cells per SWEEP chunk
-    const size_t rowstride = (size_t)N * S;
-    const int NB = (T + BK - 1) / BK;
-    const int t0 = jb * BK;
-    // WHAT THE WAVE NEEDS BEFORE IT CAN DECIDE ANYTHING, ISSUED TOGETHER (round 4, LABNOTES R4.11): the read's length
-    // and offsets, the two sweep scores, the block's score rows, the frame bases of the block's chunks (lane =
-    // chunk) -- addresses that depend on nothing but the launch's arguments.  Length -> scores were two round trips
-    // one after the other.  (Also issuing the frame columns of all chunks of a short read here -- the mask pass's
-    // loads, a third round trip -- costs 32 registers: cat-mod fell from 6 to 5 waves per SIMD and lost 6 us.)
-    const int jbc = min(jb, NB - 1);                            // (waves past the last block leave below)
-    const size_t ckrow = ((size_t)ws * NB + jbc) * a.LP;
-    const size_t ckbase = ((size_t)ws * NB + jbc) * a.W;          // the block's frame bases, one per sweep chunk
-    const int pws_sh = 31 - __builtin_clz(PWS);                  // (PWS = 64, 128 or 256 cells)
-    const bool coltest = jbc >= 1;
-    const unsigned lane4 = 4u * (unsigned)lane;
-    const __amdgpu_buffer_rsrc_t rFf = __builtin_amdgcn_make_buffer_rsrc(a.ckFf + ckrow, 0, (int)(a.LP * 2), BUF_WORD3);
-    const __amdgpu_buffer_rsrc_t rBf = __builtin_amdgcn_make_buffer_rsrc(a.ckBf + ckrow, 0, (int)(a.LP * 2), BUF_WORD3);
-    const __amdgpu_buffer_rsrc_t rBt = coltest ? __builtin_amdgcn_make_buffer_rsrc(a.ckBf + ckrow - a.LP, 0, (int)(a.LP * 2), BUF_WORD3) : rBf;
-    const size_t ckbase_t = coltest ? ckbase - a.W : ckbase;
-    const int seqlen_n = a.seqlen[n];
-    const int64_t off = a.seqoff[n], off_next = a.seqoff[n + 1];
-    const double scoreF = a.scoreF[ws], scoreB = a.scoreB[ws];
-    const float *lpn = a.lp + (size_t)n * S;
-    const int col = min(lane, S - 1);
-    float raw[BK], er[BK];      // the wave's score rows, one register each (lane = transition id), raw and exponentiated
-#pragma unroll
-    for (int k = 0; k < BK; ++k) raw[k] = lpn[(size_t)min(t0 + k, T - 1) * rowstride + col];
-    const int bidx = (min(lane, W - 1) * PW) >> pws_sh;
-    const int baseF_l = a.ckFb[ckbase + bidx], baseB_l = a.ckBb[ckbase + bidx];
-    const int baseT_l = coltest ? a.ckBb[ckbase_t + bidx] : baseB_l;
-    asm volatile("" ::: "memory");
-    const int L = min(seqlen_n, (int)(off_next - off));         // (offsets are clamped to the label array)
-
-    if (L == 0 || L > a.LP) {
-        if (head) {
-            a.cost[n] = (L == 0) ? crf_add_cost(a, n, 0.f) : __builtin_nanf("");   // c_crf_flipflop.c:269-272, 458-464
-            if (L != 0 && a.status) atomicOr(a.status, 16u);
-        }
-        if (lane < S) {
-            // empty read: zero rows; a read too long for the launch: NaN rows next to its NaN cost and
-            // the status bit -- never uninitialised memory on its way to an optimiser
-            const float gs0 = a.grad_scale * (a.grad_scale_vec != nullptr ? a.grad_scale_vec[n] : 1.0f);
-            for (int t = t0; t < min(t0 + BK, T); ++t)
-                a.grad[(size_t)t * rowstride + (size_t)n * S + lane] =
-                    (L == 0) ? crf_add_grad(a, (size_t)t, n, lane, 0.f, gs0) : __builtin_nanf("");
-        }
-        return 0;
-    }
-#ifdef TK_LAB_STAMPS
-    unsigned long long pst[6];
-    int pstk = 0;
-#define PSTAMP() pst[pstk++] = __builtin_amdgcn_s_memtime()
-#else
-#define PSTAMP()
-#endif
-    PSTAMP();
-    {
-        // the sweeps must have ended finite and agree (c_crf_flipflop.c:482-491 averages them)
-        const double dsc = scoreF - scoreB;
-        if (!(dsc > -(double)ROWZ_TOL && dsc < (double)ROWZ_TOL))
-            return (dsc == dsc && scoreF - scoreF == 0.0 && scoreB - scoreB == 0.0) ? 4 : 1;
-    }
-    if (jb >= NB) return 0;
-    if (head) {
-        // score = mean of the two sweeps (c_crf_flipflop.c:482-491), cost = -score / T
-        // (+ wbias T: the stored sweep scores are in the biased weights, like everything the rows below are
-        // scaled by; only the cost takes the bias back)
-        const double score2 = 0.5 * (scoreF + scoreB) + (double)a.wbias * (double)T;
-        a.cost[n] = crf_add_cost(a, n, (float)(-(score2 * 0.6931471805599453) / (double)T) * a.out_scale);
-    }
-    const int Wn = (L + PW - 1) / PW;                           // chunks this read has
-    const float c = a.c_can;
-    const bool trim = L <= T + 1;
-    const int nrows = min(BK, T - t0);
-    const int zexp = (int)floor(scoreF);
-
-    // (cat-mod with per-column factors: see band_sweep)
-    constexpr bool colw_mode = MOD && CW;
-    const float cw_lane = colw_mode ? ((int)lane < a.ncan ? c : a.colw[min(max((int)lane - a.ncan, 0), S - a.ncan - 1)] * a.c_mod) : c;
-    const float wbias = a.wbias;        // (the weights' bias: see BK_MAX)
-    const float wb_lane = (colw_mode && (int)lane >= a.ncan) ? 0.f : wbias;
-    // (the score rows are exponentiated after the mask pass below)
-
-    // live chunks of row t (column t -> t + 1): chunk [a, b] holds an instance of some complete path
-    // through row t iff  a <= t + 1  (the move INTO position t + 1 is the fastest path's)  and
-    // b + 1 >= L - T + t
-    auto chunk_lo = [&](int t) {
-        const int need = L - T + t;
-        return (trim && need > 0) ? max(0, (need + PW - 1) / PW - 1) : 0;
-    };
-    auto chunk_hi = [&](int t) { return trim ? min(Wn - 1, (t + 1) / PW) : Wn - 1; };
-    const int cmin = chunk_lo(t0), cmax = chunk_hi(t0 + nrows - 1);       // both bounds grow with t
-    // (a row of the block that a chunk is not live for only adds exact zeros: its forward or its
-    // backward cells are all dead there)
-
-    float pacc[BK];
-#pragma unroll
-    for (int k = 0; k < BK; ++k) pacc[k] = 0.f;
-    PSTAMP();
-    // Did the SWEEP chunk that holds cell p run this time block?  band_window(w) solved for the block once per
-    // wave: chunk start a = w PWS is live in block jb iff  a <= t0 + BK  and  a + PWS - 1 >= t0 - (T - L + 1)
-    // (reads without a complete path, L > T + 1, keep every block) -- two scalars per wave and three compares
-    // per chunk instead of three window evaluations per chunk.
-    const bool notrim = L > T + 1;
-    const int live_hi = t0 + BK, live_lo = t0 - (T - L + 1) - PWS + 1;
-    auto sweep_live = [&](int p) {
-        const int as = (p >> pws_sh) << pws_sh;
-        return p >= 0 && as < L && (notrim || (as <= live_hi && as >= live_lo));
-    };
-    auto frame_at = [&](const int16_t *ff, const int *fbase, int p) { return fbase[ckbase + (p >> pws_sh)] + (int)ff[ckrow + p]; };
-    const float *bndFn = a.bndF + ((size_t)ws * NB + jb) * W * BK;
-    const float *bndBn = a.bndB + ((size_t)ws * NB + jb) * W * BK;
-    // Per-wave buffer descriptors for everything a chunk loads: the chunk is then a SCALAR offset and the lane a
-    // constant vector offset -- no 64-bit address arithmetic per load -- and the descriptors' bounds return the
-    // 0 that cells past the end of the read take (stay ids at p >= L, move ids at p - 1 < 0 or p >= L - 1).
-    const __amdgpu_buffer_rsrc_t rFm = __builtin_amdgcn_make_buffer_rsrc(a.ckFm + ckrow, 0, (int)(a.LP * 4), BUF_WORD3);
-    const __amdgpu_buffer_rsrc_t rBm = __builtin_amdgcn_make_buffer_rsrc(a.ckBm + ckrow, 0, (int)(a.LP * 4), BUF_WORD3);
-    // (a call that brought its labels: ids from the flip-flop codes -- descriptor over the read's codes -- instead of
-    // from index arrays nobody wrote; see band_code)
-    const bool from_codes = a.codes != nullptr;
-    const __amdgpu_buffer_rsrc_t rSt = __builtin_amdgcn_make_buffer_rsrc(
-        const_cast<int32_t *>((from_codes ? a.codes : a.stay) + off), 0, L * 4, BUF_WORD3);
-    const __amdgpu_buffer_rsrc_t rMv = __builtin_amdgcn_make_buffer_rsrc(
-        const_cast<int32_t *>((from_codes ? a.codes : a.move) + off), 0, (from_codes ? L : L - 1) * 4, BUF_WORD3);
-    const __amdgpu_buffer_rsrc_t rRec = __builtin_amdgcn_make_buffer_rsrc(a.rec + (size_t)ws * W * EPL * WAVE, 0, (int)(W * EPL * WAVE * 4), BUF_WORD3);
-    const __amdgpu_buffer_rsrc_t rSeg = __builtin_amdgcn_make_buffer_rsrc(a.segend + (size_t)ws * W * WAVE, 0, (int)(W * WAVE * 4), BUF_WORD3);
-    const __amdgpu_buffer_rsrc_t rMd = __builtin_amdgcn_make_buffer_rsrc(
-        const_cast<int32_t *>(MOD ? (from_codes ? a.mod_cats : a.mod) + off : (from_codes ? a.codes : a.move) + off), 0,
-        (from_codes ? L : L - 1) * 4, BUF_WORD3);
-    const __amdgpu_buffer_rsrc_t rMf = __builtin_amdgcn_make_buffer_rsrc(
-        const_cast<float *>(MOD && !from_codes ? a.modfact + off : a.zeros), 0, MOD && !from_codes ? (L - 1) * 4 : 0, BUF_WORD3);
-
-    // One chunk of the wave's time block.  Everything is straight-line and branch-free so that the
-    // LDS round trips, the two recurrence chains and the RG prefix scans of a row group overlap
-    // (FULL = all BK rows exist; the last block of a T that is not a multiple of BK runs the
-    // guarded form).
-    // (Round 5, measured and not kept: touching the NEXT live chunk's checkpoint rows and boundary cells -- four loads
-    // into registers nothing reads -- once this chunk's own loads have landed, so that they are L2 hits when their
-    // turn comes.  Issued right behind the chunk's loads or behind its backward columns the op LOSES 7 % at the train
-    // step's shape and 11 % at T = 4000 / N = 256 (profiles/r5_gradient_pass_prefetch_ab.txt): the four live
-    // registers push the kernel from 8 to 60 bytes of scratch under its 96-register cap, and a wave's round trips
-    // are already covered by the other four waves of its SIMD.)
-    auto chunk_body = [&](int ck, int fF0, int fB0, auto full_tag) {
-        constexpr bool FULL = decltype(full_tag)::value;
-        const int a0 = ck * PW;
-        // the neighbouring cells exist as boundary cells iff their SWEEP chunk ran this block
-        const bool plF = ck > 0 && sweep_live(a0 - 1);
-        const bool plB = ck + 1 < Wn && sweep_live(a0 + PW);
-
-        // ---- ids, checkpoints, boundary cells, frames
-        int st4[R], mi4[R], mo4[R], di4[MOD ? R : 1], do4[MOD ? R : 1];
-        float fwi[MOD ? R : 1], fwo[MOD ? R : 1], mfi[MOD ? R : 1];
-        bool hasi[R], haso[R];
-        float fv[R], bv[BK][R];
-        int fF[R], fB[R];
-#pragma unroll
-        for (int j = 0; j < R; ++j) {
-            const int p = a0 + lane * R + j;
-            hasi[j] = p >= 1 && p < L;
-            haso[j] = p < L - 1;
-            // (R = 1: p = a0 + lane; the moves' descriptor ends at L - 1, the vector offset of p - 1 wraps to
-            // "far out of range" at p = 0)
-            if (from_codes) {
-                // codes of p - 1, p, p + 1 (0 outside the read: the descriptor's bounds), ids by the build kernel's arithmetic
-                const int ns1 = 2 * a.nbase - 1;
-                const int cb = min(max((int)__builtin_amdgcn_raw_buffer_load_b32(rSt, 4u * (unsigned)p - 4u, 0, 0), 0), ns1);
-                const int cp = min(max((int)__builtin_amdgcn_raw_buffer_load_b32(rSt, lane4, 4u * (unsigned)a0, 0), 0), ns1);
-                const int cn = min(max((int)__builtin_amdgcn_raw_buffer_load_b32(rSt, 4u * (unsigned)p + 4u, 0, 0), 0), ns1);
-                st4[j] = 4 * ((p < L) ? lbl_stay(a, cp) : 0);
-                mi4[j] = 4 * (hasi[j] ? lbl_move(a, cb, cp) : 0);
-                mo4[j] = 4 * (haso[j] ? lbl_move(a, cp, cn) : 0);
-                if (MOD) {
-                    const int cati = (int)__builtin_amdgcn_raw_buffer_load_b32(rMd, lane4, 4u * (unsigned)a0, 0);
-                    const int cato = (int)__builtin_amdgcn_raw_buffer_load_b32(rMd, 4u * (unsigned)p + 4u, 0, 0);
-                    const int mqi = lbl_mod_seq(a, cp, cati, nullptr), mqo = lbl_mod_seq(a, cn, cato, nullptr);
-                    di4[MOD ? j : 0] = 4 * (hasi[j] ? a.ncan + mqi : 0);
-                    do4[MOD ? j : 0] = 4 * (haso[j] ? a.ncan + mqo : 0);
-                    mfi[MOD ? j : 0] = hasi[j] ? a.mcw[mqi] : 0.f;
-                    fwi[MOD ? j : 0] = mfi[MOD ? j : 0] * a.c_mod;
-                    fwo[MOD ? j : 0] = (haso[j] ? a.mcw[mqo] : 0.f) * a.c_mod;
-                }
-            } else {
-                st4[j] = 4 * (int)__builtin_amdgcn_raw_buffer_load_b32(rSt, lane4, 4u * (unsigned)a0, 0);
-                mi4[j] = 4 * (int)__builtin_amdgcn_raw_buffer_load_b32(rMv, 4u * (unsigned)p - 4u, 0, 0);
-                mo4[j] = 4 * (int)__builtin_amdgcn_raw_buffer_load_b32(rMv, lane4, 4u * (unsigned)a0, 0);
-                if (MOD) {
-                    di4[MOD ? j : 0] = 4 * (int)__builtin_amdgcn_raw_buffer_load_b32(rMd, 4u * (unsigned)p - 4u, 0, 0);
-                    do4[MOD ? j : 0] = 4 * (int)__builtin_amdgcn_raw_buffer_load_b32(rMd, lane4, 4u * (unsigned)a0, 0);
-                    mfi[MOD ? j : 0] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rMf, 4u * (unsigned)p - 4u, 0, 0));
-                    fwi[MOD ? j : 0] = mfi[MOD ? j : 0] * a.c_mod;
-                    fwo[MOD ? j : 0] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rMf, lane4, 4u * (unsigned)a0, 0)) * a.c_mod;
-                }
-            }
-            fv[j] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rFm, lane4, 4u * (unsigned)a0, 0));
-            fF[j] = fF0;                                            // (the loop loaded them for its skip test)
-            bv[BK - 1][j] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rBm, lane4, 4u * (unsigned)a0, 0));
-            fB[j] = fB0;
-        }
-        // boundary cells: forward from chunk ck-1 into lane 0, backward from chunk ck+1 into lane 63
-        float einF[BK], einB[BK];
-        {
-            // (the lanes that take no boundary cell read a row of zeros instead: no selects)
-            const f4 *pF = reinterpret_cast<const f4 *>((plF && lane == 0) ? bndFn + (size_t)(ck - 1) * BK : a.zeros);
-            const f4 *pB = reinterpret_cast<const f4 *>((plB && lane == WAVE - 1) ? bndBn + (size_t)(ck + 1) * BK : a.zeros);
-#pragma unroll
-            for (int q4 = 0; q4 < BK / 4; ++q4) {
-                const f4 e = pF[q4], g = pB[q4];
-#pragma unroll
-                for (int q = 0; q < 4; ++q) {
-                    einF[q4 * 4 + q] = e[q];
-                    einB[q4 * 4 + q] = g[q];
-                }
-            }
-        }
-        float scF[R], scB[R];
-        int kx[R];
-        {
-            int fupF = __builtin_amdgcn_update_dpp(0, fF[R - 1], 0x138, 0xF, 0xF, false);       // wave_shr:1
-            if (lane == 0) fupF = plF ? frame_at(a.ckFf, a.ckFb, max(a0 - 1, 0)) : fF[0];
-            int fupB = __builtin_amdgcn_update_dpp(0, fB[0], 0x130, 0xF, 0xF, false);           // wave_shl:1
-            if (lane == WAVE - 1) fupB = plB ? frame_at(a.ckBf, a.ckBb, min(a0 + PW, (int)a.LP - 1)) : fB[R - 1];
-#pragma unroll
-            for (int j = 0; j < R; ++j) {
-                const int dF = clamp_shift((j == 0 ? fupF : fF[j > 0 ? j - 1 : 0]) - fF[j], a.klip);
-                const int dB = clamp_shift((j == R - 1 ? fupB : fB[j < R - 1 ? j + 1 : 0]) - fB[j], a.klip);
-                scF[j] = hasi[j] ? __builtin_amdgcn_ldexpf(1.f, dF) : 0.f;
-                scB[j] = haso[j] ? __builtin_amdgcn_ldexpf(1.f, dB) : 0.f;
-                kx[j] = fF[j] + fB[j] - zexp;
-            }
-        }
-        // ---- sorted order of this chunk: LDS word of every sorted position, segment-end look-up
-        int addr[EPL];
-#pragma unroll
-        for (int r = 0; r < EPL; ++r)
-            addr[r] = (int)__builtin_amdgcn_raw_buffer_load_b32(rRec, lane4, 4u * (unsigned)((ck * EPL + r) * WAVE), 0);
-        const int sidx = (int)__builtin_amdgcn_raw_buffer_load_b32(rSeg, lane4, 4u * (unsigned)(ck * WAVE), 0) - 1;
-
-        // ---- backward columns t0+1 .. t0+nrows: bv[i] = column t0+i+1 (bv[nrows-1] = the checkpoint)
-        if (!FULL) {
-#pragma unroll
-            for (int i = 0; i < BK - 1; ++i)
-                if (i == nrows - 1) {
-#pragma unroll
-                    for (int j = 0; j < R; ++j) bv[i][j] = bv[BK - 1][j];
-                }
-        }
-        float esr[BK][R];                                       // stay weights of the block's rows: both chains
-#pragma unroll
-        for (int i = 0; i < BK; ++i) {
-#pragma unroll
-            for (int j = 0; j < R; ++j) esr[i][j] = bperm(st4[j], er[i]);
-        }
-        {
-            float emo[BK][R];                                   // rows 1 .. BK-1
-#pragma unroll
-            for (int i = 1; i < BK; ++i) {
-#pragma unroll
-                for (int j = 0; j < R; ++j) {
-                    if constexpr (MOD)
-                        emo[i][j] = (colw_mode ? bperm(mo4[j], er[i]) * bperm(do4[MOD ? j : 0], er[i])
-                                               : fast_exp2(fmaf(bperm(do4[MOD ? j : 0], raw[i]), fwo[MOD ? j : 0], fmaf(bperm(mo4[j], raw[i]), c, -wbias)))) * scB[j];
-                    else
-                        emo[i][j] = bperm(mo4[j], er[i]) * scB[j];
-                }
-            }
-#pragma unroll
-            for (int i = BK - 2; i >= 0; --i) {
-                if (!FULL && i + 1 >= nrows) continue;          // wave-uniform
-                // consume row t0+i+1: column t0+i+2 -> t0+i+1
-                float nxt[R];
-                const float upl = wave_shift_down1(bv[i + 1][0], einB[i + 1]);     // the next lane's first cell (lane 63: the ring's)
-#pragma unroll
-                for (int j = 0; j < R; ++j) {
-                    const float up = (j == R - 1) ? upl : bv[i + 1][j < R - 1 ? j + 1 : 0];
-                    nxt[j] = fmaf(bv[i + 1][j], esr[i + 1][j], up * emo[i + 1][j]);
-                }
-#pragma unroll
-                for (int j = 0; j < R; ++j) bv[i][j] = nxt[j];
-            }
-        }
-
-        // ---- forward steps in groups of RG rows; a step's two terms times the backward cell are
-        //      the posteriors of the row
-#pragma unroll
-        for (int g0 = 0; g0 < BK; g0 += RG) {
-            float pr[RG][EPL];
-#pragma unroll
-            for (int kk = 0; kk < RG; ++kk) {
-                const int k = g0 + kk;
-                float Fs[R], Fm[R];
-                const float upl = wave_shift_up1(fv[R - 1], einF[k]);   // the previous lane's last cell (lane 0: the ring's)
-#pragma unroll
-                for (int j = 0; j < R; ++j) {
-                    float em;
-                    if constexpr (MOD)
-                        em = colw_mode ? bperm(mi4[j], er[k]) * bperm(di4[MOD ? j : 0], er[k])
-                                       : fast_exp2(fmaf(bperm(di4[MOD ? j : 0], raw[k]), fwi[MOD ? j : 0], fmaf(bperm(mi4[j], raw[k]), c, -wbias)));
-                    else
-                        em = bperm(mi4[j], er[k]);
-                    const float up = (j == 0) ? upl : fv[j > 0 ? j - 1 : 0];
-                    Fs[j] = fv[j] * esr[k][j];
-                    Fm[j] = up * (em * scF[j]);
-                }
-#pragma unroll
-                for (int j = 0; j < R; ++j) {
-                    float bs = __builtin_amdgcn_ldexpf(bv[k][j], kx[j]);
-                    if (!FULL && k >= nrows) bs = 0.f;
-                    pr[kk][j * KINDS + 0] = Fs[j] * bs;
-                    pr[kk][j * KINDS + 1] = Fm[j] * bs;
-                    // d/d(mod score) = posterior of the move * modfact (c_cat_mod_flipflop.c:461-467)
-                    if (MOD) pr[kk][j * KINDS + (MOD ? 2 : 0)] = pr[kk][j * KINDS + 1] * mfi[MOD ? j : 0];
-                    fv[j] = Fs[j] + Fm[j];
-                }
-            }
-            // position order -> LDS (one region per row of the group)
-#pragma unroll
-            for (int kk = 0; kk < RG; ++kk) {
-                float *dst = sP + kk * (EPL * WAVE) + lane * EPL;
-                if constexpr (EPL % 4 == 0) {
-#pragma unroll
-                    for (int e4 = 0; e4 < EPL / 4; ++e4)
-                        *reinterpret_cast<f4 *>(dst + e4 * 4) =
-                            f4{pr[kk][e4 * 4], pr[kk][e4 * 4 + 1], pr[kk][e4 * 4 + 2], pr[kk][e4 * 4 + 3]};
-                } else if constexpr (EPL % 2 == 0) {
-#pragma unroll
-                    for (int e2 = 0; e2 < EPL / 2; ++e2)
-                        *reinterpret_cast<f2 *>(dst + e2 * 2) = f2{pr[kk][e2 * 2], pr[kk][e2 * 2 + 1]};
-                } else {
-#pragma unroll
-                    for (int e = 0; e < EPL; ++e) dst[e] = pr[kk][e];
-                }
-            }
-            wave_lds_fence();
-            // sorted order <- LDS: lane l holds sorted positions l*EPL .. l*EPL + EPL-1 of every row;
-            // running (inclusive) prefix in v[]
-            float v[RG][EPL];
-#pragma unroll
-            for (int kk = 0; kk < RG; ++kk) {
-#pragma unroll
-                for (int r = 0; r < EPL; ++r) {
-                    const float x = *reinterpret_cast<const float *>(
-                        reinterpret_cast<const char *>(sP + kk * (EPL * WAVE)) + addr[r]);
-                    v[kk][r] = (r == 0) ? x : v[kk][r > 0 ? r - 1 : 0] + x;
-                }
-            }
-            float base[RG];
-            {
-                float incl[RG];
-#pragma unroll
-                for (int kk = 0; kk < RG; ++kk) incl[kk] = v[kk][EPL - 1];
-                wave_scan_fused_rows(incl);
-#pragma unroll
-                for (int kk = 0; kk < RG; ++kk) base[kk] = incl[kk] - v[kk][EPL - 1];
-            }
-            if constexpr (true) {
-                // the inclusive prefixes go back to LDS in sorted order (the rows' regions are free
-                // again: every lane has read its values), the segment ends are one read each
-                wave_lds_fence();
-#pragma unroll
-                for (int kk = 0; kk < RG; ++kk) {
-                    float *dst = sP + kk * (EPL * WAVE) + lane * EPL;
-#pragma unroll
-                    for (int r = 0; r < EPL; ++r) dst[r] = v[kk][r] + base[kk];
-                }
-                wave_lds_fence();
-            }
-#pragma unroll
-            for (int kk = 0; kk < RG; ++kk) {
-                // lane b: the prefix at the end of id b's segment, summed over the chunks (the per-id
-                // sums and the row total are differences / one lane of it: taken once, after the loop)
-                const float P = sP[kk * (EPL * WAVE) + max(sidx, 0)];
-                pacc[g0 + kk] += (sidx < 0) ? 0.f : P;
-            }
-            wave_lds_fence();
-        }
-    };
-
-    int nskip = 0;
-    // WHICH CHUNKS CARRY MASS -- decided for all of the block's chunks BEFORE any of them is computed, 8 or 16 at a
-    // time, so that their frame loads are in flight together, and by ONE compare per chunk (a ballot, no reduction):
-    // one chunk after the other (round 3) every test waited for its own loads from a workspace far larger than the
-    // L2 and paid a DPP reduction -- 35 of a wave's 74 thousand cycles at T = 4000 (LABNOTES R4.11).
-    // THE COLUMN TEST (round 4, jb >= 1).  Every complete path through an instance of rows t0 .. t0 + BK - 1 at the
-    // cells of chunk [a0, a0 + 63] passes column t0 at a position in [a0 - BK, a0 + 63] (a path gains at most one
-    // position per step), so a row's posterior mass inside the chunk is at most the sum of the CELL posteriors
-    // F_t0[p] B_t0[p] / Z over those 64 + BK positions -- and both factors are checkpoint columns: the forward
-    // sweep's of this block, the backward sweep's of block jb - 1 (its start column in flow order IS t0), with
-    // mantissas below 1, so 2^(fF + fB - zexp) bounds a cell from the frames alone.  All 64 + BK bounds below
-    // POST_COL_SKIP = -48: the chunk adds less than 76 x 2^-48 to any row total of 1, 2^-35 over a read's 64 chunks --
-    // skipped.  No growth bound: 54 % instead of 41 % of the band's chunk-blocks go at the train step's shape,
-    // 84 % instead of 75 % at T = 4000.  A sweep chunk that did not run block jb - 1 has no live cell at column t0
-    // (band_window: its first live row is >= t0, i.e. its positions are > t0).
-    // BLOCK 0 has no column before it and keeps round 3's test on the frames at both ENDS of the block:
-    // a cell's posterior is (mF es) (mB) 2^(fF + fB - zexp) with mantissas that start the block below 1 and grow
-    // by at most (1 + 2^KLIP) 2^7.2 per step for |sharp score| <= 5: mF mB es <= 2^113 whatever the row, so
-    // exponents all below POST_SKIP_BELOW = -160 (-176) add less than 2^-33 to a row total of 1.
-    // Either way the totals of the rows are still VERIFIED against the partition function (ROWZ_TOL), or the read
-    // goes to the log-domain kernel.
-    constexpr int POST_COL_SKIP = -48;
-    const int thr = coltest ? POST_COL_SKIP : POST_SKIP_BELOW<BK>;
-    const int live_hi_p = t0, live_lo_p = t0 - BK - (T - L + 1) - PWS + 1;
-    auto sweep_live_prev = [&](int p) {
-        const int as = (p >> pws_sh) << pws_sh;
-        return !coltest || notrim || (as <= live_hi_p && as >= live_lo_p);
-    };
-    unsigned long long livemask = 0;            // bit ck - cmin  (a read has at most 64 chunks of 64 cells)
-    // (the frame bases of the block's chunks: one vector load per array, lane = chunk, instead of a scalar load per chunk)
-    bool tail_prev = false;                     // did one of the last BK cells of the chunk before reach the threshold?
-    // chunk ck from its two frame columns: one compare, the lanes whose bound reaches the threshold as a mask (no
-    // reduction); chunks arrive in ascending order
-    auto decide = [&](int ck, bool valid, int rawF, int rawT) {
-        const int a0l = ck * PW;
-        const int fF = __builtin_amdgcn_readlane(baseF_l, ck) + rawF;
-        const int fBt = __builtin_amdgcn_readlane(baseT_l, ck) + rawT;
-        const unsigned long long hot = __ballot(sweep_live_prev(a0l) && a0l + lane < L && fF + fBt - zexp >= thr);
-        const bool own = hot != 0, tail = (hot >> (WAVE - BK)) != 0;
-        if (valid) {
-            if (own || (coltest && tail_prev)) livemask |= 1ull << (ck - cmin);
-            else ++nskip;
-        }
-        tail_prev = valid && tail;
-    };
-    auto mask_pass = [&](auto gtag) {
-        constexpr int G = decltype(gtag)::value;
-        for (int c0 = cmin; c0 <= cmax; c0 += G) {
-            int rawF[G], rawT[G];
-            // (all of the batch's loads first, pinned in front of the conditions: left alone hipcc sinks every pair
-            // of loads under its chunk's wave-uniform `valid` branch and waits for it there -- eight round trips
-            // one after the other, the 35 thousand cycles this pass was written to remove)
-#pragma unroll
-            for (int g = 0; g < G; ++g) {
-                const unsigned a0l2 = 2u * (unsigned)(min(c0 + g, cmax) * PW);
-                rawF[g] = (int)(short)__builtin_amdgcn_raw_buffer_load_b16(rFf, lane4 / 2, a0l2, 0);
-                rawT[g] = (int)(short)__builtin_amdgcn_raw_buffer_load_b16(rBt, lane4 / 2, a0l2, 0);
-            }
-            asm volatile("" ::: "memory");
-#pragma unroll
-            for (int g = 0; g < G; ++g) {
-                const int ck = min(c0 + g, cmax);
-                decide(ck, c0 + g <= cmax && sweep_live(ck * PW), rawF[g], rawT[g]);    // (valid: wave-uniform; never false for a live row)
-            }
-        }
-    };
-    // (one batch wherever it fits: 8 chunks cover the train step's reads, 16 most blocks of a 2000-base read)
-    if (cmax - cmin < 8) mask_pass(std::integral_constant<int, 8>{});
-    else mask_pass(std::integral_constant<int, 16>{});
-#pragma unroll
-    for (int k = 0; k < BK; ++k) er[k] = fast_exp2(fmaf(raw[k], cw_lane, -wb_lane));
-    PSTAMP();
-    for (unsigned long long m = livemask; m != 0; m &= m - 1) {
-        const int ck = cmin + __builtin_ctzll(m), a0l = ck * PW;
-        // the chunk's frames: 16-bit offsets from the base of the sweep chunk that stored them
-        const int fF0 = __builtin_amdgcn_readlane(baseF_l, ck) + (int)(short)__builtin_amdgcn_raw_buffer_load_b16(rFf, lane4 / 2, 2u * (unsigned)a0l, 0);
-        const int fB0 = __builtin_amdgcn_readlane(baseB_l, ck) + (int)(short)__builtin_amdgcn_raw_buffer_load_b16(rBf, lane4 / 2, 2u * (unsigned)a0l, 0);
-        if (nrows == BK)
-            chunk_body(ck, fF0, fB0, std::true_type{});
-        else
-            chunk_body(ck, fF0, fB0, std::false_type{});
-    }
-    PSTAMP();
-    // every row's total is Z 2^-zexp: a row that lost mass (or everything) disowns the read
-    const float zfrac = (float)(scoreF - (double)zexp);
-    const float gsc = a.grad_scale * (a.grad_scale_vec != nullptr ? a.grad_scale_vec[n] : 1.0f);
-    bool lost = false;
-    // the fused loss's add term (kernel B's gradient of these rows): all of a block's loads BEFORE its first
-    // store -- the compiler may not move a load of `add_grad` over a store to `grad`, and one exposed load
-    // latency per row put 14 us on this kernel at the train step's shape (LABNOTES R4.6)
-    const bool adds = a.add_grad != nullptr && lane < a.add_S;
-    float addv[BK];
-#pragma unroll
-    for (int k = 0; k < BK; ++k) addv[k] = 0.f;
-    if (a.add_grad != nullptr) {                                // (wave-uniform: nothing to issue for the plain operator)
-#pragma unroll
-        for (int k = 0; k < BK; ++k)
-            if (adds && k < nrows) addv[k] = a.add_grad[((size_t)(t0 + k) * (size_t)a.N + (size_t)n) * a.add_S + lane];
-    }
-#pragma unroll
-    for (int k = 0; k < BK; ++k) {
-        if (k < nrows) {
-            // per-id sums = differences of the prefixes at the segment ends.  Row normaliser: all stay
-            // and move instances (the reference's softmax over the 2L-1 transitions,
-            // c_crf_flipflop.c:400-401); mod ids sort after them
-            const float colacc = pacc[k] - wave_shift_up1(pacc[k], 0.f);
-            const float total = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(pacc[k]), a.ncan - 1));
-            const float dev = fast_log2(total) - zfrac;
-            lost |= !(dev > -ROWZ_TOL && dev < ROWZ_TOL);
-#ifdef TK_LAB_ROWDEV
-            if (!(dev > -ROWZ_TOL && dev < ROWZ_TOL) && lane == 0)
-                printf("rowdev n %d t %d L %d total %g dev %g cmin %d cmax %d nskip %d\n", n, t0 + k, L, total, dev, cmin, cmax, nskip);
-#endif
-            // gradient of -score / T  (ctc.pyx:113)
-            const float g0 = colacc * (-gsc / (total * (float)T));
-            const float g = adds ? fmaf(addv[k], a.add_scale * gsc, g0) : g0;       // (= crf_add_grad, ff_common.h)
-            if (lane < S) a.grad[(size_t)(t0 + k) * rowstride + (size_t)n * S + lane] = g;
-        }
-    }
-    (void)nskip;
-#ifdef TK_LAB_STAMPS
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    PSTAMP();
-    if (a.dbg && lane == 0 && (n & 15) == 0 && (jb & 7) == 0) {       // (a sample of the waves: every wave's atomics clog the launch)
-        atomicAdd(a.dbg + 600, (unsigned long long)nskip);
-        atomicAdd(a.dbg + 601, (unsigned long long)(cmax - cmin + 1));
-        for (int q = 0; q + 1 < pstk; ++q) atomicAdd(a.dbg + 610 + q, pst[q + 1] - pst[q]);
-        atomicAdd(a.dbg + 620, 1ull);
-        atomicAdd(a.dbg + 621, (unsigned long long)__builtin_popcountll(livemask));
-    }
-#endif
-    return lost ? 2 : 0;       // (reason codes, lab dump: 1 non-finite sweep score, 4 sweeps disagree, 2 a row lost mass)
+#define TK_POST_PREAMBLE const int lane = threadIdx.x & (WAVE - 1); const bool head = jb == 0 && lane == 0;
+#define TK_POST_WS ws
+#define TK_POST_HEAD head
+#define TK_POST_LEAVE return 0
+#define TK_POST_SWEEPS_DISAGREE(why) return (why)
+#define TK_POST_ROWS_LOST return lost ? 2 : 0
+#include "crf_band_posterior.inc"
+#undef TK_POST_PREAMBLE
+#undef TK_POST_WS
+#undef TK_POST_HEAD
+#undef TK_POST_LEAVE
+#undef TK_POST_SWEEPS_DISAGREE
+#undef TK_POST_ROWS_LOST
 }
 
+// The batch's launch: grid (N, ceil(NB / POST_WAVES)), wave = one time block (BK rows) of read n.
+// (reason codes in gate[n], lab dump: 1 non-finite sweep score, 4 sweeps disagree, 2 a row lost mass)
 template <bool MOD, bool CW, int BK>
 __global__ __launch_bounds__(POST_WAVES *WAVE) __attribute__((amdgpu_waves_per_eu(5))) void crf_band_posterior_kernel(BandArgs a) {
-    constexpr int KINDS = MOD ? 3 : 2, RG = (MOD && BK > 8) ? 4 : BK;
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    const int lane = threadIdx.x & (WAVE - 1);
-    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);      // wave-uniform: SGPR
+    const int tid = threadIdx.x;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);      // wave-uniform: SGPR
     const int n = blockIdx.x;
     const int jb = blockIdx.y * POST_WAVES + wave;                  // this wave's time block
-    const int why = band_posterior_block<MOD, CW, BK>(a, n, n, jb, reinterpret_cast<float *>(smem) + (size_t)wave * RG * KINDS * WAVE);
-    // the linear path disowns the read: the sweeps' verdict is the same in every wave (one lane records it), a row's in its own
-    if (why != 0 && lane == 0 && (why == 2 || jb == 0)) a.gate[n] = why;
+    float *sP = reinterpret_cast<float *>(smem) + (size_t)wave * ((MOD && BK > 8) ? 4 : BK) * (MOD ? 3 : 2) * WAVE;
+#define TK_POST_PREAMBLE const int lane = tid & (WAVE - 1);
+#define TK_POST_WS n
+#define TK_POST_HEAD (blockIdx.y == 0 && tid == 0)
+#define TK_POST_LEAVE return
+#define TK_POST_SWEEPS_DISAGREE(why) do { if (blockIdx.y == 0 && tid == 0) a.gate[n] = (why); return; } while (0)
+#define TK_POST_ROWS_LOST do { if (lost && lane == 0) a.gate[n] = 2; } while (0)
+#include "crf_band_posterior.inc"
+#undef TK_POST_PREAMBLE
+#undef TK_POST_WS
+#undef TK_POST_HEAD
+#undef TK_POST_LEAVE
+#undef TK_POST_SWEEPS_DISAGREE
+#undef TK_POST_ROWS_LOST
 }
-
-
 
 // ===========================================================================
 // Round 6 -- THE TAIL LAUNCH of the linear path: the per-read second chance (BandRetry, crf_band.h), and behind it, in

@@ -422,7 +422,10 @@ __global__ __launch_bounds__(3 * WAVE) void viterbi3_kernel(const float *__restr
 #pragma unroll
                     for (int q = 0; q < TH; ++q) {
                         const int k = 2 * q + par;                  // step inside the tile
-#if TK_VIT_RING2
+#if defined(TK_VIT_TRACE_NOLDS)
+                        mm[q] = (float)(slot0 + k + lane);          // lab (timing only, wrong bytes): no ring reads
+                        cd[q] = (float)(slot0 + k + (lane & 56));
+#elif TK_VIT_RING2
                         const f2 mc = ring2_lane[(slot0 + k) * WAVE];
                         mm[q] = mc.x;
                         cd[q] = mc.y;
@@ -447,6 +450,10 @@ __global__ __launch_bounds__(3 * WAVE) void viterbi3_kernel(const float *__restr
                                 const unsigned long long bits = (eq >> sub) & 0x0101010101010101ull;
                                 arg = ((unsigned)__builtin_ctzll(bits | (1ull << 63)) >> 3) & 7u;
                             }
+#ifdef TK_VIT_TRACE_NOSTORE
+                            asm volatile("" :: "v"(arg));           // lab (timing only): the bytes are formed and dropped
+                            continue;
+#endif
                             if (ALL_GROUPS_LIVE || st_to < F::NS) {
                                 __builtin_amdgcn_raw_buffer_store_b8((unsigned char)arg, rtb, lane_tb, (unsigned)(kk * pstride), 0);
                                 if (FULLOUT) {

@@ -238,6 +238,101 @@ __global__ __launch_bounds__(WAVE) void viterbi_kernel(const float *__restrict__
 }
 
 
+// ---- the traceback walk on THREE waves (round 6).  The one-wave walk above scans batches of 64 steps one after the
+// other (four in flight): 22 of the kernel's 206 us at T 4000.  A batch's scan needs nothing from the batches before it --
+// only the LOOK-UP with the batch's start state chains them.  So: (A) the waves take the batches of a segment (64 batches =
+// 4096 steps) in turn, scan them and leave every lane's table in LDS (the forward pass's ring, free by now: 64 x 64 x 8 B);
+// (B) wave 0 scans the 64 WHOLE-batch tables once more -- the same composition, one level up -- which gives every batch its
+// start state; (C) the waves look their batches' states up and store them.  Integer table composition throughout: the same
+// path, bit for bit.  `tabs`: 64 x 64 eight-byte words of LDS; `stsh`: 66 words.
+template <int NB>
+__device__ __forceinline__ void viterbi_path_pass3(float m, int T, int N, int n, int lane, int wave, int nwaves,
+                                                   int64_t *__restrict__ path_out, const unsigned char *__restrict__ packed,
+                                                   int npad, unsigned long long *tabs, unsigned *stsh) {
+    using F = FF<NB>;
+    if (wave == 0) {
+        // ---- decode.py:108-113: argmax of the last column = first maximal state (alternating layout: see viterbi_path_pass)
+        unsigned st = 0;
+        const int per_state = ((T & 1) == 0) ? 1 : VIT_GRP;
+        float top = __shfl(m, 0, WAVE);
+        if (T == 0) top = 0.f;
+#pragma unroll
+        for (int s = 1; s < F::NS; ++s) {
+            float v = __shfl(m, s * per_state, WAVE);
+            if (T == 0) v = (s < NB) ? 0.f : NEG_LARGE;
+            if (v > top) {
+                top = v;
+                st = s;
+            }
+        }
+        if (lane == 0) {
+            path_out[(size_t)T * N + n] = (int64_t)st;
+            stsh[0] = st;
+        }
+    }
+    const unsigned long long *words = reinterpret_cast<const unsigned long long *>(packed) + n;
+    auto load_batch = [&](int thi) {                            // lane k: the word of step thi - 1 - k
+        const int t = max(thi - 1 - lane, 0);                   // clamped, never branched
+        return words[(size_t)t * npad];
+    };
+    auto scan = [&](unsigned long long cur, unsigned &lo, unsigned &hi) {
+        lo = (unsigned)cur;
+        hi = (unsigned)(cur >> 32);
+#pragma unroll
+        for (int d = 1; d < WAVE; d <<= 1) {
+            const int src4 = 4 * (lane - d);                    // (wraps for lane < d: not used there)
+            const unsigned blo = (unsigned)__builtin_amdgcn_ds_bpermute(src4, (int)lo);
+            const unsigned bhi = (unsigned)__builtin_amdgcn_ds_bpermute(src4, (int)hi);
+            // (this step's table) o (the steps before): entry s = mine[theirs[s]]
+            const unsigned nlo = __builtin_amdgcn_perm(hi, lo, blo), nhi = __builtin_amdgcn_perm(hi, lo, bhi);
+            if (lane >= d) {
+                lo = nlo;
+                hi = nhi;
+            }
+        }
+    };
+    constexpr int SEG = WAVE;                                   // batches per segment
+    constexpr int PIPE = 3;                                     // batches of a wave in flight
+    for (int thi_seg = T; thi_seg > 0; thi_seg -= SEG * WAVE) {
+        const int nb = min(SEG, (thi_seg + WAVE - 1) / WAVE);
+        __syncthreads();                                        // stsh[0] is there; the segment before is done with `tabs`
+        // (A) every lane's table of this wave's batches
+        for (int b0 = wave; b0 < nb; b0 += PIPE * nwaves) {
+            unsigned long long q[PIPE];
+#pragma unroll
+            for (int u = 0; u < PIPE; ++u) q[u] = load_batch(thi_seg - min(b0 + u * nwaves, nb - 1) * WAVE);
+            unsigned lo[PIPE], hi[PIPE];
+#pragma unroll
+            for (int u = 0; u < PIPE; ++u) scan(q[u], lo[u], hi[u]);
+#pragma unroll
+            for (int u = 0; u < PIPE; ++u)
+                if (b0 + u * nwaves < nb)                       // (wave-uniform)
+                    tabs[(size_t)(b0 + u * nwaves) * WAVE + lane] = ((unsigned long long)hi[u] << 32) | lo[u];
+        }
+        __syncthreads();
+        // (B) the start state of every batch: a scan over the whole-batch tables (lane = batch)
+        if (wave == 0) {
+            const unsigned long long whole = (lane < nb) ? tabs[(size_t)lane * WAVE + (WAVE - 1)] : 0x0706050403020100ull;
+            unsigned lo, hi;
+            scan(whole, lo, hi);
+            const unsigned st_in = stsh[0];
+            const unsigned after = __builtin_amdgcn_perm(hi, lo, st_in) & 0xffu;   // the state the batch hands to the next one
+            stsh[1 + lane] = after;                             // batch lane + 1 starts there
+        }
+        __syncthreads();
+        // (C) every step's state
+        for (int b = wave; b < nb; b += nwaves) {
+            const unsigned long long tb = tabs[(size_t)b * WAVE + lane];
+            const unsigned st = stsh[b];
+            const unsigned mine = __builtin_amdgcn_perm((unsigned)(tb >> 32), (unsigned)tb, st) & 0xffu;
+            const int t = thi_seg - b * WAVE - 1 - lane;
+            if (t >= 0) path_out[(size_t)t * N + n] = (int64_t)mine;
+        }
+        __syncthreads();
+        if (wave == 0 && lane == 0) stsh[0] = stsh[nb];         // the next segment starts where this one ended
+    }
+}
+
 // ===========================================================================
 // Round 5: THREE WAVES PER READ.  The one-wave kernel above spends ~30 instructions per step on one
 // wave's issue stream, a third of them the traceback byte (ballot, shifts, find-first, store) and the
@@ -321,6 +416,7 @@ __global__ __launch_bounds__(3 * WAVE) void viterbi3_kernel(const float *__restr
     using F = FF<NB>;
     static_assert(F::NS <= VIT_GRP, "one lane group per state");
     static_assert(VIT_GROUP == VIT_RING * VIT_TILE && VIT_RING >= 2 && VIT_TILE % 2 == 0, "the ring holds one group; tiles start with an even step");
+    static_assert(VIT_RING * VIT_TILE * 2 * WAVE * sizeof(float) >= (size_t)WAVE * WAVE * sizeof(unsigned long long), "the traceback walk keeps a segment's tables in the ring");
     __shared__ __attribute__((aligned(16))) float ring[VIT_RING * VIT_TILE * 2 * WAVE];      // per step: the maxima (the new state vector) and the candidates
     const int lane = lane_id();
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -471,13 +567,20 @@ __global__ __launch_bounds__(3 * WAVE) void viterbi3_kernel(const float *__restr
         if (tfull < T) group(tfull, std::false_type{});
     }
     (void)NT;
-    // the trace waves' bytes must have landed before wave 0 walks them
+    // the trace waves' bytes must have landed before the walk
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
-    if (wave != 0) return;
 #ifdef TK_VIT_NOPATH
     return;                                     // lab: forward pass alone
 #endif
+#ifdef TK_VIT_PATH1
+    if (wave != 0) return;                      // lab: round 5's one-wave walk
     viterbi_path_pass<NB>(m, T, N, n, lane, path_out, packed, npad, /*alternating=*/true);
+#else
+    // (the bytes were written by other waves of this workgroup and have landed: vmcnt(0) before the barrier above; no line of
+    // them was read before, so no stale copy can answer.  The ring is free by now.)
+    __shared__ unsigned stsh[WAVE + 2];
+    viterbi_path_pass3<NB>(m, T, N, n, lane, wave, 3, path_out, packed, npad, reinterpret_cast<unsigned long long *>(ring), stsh);
+#endif
 }
 
 size_t viterbi_workspace_bytes(size_t T, size_t N, size_t nbase) {

@@ -46,6 +46,8 @@ struct BandArgs {
     int *segend;                // [N][Wp][64]  end of every transition id's segment
     const float *zeros;         // 64 B of zeros (the boundary row of lanes that take none)
     int *gate;                  // [N]  != 0: the batch's launch disowns this read (retried by crf_band_retry_kernel, else redone by crf_kernel)
+    int *anygate;               // one word, nullable: != 0 iff the batch's gradient pass disowned ANY read (the tail launch looks
+                                // at this word first: on the common path it leaves without a pass over the gate array)
     int *gate2;                 // [N]  nullable; the retry launch's verdicts: the batch's launch sets -1 ("not retried"), the retry
                                 // launch 0 (it owns the read) or why not
     unsigned long long *dbg;    // lab builds only (TK_LAB_STAMPS)
@@ -88,6 +90,7 @@ struct BandRetry {
     const double *firstF, *firstB;  // cost-only calls: the batch launch's two sweep scores (a pending read is retried iff they
                                     // are not finite or disagree); null for gradient calls
     float first_wbias;              // ... and that launch's weight bias: a pending read whose scores agree gets its cost here
+    const int *anygate;             // gradient calls: see BandArgs::anygate; null: look at the gate array
     int retry;                      // 0: no retry configuration for this call -- disowned reads go straight to the log domain
     int log_domain;                 // 1; lab builds: 0 = leave what the linear path disowned alone (TK_CRF_NO_FALLBACK)
 };
@@ -101,7 +104,7 @@ struct BandBlock {
 struct BandLayout {
     int R, W, BK;
     size_t LP;
-    size_t ckFm, ckBm, ckFf, ckBf, ckFb, ckBb, bndF, bndB, scoreF, scoreB, rec, segend, gate, gate2, zeros, total;
+    size_t ckFm, ckBm, ckFf, ckBf, ckFb, ckBb, bndF, bndB, scoreF, scoreB, rec, segend, gate, gate2, anygate, zeros, total;
 };
 
 bool crf_band_fits(size_t max_seqlen);

@@ -1019,6 +1019,7 @@ __global__ __launch_bounds__(WCAP *WAVE) void crf_band_sweep_kernel(BandArgs a) 
     if (role == 2 && tid == 0) a.gate[n] = 0;
     if (!want_grad && role == 0 && tid == 0) a.gate[n] = 2;     // cost only: pending -- crf_kernel compares the two sweep scores
     if (a.gate2 != nullptr && role == (want_grad ? 2 : 0) && tid == 0) a.gate2[n] = -1;     // not retried (yet)
+    if (a.anygate != nullptr && role == 2 && n == 0 && tid == 0) *a.anygate = 0;
     if (role == 2 && tid < 16) const_cast<float *>(a.zeros)[tid] = 0.f;   // (every rank workgroup: the same zeros)
     if (L == 0 || L > W * PW) {
         // c_crf_flipflop.c:269-272: cost 0 for an empty read (the gradient pass does it when
@@ -1153,8 +1154,8 @@ __global__ __launch_bounds__(POST_WAVES *WAVE) __attribute__((amdgpu_waves_per_e
 #define TK_POST_WS n
 #define TK_POST_HEAD (blockIdx.y == 0 && tid == 0)
 #define TK_POST_LEAVE return
-#define TK_POST_SWEEPS_DISAGREE(why) do { if (blockIdx.y == 0 && tid == 0) a.gate[n] = (why); return; } while (0)
-#define TK_POST_ROWS_LOST do { if (lost && lane == 0) a.gate[n] = 2; } while (0)
+#define TK_POST_SWEEPS_DISAGREE(why) do { if (blockIdx.y == 0 && tid == 0) { a.gate[n] = (why); if (a.anygate) *a.anygate = 1; } return; } while (0)
+#define TK_POST_ROWS_LOST do { if (lost && lane == 0) { a.gate[n] = 2; if (a.anygate) *a.anygate = 1; } } while (0)
 #include "crf_band_posterior.inc"
 #undef TK_POST_PREAMBLE
 #undef TK_POST_WS
@@ -1203,6 +1204,8 @@ __global__ __launch_bounds__(BAND_MAXW *WAVE) void crf_band_tail_kernel(BandArgs
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6), nwaves = (int)(blockDim.x >> 6);
     const bool want_grad = a.grad != nullptr;
     const int T = a.T, NB = (T + BK - 1) / BK;
+    // the common path of a gradient call: the batch's gradient pass disowned nobody -- one word says so
+    if (r.anygate != nullptr && *r.anygate == 0) return;
     {
         const bool writer = blockIdx.x == 0 && w == 0;          // (one wave writes the cost-only calls' costs)
         unsigned long long any = 0;
@@ -1425,6 +1428,8 @@ BandLayout crf_band_layout(size_t ntrans, size_t nblk, size_t nbatch, size_t max
     off += (nbatch * sizeof(int) + 255) / 256 * 256;
     l.gate2 = off;              // the retry launch's verdicts, per read of the batch
     off += (nbatch * sizeof(int) + 255) / 256 * 256;
+    l.anygate = off;
+    off += 256;
     l.zeros = off;
     off += 256;
     l.total = off + 256;

@@ -454,6 +454,7 @@ int crf_dispatch(const float *logprob, size_t ntrans, size_t nblk, size_t nbatch
         b.segend = g ? reinterpret_cast<int *>(wb + l.segend) : nullptr;
         b.gate = reinterpret_cast<int *>(wb + l.gate);
         b.gate2 = reinterpret_cast<int *>(wb + l.gate2);
+        b.anygate = g ? reinterpret_cast<int *>(wb + l.anygate) : nullptr;
         b.zeros = reinterpret_cast<const float *>(wb + l.zeros);
         b.dbg = nullptr;
         b.before_gradient = add_ready;
@@ -490,6 +491,7 @@ int crf_dispatch(const float *logprob, size_t ntrans, size_t nblk, size_t nbatch
         BandArgs c = b;
         c.gate = nullptr;
         c.gate2 = nullptr;
+        c.anygate = nullptr;
         if (rblk.bk > 0) {
             const BandLayout q = crf_band_layout(ntrans, nblk, retry_slots, max_seqlen, mod, true, rblk.bk);
             if (q.R != l.R || q.W != l.W) return 2;
@@ -517,6 +519,7 @@ int crf_dispatch(const float *logprob, size_t ntrans, size_t nblk, size_t nbatch
         r.firstF = g ? nullptr : b.scoreF;
         r.firstB = g ? nullptr : b.scoreB;
         r.first_wbias = blk.wbias;
+        r.anygate = b.anygate;
         r.retry = rblk.bk > 0 ? 1 : 0;
         r.log_domain = 1;
         if (const char *e = TK_LAB_ENV("TK_CRF_NO_FALLBACK"))       // lab: time / test the linear path alone

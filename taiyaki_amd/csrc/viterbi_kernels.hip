@@ -38,6 +38,8 @@ constexpr float VIT_NEG_INF = -__builtin_huge_valf();
 
 // maximum over the 8-lane group, in every lane of the group
 __device__ __forceinline__ float vit_grp_max(float x) {
+    // (round 6, tried: the three levels through __builtin_amdgcn_update_dpp + fmaxf so that the compiler may fill the wait slots --
+    // it does not fuse them: mov, mov_dpp, canonicalising max, max per level, 475 more instructions per kernel.  The asm stays.)
     float r;
     asm("s_nop 1\n\t"
         "v_max_f32_dpp %0, %1, %1 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"

@@ -51,6 +51,28 @@ __device__ __forceinline__ float vit_grp_max(float x) {
     return r;
 }
 
+// vit_grp_max with the two wait slots in front of its first two DPP reads FILLED (round 6): the invalid-source masks of the
+// next two steps' scores (v_cndmask: -inf where the lane's (to, from) pair does not exist) take the place of an s_nop each --
+// two issue slots less per pair of steps on a chain that is bound by its instruction count.  Same values, same order.
+// (used by the five-wave form only: beside ONE trace wave per parity the faster chain gains nothing -- a tile's sixteen steps then
+// take it less than that trace wave needs for its eight, and the three-wave kernel measures 196 against 189 us with it)
+__device__ __forceinline__ float vit_grp_max_fill(float x, float s1, unsigned long long m1, float s2, unsigned long long m2,
+                                                  float &o1, float &o2) {
+    float r;
+    const float ninf = VIT_NEG_INF;
+    asm("v_cndmask_b32_e64 %1, %4, %5, %7\n\t"
+        "s_nop 0\n\t"
+        "v_max_f32_dpp %0, %3, %3 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
+        "v_cndmask_b32_e64 %2, %4, %6, %8\n\t"
+        "s_nop 0\n\t"
+        "v_max_f32_dpp %0, %0, %0 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n\t"
+        "s_nop 1\n\t"
+        "v_max_f32_dpp %0, %0, %0 row_half_mirror row_mask:0xf bank_mask:0xf"
+        : "=&v"(r), "=&v"(o1), "=&v"(o2)
+        : "v"(x), "v"(ninf), "v"(s1), "v"(s2), "s"(m1), "s"(m2));
+    return r;
+}
+
 // ---- traceback (decode.py:108-113); argmax = first maximal state.  `m`: the last step's maxima as the
 // forward pass left them -- state s in group s (one-wave kernel, and the alternating layout after an even
 // last step, i.e. T odd) or in lane s of every group (alternating layout, T even).
@@ -358,6 +380,10 @@ __device__ __forceinline__ void viterbi_path_pass3(float m, int T, int N, int n,
 #define TK_VIT_GROUP 64
 #endif
 constexpr int VIT_TILE = TK_VIT_TILE;       // steps per hand-over (one s_barrier)
+// trace waves per step parity (round 6): 1 = three waves per read (round 5); 2 = five -- with the chain wave's wait slots filled
+// (vit_grp_max_fill) a tile's sixteen steps take it ~1260 cycles, less than ONE trace wave needs for its eight steps of the tile
+// (a template parameter of the kernel: five waves per read oversubscribe the SIMDs once several reads share a CU -- viterbi_launch)
+__host__ __device__ constexpr int vit_waves(int split) { return 1 + 2 * split; }
 #ifndef TK_VIT_RING2
 #define TK_VIT_RING2 1
 #endif
@@ -409,8 +435,8 @@ __device__ __forceinline__ void vit_handover() {
     asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
 }
 
-template <int NB, bool FULLOUT>
-__global__ __launch_bounds__(3 * WAVE) void viterbi3_kernel(const float *__restrict__ scores, int T,
+template <int NB, bool FULLOUT, int VIT_TRACE_SPLIT>
+__global__ __launch_bounds__(vit_waves(VIT_TRACE_SPLIT) * WAVE) void viterbi3_kernel(const float *__restrict__ scores, int T,
                                                            int N, float *__restrict__ fwd_out,
                                                            int64_t *__restrict__ tb_out,
                                                            int64_t *__restrict__ path_out,
@@ -461,6 +487,11 @@ __global__ __launch_bounds__(3 * WAVE) void viterbi3_kernel(const float *__restr
                 sc[k] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rs, (k & 1) ? ld4B : ld4A, rs4 * (unsigned)min(k, Tm1), 0));
         }
         float snext = validA ? sc[0] : VIT_NEG_INF;
+        constexpr bool FILL = VIT_TRACE_SPLIT > 1;
+        const unsigned long long maskA = __ballot(validA), maskB = __ballot(validB);
+        float snext2 = VIT_NEG_INF;             // (FILL) the masked score of the step after the next one
+        (void)maskA;
+        (void)maskB;
         auto group = [&](int t0, auto full) {
             constexpr bool FULL = decltype(full)::value;
             const __amdgpu_buffer_rsrc_t rnext = rows_from(t0 + VIT_GROUP);
@@ -470,7 +501,11 @@ __global__ __launch_bounds__(3 * WAVE) void viterbi3_kernel(const float *__restr
                 if (FULL || t0 + k < T) {                           // (wave-uniform)
                     const bool odd = (k & 1) != 0;                  // (compile time: unrolled, t0 is even)
                     const float cand = f + snext;
-                    m = odd ? vit_cross_max(cand) : vit_grp_max(cand);
+                    // (FILL, even step: the masks of the next two steps' scores ride in its wait slots -- sc[k + 1] and sc[k + 2] were
+                    // requested a group ago; at the group's last pair sc[0] is the row this group's step 0 has just re-requested)
+                    float sn1 = 0.f, sn2 = 0.f;
+                    if (FILL && !odd) m = vit_grp_max_fill(cand, sc[(k + 1) % VIT_GROUP], maskB, sc[(k + 2) % VIT_GROUP], maskA, sn1, sn2);
+                    else m = odd ? vit_cross_max(cand) : vit_grp_max(cand);
                     f = m;                                          // the next step's lane holds what it needs
                     // ---- off the chain: the vector for the trace waves, the row 64 steps ahead, the next mask
 #if TK_VIT_RING2
@@ -482,7 +517,16 @@ __global__ __launch_bounds__(3 * WAVE) void viterbi3_kernel(const float *__restr
                     ring_lane[(2 * k + 1) * WAVE] = cand;
 #endif
                     sc[k] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rnext, odd ? ld4B : ld4A, rs4 * (unsigned)min(k, lastn), 0));
-                    snext = (odd ? validA : validB) ? sc[(k + 1) % VIT_GROUP] : VIT_NEG_INF;
+                    if (FILL) {
+                        if (!odd) {
+                            snext = sn1;
+                            snext2 = sn2;
+                        } else {
+                            snext = snext2;
+                        }
+                    } else {
+                        snext = (odd ? validA : validB) ? sc[(k + 1) % VIT_GROUP] : VIT_NEG_INF;
+                    }
                 }
                 if (k % VIT_TILE == VIT_TILE - 1 && (FULL || t0 + k - (VIT_TILE - 1) < T)) vit_handover();
             }
@@ -492,7 +536,8 @@ __global__ __launch_bounds__(3 * WAVE) void viterbi3_kernel(const float *__restr
         if (tfull < T) group(tfull, std::false_type{});
     } else {
         // ---------------------------------------------------------------- traceback bytes (+ full outputs) of the even / odd steps
-        const int par = wave - 1;                               // this wave's steps: t = par (mod 2)
+        const int par = (wave - 1) & 1;                         // this wave's steps: t = par (mod 2) ...
+        const int part = VIT_TRACE_SPLIT == 1 ? 0 : (wave - 1) >> 1;    // ... of this part of every tile
         const bool odd = par != 0;
         const int st_to = odd ? sub : grp;                      // the state a lane's candidate belongs to
         const unsigned lane_tb = (unsigned)((size_t)n * VIT_GRP + st_to);
@@ -500,7 +545,8 @@ __global__ __launch_bounds__(3 * WAVE) void viterbi3_kernel(const float *__restr
         const size_t pstride = (size_t)npad * VIT_GRP;           // traceback bytes [t][npad][8]
         const size_t ostride = (size_t)N * F::NS;
         constexpr bool ALL_GROUPS_LIVE = F::NS == VIT_GRP;
-        constexpr int TH = VIT_TILE / 2;                         // this wave's steps per tile
+        constexpr int TH = VIT_TILE / 2 / VIT_TRACE_SPLIT;      // this wave's steps per tile
+        static_assert(VIT_TILE % (2 * VIT_TRACE_SPLIT) == 0, "a tile's steps of one parity are shared out evenly");
         if (FULLOUT && par == 0 && sub == 0 && grp < F::NS) fwd_out[(size_t)n * F::NS + grp] = (grp < NB) ? 0.f : NEG_LARGE;
         auto group = [&](int t0, auto full) {
             constexpr bool FULL = decltype(full)::value;
@@ -519,7 +565,7 @@ __global__ __launch_bounds__(3 * WAVE) void viterbi3_kernel(const float *__restr
                     float mm[TH], cd[TH];
 #pragma unroll
                     for (int q = 0; q < TH; ++q) {
-                        const int k = 2 * q + par;                  // step inside the tile
+                        const int k = 2 * (part * TH + q) + par;    // step inside the tile
 #if defined(TK_VIT_TRACE_NOLDS)
                         mm[q] = (float)(slot0 + k + lane);          // lab (timing only, wrong bytes): no ring reads
                         cd[q] = (float)(slot0 + k + (lane & 56));
@@ -534,7 +580,7 @@ __global__ __launch_bounds__(3 * WAVE) void viterbi3_kernel(const float *__restr
                     }
 #pragma unroll
                     for (int q = 0; q < TH; ++q) {
-                        const int kk = tile * VIT_TILE + 2 * q + par;   // step inside the group
+                        const int kk = tile * VIT_TILE + 2 * (part * TH + q) + par;   // step inside the group
                         if (FULL || t0 + kk < T) {
                             const float cand = cd[q];
                             // "first index wins": the lowest set bit among the ballot bits (candidate == maximum)
@@ -581,7 +627,7 @@ __global__ __launch_bounds__(3 * WAVE) void viterbi3_kernel(const float *__restr
     // (the bytes were written by other waves of this workgroup and have landed: vmcnt(0) before the barrier above; no line of
     // them was read before, so no stale copy can answer.  The ring is free by now.)
     __shared__ unsigned stsh[WAVE + 2];
-    viterbi_path_pass3<NB>(m, T, N, n, lane, wave, 3, path_out, packed, npad, reinterpret_cast<unsigned long long *>(ring), stsh);
+    viterbi_path_pass3<NB>(m, T, N, n, lane, wave, vit_waves(VIT_TRACE_SPLIT), path_out, packed, npad, reinterpret_cast<unsigned long long *>(ring), stsh);
 #endif
 }
 
@@ -603,12 +649,23 @@ static int viterbi_launch(const float *scores, size_t T, size_t N, float *fwd, i
     const char *v1 = TK_LAB_ENV("TK_VIT_V1");                   // lab: 1 = the one-wave kernel of rounds 1-4, 0 = three waves, for A/B
     const bool three = v1 ? v1[0] != '1' : N <= 1536;
     if (three) {
-        if (fwd != nullptr && tb != nullptr)
-            hipLaunchKernelGGL((viterbi3_kernel<NB, true>), dim3((unsigned)N), dim3(3 * WAVE), 0, stream, scores, (int)T,
-                               (int)N, fwd, tb, path, static_cast<unsigned char *>(workspace), npad);
-        else
-            hipLaunchKernelGGL((viterbi3_kernel<NB, false>), dim3((unsigned)N), dim3(3 * WAVE), 0, stream, scores, (int)T,
-                               (int)N, fwd, tb, path, static_cast<unsigned char *>(workspace), npad);
+        // trace waves per step parity: 2 (five waves per read) while a read has a CU nearly to itself -- T 4000 / N 256 193 -> 180 us
+        // path only, 233 -> 184 with the full outputs, N 512 230 -> 215; beyond ~2 reads per CU the extra waves share SIMDs with chain
+        // waves (N 1024: 326 -> 427 us) and the three-wave form stays (profiles/r6_viterbi_fill_split_ab.txt).  TK_VIT_SPLIT = 1 | 2 | 4 (lab)
+        int split = N <= 640 ? 2 : 1;
+        if (const char *e = TK_LAB_ENV("TK_VIT_SPLIT")) split = atoi(e);
+        auto go = [&](auto sp) {
+            constexpr int SP = decltype(sp)::value;
+            if (fwd != nullptr && tb != nullptr)
+                hipLaunchKernelGGL((viterbi3_kernel<NB, true, SP>), dim3((unsigned)N), dim3(vit_waves(SP) * WAVE), 0, stream, scores,
+                                   (int)T, (int)N, fwd, tb, path, static_cast<unsigned char *>(workspace), npad);
+            else
+                hipLaunchKernelGGL((viterbi3_kernel<NB, false, SP>), dim3((unsigned)N), dim3(vit_waves(SP) * WAVE), 0, stream, scores,
+                                   (int)T, (int)N, fwd, tb, path, static_cast<unsigned char *>(workspace), npad);
+        };
+        if (split == 4) go(std::integral_constant<int, 4>{});
+        else if (split == 2) go(std::integral_constant<int, 2>{});
+        else go(std::integral_constant<int, 1>{});
         return hipGetLastError() == hipSuccess ? 0 : 4;
     }
     if (fwd != nullptr && tb != nullptr)

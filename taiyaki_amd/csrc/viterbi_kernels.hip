@@ -386,7 +386,9 @@ constexpr int VIT_TILE = TK_VIT_TILE;       // steps per hand-over (one s_barrie
 __host__ __device__ constexpr int vit_waves(int split) { return 1 + 2 * split; }
 // (round 6, measured and not kept: a SIXTH wave that ends at once, so that -- if a workgroup's waves go to the CU's four SIMDs in
 // turn -- the fifth does not share the chain wave's SIMD: 181.4 against 180.5 us at T 4000 / N 256, 221 against 215 at N 512;
-// tiles of 32 steps instead of 16: 179.6 against 180.3; of 8: 187 -- profiles/r6_viterbi_fill_split_ab.txt)
+// tiles of 32 steps instead of 16: 179.6 against 180.3; of 8: 187; the ODD step's wait slots filled with the scalar row offsets of
+// the next loads (s_min_i32 + s_mul_i32 in place of two s_nop 1; mind the SCC clobber): 178.5 against 179.9 -- within the noise:
+// with five waves the kernel is no longer bound by the chain wave alone -- profiles/r6_viterbi_fill_split_ab.txt)
 #ifndef TK_VIT_RING2
 #define TK_VIT_RING2 1
 #endif

@@ -1014,6 +1014,43 @@ def test_crf_disowned_reads_are_counted_and_redone_in_shared_slots(oracle_mod, g
         _lib.set_strict(True)
 
 
+@pytest.mark.parametrize("catmod", [False, True])
+def test_tail_launch_paths_cost_only_and_fused(oracle_mod, gpu_device, catmod):
+    """Round 6: the tail launch behind the gradient pass (crf_band_tail_kernel) on a batch of ordinary reads with a few bands a
+    few cells wide among them -- the fast configuration disowns those, the retry keeps most, the log domain takes the rest.  The three
+    forms a caller can reach it by: a gradient call, a COST-ONLY call (the batch's launch leaves every read pending; the tail launch
+    compares the sweeps, writes the costs and retries where they disagree) and the FUSED loss (kernel B's gradient is folded into
+    the rows the retry's gradient pass writes, too) -- every read is the oracle's."""
+    import torch
+    from taiyaki_amd import ctc, synth
+    T, N = 200, 24
+    Ls = np.array([T - 2 - (k % 5) if k % 6 == 0 else 70 + 3 * k for k in range(N)], dtype=np.int32)    # 4 narrow bands among 20 ordinary reads
+    inp = synth.crf_case(T, N, 7, seqlens=Ls, nmods_per_base=(1, 1, 0, 0) if catmod else None)
+    if catmod:
+        synth.normalise_mod_columns(inp, logit_scale=0.2)
+    r = parity.compare_crf(oracle_mod, inp, 1.0, gpu_device)
+    retried, redone = ctc.last_retry_count(), ctc.last_gate_count()
+    assert r["finite"] and parity.crf_loss_ok(r) and parity.crf_grad_ok(r), (r["loss_rel"], r["grad_f64_scaled"], r["ref_noise_scaled"])
+    assert 1 <= retried <= 4 and redone <= retried, (retried, redone)
+    # cost only
+    c0, _ = parity.run_crf(inp, 1.0, gpu_device, want_grad=False)
+    assert ctc.last_retry_count() >= 1 and ctc.last_gate_count() <= ctc.last_retry_count()
+    assert np.all((np.abs(c0 - r["oloss"]) <= 1e-5 * np.abs(r["oloss"])) | (np.abs(c0 - r["oloss"]) <= 2e-6)), np.abs(c0 - r["oloss"]).max()
+    # the fused loss: (A) + logZ / T with one gradient tensor
+    x = torch.from_numpy(inp["scores"]).to(gpu_device).requires_grad_()
+    extra = (torch.from_numpy(inp["mod_cats"]), inp["can_mods_offsets"], inp["mod_cat_weights"]) if catmod else ()
+    lv = ctc.flipflop_loss(x, torch.from_numpy(inp["seqs"]), torch.from_numpy(inp["seqlens"]), 1.0, *extra)
+    lv.sum().backward()
+    assert ctc.last_retry_count() >= 1
+    sc40 = np.ascontiguousarray(inp["scores"][:, :, :40])
+    olz, olgrad = oracle_mod.flipflop_logz_grad(sc40)
+    np.testing.assert_allclose(lv.detach().cpu().numpy(), r["oloss"] + olz / T, rtol=1e-5, atol=2e-6)
+    want = r["ograd"].copy()
+    want[:, :, :40] += olgrad / T
+    ps = parity.posterior_scale(inp) * T
+    assert np.abs((x.grad.cpu().numpy() - want) * ps).max() < parity.GRAD_T_ATOL + 2.5 * r["ref_noise_scaled"]
+
+
 def test_crf_log_probability_inputs(oracle_mod, gpu_device, labenv):
     """Scores that are log-probabilities (all <= 0, a log-softmax over the 40 transitions: what
     test_ctc_loss.py feeds the reference) shrink every cell by ~2^-5 per step: inside the range of

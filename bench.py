@@ -316,7 +316,7 @@ def kernel_hash():
     h = hashlib.sha256()
     d = os.path.join(ROOT, "taiyaki_amd", "csrc")
     for name in sorted(os.listdir(d)):
-        if name.endswith((".hip", ".h")):
+        if name.endswith((".hip", ".h", ".inc")):
             with open(os.path.join(d, name), "rb") as fh:
                 h.update(fh.read())
     return h.hexdigest()[:16]
@@ -678,7 +678,7 @@ def kernel_records(out, args, cfg, dev, world, T, nbatch, chunk_len, cat_mod, S)
     def crf_roofline(ops, reps, label, realistic):
         mean_s, min_s = _events_mean_min(ops.crf, reps, warm=5)
         tr, src = traffic_of("crf", ops.T, ops.N, realistic)
-        rec = roofline_record("sequence CRF op (crf_band_sweep incl. the index build + crf_band_posterior + gated crf_kernel), "
+        rec = roofline_record("sequence CRF op (crf_band_sweep incl. the index build + crf_band_posterior + crf_band_tail: retry / log-domain redo of disowned reads), "
                               "T=%d N=%d S=%d, max L %d (%s)" % (ops.T, ops.N, ops.S, ops.maxlen, label),
                               3.0 * ops.T * ops.N * ops.S * 4, mean_s, min_s, reps, tr, src)
         # the bound that applies: instruction issue (the HBM fraction above is reported because SURVEY 8d asks for it)
@@ -704,8 +704,8 @@ def kernel_records(out, args, cfg, dev, world, T, nbatch, chunk_len, cat_mod, S)
                  "bound by instruction issue -- T serial steps per read, all of a read's waves on one CU -- "
                  "not by HBM; `traffic` = scores read three times, one checkpoint column + boundary cells per "
                  "time block (12 steps; cat-mod 8) written and read, the gradient written once; achieved is the algorithmic "
-                 "3*T*N*S*4 bytes over the op's duration (build_indices + sweeps + gradient pass + the gated "
-                 "log-domain launch, which finds nothing to redo on these inputs)")
+                 "3*T*N*S*4 bytes over the op's duration (sweeps with the index build inside + gradient pass + the tail "
+                 "launch -- per-read retry, then the log domain --, which finds nothing to do on these inputs)")
     else:
         out["roofline"] = logz_roofline(step_ops, 30, "the train step's own launch")
     # ---- Viterbi (north_star: a hand-written kernel of the path; decode.py:75-115, flipflop.py:387-518) --------

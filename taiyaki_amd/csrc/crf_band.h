@@ -45,7 +45,7 @@ struct BandArgs {
     uint32_t *rec;              // [N][Wp][KINDS][64]  sorted transition instances of every 64-cell chunk
     int *segend;                // [N][Wp][64]  end of every transition id's segment
     const float *zeros;         // 64 B of zeros (the boundary row of lanes that take none)
-    int *gate;                  // [N]  != 0: the batch's launch disowns this read (retried by crf_band_retry_kernel, else redone by crf_kernel)
+    int *gate;                  // [N]  != 0: the batch's launch disowns this read (retried, and if need be redone in the log domain, by crf_band_tail_kernel)
     int *anygate;               // one word, nullable: != 0 iff the batch's gradient pass disowned ANY read (the tail launch looks
                                 // at this word first: on the common path it leaves without a pass over the gate array)
     int *gate2;                 // [N]  nullable; the retry launch's verdicts: the batch's launch sets -1 ("not retried"), the retry
@@ -59,7 +59,7 @@ struct BandArgs {
     // Round 5 -- the index build INSIDE the sweep launch (codes != null): stay / move / mod / modfact / seqoff above
     // are then OUTPUTS of this launch, not inputs.  Every sweep workgroup forms its read's offset and its cells'
     // ids from the flip-flop codes itself; the rank workgroups (a cost-only call: the forward sweeps) also write
-    // the arrays for the launches behind (gradient pass, crf_kernel).  Saves tk_flipflop_build_indices_dev's
+    // the arrays for the launches behind (gradient pass, tail launch).  Saves tk_flipflop_build_indices_dev's
     // launch: ~5 us of the op's ~99 at the train step's shape.
     const int32_t *codes;       // (total_len) flip-flop codes 0 .. 2 nbase - 1, reads concatenated; null: ids are inputs
     const int32_t *mod_cats;    // (total_len) or null

@@ -817,7 +817,7 @@ __device__ __forceinline__ void band_sweep(const BandArgs &a, int n, int ws, int
             // (a cost-only call, too: round 5 -- its forward sweep used to write the cost by itself whenever the score
             // was finite, and a read outside the linear path's range came back silently WRONG, e.g. cat-mod with five
             // modifications per base: costs off by 0.02 .. 0.19.  Now both sweeps run, and the launch behind them
-            // (crf_kernel's vote pass) writes the cost where they agree and redoes the read where they do not.)
+            // (the tail launch's vote pass, crf_band_tail_kernel) writes the cost where they agree and retries / redoes the read where they do not.)
             const double sc2 = (double)f[j] + log2((double)m[j]);
             (FWD ? a.scoreF : a.scoreB)[ws] = sc2;
         }
@@ -964,7 +964,7 @@ __device__ __forceinline__ void band_rank(const BandArgs &a, int ws, int L, int6
 // ===========================================================================
 // sweep + rank launch.  blockIdx.x in [0, N): sorted-instance records for the gradient pass;
 // [N, 2N): forward sweep of read n; [2N, 3N): backward sweep.  Cost-only calls launch 2 N
-// workgroups: the two sweeps (their scores are compared by the launch behind them, crf_kernel's vote pass).
+// workgroups: the two sweeps (their scores are compared by the launch behind them: the tail launch's vote pass).
 // ===========================================================================
 // WCAP = the most waves a launch of this instantiation may have: the register budget of a lane is
 // 512 / ceil(WCAP / 4) (R = 4 wants more than the 128 that 16 waves leave).
@@ -1007,7 +1007,7 @@ __global__ __launch_bounds__(WCAP *WAVE) void crf_band_sweep_kernel(BandArgs a) 
         L = min(a.seqlen[n], (int)(a.seqoff[n + 1] - a.seqoff[n]));            // (offsets are clamped to the label array)
     }
     // (what is left of build_indices_kernel's outputs: the read's offset, for the launches behind -- the gradient pass
-    // and crf_kernel take a read's offset and length from seqoff; its label checks ride in the forward sweep's set-up)
+    // and the tail launch take a read's offset and length from seqoff; its label checks ride in the forward sweep's set-up)
     if (a.codes != nullptr && role == 0 && tid == 0) {
         int64_t *seqoff = const_cast<int64_t *>(a.seqoff);
         seqoff[n] = min(off_raw, a.total_len);
@@ -1017,7 +1017,7 @@ __global__ __launch_bounds__(WCAP *WAVE) void crf_band_sweep_kernel(BandArgs a) 
         }
     }
     if (role == 2 && tid == 0) a.gate[n] = 0;
-    if (!want_grad && role == 0 && tid == 0) a.gate[n] = 2;     // cost only: pending -- crf_kernel compares the two sweep scores
+    if (!want_grad && role == 0 && tid == 0) a.gate[n] = 2;     // cost only: pending -- the tail launch compares the two sweep scores
     if (a.gate2 != nullptr && role == (want_grad ? 2 : 0) && tid == 0) a.gate2[n] = -1;     // not retried (yet)
     if (a.anygate != nullptr && role == 2 && n == 0 && tid == 0) *a.anygate = 0;
     if (role == 2 && tid < 16) const_cast<float *>(a.zeros)[tid] = 0.f;   // (every rank workgroup: the same zeros)

@@ -205,7 +205,8 @@ static size_t crf_ckpt_bytes(size_t nblk, size_t nbatch, CrfShape sh, bool want_
 
 // Which form of kernel A runs (TK_CRF_MODE overrides: band | ckpt):
 //   band     crf_band.hip -- linear-domain banded skewed sweep + recomputing gradient pass, followed
-//            by a GATED launch of crf_kernel that redoes the reads the band path disowned
+//            by ONE tail launch (crf_band.hip: crf_band_tail_kernel) that retries the reads the band path disowned alone
+//            and redoes in the log domain (crf_read, crf_log.h) what it disowns twice
 //            (default whenever the sequences fit 16 waves x 256 cells and the checkpoint columns
 //            fit the workspace cap)
 //   ckpt     the single-launch log-domain checkpoint/recompute kernel of this file on every read:

@@ -60,7 +60,9 @@ class GateWatch:
         self.every, self.fraction = every, fraction
         self.steps = self.reads = 0
         self.seen_total = _lib.gated_total()
+        self.seen_retried = _lib.retried_total()
         self.last_fraction = 0.0
+        self.last_retried_fraction = 0.0        # (round 6) reads swept again alone on the linear path: ~0.3 ms each, not 2.5
 
     def note(self, nreads):
         from taiyaki_amd import _lib
@@ -72,12 +74,16 @@ class GateWatch:
             _lib.take_gate_count()
         total = _lib.gated_total()
         redone, self.seen_total = total - self.seen_total, total
+        rt = _lib.retried_total()
+        retried, self.seen_retried = rt - self.seen_retried, rt
         self.last_fraction = redone / max(1, self.reads)
+        self.last_retried_fraction = retried / max(1, self.reads)
         if redone > self.fraction * self.reads:
             import warnings
             warnings.warn("flip-flop loss: %d of the last %d reads (%.1f %%) were redone by the log-domain kernel "
                           "(~1000x the cost of a read on the linear path): scores outside the range the linear path "
-                          "represents -- see taiyaki_amd.ctc.last_gate_count" % (redone, self.reads, 100.0 * self.last_fraction),
+                          "represents (%d more were kept by the per-read retry) -- see taiyaki_amd.ctc.last_gate_count"
+                          % (redone, self.reads, 100.0 * self.last_fraction, retried - redone if retried > redone else 0),
                           RuntimeWarning, stacklevel=3)
         self.reads = 0
 

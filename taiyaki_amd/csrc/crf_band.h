@@ -114,8 +114,11 @@ BandBlock crf_band_pick_block(float sharp, bool mod, size_t max_seqlen, bool col
 // the retry launch's configuration for this call (bk = 0: none -- the batch's launch already ran it, or nothing milder exists)
 BandBlock crf_band_pick_retry(float sharp, BandBlock fast);
 size_t crf_band_retry_slots(size_t nbatch);
+// `force_R` > 0: that many cells per lane instead of the batch launch's choice (the retry's own layout: crf_band_retry_R)
 BandLayout crf_band_layout(size_t ntrans, size_t nblk, size_t nbatch, size_t max_seqlen, bool mod,
-                           bool want_grad, int bk);
+                           bool want_grad, int bk, int force_R = 0);
+// cells per lane of the RETRY: the smallest that leaves 2 W <= 16 waves, so that the tail launch's workgroup runs both sweeps at once
+int crf_band_retry_R(size_t max_seqlen);
 int crf_band_dispatch(const BandArgs &a, int R, bool mod, int bk, hipStream_t stream);
 // (the tail launch -- retry, then the log domain: crf_log.h: crf_band_tail_dispatch)
 

@@ -1391,13 +1391,19 @@ size_t crf_band_retry_slots(size_t nbatch) {
     return s < nbatch ? s : nbatch;
 }
 
+int crf_band_retry_R(size_t max_seqlen) {
+    int R = 1;
+    while (R < 4 && (size_t)R * WAVE * (BAND_MAXW / 2) < max_seqlen) R *= 2;
+    return R;
+}
+
 BandLayout crf_band_layout(size_t ntrans, size_t nblk, size_t nbatch, size_t max_seqlen, bool mod,
-                           bool want_grad, int bk) {
+                           bool want_grad, int bk, int force_R) {
     (void)ntrans;
     BandLayout l;
     const size_t BK = (size_t)(bk > 0 ? bk : 8);
     l.BK = (int)BK;
-    l.R = crf_band_pick_R(max_seqlen, mod);
+    l.R = force_R > 0 ? force_R : crf_band_pick_R(max_seqlen, mod);
     const size_t PW = (size_t)l.R * WAVE;
     l.W = (int)((max_seqlen + PW - 1) / PW);
     if (l.W < 1) l.W = 1;

@@ -253,19 +253,17 @@ static CrfMode crf_pick_mode(size_t ntrans, size_t nblk, size_t nbatch, size_t m
 // the retry's workspace (round 6): the band layout of 4-step blocks for crf_band_retry_slots(nbatch) reads (gradient
 // form whatever the call: a cost-only retry runs the same sweeps)
 static size_t crf_retry_bytes(size_t ntrans, size_t nblk, size_t nbatch, size_t max_seqlen) {
-    return crf_band_total_bound(ntrans, nblk, crf_band_retry_slots(nbatch), max_seqlen, true, 4);
+    const int R = crf_band_retry_R(max_seqlen);
+    const size_t a = crf_band_layout(ntrans, nblk, crf_band_retry_slots(nbatch), max_seqlen, true, true, 4, R).total;
+    const size_t b = crf_band_layout(ntrans, nblk, crf_band_retry_slots(nbatch), max_seqlen, false, true, 4, R).total;
+    return a > b ? a : b;
 }
 // the log-domain form's checkpoint columns behind the band path: one set per workgroup of the TAIL launch (crf_band.hip:
 // crf_band_tail_kernel -- 16 waves, cells per lane by the band launch's)
 static CrfShape crf_tail_shape(int band_R) { return {crf_tail_log_R(band_R), 16}; }
 static size_t crf_tail_ckpt_bound(size_t ntrans, size_t nblk, size_t nbatch, size_t max_seqlen, bool want_grad) {
-    size_t m = 0;
-    for (int mod = 0; mod < 2; ++mod) {
-        const int R = crf_band_layout(ntrans, nblk, nbatch, max_seqlen, mod != 0, want_grad, 8).R;
-        const size_t b = crf_ckpt_bytes(nblk, crf_band_retry_slots(nbatch), crf_tail_shape(R), want_grad);
-        m = b > m ? b : m;
-    }
-    return m;
+    (void)ntrans;
+    return crf_ckpt_bytes(nblk, crf_band_retry_slots(nbatch), crf_tail_shape(crf_band_retry_R(max_seqlen)), want_grad);
 }
 
 // workspace = [band layout (band mode only)] [the retry's band layout] [checkpoint columns + offsets of the log-domain form:
@@ -360,9 +358,11 @@ int crf_dispatch(const float *logprob, size_t ntrans, size_t nblk, size_t nbatch
     const size_t retry_slots = crf_band_retry_slots(nbatch);
     const BandLayout bl = crf_band_layout(ntrans, nblk, nbatch, max_seqlen, mod, grad != nullptr, blk.bk > 0 ? blk.bk : 8);
     const size_t band_bytes = band ? bl.total : 0;
-    const CrfShape tsh = crf_tail_shape(bl.R);
+    // (the tail launch has its own cells per lane: the retry's sweeps run side by side when 2 W waves fit its 16)
+    const int tailR = crf_band_retry_R(max_seqlen);
+    const CrfShape tsh = crf_tail_shape(tailR);
     const size_t tail_ckpt = crf_ckpt_bytes(nblk, retry_slots, tsh, grad != nullptr);
-    size_t retry_bytes = (band && rblk.bk > 0) ? crf_band_layout(ntrans, nblk, retry_slots, max_seqlen, mod, true, rblk.bk).total : 0;
+    size_t retry_bytes = (band && rblk.bk > 0) ? crf_band_layout(ntrans, nblk, retry_slots, max_seqlen, mod, true, rblk.bk, tailR).total : 0;
     if (band && tail_ckpt + band_bytes + retry_bytes > workspace_bytes) {
         rblk.bk = 0;
         retry_bytes = 0;
@@ -494,9 +494,11 @@ int crf_dispatch(const float *logprob, size_t ntrans, size_t nblk, size_t nbatch
         c.gate2 = nullptr;
         c.anygate = nullptr;
         if (rblk.bk > 0) {
-            const BandLayout q = crf_band_layout(ntrans, nblk, retry_slots, max_seqlen, mod, true, rblk.bk);
-            if (q.R != l.R || q.W != l.W) return 2;
+            const BandLayout q = crf_band_layout(ntrans, nblk, retry_slots, max_seqlen, mod, true, rblk.bk, tailR);
             char *wr = wb + l.total;
+            c.W = q.W;
+            c.LP = (int)q.LP;
+            c.Wp = (int)(q.LP / WAVE);
             c.ckFm = reinterpret_cast<float *>(wr + q.ckFm);
             c.ckBm = reinterpret_cast<float *>(wr + q.ckBm);
             c.ckFf = reinterpret_cast<int16_t *>(wr + q.ckFf);
@@ -538,7 +540,7 @@ int crf_dispatch(const float *logprob, size_t ntrans, size_t nblk, size_t nbatch
             a.ckpt = reinterpret_cast<float *>(wb);
             a.ckoff = reinterpret_cast<double *>(wb + (grad ? ckb : 0));
         }
-        const int rr = crf_band_tail_dispatch(c, r, a, l.R, mod, retry_slots, stream);
+        const int rr = crf_band_tail_dispatch(c, r, a, tailR, mod, retry_slots, stream);
         if (rr != 0) return rr;
         if (TK_LAB_ENV("TK_CRF_GATE_DUMP")) {
             (void)hipStreamSynchronize(stream);

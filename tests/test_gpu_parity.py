@@ -1054,6 +1054,23 @@ def test_tail_launch_paths_cost_only_and_fused(oracle_mod, gpu_device, catmod):
     assert np.abs((x.grad.cpu().numpy() - want) * ps).max() < parity.GRAD_T_ATOL + 2.5 * r["ref_noise_scaled"]
 
 
+@pytest.mark.parametrize("catmod", [False, True])
+def test_tail_launch_retry_with_its_own_cells_per_lane(oracle_mod, gpu_device, catmod):
+    """The retry's layout has its own cells per lane (crf_band_retry_R: the smallest that leaves 2 W <= 16 waves, so that the tail
+    launch's workgroup runs both sweeps at once) -- at 744 bases the batch's launch runs cat-mod at one cell per lane (12 chunk waves)
+    and the retry at two (6 + 6).  Long reads among ordinary ones at T 800, lengths without a bulk: retried, kept, the oracle's."""
+    from taiyaki_amd import ctc, synth
+    T, N = 800, 10
+    Ls = np.array([744, 440, 743, 401, 470, 742, 433, 500, 741, 420], dtype=np.int32)
+    inp = synth.crf_case(T, N, 21, seqlens=Ls, nmods_per_base=(1, 1, 0, 0) if catmod else None)
+    if catmod:
+        synth.normalise_mod_columns(inp, logit_scale=0.2)
+    r = parity.compare_crf(oracle_mod, inp, 1.0, gpu_device, max_seqlen=int(Ls.max()))
+    retried, redone = ctc.last_retry_count(), ctc.last_gate_count()
+    assert r["finite"] and parity.crf_loss_ok(r) and parity.crf_grad_ok(r), (r["loss_rel"], r["grad_f64_scaled"], r["ref_noise_scaled"])
+    assert 1 <= retried <= 4 and redone == 0, (retried, redone)
+
+
 def test_crf_log_probability_inputs(oracle_mod, gpu_device, labenv):
     """Scores that are log-probabilities (all <= 0, a log-softmax over the 40 transitions: what
     test_ctc_loss.py feeds the reference) shrink every cell by ~2^-5 per step: inside the range of

@@ -480,3 +480,27 @@ def test_gate_count_is_read_unsigned_and_taken_out_exactly():
     finally:
         _lib._deferred.pop(("cpu", None), None)
         _lib.set_strict(was)
+
+
+def test_bulk_length_hint_host_logic():
+    """Round 6: `tk_seq_labels.bulk_seqlen` -- a length all but a sixteenth of the batch (at least one read) stay below -- picks the CRF
+    launch's block configuration where `max_seqlen` only sizes it.  Host side: computed from lengths that live on the host, taken from
+    the hint where the tensor carries one, unknown (0) otherwise; the ctypes struct follows the header's seven fields."""
+    import ctypes
+    from taiyaki_amd import _lib, ctc
+    assert ctc.bulk_of([]) == 0 and ctc.bulk_of([7]) == 7
+    assert ctc.bulk_of([400, 410, 744, 420]) == 420                     # one long read of four set aside
+    lens = np.array([430] * 120 + [744] * 8)
+    assert ctc.bulk_of(lens) == 430                                     # 8 of 128 = a sixteenth: set aside
+    assert ctc.bulk_of(np.array([430] * 119 + [744] * 9)) == 744        # one more: the bulk itself is long
+    t = torch.tensor([400, 410, 744, 420])
+    assert ctc._bulk_seqlen(t) == 420 and ctc._max_seqlen(t) == 744
+    assert ctc._bulk_seqlen(ctc.set_max_seqlen(torch.tensor([400, 410, 744, 420]), 744)) == 0          # a maximum, no bulk: unknown
+    assert ctc._bulk_seqlen(ctc.set_max_seqlen(torch.tensor([400, 410, 744, 420]), 744, bulk=450)) == 450
+    assert ctc._bulk_seqlen(torch.zeros(0, dtype=torch.int64)) == 0
+    assert ctypes.sizeof(_lib.SeqLabels) == 7 * ctypes.sizeof(ctypes.c_void_p)
+    hdr = open(os.path.join(ROOT, "include", "taiyaki_amd_flipflop.h")).read()
+    body = hdr[hdr.index("typedef struct tk_seq_labels {"):hdr.index("} tk_seq_labels;")]
+    assert [f for f in ("seqs;", "total_len;", "nbase;", "mod_cats;", "can_mods_offsets;", "mod_cat_weights;", "bulk_seqlen;")
+            if f not in body] == []
+    assert "TK_STATUS_RETRIED_SHIFT 20" in hdr and "TK_STATUS_GATED_SHIFT 8" in hdr and _lib._RETRIED_SHIFT == 20 and _lib._GATED_SHIFT == 8

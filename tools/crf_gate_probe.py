@@ -2,9 +2,10 @@
 """Which reads does kernel A's linear band path disown (gate -> log-domain crf_kernel), and how far is
 it from the checkpoint kernel on the reads it keeps?
 
-    python tools/crf_gate_probe.py [--shapes cfg2,cfg2r,cfg5,rowK,narrow,sharp]
-Runs every shape three times: TK_CRF_MODE=ckpt (the log-domain kernel on every read = the reference
-arithmetic), band with TK_CRF_NO_FALLBACK=1 (the linear path alone) and band as shipped."""
+    python tools/crf_gate_probe.py [--shapes cfg2,cfg2r,cfg5,rowK,narrow,sharp,realnet,realfast_cm_s2]
+Runs every shape three times: TK_CRF_MODE=ckpt (the log-domain form on every read = the reference
+arithmetic), band with TK_CRF_NO_FALLBACK=1 (the linear path alone: the batch's launch AND the tail launch's
+per-read retry, no log-domain redo) and band as shipped.  "gated" = reads neither linear attempt kept."""
 import argparse
 import os
 import sys
@@ -90,7 +91,7 @@ def run(x, seqs, seqlens, sharp, extra, env):
 
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument("--shapes", default="tiny,t19,t37,t200,cfg2,cfg2r,narrow,pathbuf,lenramp,initramp,conframp,sharp,sharp13,sharp15,sharp17,sharp2,sharp3,sharp4,sharp2K,cfg4,cfg4r,cfg4rharsh,cfg4sharp2,cfg5,rowK,conf,confburst,confK")
+    ap.add_argument("--shapes", default="tiny,t19,t37,t200,cfg2,cfg2r,narrow,pathbuf,lenramp,initramp,conframp,sharp,sharp13,sharp15,sharp17,sharp2,sharp3,sharp4,sharp2K,cfg4,cfg4r,cfg4rharsh,cfg4sharp2,cfg4sharp25,cfg4sharp3,cfg5,rowK,conf,confburst,confK," + ",".join(REALNET))
     args = ap.parse_args()
     dev = torch.device("cuda:0")
     _lib.set_strict(False)
